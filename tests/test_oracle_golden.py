@@ -1,0 +1,252 @@
+"""Pin the CPU oracle (oracle/sdrm_oracle.c) against everything the reference's own tests hold for the
+fsk_demod path: the four end-to-end golden files (test/test_fsk_demod.c), the inline known answers of the
+stage unit tests (tests/golden/ref_unit_vectors.json, extracted by make_golden.py) and -- where it builds
+without libvolk -- the reference's own code (oracle/_ref).  CPU only.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+VEC = json.load(open(os.path.join(GOLDEN, "ref_unit_vectors.json")))["vectors"]
+
+
+def ramp(n, off=0):
+    """test/utils.c:104-112 setup_input_data"""
+    return np.arange(off, off + n, dtype=np.float64).astype(np.float32)
+
+
+def cramp(n, off=0):
+    """test/utils.c:124-132 setup_input_complex_data, interleaved: re = 2(off+i), im = 2(off+i)+1"""
+    return np.arange(2 * off, 2 * (off + n), dtype=np.float64).astype(np.float32)
+
+
+# ---------------------------------------------------------------- end-to-end goldens (test/test_fsk_demod.c)
+
+E2E = [
+    # name, create args (fs, baud, dev, decim, tw, dc), input, expected          (test_fsk_demod.c:52-79)
+    ("lucky7", (48000, 4800, 5000, 2, 2000, True), "lucky7.expected.cf32", "lucky7.expected.s8"),
+    ("lucky7_nodc", (48000, 4800, 5000, 2, 2000, False), "lucky7.expected.cf32", "lucky7.expected.nodc.s8"),
+    ("nusat", (192000, 40000, 5000, 1, 2000, True), "nusat.cf32", "processed.s8"),
+    ("nan", (240000, 9600, 5000, 1, 2000, True), "inputnan.cf32", "nan.s8"),
+]
+
+
+@pytest.mark.parametrize("name,cfg,inp,exp", E2E, ids=[e[0] for e in E2E])
+def test_e2e_golden_files(name, cfg, inp, exp):
+    iq = np.fromfile(os.path.join(GOLDEN, inp), dtype=np.float32)
+    want = np.fromfile(os.path.join(GOLDEN, exp), dtype=np.int8)
+    got, _ = orc.demod_stream(cfg, iq, 4096)  # 4096 = the harness's buffer, test_fsk_demod.c:20
+    assert len(got) == len(want)
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    # the reference's own tolerance is 2 LSB (test_fsk_demod.c:47); the oracle is within 1
+    assert diff.max() <= 1, (name, int(diff.max()))
+    assert (diff != 0).mean() < 0.005, (name, int((diff != 0).sum()))
+
+
+@pytest.mark.parametrize("chunk", [1000, 2000, 4096, 96000])
+def test_e2e_chunk_invariance_sps_lt_8(chunk):
+    """sps < 8 => any chunking gives the same stream (SURVEY finding 3)."""
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.float32)
+    cfg = (48000, 4800, 5000, 2, 2000, True)
+    a8, af = orc.demod_stream(cfg, iq, 4096)
+    b8, bf = orc.demod_stream(cfg, iq, chunk)
+    assert np.array_equal(a8, b8)
+    assert np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+
+
+def test_e2e_oversize_input_gives_no_output(capfd):
+    d = orc.Fsk(48000, 4800, 5000, 2, 2000, True, 100)
+    assert d.code == 0
+    out, soft = d.process(cramp(101))
+    assert len(out) == 0
+    assert "<3>requested buffer 101 is more than max: 100" in capfd.readouterr().err
+
+
+def test_create_errors():
+    # cutoff above fs/2 => -1, as test/test_dsp_worker.c baud==fs case (lpf_taps.c:20-23)
+    assert orc.Fsk(48000, 48000, 5000, 1, 2000, True, 4096).code == -1
+    assert orc.Fsk(0, 4800, 5000, 1, 2000, True, 4096).code == -1
+    assert orc.Fsk(48000, 4800, 5000, 1, 0, True, 4096).code == -1
+
+
+# ---------------------------------------------------------------- stage known answers
+
+def test_lpf_taps_known_answer():
+    v = VEC["test_lpf_taps.c:expected_taps"]
+    code, taps = orc.lowpass_taps(8000, 1750, 500)
+    assert code == 0 and len(taps) == 39
+    want = np.array(v["values"], dtype=np.float32)
+    assert np.array_equal((want * 10000).astype(np.int32), (taps * 10000).astype(np.int32))
+
+
+def test_lpf_taps_bounds():
+    # test/test_lpf_taps.c:7-26
+    assert orc.lowpass_taps(0, 1750, 500)[0] == -1
+    assert orc.lowpass_taps(8000, 0, 500)[0] == -1
+    assert orc.lowpass_taps(8000, 4001, 500)[0] == -1
+    assert orc.lowpass_taps(8000, 1750, 0)[0] == -1
+
+
+def test_lpf_complex_two_calls():
+    f = orc.Fir(1, 48000, 4800, 2000, 2000, 2)
+    x = cramp(500)
+    for lab, sl in (("complex_call1", slice(0, 500)), ("complex_call2", slice(500, 1000))):
+        v = VEC["test_lpf.c:" + lab]
+        got = f.process(x[sl])
+        want = np.array(v["values"], dtype=np.float32)
+        assert len(got) == len(want)
+        assert np.abs(got.astype(np.float64) - want).max() < v["tolerance"]
+
+
+def test_lpf_float_decim2_two_calls():
+    f = orc.Fir(2, 48000, 4800, 2000, 2000, 1)
+    x = ramp(1000)
+    for lab, sl in (("float_call1", slice(0, 500)), ("float_call2", slice(500, 1000))):
+        v = VEC["test_lpf.c:" + lab]
+        got = f.process(x[sl])
+        want = np.array(v["values"], dtype=np.float32)
+        assert len(got) == len(want)
+        assert np.abs(got.astype(np.float64) - want).max() < v["tolerance"]
+
+
+def test_lpf_small_buffer_counts():
+    v = VEC["test_lpf.c:small_buffer"]
+    f = orc.Fir(2, 48000, 4800, 2000, 2000, 2)
+    x = cramp(500)
+    lens = [len(f.process(x[0:0])) // 2, len(f.process(x[0:2])) // 2, len(f.process(x[2:4])) // 2]
+    last = f.process(x[4:6])
+    lens.append(len(last) // 2)
+    assert lens == v["output_lens"]
+    assert abs(last[0] - v["last_value"][0]) < 1e-3 and abs(last[1] - v["last_value"][1]) < 1e-3
+
+
+def test_lpf_big_buffer(capfd):
+    f = orc.Fir(2, 48000, 4800, 2000, 100, 2)
+    assert len(f.process(cramp(101))) == 0
+    assert "more than max" in capfd.readouterr().err
+
+
+def test_quadrature_demod_known_answer():
+    q = orc.Quad(25.4, 2000)
+    x = cramp(200)
+    got1 = q.process(x[:4])
+    got2 = q.process(x[4:])
+    w1 = np.array(VEC["test_quadrature_demod.c:expected"]["values"])
+    w2 = np.array(VEC["test_quadrature_demod.c:expected2"]["values"])
+    assert len(got1) == 2 and len(got2) == 198
+    assert np.abs(got1 - w1).max() < 1e-3
+    assert np.abs(got2 - w2).max() < 1e-3
+
+
+def test_dc_blocker_known_answer():
+    d = orc.Dc(32)
+    got = d.process(ramp(200))
+    want = np.array(VEC["test_dc_blocker.c:expected"]["values"])
+    assert np.abs(got - want).max() < 1e-3
+
+
+def test_mmse_known_answer():
+    got = orc.mmse_interp(ramp(8), 0, 0.14)
+    assert abs(got - VEC["test_mmse_fir_interpolator.c:normal"]["values"][0]) < 1e-3
+
+
+def test_mmse_alignment_lead_is_neutral_for_finite_data_and_nan_otherwise():
+    x = np.random.default_rng(1).standard_normal(32).astype(np.float32)
+    base = orc.mmse_interp(x[5:], 0, 0.3)  # window x[5:13], no leading samples
+    assert orc.mmse_interp(x, 5, 0.3) == base  # idx 5 -> one leading sample times 0
+    y = x.copy()
+    y[4] = np.inf
+    assert np.isnan(orc.mmse_interp(y, 5, 0.3))  # reference fir_filter.c:116-121 multiplies it by a zero tap
+
+
+def test_clock_recovery_known_answer():
+    c = orc.Clock(2.0, 0.25 * 0.175 * 0.175, 0.005, 0.175, 0.005, 100)
+    x = ramp(100)
+    got1 = c.process(x[:42])
+    got2 = c.process(x[42:78])
+    w1 = np.array(VEC["test_clock_recovery_mm.c:expected"]["values"])
+    w2 = np.array(VEC["test_clock_recovery_mm.c:expected2"]["values"])
+    assert len(got1) == len(w1) and len(got2) == len(w2)
+    assert np.abs(got1 - w1).max() < 1e-3
+    assert np.abs(got2 - w2).max() < 1e-3
+
+
+def test_clock_recovery_small_buffers():
+    c = orc.Clock(2.0, 0.25 * 0.175 * 0.175, 0.005, 0.175, 0.005, 100)
+    x = ramp(100)
+    lens = [len(c.process(x[0:0])), len(c.process(x[0:4])), len(c.process(x[4:7])), len(c.process(x[7:8]))]
+    assert lens == VEC["test_clock_recovery_mm.c:small_buffers"]["output_lens"]
+
+
+def test_clock_recovery_big_buffer(capfd):
+    c = orc.Clock(2.0, 0.25 * 0.175 * 0.175, 0.005, 0.175, 0.005, 100)
+    assert len(c.process(ramp(101))) == 0
+    assert "more than max" in capfd.readouterr().err
+
+
+def test_nco_known_answer():
+    s = orc.Nco(1.0, 4, 4)
+    got = s.process(1, 4)
+    want = np.array(VEC["test_sig_source.c:success"]["values"], dtype=np.float32)
+    assert np.abs(got - want).max() < 1e-2
+
+
+# ---------------------------------------------------------------- against the reference's own code (oracle/_ref)
+
+needs_ref = pytest.mark.skipif(orc.ref_lib() is None, reason="oracle/_ref not built (reference tree absent)")
+
+CONFIG_FILTERS = [
+    (48000, 9800, 980), (48000, 4800, 2000), (48000, 7400, 740), (48000, 2400, 2000),
+    (240000, 14600, 1460), (240000, 9600, 2000), (48000, 5600, 560), (48000, 600, 2000),
+    (192000, 25000, 2500), (192000, 20000, 2000), (240000, 9800, 980), (240000, 4800, 2000), (8000, 1750, 500),
+]
+
+
+@needs_ref
+@pytest.mark.parametrize("fs,fc,tw", CONFIG_FILTERS)
+def test_taps_bit_identical_to_reference_code(fs, fc, tw):
+    c1, a = orc.lowpass_taps(fs, fc, tw)
+    c2, b = orc.ref_lowpass_taps(fs, fc, tw)
+    assert c1 == c2 == 0 and len(a) == len(b)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@needs_ref
+@pytest.mark.parametrize("length", [2, 3, 32, 80, 154, 160])
+def test_dc_blocker_bit_identical_to_reference_code(length):
+    rng = np.random.default_rng(length)
+    x = (rng.standard_normal(3000) * 3 + 0.7).astype(np.float32)
+    x[100] = 1e-41  # denormal
+    a, b = orc.Dc(length), orc.RefDc(length)
+    for sl in (slice(0, 1), slice(1, 700), slice(700, 3000)):
+        ga, gb = a.process(x[sl]), b.process(x[sl])
+        assert np.array_equal(ga.view(np.uint32), gb.view(np.uint32))
+
+
+@needs_ref
+def test_dc_blocker_nan_poisons_like_reference_code():
+    x = np.ones(500, dtype=np.float32)
+    x[50] = np.nan
+    ga, gb = orc.Dc(32).process(x), orc.RefDc(32).process(x)
+    assert np.array_equal(np.isnan(ga), np.isnan(gb))
+    assert np.array_equal(ga[~np.isnan(ga)].view(np.uint32), gb[~np.isnan(gb)].view(np.uint32))
+
+
+@needs_ref
+def test_fast_atan2f_bit_identical_to_reference_code():
+    rng = np.random.default_rng(7)
+    ys = np.concatenate([rng.standard_normal(20000), [0, 0, 1, -1, 1e-3, -1e-9, 0.0, -0.0, np.inf, np.nan, 1e-42, 3e38]])
+    xs = np.concatenate([rng.standard_normal(20000), [0, -1, 1, -1, 1, -1, -0.0, 0.0, 1.0, 1.0, 1e-40, 3e38]])
+    # ratios straddling the small-angle threshold and the table knots
+    k = np.arange(1, 256, dtype=np.float64) / 255.0
+    ys = np.concatenate([ys, k, k * (1 + 1e-7), k * (1 - 1e-7), [0.003921569, 0.0039215689, 0.00392157]])
+    xs = np.concatenate([xs, np.ones(3 * 255 + 3)])
+    L, R = orc.lib(), orc.ref_lib()
+    for y, x in zip(ys.astype(np.float32), xs.astype(np.float32)):
+        a, b = np.float32(L.orc_fast_atan2f(y, x)), np.float32(R.fast_atan2f(y, x))
+        assert a.view(np.uint32) == b.view(np.uint32) or (np.isnan(a) and np.isnan(b)), (y, x, a, b)
