@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the GMSK/FSK demodulation hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the largest single-GPU configuration): 256 concurrent 48 kHz GMSK channels at
+9600 baud per GPU -- fsk_demod_create(48000, 9600, 5000, 1, 2000, true) each -- fed one 131072-sample chunk per
+channel per step (the reference's shipped buffer_size, src/resources/config.conf:11), inputs resident in HBM,
+streaming state carried across steps.  A "step" = one pass of the whole path (LPF1 -> quadrature demod -> LPF2 ->
+DC blocker -> M&M clock recovery -> int8 soft bits) over one chunk of every channel of this rank.
+Channels are independent, so N GPUs = N shards with no data-path collective (weak scaling); the only collective is
+the RCCL broadcast of the channel configuration from rank 0 at setup.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FS, BAUD, DEV, DECIM, TW, DC = 48000, 9600, 5000, 1, 2000, True
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DISTINCT = 32          # distinct seeded waveforms per rank; further channels are circular shifts of them
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--channels-per-gpu", type=int, default=256)
+    ap.add_argument("--chunk", type=int, default=131072)
+    ap.add_argument("--chunks-resident", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0)
+    ap.add_argument("--verify", action="store_true", help="also check 2 channels of the last step against the oracle")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import sdrm_pkg
+    sdrm_pkg.load()
+    from sdr_modem_amd import binding, siggen
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the demodulator has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    C, N, R = args.channels_per_gpu, args.chunk, args.chunks_resident
+    total_ch = C * world
+
+    # --- configuration fan-out: rank 0 owns the channel table; RCCL broadcast (the only collective on this path)
+    cfg_table = torch.zeros((total_ch, 7), dtype=torch.int64, device=dev)
+    if rank == 0:
+        cfg_table[:] = torch.tensor([FS, BAUD, DEV, DECIM, TW, int(DC), N], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(cfg_table, src=0)
+    mine = cfg_table[rank * C:(rank + 1) * C].cpu().numpy()
+    cfgs = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), bool(r[5]), int(r[6])) for r in mine]
+
+    # --- synthetic input, resident in HBM: [C][R*N] complex64
+    n_total = R * N
+    first = rank * C
+    k = min(C, DISTINCT)
+    base = np.stack([siggen.gmsk_channel(first + i, n_total, FS, BAUD) for i in range(k)])
+    base_t = torch.from_numpy(base.view(np.float32).reshape(k, 2 * n_total)).to(dev)
+    x = torch.empty((C, 2 * n_total), dtype=torch.float32, device=dev)
+    for c in range(C):
+        x[c] = torch.roll(base_t[c % k], shifts=2 * 977 * (c // k))
+    del base_t
+    torch.cuda.synchronize()
+
+    batch = binding.Batch(cfgs, device=local_rank)
+    if batch.code != 0:
+        sys.exit("sdrm_batch_create failed: %d" % batch.code)
+    stream = torch.cuda.current_stream().cuda_stream
+    lens = [N] * C
+    base_ptr = x.data_ptr()
+
+    def step(i):
+        off = (i % R) * N * 8  # bytes into each channel row
+        batch.process_device(base_ptr + off, n_total, lens, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    batch.timing_enable(True)  # HIP events around each kernel, on the launch stream, inside the timed region
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms = []
+    for which in range(3):
+        ms, n = batch.timing_read(which)
+        k_ms.append(ms / max(n, 1))
+    batch.timing_enable(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    samples_per_step = C * N * world
+    msps = samples_per_step * args.steps / elapsed / 1e6
+
+    verify = None
+    if args.verify and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        data, olen = batch.fetch(N)
+        verify = True
+        for c in (0, C - 1):
+            o = orc.Fsk(FS, BAUD, DEV, DECIM, TW, DC, N)
+            row = x[c].cpu().numpy().view(np.complex64)
+            last = None
+            for i in range(args.warmup + args.steps):
+                j = i % R
+                last, _ = o.process(row[j * N:(j + 1) * N])
+            verify = verify and bool(np.array_equal(last, data[c, :olen[c]]))
+
+    out = None
+    if rank == 0:
+        front_ms = k_ms[0]
+        achieved = (C * N * 8.0) / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k1_front_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("channels") == C and tj.get("chunk") == N:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "IQ Msamples/s demodulated (whole node), 48 kHz GMSK 9600 baud",
+            "value": round(msps, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic GMSK (BT 0.5, h 0.5, AWGN sigma 0.05; %d seeded waveforms per rank, further channels "
+                    "are circular shifts), resident in HBM" % k,
+            "config": {"workload": "BASELINE configs[2]: %d concurrent 48 kHz / 9600 baud GMSK channels per GPU, "
+                                   "fsk_demod(48000,9600,5000,1,2000,dc), %d-sample chunks" % (C, N),
+                       "channels_per_gpu": C, "chunk_samples": N, "mode": "exact (bit-identical to CPU reference)",
+                       "parallelism": "channel-sharded x%d, no data-path collective" % world},
+            "channels_at_realtime": int(msps * 1e6 / FS),
+            "kernel_ms": {"front_lpf1_quad_lpf2": round(k_ms[0], 4), "dc_blocker": round(k_ms[1], 4),
+                          "clock_recovery": round(k_ms[2], 4)},
+            "roofline": {"kernel": "k1_front (LPF1+quadrature demod+LPF2)", "bound": "hbm",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": C * N * 8,
+                         "note": "8 B of IQ read per input sample (SURVEY 8d LPF-stage HBM-read term); exact mode is "
+                                 "fp32-VALU-bound: 2 ops per tap per component, no FMA"},
+        }
+        if verify is not None:
+            out["verified_vs_oracle"] = verify
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orc
+            cores = os.cpu_count() or 1
+            row = x[0].cpu().numpy().view(np.complex64)[:2 * N]
+            one, _, _ = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), 1, min(2.0, args.cpu_seconds))
+            allc, secs, smp = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), cores, args.cpu_seconds)
+            out["cpu_baseline"] = {
+                "value": round(allc, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "single_thread_value": round(one, 3),
+                "sample": "oracle (plain-C restatement of the reference path, gcc -O2 -ffp-contract=off), one "
+                          "independent channel per thread on %d threads, %d-sample chunks of channel 0 looped for "
+                          "%.1f s wall (%.0f Msamples total)" % (cores, N, secs, smp / 1e6)}
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

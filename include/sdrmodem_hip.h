@@ -1,0 +1,156 @@
+/*
+ * sdrmodem_hip.h -- C-ABI of libsdrmodem_hip.so: the MI355X (gfx950) GMSK/FSK demodulation path.
+ *
+ * Drop-in boundary for dernasherbrezon/sdr-modem's fsk_demod operator and the dsp_worker push/pull
+ * surface around it.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Three layers, bottom-up:
+ *   1. sdrm_batch_*      many independent RX channels demodulated per launch on one GPU (the new part);
+ *   2. fsk_demod_*       the reference operator, same names/signature/semantics (a batch of one);
+ *   3. create_queue/...  and sdrm_worker_*: the reference's queue + dsp_worker surface, feeding (2).
+ *
+ * Every entry point fails loudly (non-zero return / abort message on stderr with the "<3>" systemd
+ * prefix the reference uses) when no HIP device is usable: there is NO CPU fallback in this library.
+ */
+#ifndef SDRMODEM_HIP_H
+#define SDRMODEM_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+typedef struct sdrm_cf32_s { float re, im; } sdrm_cf32; /* layout of C99 `float complex` */
+#else
+#include <complex.h>
+typedef float complex sdrm_cf32;
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * (2) Reference operator API -- replaces src/dsp/fsk_demod.h:11-15 (implementation src/dsp/fsk_demod.c:28-135).
+ * Same argument meaning, same return codes (0, -ENOMEM, -1 for a bad cutoff/transition width,
+ * lpf_taps.c:14-31), same ownership: *output is a buffer owned by the handle, valid until the next
+ * process/destroy on it; oversize input prints "<3>requested buffer N is more than max: M" and yields
+ * *output_len = 0 (fir_filter.c:147-152).  A handle is used by one thread at a time.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct fsk_demod_t fsk_demod;
+
+int fsk_demod_create(uint64_t sampling_freq, uint32_t baud_rate, int64_t deviation, uint8_t decimation,
+                     uint32_t transition_width, bool use_dc_block, uint32_t max_input_buffer_length,
+                     fsk_demod **demod);
+void fsk_demod_process(const sdrm_cf32 *input, size_t input_len, int8_t **output, size_t *output_len,
+                       fsk_demod *demod);
+void fsk_demod_destroy(fsk_demod *demod);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) Batched extension (not in the reference): C channels, each with its own fsk_demod_create()
+ * parameters and its own streaming state, advanced together by one call.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct sdrm_batch_t sdrm_batch;
+
+/* exactly the arguments of fsk_demod_create(), src/dsp/fsk_demod.h:11 */
+typedef struct {
+    uint64_t sampling_freq;
+    uint32_t baud_rate;
+    int64_t deviation;
+    uint8_t decimation;
+    uint32_t transition_width;
+    bool use_dc_block;
+    uint32_t max_input_buffer_length;
+} sdrm_fsk_config;
+
+/* parameters derived by create (fsk_demod.c:36-63), for inspection and parity tests */
+typedef struct {
+    uint32_t taps1_len, taps2_len, dc_length;
+    float quad_gain, sps, gain_omega, gain_mu, omega_lim;
+} sdrm_fsk_info;
+
+#define SDRM_FLAG_KEEP_SOFT_F32 1u /* also keep the float soft bits (clock-recovery output) per call */
+
+/* device < 0: current HIP device.  Returns 0, -ENOMEM, -1 (bad parameters), -ENODEV (no usable GPU),
+ * -ENOTSUP (samples-per-symbol outside the supported range). */
+int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels, int device, uint32_t flags, sdrm_batch **batch);
+void sdrm_batch_destroy(sdrm_batch *batch);
+size_t sdrm_batch_channels(const sdrm_batch *batch);
+int sdrm_batch_info(const sdrm_batch *batch, size_t channel, sdrm_fsk_info *info);
+/* copy out the designed low-pass taps (design order) of stage 1 or 2; returns the tap count */
+size_t sdrm_batch_taps(const sdrm_batch *batch, size_t channel, int stage, float *dst, size_t dst_cap);
+
+/* Host-buffer call: inputs[c] points at input_lens[c] complex samples (may be NULL when the length is 0).
+ * Blocks until done.  outputs[c] / output_lens[c] receive borrowed pointers into handle-owned host memory,
+ * valid until the next process/destroy.  Channels whose input exceeds their max get output_len 0. */
+int sdrm_batch_process(sdrm_batch *batch, const sdrm_cf32 *const *inputs, const size_t *input_lens,
+                       int8_t **outputs, size_t *output_lens);
+
+/* Device-resident call (what bench.py times): d_input is a device pointer to [C][in_stride] complex samples,
+ * channel-major; input_lens is a HOST array.  Enqueues on `stream` (a hipStream_t, NULL = default stream) and
+ * returns without synchronising.  Results stay on the device: see sdrm_batch_device_outputs(). */
+int sdrm_batch_process_device(sdrm_batch *batch, const void *d_input, size_t in_stride, const size_t *input_lens,
+                              void *stream);
+/* device pointers: int8 soft bits [C][out_stride], per-channel counts uint32[C], float soft bits or NULL */
+int sdrm_batch_device_outputs(sdrm_batch *batch, void **d_out_i8, size_t *out_stride, void **d_out_len,
+                              void **d_out_f32);
+/* after a synchronised call: copy channel c's float soft bits of the last call to host (needs KEEP_SOFT_F32) */
+int sdrm_batch_last_soft(sdrm_batch *batch, size_t channel, float *dst, size_t dst_cap, size_t *len);
+/* copy the last call's int8 outputs of every channel to host: lens[C], data[C][stride] */
+int sdrm_batch_fetch(sdrm_batch *batch, int8_t *data, size_t stride, size_t *lens);
+
+/* Per-kernel device time, measured with HIP events on the launch stream when enabled.
+ * which: 0 = front-end (LPF1+quadrature demod+LPF2), 1 = DC blocker, 2 = clock recovery + int8. */
+int sdrm_batch_timing_enable(sdrm_batch *batch, int enable);
+int sdrm_batch_timing_read(sdrm_batch *batch, int which, double *total_ms, uint64_t *launches);
+
+/* Stage probes for tests: run ONE stage of the device pipeline on a host vector (state-free where the
+ * stage is). Return 0 on success. */
+int sdrm_probe_atan2(const float *y, const float *x, float *out, size_t n);
+int sdrm_probe_wave_scan(const float *terms, float carry_in, float *out, size_t n); /* in-order fp32 running sum */
+/* in-order scan flavour used by the probe and the DC kernel: 0 = DPP wave_shr, 1 = DPP row_shr + readlane */
+void sdrm_set_scan_mode(int mode);
+
+const char *sdrm_version(void);
+int sdrm_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) Queue + worker surface (host side, C, pthreads).
+ * Queue: same names/semantics as src/queue.h:10-18 (blocking put for file sources, overwrite-newest for
+ * live sources, poison pill, detached node while processing).
+ * Worker: mirror of src/dsp_worker.h:14-22 taking a plain C config instead of the protobuf RxRequest /
+ * libconfig server_config (those headers are outside the path; field-by-field mapping in INTEGRATION.md).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct queue_t queue;
+int create_queue(uint32_t buffer_size, uint16_t queue_size, bool blocking, queue **queue);
+int queue_put(const sdrm_cf32 *buffer, size_t len, queue *queue);
+void take_buffer_for_processing(sdrm_cf32 **buffer, size_t *len, queue *queue);
+void complete_buffer_processing(queue *queue);
+void interrupt_waiting_the_data(queue *queue);
+void destroy_queue(queue *queue);
+
+typedef struct {
+    /* from RxRequest (src/api.pb-c.h:104-121, read at src/dsp_worker.c:120-163) */
+    uint64_t rx_sampling_freq;
+    uint32_t demod_baud_rate;
+    int64_t demod_fsk_deviation;
+    uint32_t demod_decimation;
+    uint32_t demod_fsk_transition_width;
+    bool demod_fsk_use_dc_block;
+    bool rx_dump_file;      /* write rx.sdr2demod.<id>.cf32 */
+    int demod_destination;  /* 0 FILE, 1 SOCKET, 2 BOTH (api.proto DemodDestination) */
+    /* from server_config (src/server_config.h:16-40) */
+    uint32_t buffer_size;
+    uint16_t queue_size;
+    bool rx_file_source;    /* rx_sdr_type == RX_SDR_TYPE_FILE => blocking queue */
+    const char *base_path;
+} sdrm_worker_config;
+
+typedef struct dsp_worker_t dsp_worker;
+int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *config, dsp_worker **result);
+void dsp_worker_put(sdrm_cf32 *output, size_t output_len, dsp_worker *worker);
+void dsp_worker_shutdown(void *arg, void *data);
+bool dsp_worker_find_by_id(void *id, void *data);
+void dsp_worker_destroy(void *data);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRMODEM_HIP_H */

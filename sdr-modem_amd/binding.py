@@ -1,0 +1,278 @@
+"""ctypes binding of csrc/libsdrmodem_hip.so (include/sdrmodem_hip.h).  Thin: every call goes straight to the C-ABI.
+
+No fallback: load() raises when the shared library is absent, and the C-ABI itself returns -ENODEV / aborts with a
+"<3>" message when no HIP device is usable.
+"""
+import ctypes as C
+import errno
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libsdrmodem_hip.so")
+_LIB = None
+
+f32p = C.POINTER(C.c_float)
+i8p = C.POINTER(C.c_int8)
+
+
+class FskConfig(C.Structure):
+    """== the arguments of fsk_demod_create() (reference src/dsp/fsk_demod.h:11)"""
+    _fields_ = [("sampling_freq", C.c_uint64), ("baud_rate", C.c_uint32), ("deviation", C.c_int64),
+                ("decimation", C.c_uint8), ("transition_width", C.c_uint32), ("use_dc_block", C.c_bool),
+                ("max_input_buffer_length", C.c_uint32)]
+
+
+class FskInfo(C.Structure):
+    _fields_ = [("taps1_len", C.c_uint32), ("taps2_len", C.c_uint32), ("dc_length", C.c_uint32),
+                ("quad_gain", C.c_float), ("sps", C.c_float), ("gain_omega", C.c_float),
+                ("gain_mu", C.c_float), ("omega_lim", C.c_float)]
+
+
+class WorkerConfig(C.Structure):
+    _fields_ = [("rx_sampling_freq", C.c_uint64), ("demod_baud_rate", C.c_uint32), ("demod_fsk_deviation", C.c_int64),
+                ("demod_decimation", C.c_uint32), ("demod_fsk_transition_width", C.c_uint32),
+                ("demod_fsk_use_dc_block", C.c_bool), ("rx_dump_file", C.c_bool), ("demod_destination", C.c_int),
+                ("buffer_size", C.c_uint32), ("queue_size", C.c_uint16), ("rx_file_source", C.c_bool),
+                ("base_path", C.c_char_p)]
+
+
+# every symbol include/sdrmodem_hip.h declares
+EXPORTS = [
+    "fsk_demod_create", "fsk_demod_process", "fsk_demod_destroy",
+    "sdrm_batch_create", "sdrm_batch_destroy", "sdrm_batch_channels", "sdrm_batch_info", "sdrm_batch_taps",
+    "sdrm_batch_process", "sdrm_batch_process_device", "sdrm_batch_device_outputs", "sdrm_batch_last_soft",
+    "sdrm_batch_fetch", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
+    "sdrm_probe_atan2", "sdrm_probe_wave_scan", "sdrm_set_scan_mode", "sdrm_version", "sdrm_device_count",
+    "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
+    "interrupt_waiting_the_data", "destroy_queue",
+    "dsp_worker_create", "dsp_worker_put", "dsp_worker_shutdown", "dsp_worker_find_by_id", "dsp_worker_destroy",
+]
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libsdrmodem_hip.so is not built (run __graft_entry__.build() or make -C sdr-modem_amd/csrc); "
+                           "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.sdrm_version.restype = C.c_char_p
+    L.sdrm_device_count.restype = C.c_int
+    L.sdrm_batch_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.c_int, C.c_uint32, C.POINTER(vp)]
+    L.sdrm_batch_destroy.argtypes = [vp]
+    L.sdrm_batch_destroy.restype = None
+    L.sdrm_batch_channels.argtypes = [vp]
+    L.sdrm_batch_channels.restype = C.c_size_t
+    L.sdrm_batch_info.argtypes = [vp, C.c_size_t, C.POINTER(FskInfo)]
+    L.sdrm_batch_taps.argtypes = [vp, C.c_size_t, C.c_int, f32p, C.c_size_t]
+    L.sdrm_batch_taps.restype = C.c_size_t
+    L.sdrm_batch_process.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(i8p), C.POINTER(C.c_size_t)]
+    L.sdrm_batch_process_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.sdrm_batch_device_outputs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(vp)]
+    L.sdrm_batch_last_soft.argtypes = [vp, C.c_size_t, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdrm_batch_fetch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdrm_batch_timing_enable.argtypes = [vp, C.c_int]
+    L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sdrm_probe_atan2.argtypes = [vp, vp, vp, C.c_size_t]
+    L.sdrm_probe_wave_scan.argtypes = [vp, C.c_float, vp, C.c_size_t]
+    L.sdrm_set_scan_mode.argtypes = [C.c_int]
+    L.sdrm_set_scan_mode.restype = None
+    L.fsk_demod_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_uint8, C.c_uint32, C.c_bool, C.c_uint32,
+                                   C.POINTER(vp)]
+    L.fsk_demod_process.argtypes = [vp, C.c_size_t, C.POINTER(i8p), C.POINTER(C.c_size_t), vp]
+    L.fsk_demod_process.restype = None
+    L.fsk_demod_destroy.argtypes = [vp]
+    L.fsk_demod_destroy.restype = None
+    L.create_queue.argtypes = [C.c_uint32, C.c_uint16, C.c_bool, C.POINTER(vp)]
+    L.queue_put.argtypes = [vp, C.c_size_t, vp]
+    L.take_buffer_for_processing.argtypes = [C.POINTER(vp), C.POINTER(C.c_size_t), vp]
+    L.take_buffer_for_processing.restype = None
+    L.complete_buffer_processing.argtypes = [vp]
+    L.complete_buffer_processing.restype = None
+    L.interrupt_waiting_the_data.argtypes = [vp]
+    L.interrupt_waiting_the_data.restype = None
+    L.destroy_queue.argtypes = [vp]
+    L.destroy_queue.restype = None
+    L.dsp_worker_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(WorkerConfig), C.POINTER(vp)]
+    L.dsp_worker_put.argtypes = [vp, C.c_size_t, vp]
+    L.dsp_worker_put.restype = None
+    L.dsp_worker_shutdown.argtypes = [vp, vp]
+    L.dsp_worker_shutdown.restype = None
+    L.dsp_worker_find_by_id.argtypes = [vp, vp]
+    L.dsp_worker_find_by_id.restype = C.c_bool
+    L.dsp_worker_destroy.argtypes = [vp]
+    L.dsp_worker_destroy.restype = None
+    _LIB = L
+    return L
+
+
+def make_configs(cfgs):
+    """cfgs: iterable of (fs, baud, deviation, decimation, transition_width, use_dc, max_len)."""
+    arr = (FskConfig * len(cfgs))()
+    for i, (fs, baud, dev, decim, tw, dc, maxlen) in enumerate(cfgs):
+        arr[i] = FskConfig(fs, baud, dev, decim, tw, dc, maxlen)
+    return arr
+
+
+def _as_f32(iq):
+    iq = np.ascontiguousarray(iq)
+    if iq.dtype == np.complex64:
+        return iq.view(np.float32)
+    return np.ascontiguousarray(iq, dtype=np.float32)
+
+
+class Batch:
+    """sdrm_batch_*: many channels per launch."""
+
+    def __init__(self, cfgs, device=-1, keep_soft=False):
+        self.L = load()
+        self.n = len(cfgs)
+        self._cfgs = make_configs(list(cfgs))
+        self.h = C.c_void_p()
+        self.code = self.L.sdrm_batch_create(self._cfgs, self.n, device, 1 if keep_soft else 0, C.byref(self.h))
+        if self.code != 0:
+            self.h = C.c_void_p()
+
+    def close(self):
+        if self.h:
+            self.L.sdrm_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self, c=0):
+        inf = FskInfo()
+        assert self.L.sdrm_batch_info(self.h, c, C.byref(inf)) == 0
+        return inf
+
+    def taps(self, c, stage):
+        n = self.L.sdrm_batch_taps(self.h, c, stage, None, 0)
+        out = np.zeros(n, dtype=np.float32)
+        self.L.sdrm_batch_taps(self.h, c, stage, out.ctypes.data_as(f32p), n)
+        return out
+
+    def process(self, inputs):
+        """inputs: list (len C) of complex64 / interleaved-float32 arrays (or None). Returns list of int8 arrays."""
+        keep = [None if x is None else _as_f32(x) for x in inputs]
+        ptrs = (C.c_void_p * self.n)(*[None if k is None or len(k) == 0 else k.ctypes.data for k in keep])
+        lens = (C.c_size_t * self.n)(*[0 if k is None else len(k) // 2 for k in keep])
+        outs = (i8p * self.n)()
+        olens = (C.c_size_t * self.n)()
+        code = self.L.sdrm_batch_process(self.h, ptrs, lens, outs, olens)
+        if code != 0:
+            raise RuntimeError("sdrm_batch_process failed: %d" % code)
+        res = []
+        for c in range(self.n):
+            n = olens[c]
+            res.append(np.ctypeslib.as_array(outs[c], shape=(n,)).copy() if n else np.zeros(0, np.int8))
+        return res
+
+    def process_device(self, d_ptr, in_stride, lens, stream=None):
+        arr = (C.c_size_t * self.n)(*[int(x) for x in lens])
+        code = self.L.sdrm_batch_process_device(self.h, C.c_void_p(d_ptr), in_stride, arr, C.c_void_p(stream or 0))
+        if code != 0:
+            raise RuntimeError("sdrm_batch_process_device failed: %d" % code)
+
+    def last_soft(self, c):
+        n = C.c_size_t()
+        code = self.L.sdrm_batch_last_soft(self.h, c, None, 0, C.byref(n))
+        if code != 0:
+            raise RuntimeError("sdrm_batch_last_soft failed: %d (created without keep_soft?)" % code)
+        out = np.zeros(n.value, dtype=np.float32)
+        if n.value:
+            self.L.sdrm_batch_last_soft(self.h, c, out.ctypes.data_as(f32p), n.value, C.byref(n))
+        return out
+
+    def fetch(self, stride):
+        data = np.zeros((self.n, stride), dtype=np.int8)
+        lens = (C.c_size_t * self.n)()
+        code = self.L.sdrm_batch_fetch(self.h, data.ctypes.data, stride, lens)
+        if code != 0:
+            raise RuntimeError("sdrm_batch_fetch failed: %d" % code)
+        return data, np.array(list(lens), dtype=np.int64)
+
+    def timing_enable(self, on=True):
+        self.L.sdrm_batch_timing_enable(self.h, 1 if on else 0)
+
+    def timing_read(self, which):
+        ms, n = C.c_double(), C.c_uint64()
+        self.L.sdrm_batch_timing_read(self.h, which, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+
+class FskDemod:
+    """fsk_demod_create/process/destroy: the reference operator (src/dsp/fsk_demod.h:11-15)."""
+
+    def __init__(self, fs, baud, dev, decim, tw, dc, maxlen):
+        self.L = load()
+        self.h = C.c_void_p()
+        self.code = self.L.fsk_demod_create(fs, baud, dev, decim, tw, dc, maxlen, C.byref(self.h))
+        if self.code != 0:
+            self.h = C.c_void_p()
+
+    def process(self, iq):
+        k = _as_f32(iq)
+        out, n = i8p(), C.c_size_t()
+        self.L.fsk_demod_process(k.ctypes.data, len(k) // 2, C.byref(out), C.byref(n), self.h)
+        return np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int8)
+
+    def close(self):
+        if self.h:
+            self.L.fsk_demod_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Queue:
+    """create_queue & co (reference src/queue.h:10-18); host-only, works without a GPU."""
+
+    def __init__(self, buffer_size, queue_size, blocking):
+        self.L = load()
+        self.h = C.c_void_p()
+        self.code = self.L.create_queue(buffer_size, queue_size, blocking, C.byref(self.h))
+        if self.code != 0:
+            self.h = C.c_void_p()
+
+    def put(self, iq):
+        if iq is None:
+            return self.L.queue_put(None, 25, self.h)
+        k = _as_f32(iq)
+        return self.L.queue_put(k.ctypes.data if len(k) else None, len(k) // 2, self.h)
+
+    def put_raw(self, ptr, n):
+        return self.L.queue_put(ptr, n, self.h)
+
+    def take(self):
+        buf, n = C.c_void_p(), C.c_size_t()
+        self.L.take_buffer_for_processing(C.byref(buf), C.byref(n), self.h)
+        if not buf.value:
+            return None
+        return np.ctypeslib.as_array(C.cast(buf, f32p), shape=(2 * n.value,)).copy()
+
+    def complete(self):
+        self.L.complete_buffer_processing(self.h)
+
+    def interrupt(self):
+        self.L.interrupt_waiting_the_data(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.destroy_queue(self.h)
+            self.h = C.c_void_p()
+
+
+def strerror(code):
+    return errno.errorcode.get(-code, str(code))

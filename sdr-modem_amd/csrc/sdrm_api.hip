@@ -1,0 +1,624 @@
+// sdrm_api.hip -- the C-ABI of libsdrmodem_hip.so (include/sdrmodem_hip.h): batched demodulator object,
+// the reference-compatible fsk_demod_* operator on top of it, and small test probes.
+// There is no CPU fallback here: every compute entry point needs a HIP device and says so when it has none.
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/sdrmodem_hip.h"
+#include "sdrm_design.h"
+#include "sdrm_plan.h"
+#include "sdrm_launch.h"
+#include "sdrm_tables.h"
+
+namespace sdrm {
+void set_scan_mode(int mode);
+}
+
+#define SDRM_CTL_SLOTS 8
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            fprintf(stderr, "<3>sdrmodem_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_),   \
+                    __FILE__, __LINE__);                                                                \
+            return -EIO;                                                                                \
+        }                                                                                               \
+    } while (0)
+
+struct TimingLane {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+struct sdrm_batch_t {
+    int device = 0;
+    uint32_t flags = 0;
+    sdrm::BatchPlan plan;  // designs, packed parameters, host-side streaming bookkeeping
+    // device memory
+    sdrm_chan_params *d_params = nullptr;
+    sdrm_chunk_ctl *d_ctl = nullptr;  // [SLOTS][C]
+    float *d_taps = nullptr, *d_atan = nullptr, *d_bank = nullptr;
+    sdrm_f2 *d_hist = nullptr;
+    float *d_z = nullptr, *d_dcout = nullptr, *d_dcstate = nullptr;
+    sdrm_clock_state *d_clock = nullptr;
+    int8_t *d_out8 = nullptr;
+    float *d_outf = nullptr;
+    uint32_t *d_outlen = nullptr;
+    sdrm_f2 *d_in = nullptr;  // staging for the host-buffer API (lazy)
+    // host (pinned) mirrors
+    sdrm_chunk_ctl *h_ctl = nullptr;  // [SLOTS][C]
+    uint32_t *h_outlen = nullptr;
+    int8_t *h_out8 = nullptr;  // lazy
+    hipEvent_t slot_done[SDRM_CTL_SLOTS] = {};
+    bool slot_used[SDRM_CTL_SLOTS] = {};
+    uint64_t calls = 0;
+    hipStream_t stream = nullptr;  // private stream of the host-buffer API
+    sdrm::DeviceBatch dev = {};
+    uint32_t in_stride = 0;  // staging stride (samples)
+    bool timing = false;
+    TimingLane lanes[3];
+    std::vector<uint32_t> last_lens;
+};
+
+extern "C" int sdrm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+extern "C" const char *sdrm_version(void) { return "sdrmodem_hip 0.1 (gfx950, exact mode)"; }
+
+static void batch_free(sdrm_batch_t *b) {
+    if (b == nullptr) {
+        return;
+    }
+    (void) hipSetDevice(b->device);
+    if (b->stream) {
+        (void) hipStreamSynchronize(b->stream);
+    }
+    (void) hipDeviceSynchronize();
+    for (auto &lane : b->lanes) {
+        for (auto &pr : lane.pending) {
+            (void) hipEventDestroy(pr.first);
+            (void) hipEventDestroy(pr.second);
+        }
+        for (auto &pr : lane.free_list) {
+            (void) hipEventDestroy(pr.first);
+            (void) hipEventDestroy(pr.second);
+        }
+    }
+    for (int i = 0; i < SDRM_CTL_SLOTS; i++) {
+        if (b->slot_done[i]) {
+            (void) hipEventDestroy(b->slot_done[i]);
+        }
+    }
+    void *dev_ptrs[] = {b->d_params, b->d_ctl, b->d_taps, b->d_atan, b->d_bank, b->d_hist, b->d_z, b->d_dcout,
+                        b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in};
+    for (void *p : dev_ptrs) {
+        if (p) {
+            (void) hipFree(p);
+        }
+    }
+    if (b->h_ctl) {
+        (void) hipHostFree(b->h_ctl);
+    }
+    if (b->h_outlen) {
+        (void) hipHostFree(b->h_outlen);
+    }
+    if (b->h_out8) {
+        (void) hipHostFree(b->h_out8);
+    }
+    if (b->stream) {
+        (void) hipStreamDestroy(b->stream);
+    }
+    delete b;
+}
+
+template <typename T>
+static int dev_alloc_zero(T **ptr, size_t count) {
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **) ptr, bytes);
+    if (e != hipSuccess) {
+        fprintf(stderr, "<3>sdrmodem_hip: hipMalloc(%zu) failed: %s\n", bytes, hipGetErrorString(e));
+        return -ENOMEM;
+    }
+    e = hipMemset(*ptr, 0, bytes);
+    return e == hipSuccess ? 0 : -EIO;
+}
+
+extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels, int device, uint32_t flags,
+                                 sdrm_batch **out) {
+    if (cfgs == nullptr || n_channels == 0 || out == nullptr) {
+        return -1;
+    }
+    // design + planning first: parameter errors are reported exactly like the reference, GPU or not
+    sdrm_batch_t *b = new sdrm_batch_t();
+    int code = sdrm::plan_batch(cfgs, n_channels, b->plan);
+    if (code != 0) {
+        delete b;
+        return code;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "<3>sdrmodem_hip: no HIP device available; this library has no CPU fallback\n");
+        delete b;
+        return -ENODEV;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) {
+        delete b;
+        return -ENODEV;
+    }
+    if (device >= ndev) {
+        fprintf(stderr, "<3>sdrmodem_hip: device %d out of range (%d devices)\n", device, ndev);
+        delete b;
+        return -ENODEV;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        delete b;
+        return -ENODEV;
+    }
+    b->device = device;
+    b->flags = flags;
+    const size_t C = n_channels;
+    b->last_lens.assign(C, 0);
+    const sdrm::BatchPlan &pl = b->plan;
+    const std::vector<float> &pool = pl.tap_pool;
+    const int any_dc = pl.any_dc;
+    const size_t dc_floats = pl.dc_state_floats;
+
+    const uint32_t hist_stride = pl.hist_stride, z_stride = pl.z_stride, out_stride = pl.out_stride;
+    code = code ? code : dev_alloc_zero(&b->d_params, C);
+    code = code ? code : dev_alloc_zero(&b->d_ctl, C * SDRM_CTL_SLOTS);
+    code = code ? code : dev_alloc_zero(&b->d_taps, pool.size() + 16);
+    code = code ? code : dev_alloc_zero(&b->d_atan, 260);
+    code = code ? code : dev_alloc_zero(&b->d_bank, 129 * 8);
+    code = code ? code : dev_alloc_zero(&b->d_hist, C * 2 * (size_t) hist_stride);
+    code = code ? code : dev_alloc_zero(&b->d_z, C * (size_t) z_stride);
+    if (any_dc) {
+        code = code ? code : dev_alloc_zero(&b->d_dcout, C * (size_t) z_stride);
+        code = code ? code : dev_alloc_zero(&b->d_dcstate, dc_floats);
+    }
+    code = code ? code : dev_alloc_zero(&b->d_clock, C);
+    code = code ? code : dev_alloc_zero(&b->d_out8, C * (size_t) out_stride);
+    if (flags & SDRM_FLAG_KEEP_SOFT_F32) {
+        code = code ? code : dev_alloc_zero(&b->d_outf, C * (size_t) out_stride);
+    }
+    code = code ? code : dev_alloc_zero(&b->d_outlen, C);
+    if (code != 0) {
+        batch_free(b);
+        return code;
+    }
+    if (hipHostMalloc((void **) &b->h_ctl, sizeof(sdrm_chunk_ctl) * C * SDRM_CTL_SLOTS) != hipSuccess ||
+        hipHostMalloc((void **) &b->h_outlen, sizeof(uint32_t) * C) != hipSuccess) {
+        batch_free(b);
+        return -ENOMEM;
+    }
+    // initial clock state: mu = 0.5, omega = sps (fsk_demod.c:63, clock_recovery_mm.c:37-45)
+    std::vector<sdrm_clock_state> cs(C);
+    for (size_t c = 0; c < C; c++) {
+        memset(&cs[c], 0, sizeof(cs[c]));
+        cs[c].mu = 0.5f;
+        cs[c].omega = pl.design[c].sps;
+        cs[c].last = 0.0f;
+        cs[c].kept = 0;
+    }
+    hipError_t e = hipSuccess;
+    e = e ? e : hipMemcpy(b->d_params, pl.params.data(), sizeof(sdrm_chan_params) * C, hipMemcpyHostToDevice);
+    e = e ? e : hipMemcpy(b->d_taps, pool.data(), sizeof(float) * pool.size(), hipMemcpyHostToDevice);
+    e = e ? e : hipMemcpy(b->d_atan, sdrm_atan_tab, sizeof(float) * 257, hipMemcpyHostToDevice);
+    e = e ? e : hipMemcpy(b->d_bank, sdrm_mmse_bank, sizeof(float) * 129 * 8, hipMemcpyHostToDevice);
+    e = e ? e : hipMemcpy(b->d_clock, cs.data(), sizeof(sdrm_clock_state) * C, hipMemcpyHostToDevice);
+    e = e ? e : hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    for (int i = 0; i < SDRM_CTL_SLOTS && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        fprintf(stderr, "<3>sdrmodem_hip: device initialisation failed: %s\n", hipGetErrorString(e));
+        batch_free(b);
+        return -EIO;
+    }
+    // K1 uses more than the default 64 KiB of dynamic LDS only for very long filters; raise the cap once
+    sdrm::DeviceBatch &d = b->dev;
+    d.n_channels = (int) C;
+    d.params = b->d_params;
+    d.tap_pool = b->d_taps;
+    d.atan_tab = b->d_atan;
+    d.mmse_bank = b->d_bank;
+    d.raw_hist = b->d_hist;
+    d.hist_stride = hist_stride;
+    d.z = b->d_z;
+    d.dcout = b->d_dcout;
+    d.z_stride = z_stride;
+    d.dc_state = b->d_dcstate;
+    d.clock_state = b->d_clock;
+    d.out_i8 = b->d_out8;
+    d.out_f32 = b->d_outf;
+    d.out_len = b->d_outlen;
+    d.out_stride = out_stride;
+    d.t1_max = pl.t1_max;
+    d.rx_cap = pl.rx_cap;
+    d.rs_cap = pl.rs_cap;
+    d.any_dc = any_dc;
+    b->in_stride = pl.in_stride;
+    *out = b;
+    return 0;
+}
+
+extern "C" void sdrm_batch_destroy(sdrm_batch *b) { batch_free(b); }
+
+extern "C" size_t sdrm_batch_channels(const sdrm_batch *b) { return b ? b->plan.design.size() : 0; }
+
+extern "C" int sdrm_batch_info(const sdrm_batch *b, size_t c, sdrm_fsk_info *info) {
+    if (b == nullptr || c >= b->plan.design.size() || info == nullptr) {
+        return -1;
+    }
+    const sdrm::ChannelDesign &d = b->plan.design[c];
+    info->taps1_len = (uint32_t) d.taps1.size();
+    info->taps2_len = (uint32_t) d.taps2.size();
+    info->dc_length = d.dc_length;
+    info->quad_gain = d.quad_gain;
+    info->sps = d.sps;
+    info->gain_omega = d.gain_omega;
+    info->gain_mu = d.gain_mu;
+    info->omega_lim = d.omega_lim;
+    return 0;
+}
+
+extern "C" size_t sdrm_batch_taps(const sdrm_batch *b, size_t c, int stage, float *dst, size_t cap) {
+    if (b == nullptr || c >= b->plan.design.size()) {
+        return 0;
+    }
+    const std::vector<float> &t = (stage == 2) ? b->plan.design[c].taps2 : b->plan.design[c].taps1;
+    if (dst != nullptr) {
+        memcpy(dst, t.data(), sizeof(float) * std::min(cap, t.size()));
+    }
+    return t.size();
+}
+
+// --- timing helpers ------------------------------------------------------------------------------
+
+static void timing_begin(sdrm_batch_t *b, int which, hipStream_t s, std::pair<hipEvent_t, hipEvent_t> *pr) {
+    TimingLane &lane = b->lanes[which];
+    if (lane.free_list.empty()) {
+        hipEvent_t a, z;
+        (void) hipEventCreate(&a);
+        (void) hipEventCreate(&z);
+        *pr = {a, z};
+    } else {
+        *pr = lane.free_list.back();
+        lane.free_list.pop_back();
+    }
+    (void) hipEventRecord(pr->first, s);
+}
+
+static void timing_end(sdrm_batch_t *b, int which, hipStream_t s, const std::pair<hipEvent_t, hipEvent_t> &pr) {
+    (void) hipEventRecord(pr.second, s);
+    b->lanes[which].pending.push_back(pr);
+}
+
+static void timing_collect(sdrm_batch_t *b) {
+    for (auto &lane : b->lanes) {
+        for (auto &pr : lane.pending) {
+            (void) hipEventSynchronize(pr.second);
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                lane.total_ms += ms;
+                lane.launches++;
+            }
+            lane.free_list.push_back(pr);
+        }
+        lane.pending.clear();
+    }
+}
+
+extern "C" int sdrm_batch_timing_enable(sdrm_batch *b, int enable) {
+    if (b == nullptr) {
+        return -1;
+    }
+    timing_collect(b);
+    for (auto &lane : b->lanes) {
+        lane.total_ms = 0.0;
+        lane.launches = 0;
+    }
+    b->timing = enable != 0;
+    return 0;
+}
+
+extern "C" int sdrm_batch_timing_read(sdrm_batch *b, int which, double *total_ms, uint64_t *launches) {
+    if (b == nullptr || which < 0 || which > 2) {
+        return -1;
+    }
+    timing_collect(b);
+    if (total_ms) {
+        *total_ms = b->lanes[which].total_ms;
+    }
+    if (launches) {
+        *launches = b->lanes[which].launches;
+    }
+    return 0;
+}
+
+// --- the call ------------------------------------------------------------------------------------
+
+static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t s) {
+    const size_t C = b->plan.design.size();
+    const int slot = (int) (b->calls % SDRM_CTL_SLOTS);
+    if (b->slot_used[slot]) {
+        HIP_TRY(hipEventSynchronize(b->slot_done[slot]));  // that call's kernels have consumed the slot
+    }
+    sdrm_chunk_ctl *h = b->h_ctl + (size_t) slot * C;
+    const uint32_t max_tiles = sdrm::plan_call(b->plan, lens, h);
+    sdrm_chunk_ctl *d_ctl = b->d_ctl + (size_t) slot * C;
+    HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, s));
+    sdrm::DeviceBatch d = b->dev;
+    d.ctl = d_ctl;
+    d.max_tiles = max_tiles;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (b->timing) {
+        timing_begin(b, 0, s, &ev);
+    }
+    sdrm::launch_front(d, d_in, in_stride, s);
+    if (b->timing) {
+        timing_end(b, 0, s, ev);
+    }
+    sdrm::launch_hist_roll(d, d_in, in_stride, s);
+    if (b->timing) {
+        timing_begin(b, 1, s, &ev);
+    }
+    sdrm::launch_dc(d, s);
+    if (b->timing) {
+        timing_end(b, 1, s, ev);
+        timing_begin(b, 2, s, &ev);
+    }
+    sdrm::launch_clock(d, s);
+    if (b->timing) {
+        timing_end(b, 2, s, ev);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->slot_done[slot], s));
+    b->slot_used[slot] = true;
+    b->calls++;
+    if (b->timing && b->lanes[0].pending.size() > 4096) {
+        timing_collect(b);
+    }
+    return 0;
+}
+
+extern "C" int sdrm_batch_process_device(sdrm_batch *b, const void *d_input, size_t in_stride, const size_t *input_lens,
+                                         void *stream) {
+    if (b == nullptr || input_lens == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    // the K1 LDS request can exceed the 64 KiB default for long filters
+    return enqueue_call(b, (const sdrm_f2 *) d_input, in_stride, input_lens, (hipStream_t) stream);
+}
+
+extern "C" int sdrm_batch_device_outputs(sdrm_batch *b, void **d_out_i8, size_t *out_stride, void **d_out_len,
+                                         void **d_out_f32) {
+    if (b == nullptr) {
+        return -1;
+    }
+    if (d_out_i8) {
+        *d_out_i8 = b->d_out8;
+    }
+    if (out_stride) {
+        *out_stride = b->dev.out_stride;
+    }
+    if (d_out_len) {
+        *d_out_len = b->d_outlen;
+    }
+    if (d_out_f32) {
+        *d_out_f32 = b->d_outf;
+    }
+    return 0;
+}
+
+static int ensure_host_staging(sdrm_batch_t *b) {
+    const size_t C = b->plan.design.size();
+    if (b->d_in == nullptr) {
+        int code = dev_alloc_zero(&b->d_in, C * (size_t) b->in_stride);
+        if (code != 0) {
+            return code;
+        }
+    }
+    if (b->h_out8 == nullptr) {
+        if (hipHostMalloc((void **) &b->h_out8, C * (size_t) b->dev.out_stride) != hipSuccess) {
+            return -ENOMEM;
+        }
+    }
+    return 0;
+}
+
+extern "C" int sdrm_batch_process(sdrm_batch *b, const sdrm_cf32 *const *inputs, const size_t *input_lens,
+                                  int8_t **outputs, size_t *output_lens) {
+    if (b == nullptr || input_lens == nullptr || outputs == nullptr || output_lens == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    int code = ensure_host_staging(b);
+    if (code != 0) {
+        return code;
+    }
+    const size_t C = b->plan.design.size();
+    for (size_t c = 0; c < C; c++) {
+        size_t n = input_lens[c];
+        if (n == 0 || n > b->plan.params[c].max_len || inputs == nullptr || inputs[c] == nullptr) {
+            continue;
+        }
+        HIP_TRY(hipMemcpyAsync(b->d_in + c * (size_t) b->in_stride, inputs[c], n * sizeof(sdrm_f2), hipMemcpyHostToDevice,
+                               b->stream));
+    }
+    code = enqueue_call(b, b->d_in, b->in_stride, input_lens, b->stream);
+    if (code != 0) {
+        return code;
+    }
+    HIP_TRY(hipMemcpyAsync(b->h_outlen, b->d_outlen, sizeof(uint32_t) * C, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (size_t c = 0; c < C; c++) {
+        uint32_t n = b->h_outlen[c];
+        b->last_lens[c] = n;
+        int8_t *dst = b->h_out8 + c * (size_t) b->dev.out_stride;
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync(dst, b->d_out8 + c * (size_t) b->dev.out_stride, n, hipMemcpyDeviceToHost, b->stream));
+        }
+        outputs[c] = dst;
+        output_lens[c] = n;
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+extern "C" int sdrm_batch_fetch(sdrm_batch *b, int8_t *data, size_t stride, size_t *lens) {
+    if (b == nullptr || lens == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t C = b->plan.design.size();
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(b->h_outlen, b->d_outlen, sizeof(uint32_t) * C, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < C; c++) {
+        uint32_t n = b->h_outlen[c];
+        b->last_lens[c] = n;
+        lens[c] = n;
+        if (data != nullptr && n > 0) {
+            HIP_TRY(hipMemcpy(data + c * stride, b->d_out8 + c * (size_t) b->dev.out_stride, std::min<size_t>(n, stride),
+                              hipMemcpyDeviceToHost));
+        }
+    }
+    return 0;
+}
+
+extern "C" int sdrm_batch_last_soft(sdrm_batch *b, size_t c, float *dst, size_t cap, size_t *len) {
+    if (b == nullptr || c >= b->plan.design.size() || b->d_outf == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, b->d_outlen + c, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (len) {
+        *len = n;
+    }
+    if (dst != nullptr && n > 0) {
+        HIP_TRY(hipMemcpy(dst, b->d_outf + c * (size_t) b->dev.out_stride, sizeof(float) * std::min<size_t>(n, cap),
+                          hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// ================================================================================================
+// Reference operator API (src/dsp/fsk_demod.h:11-15): a batch of one channel.
+
+struct fsk_demod_t {
+    sdrm_batch_t *batch;
+};
+
+extern "C" int fsk_demod_create(uint64_t sampling_freq, uint32_t baud_rate, int64_t deviation, uint8_t decimation,
+                                uint32_t transition_width, bool use_dc_block, uint32_t max_input_buffer_length,
+                                fsk_demod **demod) {
+    fsk_demod_t *d = (fsk_demod_t *) malloc(sizeof(fsk_demod_t));
+    if (d == nullptr) {
+        return -ENOMEM;
+    }
+    sdrm_fsk_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.sampling_freq = sampling_freq;
+    cfg.baud_rate = baud_rate;
+    cfg.deviation = deviation;
+    cfg.decimation = decimation;
+    cfg.transition_width = transition_width;
+    cfg.use_dc_block = use_dc_block;
+    cfg.max_input_buffer_length = max_input_buffer_length;
+    int code = sdrm_batch_create(&cfg, 1, -1, 0, &d->batch);
+    if (code != 0) {
+        free(d);
+        return code;
+    }
+    *demod = d;
+    return 0;
+}
+
+extern "C" void fsk_demod_process(const sdrm_cf32 *input, size_t input_len, int8_t **output, size_t *output_len,
+                                  fsk_demod *demod) {
+    const sdrm_cf32 *ins[1] = {input};
+    size_t lens[1] = {input_len};
+    int8_t *outs[1] = {nullptr};
+    size_t olens[1] = {0};
+    int code = sdrm_batch_process(demod->batch, ins, lens, outs, olens);
+    if (code != 0) {
+        // the reference's process() cannot fail; a dead GPU must not look like "no symbols"
+        fprintf(stderr, "<3>sdrmodem_hip: fsk_demod_process failed on the device (code %d)\n", code);
+        abort();
+    }
+    *output = outs[0];
+    *output_len = olens[0];
+}
+
+extern "C" void fsk_demod_destroy(fsk_demod *demod) {
+    if (demod == nullptr) {
+        return;
+    }
+    batch_free(demod->batch);
+    free(demod);
+}
+
+// ================================================================================================ probes
+
+extern "C" int sdrm_probe_atan2(const float *y, const float *x, float *out, size_t n) {
+    if (sdrm_device_count() <= 0) {
+        fprintf(stderr, "<3>sdrmodem_hip: no HIP device available\n");
+        return -ENODEV;
+    }
+    float *dy = nullptr, *dx = nullptr, *dt = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **) &dy, n * 4 + 4));
+    HIP_TRY(hipMalloc((void **) &dx, n * 4 + 4));
+    HIP_TRY(hipMalloc((void **) &dout, n * 4 + 4));
+    HIP_TRY(hipMalloc((void **) &dt, 260 * 4));
+    HIP_TRY(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dt, sdrm_atan_tab, 257 * 4, hipMemcpyHostToDevice));
+    sdrm::launch_probe_atan2(dy, dx, dt, dout, n, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    (void) hipFree(dy);
+    (void) hipFree(dx);
+    (void) hipFree(dt);
+    (void) hipFree(dout);
+    return 0;
+}
+
+static int g_probe_scan_mode = 0;
+
+extern "C" int sdrm_probe_wave_scan(const float *terms, float carry_in, float *out, size_t n) {
+    if (sdrm_device_count() <= 0) {
+        fprintf(stderr, "<3>sdrmodem_hip: no HIP device available\n");
+        return -ENODEV;
+    }
+    float *dt = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **) &dt, n * 4 + 4));
+    HIP_TRY(hipMalloc((void **) &dout, n * 4 + 4));
+    HIP_TRY(hipMemcpy(dt, terms, n * 4, hipMemcpyHostToDevice));
+    sdrm::launch_probe_scan(dt, carry_in, dout, n, g_probe_scan_mode, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    (void) hipFree(dt);
+    (void) hipFree(dout);
+    return 0;
+}
+
+// selects the in-order scan flavour (0 = wave_shr DPP, 1 = row_shr DPP + readlane) for the probe and the DC kernel
+extern "C" void sdrm_set_scan_mode(int mode) {
+    g_probe_scan_mode = mode;
+    sdrm::set_scan_mode(mode);
+}

@@ -1,0 +1,161 @@
+// sdrm_core.h -- per-sample / per-symbol arithmetic of the demodulation path, written once and compiled
+// both for gfx950 (inside the HIP kernels) and for the host (tests/emu: a thread-by-thread emulation of
+// the kernels used by the CPU-only test suite to check indexing and state hand-off without a GPU).
+//
+// EXACT MODE CONTRACT: every expression below is evaluated in fp32 with one rounding per written
+// operation, left to right; translation units including this header must be compiled with
+// -ffp-contract=off (no FMA), IEEE division, denormals preserved.  That is what makes the soft bits
+// bit-identical to the reference's generic-kernel CPU path (SURVEY.md finding 2).
+#ifndef SDRM_CORE_H
+#define SDRM_CORE_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SDRM_HD __host__ __device__ __forceinline__
+#else
+#define SDRM_HD static inline
+#endif
+
+#define SDRM_MMSE_TAPS 8
+#define SDRM_MMSE_STEPS 128
+#define SDRM_CLOCK_HCAP 64   // max samples the clock stage carries between calls
+#define SDRM_INT_MIN (-2147483647 - 1)
+
+struct sdrm_f2 {
+    float x, y;
+};
+
+// float -> int32 with the x86-64 cvttss2si result for out-of-range / NaN (INT_MIN); the reference relies on
+// that behaviour at src/math/fast_atan2f.c:112 and src/dsp/clock_recovery_mm.c:110,122.
+SDRM_HD int sdrm_cvt_i32(float v) {
+    if (v >= -2147483648.0f && v < 2147483648.0f) {
+        return (int) v;
+    }
+    return SDRM_INT_MIN;
+}
+
+// reference src/math/fast_atan2f.c:87-157; tab = 257-entry arctan table (sdrm_tables.h)
+SDRM_HD float sdrm_fast_atan2f(float y, float x, const float *tab) {
+    float ya = fabsf(y), xa = fabsf(x);
+    if (!(ya > 0.0f || xa > 0.0f)) {
+        return 0.0f;
+    }
+    float z = (ya < xa) ? ya / xa : xa / ya;
+    float base;
+    if ((double) z < 0.003921569) {
+        base = z;
+    } else {
+        float a = z * 255.0f;
+        int idx = sdrm_cvt_i32(a) & 0xff;
+        a = a - (float) idx;
+        float t0 = tab[idx];
+        float t1 = tab[idx + 1];
+        base = t0 + (t1 - t0) * a;
+    }
+    const float pi_f = 3.14159265358979323846f;
+    const float half_pi_f = 1.57079632679489661923f;
+    if (xa > ya) {
+        if (x >= 0.0f) {
+            return (y >= 0.0f) ? base : -base;
+        }
+        return (y >= 0.0f) ? pi_f - base : base - pi_f;
+    }
+    if (y >= 0.0f) {
+        return (x >= 0.0f) ? half_pi_f - base : half_pi_f + base;
+    }
+    return (x >= 0.0f) ? -half_pi_f + base : -half_pi_f - base;
+}
+
+// reference src/dsp/quadrature_demod.c:65-67: gain * atan2(x[n] * conj(x[n-1]))
+SDRM_HD float sdrm_quad_sample(sdrm_f2 cur, sdrm_f2 prev, float gain, const float *tab) {
+    float re = cur.x * prev.x + cur.y * prev.y;
+    float im = cur.y * prev.x - cur.x * prev.y;
+    return gain * sdrm_fast_atan2f(im, re, tab);
+}
+
+// one boxcar stage of the DC blocker, pointwise parts (reference src/dsp/dc_blocker.c:61-63).
+// The running sum itself (y = t + y_prev) is the in-order chain done by the caller.
+SDRM_HD float sdrm_boxcar_term(float u, float u_delayed) { return u - u_delayed; }
+SDRM_HD float sdrm_boxcar_out(float running, float len_f) { return running / len_f; }
+
+// reference src/dsp/fsk_demod.c:106 (VOLK generic volk_32f_s32f_convert_8i, scale 127)
+SDRM_HD int8_t sdrm_soft_to_i8(float v) {
+    float r = v * 127.0f;
+    if (r > 127.0f) {
+        return 127;
+    }
+    if (r < -128.0f) {
+        return -128;
+    }
+    return (int8_t) (int) rintf(r);
+}
+
+// Mueller & Mueller loop state of one channel (reference struct clock_mm_t, clock_recovery_mm.c:9-26)
+struct sdrm_mm_state {
+    float mu, omega, last;
+    int ii;    // position in the call's working buffer (history + input), as in the reference
+    int prev;  // position of the last produced symbol
+};
+
+struct sdrm_mm_consts {
+    float omega_mid, omega_lim, gain_omega, gain_mu;
+};
+
+// MMSE bank row for a fractional delay (reference src/dsp/mmse_fir_interpolator.c:189); -1 = invalid (mu is NaN)
+SDRM_HD int sdrm_mmse_row(float mu) {
+    float scaled = mu * (float) SDRM_MMSE_STEPS;
+    int imu = sdrm_cvt_i32(rintf(scaled));  // rint((double)f) == rintf(f) for every float
+    if (imu < 0 || imu > SDRM_MMSE_STEPS) {
+        return -1;
+    }
+    return imu;
+}
+
+// 8-tap interpolation, reference src/dsp/mmse_fir_interpolator.c:188-191 + src/dsp/fir_filter.c:116-121.
+// w[0..7] = samples at ii..ii+7; lead[0..2] = samples at ii-3..ii-1 (only the last `nlead` = ii & 3 of them are
+// touched: the reference's 16-byte aligned dot product multiplies them by zero taps first).
+// row = bank row (8 taps, listing order); applied reversed.
+SDRM_HD float sdrm_mmse_dot(const float *w, const float *lead, int nlead, const float *row) {
+    float acc = 0.0f;
+    if (nlead >= 3) acc = acc + lead[0] * 0.0f;
+    if (nlead >= 2) acc = acc + lead[1] * 0.0f;
+    if (nlead >= 1) acc = acc + lead[2] * 0.0f;
+    acc = acc + w[0] * row[7];
+    acc = acc + w[1] * row[6];
+    acc = acc + w[2] * row[5];
+    acc = acc + w[3] * row[4];
+    acc = acc + w[4] * row[3];
+    acc = acc + w[5] * row[2];
+    acc = acc + w[6] * row[1];
+    acc = acc + w[7] * row[0];
+    return acc;
+}
+
+// One symbol of the loop (reference src/dsp/clock_recovery_mm.c:103-125).  `o` is the interpolator output for
+// the current (ii, mu).  Returns the soft value to emit and advances the state.
+SDRM_HD float sdrm_mm_advance(sdrm_mm_state &s, const sdrm_mm_consts &k, float o) {
+    if (isnan(o)) {
+        s.prev = s.ii;
+        s.ii = (int) ((uint32_t) s.ii + (uint32_t) sdrm_cvt_i32(floorf(s.omega)));
+        return 0.0f;
+    }
+    float s_last = (s.last < 0.0f) ? -1.0f : 1.0f;
+    float s_o = (o < 0.0f) ? -1.0f : 1.0f;
+    float mm = s_last * o - s_o * s.last;
+    s.last = o;
+    s.prev = s.ii;
+    s.omega = s.omega + k.gain_omega * mm;
+    float dev = s.omega - k.omega_mid;
+    float clipped = 0.5f * (fabsf(dev + k.omega_lim) - fabsf(dev - k.omega_lim));
+    s.omega = k.omega_mid + clipped;
+    s.mu = s.mu + s.omega + k.gain_mu * mm;
+    float whole = floorf(s.mu);
+    s.ii = (int) ((uint32_t) s.ii + (uint32_t) sdrm_cvt_i32(whole));
+    s.mu = s.mu - whole;
+    return o;
+}
+
+#endif  // SDRM_CORE_H

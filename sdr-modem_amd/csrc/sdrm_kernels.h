@@ -1,0 +1,314 @@
+// sdrm_kernels.h -- device data layout and the per-thread bodies of the three pipeline kernels.
+//
+// The bodies are plain functions of (thread id, shared-memory pointers, global pointers) so that the HIP
+// kernels in sdrm_kernels.hip are thin launch glue, and the SAME bodies can be driven thread-by-thread on
+// the host by tests/emu (CPU-only suite: catches tiling / history / ring indexing mistakes without a GPU).
+// The host drive is test infrastructure; the product library only ever runs these on the GPU.
+//
+// Pipeline per call (one "chunk" per channel, channels batched):
+//   K1 front  : LPF1 (complex FIR, T1 taps) -> quadrature demod -> LPF2 (real FIR, T2 taps, decimate d)
+//               grid (tiles, channels), 256 threads, IQ tile + halo staged in LDS        [parallel in time]
+//   K1h       : roll the raw-IQ history (T1+T2-1 samples per channel) for the next call
+//   K2 dc     : 4 cascaded boxcars + delay; one wave per channel, 64 consecutive samples per step,
+//               running sums as an in-order 64-lane DPP chain with carry hand-off          [sequential]
+//   K3 clock  : MMSE interpolator + Mueller&Mueller loop + int8; one lane per channel       [sequential]
+#ifndef SDRM_KERNELS_H
+#define SDRM_KERNELS_H
+
+#include "sdrm_core.h"
+
+#define SDRM_K1_THREADS 256
+#define SDRM_K1_R 15   // LPF1 outputs per thread (odd: lane stride 15*8 B is LDS-bank-conflict free)
+#define SDRM_K1_RZ 15  // LPF2 outputs per thread
+#define SDRM_K1_U 8    // taps per unrolled step
+#define SDRM_K1_NY (SDRM_K1_THREADS * SDRM_K1_R)
+#define SDRM_K1_QPAD 16
+
+#define SDRM_K3_LANES 64
+#define SDRM_K3_RING 256    // per-channel sample ring in LDS (power of two)
+#define SDRM_K3_ROW (SDRM_K3_RING + 1)
+#define SDRM_K3_BLOCK 128   // samples staged per channel per step
+
+// immutable per-channel parameters (device array, one per channel)
+struct sdrm_chan_params {
+    uint32_t T1, T2, decim, dc_len;
+    uint32_t taps1_off, taps2_off;  // float offsets into the tap pool; taps are stored REVERSED (fir_filter.c:25-28)
+    uint32_t hist_len;              // raw-IQ history carried between calls: T1 + T2 - 1 samples
+    uint32_t tile_m;                // LPF2 outputs produced by one K1 tile
+    uint32_t max_len;               // max_input_buffer_length
+    uint32_t rx_mask, rs_mask;      // DC ring sizes - 1 (input ring, stage rings)
+    uint32_t dc_state_off;          // float offset of this channel's DC state in the dc state pool
+    float quad_gain;
+    float dc_len_f;
+    float omega_mid, omega_lim, gain_omega, gain_mu;
+};
+
+// per-call, per-channel control block, written by the host before every launch
+struct sdrm_chunk_ctl {
+    uint32_t n_in;    // complex input samples consumed by this call
+    uint32_t i0;      // in-chunk input index of the first LPF2 output (decimation phase)
+    uint32_t nz;      // LPF2 outputs of this call
+    uint32_t tiles;   // K1 tiles for this channel
+    uint32_t parity;  // which of the two raw-history buffers is current
+    uint32_t zbase;   // LPF2 outputs produced by earlier calls (mod 2^32): DC ring phase
+};
+
+// mutable clock-recovery state (device array, one per channel)
+struct sdrm_clock_state {
+    float mu, omega, last;
+    uint32_t kept;  // samples carried in hist[] (< SDRM_CLOCK_HCAP)
+    float hist[SDRM_CLOCK_HCAP];
+};
+
+// ------------------------------------------------------------------------------------------------ K1
+
+struct sdrm_k1_tile {
+    int m;        // LPF2 outputs of this tile
+    int o_lo;     // chunk-relative index of the first one
+    int nq;       // quadrature-demod samples needed: (m-1)*d + T2
+    int ny;       // LPF1 outputs needed: nq + 1 (one predecessor)
+    int nx;       // raw samples needed: ny + T1 - 1
+    int x_first;  // in-chunk index of the first raw sample (negative => history)
+};
+
+SDRM_HD sdrm_k1_tile sdrm_k1_tile_setup(const sdrm_chan_params &p, const sdrm_chunk_ctl &c, int tile) {
+    sdrm_k1_tile t;
+    t.o_lo = tile * (int) p.tile_m;
+    int left = (int) c.nz - t.o_lo;
+    t.m = left < (int) p.tile_m ? left : (int) p.tile_m;
+    t.nq = (t.m - 1) * (int) p.decim + (int) p.T2;
+    t.ny = t.nq + 1;
+    t.nx = t.ny + (int) p.T1 - 1;
+    t.x_first = (int) c.i0 + t.o_lo * (int) p.decim - ((int) p.T2 - 1) - 1 - ((int) p.T1 - 1);
+    return t;
+}
+
+// logical input stream of a call: history for negative indices, the caller's buffer otherwise
+SDRM_HD sdrm_f2 sdrm_ext_sample(const sdrm_f2 *in, const sdrm_f2 *hist, int hist_len, int i) {
+    return (i < 0) ? hist[hist_len + i] : in[i];
+}
+
+// K sequential taps on N adjacent outputs of a unit-stride FIR, register blocked: for every output the
+// taps are visited in increasing j, one fp32 multiply and one fp32 add each -- the reference's order
+// (fir_filter.c:100-105 / :130-135 with VOLK generic dot products).
+template <int N, int K>
+SDRM_HD void sdrm_fir_block_c(const sdrm_f2 *xs, const float *taps, int ntaps, sdrm_f2 (&acc)[N]) {
+    int j0 = 0;
+    for (; j0 + K <= ntaps; j0 += K) {
+        sdrm_f2 w[N + K - 1];
+#pragma unroll
+        for (int k = 0; k < N + K - 1; k++) {
+            w[k] = xs[j0 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const float tp = taps[j0 + u];
+#pragma unroll
+            for (int r = 0; r < N; r++) {
+                acc[r].x = acc[r].x + w[r + u].x * tp;
+                acc[r].y = acc[r].y + w[r + u].y * tp;
+            }
+        }
+    }
+    for (; j0 < ntaps; j0++) {
+        const float tp = taps[j0];
+#pragma unroll
+        for (int r = 0; r < N; r++) {
+            sdrm_f2 v = xs[j0 + r];
+            acc[r].x = acc[r].x + v.x * tp;
+            acc[r].y = acc[r].y + v.y * tp;
+        }
+    }
+}
+
+template <int N, int K>
+SDRM_HD void sdrm_fir_block_r(const float *xs, const float *taps, int ntaps, float (&acc)[N]) {
+    int j0 = 0;
+    for (; j0 + K <= ntaps; j0 += K) {
+        float w[N + K - 1];
+#pragma unroll
+        for (int k = 0; k < N + K - 1; k++) {
+            w[k] = xs[j0 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const float tp = taps[j0 + u];
+#pragma unroll
+            for (int r = 0; r < N; r++) {
+                acc[r] = acc[r] + w[r + u] * tp;
+            }
+        }
+    }
+    for (; j0 < ntaps; j0++) {
+        const float tp = taps[j0];
+#pragma unroll
+        for (int r = 0; r < N; r++) {
+            acc[r] = acc[r] + xs[j0 + r] * tp;
+        }
+    }
+}
+
+// values a K1 thread keeps in registers between phases
+struct sdrm_k1_regs {
+    sdrm_f2 y[SDRM_K1_R];
+};
+
+// phase 0: stage the raw tile (+halo) and the arctan table into LDS
+SDRM_HD void sdrm_k1_phase_load(int tid, const sdrm_k1_tile &t, const sdrm_f2 *in, const sdrm_f2 *hist, int hist_len,
+                                const float *atan_tab, sdrm_f2 *xs, float *tab) {
+    for (int k = tid; k < t.nx; k += SDRM_K1_THREADS) {
+        xs[k] = sdrm_ext_sample(in, hist, hist_len, t.x_first + k);
+    }
+    for (int k = tid; k < 257; k += SDRM_K1_THREADS) {
+        tab[k] = atan_tab[k];
+    }
+}
+
+// phase 1: LPF1 on R adjacent positions (reference src/dsp/fir_filter.c:123-144 via lpf.c:38-40)
+SDRM_HD void sdrm_k1_phase_lpf1(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps1_rev,
+                                const sdrm_f2 *xs, sdrm_f2 *bnd, sdrm_k1_regs &regs) {
+#pragma unroll
+    for (int r = 0; r < SDRM_K1_R; r++) {
+        regs.y[r].x = 0.0f;
+        regs.y[r].y = 0.0f;
+    }
+    if (tid * SDRM_K1_R < t.ny) {
+        sdrm_fir_block_c<SDRM_K1_R, SDRM_K1_U>(xs + tid * SDRM_K1_R, taps1_rev, (int) p.T1, regs.y);
+    }
+    bnd[tid] = regs.y[SDRM_K1_R - 1];
+}
+
+// phase 2: quadrature demod (reference src/dsp/quadrature_demod.c:57-73) into LDS
+SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *tab,
+                                const sdrm_f2 *bnd, const sdrm_k1_regs &regs, float *qs) {
+    sdrm_f2 prev;
+    prev.x = 0.0f;
+    prev.y = 0.0f;
+    if (tid > 0) {
+        prev = bnd[tid - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < SDRM_K1_R; r++) {
+        int k = tid * SDRM_K1_R + r - 1;
+        if (k >= 0 && k < t.nq) {
+            qs[k] = sdrm_quad_sample(regs.y[r], prev, p.quad_gain, tab);
+        }
+        prev = regs.y[r];
+    }
+}
+
+// phase 3: LPF2 with decimation (reference src/dsp/fir_filter.c:93-114), results to global z
+SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps2_rev,
+                                const float *qs, float *z_out) {
+    const int base = tid * SDRM_K1_RZ;
+    if (base >= t.m) {
+        return;
+    }
+    float acc[SDRM_K1_RZ];
+#pragma unroll
+    for (int r = 0; r < SDRM_K1_RZ; r++) {
+        acc[r] = 0.0f;
+    }
+    if (p.decim == 1) {
+        sdrm_fir_block_r<SDRM_K1_RZ, SDRM_K1_U>(qs + base, taps2_rev, (int) p.T2, acc);
+    } else {
+        const int d = (int) p.decim;
+        for (int j = 0; j < (int) p.T2; j++) {
+            const float tp = taps2_rev[j];
+#pragma unroll
+            for (int r = 0; r < SDRM_K1_RZ; r++) {
+                int ol = base + r;
+                float v = (ol < t.m) ? qs[ol * d + j] : 0.0f;
+                acc[r] = acc[r] + v * tp;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < SDRM_K1_RZ; r++) {
+        if (base + r < t.m) {
+            z_out[t.o_lo + base + r] = acc[r];
+        }
+    }
+}
+
+// K1h: next call's history = the last hist_len samples of (history ++ input)
+SDRM_HD void sdrm_hist_roll(int tid, int nthreads, const sdrm_chan_params &p, const sdrm_chunk_ctl &c, const sdrm_f2 *in,
+                            const sdrm_f2 *hist_cur, sdrm_f2 *hist_next) {
+    const int H = (int) p.hist_len;
+    for (int j = tid; j < H; j += nthreads) {
+        hist_next[j] = sdrm_ext_sample(in, hist_cur, H, (int) c.n_in - H + j);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3
+
+// per-lane context of the clock-recovery kernel; ring = this channel's row of the LDS sample ring.
+// Ring slot of chunk-relative sample n (n < 0: carried history) is n & (SDRM_K3_RING-1).
+struct sdrm_k3_lane {
+    sdrm_mm_state st;
+    sdrm_mm_consts k;
+    int kept;          // carried samples at the start of the call
+    int nz;            // new samples this call
+    uint32_t oo;       // symbols produced so far
+    uint32_t cap;      // max symbols per call (= max_input_buffer_length, clock_recovery_mm.c:103)
+};
+
+SDRM_HD float sdrm_k3_ring_get(const float *ring, int n) { return ring[n & (SDRM_K3_RING - 1)]; }
+
+// can this lane produce its next symbol with `avail` chunk samples staged?  Mirrors the loop condition
+// `ii < working_len - 7 && oo < output_len` (clock_recovery_mm.c:103) with ii compared as size_t.
+SDRM_HD bool sdrm_k3_can_step(const sdrm_k3_lane &L, int avail) {
+    if (L.st.ii < 0 || L.oo >= L.cap) {
+        return false;
+    }
+    // chunk-relative index of the first of the 8 samples is ii - kept; need +7 < avail
+    return (int64_t) L.st.ii - L.kept + 7 < (int64_t) avail;
+}
+
+// one symbol; bank = MMSE table [129][8]; returns the float soft value
+SDRM_HD float sdrm_k3_step(sdrm_k3_lane &L, const float *ring, const float *bank) {
+    const int n = L.st.ii - L.kept;
+    float w[8], lead[3];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        w[j] = sdrm_k3_ring_get(ring, n + j);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        lead[j] = sdrm_k3_ring_get(ring, n - 3 + j);
+    }
+    const int row = sdrm_mmse_row(L.st.mu);
+    float o;
+    if (row < 0) {
+        o = NAN;
+    } else {
+        o = sdrm_mmse_dot(w, lead, L.st.ii & 3, bank + row * 8);
+    }
+    return sdrm_mm_advance(L.st, L.k, o);
+}
+
+// after the last block: decide what to carry (clock_recovery_mm.c:127-135). Returns the chunk-relative index of
+// the first carried sample and the new kept count.
+SDRM_HD void sdrm_k3_finish(const sdrm_k3_lane &L, int *from_n, int *new_kept) {
+    const int64_t len = (int64_t) L.kept + L.nz;
+    int64_t from;
+    if (len < SDRM_MMSE_TAPS) {
+        from = 0;  // :94-99 keep everything, no symbols
+    } else {
+        const bool past = (L.st.ii < 0) || ((int64_t) L.st.ii > len);  // `ii > working_len` as size_t
+        from = past ? (int64_t) L.st.prev : (int64_t) L.st.ii;
+    }
+    int64_t keep = len - from;
+    if (keep > SDRM_CLOCK_HCAP - 1) {  // bounded where the reference overruns its buffer
+        keep = SDRM_CLOCK_HCAP - 1;
+        from = len - keep;
+    }
+    if (keep < 0) {
+        keep = 0;
+        from = len;
+    }
+    *from_n = (int) (from - L.kept);
+    *new_kept = (int) keep;
+}
+
+#endif  // SDRM_KERNELS_H

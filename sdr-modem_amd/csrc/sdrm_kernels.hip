@@ -1,0 +1,403 @@
+// sdrm_kernels.hip -- gfx950 kernels of the GMSK/FSK demodulation pipeline (exact mode).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile): no FMA contraction, IEEE
+// division, fp32 denormals preserved -- required for bit parity with the reference's CPU path.
+#include "sdrm_launch.h"
+
+namespace sdrm {
+
+// ================================================================================================ K1
+
+size_t k1_lds_bytes(uint32_t t1_max) {
+    size_t xs = (size_t) (SDRM_K1_NY + t1_max) * sizeof(sdrm_f2);
+    size_t qs = (size_t) (SDRM_K1_NY + SDRM_K1_QPAD) * sizeof(float);
+    size_t bnd = (size_t) SDRM_K1_THREADS * sizeof(sdrm_f2);
+    size_t tab = 260 * sizeof(float);
+    return xs + qs + bnd + tab;
+}
+
+// grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
+// per-thread boundary samples | arctan table.
+__global__ __launch_bounds__(SDRM_K1_THREADS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
+                                                            size_t in_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
+    const int c = blockIdx.y;
+    const sdrm_chunk_ctl ctl = b.ctl[c];
+    if (blockIdx.x >= ctl.tiles) {
+        return;
+    }
+    const sdrm_chan_params p = b.params[c];
+    sdrm_f2 *xs = reinterpret_cast<sdrm_f2 *>(k1_lds);
+    float *qs = reinterpret_cast<float *>(xs + SDRM_K1_NY + b.t1_max);
+    sdrm_f2 *bnd = reinterpret_cast<sdrm_f2 *>(qs + SDRM_K1_NY + SDRM_K1_QPAD);
+    float *tab = reinterpret_cast<float *>(bnd + SDRM_K1_THREADS);
+
+    const int tid = threadIdx.x;
+    const sdrm_k1_tile t = sdrm_k1_tile_setup(p, ctl, (int) blockIdx.x);
+    const sdrm_f2 *in = d_in + (size_t) c * in_stride;
+    const sdrm_f2 *hist = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
+
+    sdrm_k1_phase_load(tid, t, in, hist, (int) p.hist_len, b.atan_tab, xs, tab);
+    __syncthreads();
+    sdrm_k1_regs regs;
+    sdrm_k1_phase_lpf1(tid, t, p, b.tap_pool + p.taps1_off, xs, bnd, regs);
+    __syncthreads();
+    sdrm_k1_phase_quad(tid, t, p, tab, bnd, regs, qs);
+    __syncthreads();
+    sdrm_k1_phase_lpf2(tid, t, p, b.tap_pool + p.taps2_off, qs, b.z + (size_t) c * b.z_stride);
+}
+
+__global__ __launch_bounds__(256) void k1_hist_roll(DeviceBatch b, const sdrm_f2 *__restrict__ d_in, size_t in_stride) {
+    const int c = blockIdx.x;
+    const sdrm_chunk_ctl ctl = b.ctl[c];
+    const sdrm_chan_params p = b.params[c];
+    const sdrm_f2 *cur = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
+    sdrm_f2 *next = b.raw_hist + ((size_t) c * 2 + (ctl.parity ^ 1u)) * b.hist_stride;
+    sdrm_hist_roll((int) threadIdx.x, (int) blockDim.x, p, ctl, d_in + (size_t) c * in_stride, cur, next);
+}
+
+// dynamic LDS above the 64 KiB default has to be requested per kernel (up to the CU's 160 KiB)
+template <typename K>
+static void allow_lds(K kernel, size_t bytes, size_t *granted) {
+    if (bytes > 64 * 1024 && bytes > *granted) {
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+        *granted = bytes;
+    }
+}
+
+void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s) {
+    if (b.max_tiles == 0) {
+        return;
+    }
+    static size_t granted = 0;
+    const size_t lds = k1_lds_bytes(b.t1_max);
+    allow_lds(k1_front, lds, &granted);
+    dim3 grid(b.max_tiles, (unsigned) b.n_channels);
+    hipLaunchKernelGGL(k1_front, grid, dim3(SDRM_K1_THREADS), lds, s, b, d_in, in_stride);
+}
+
+void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s) {
+    hipLaunchKernelGGL(k1_hist_roll, dim3((unsigned) b.n_channels), dim3(256), 0, s, b, d_in, in_stride);
+}
+
+// ================================================================================================ K2
+
+// In-order fp32 running sum across the 64 lanes of a wave: s[i] = fl(s[i-1] + t[i]), s[-1] = carry.
+// fp32 addition is not associative, so this is a chain of 63 dependent adds; each step moves the partial sums
+// one lane up with a DPP shift (no LDS).  Lanes whose predecessor is already final compute their final value,
+// finished lanes recompute the same value, unfinished lanes hold scratch.
+// MODE 0: wave_shr:1 (one shift across the whole wave).  MODE 1: row_shr:1 in 16-lane rows + readlane carries.
+template <int MODE>
+__device__ __forceinline__ float wave_inorder_sum(float t, float carry) {
+    float s = carry + t;  // lane 0 is final; the DPP below leaves lane 0's operand = carry
+    if (MODE == 0) {
+        const int ci = __builtin_bit_cast(int, carry);
+#pragma unroll
+        for (int k = 1; k < 64; k++) {
+            int up = __builtin_amdgcn_update_dpp(ci, __builtin_bit_cast(int, s), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            s = __builtin_bit_cast(float, up) + t;
+        }
+    } else {
+#pragma unroll
+        for (int row = 0; row < 4; row++) {
+            float cv = carry;
+            if (row > 0) {
+                cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16 * row - 1));
+            }
+            const int ci = __builtin_bit_cast(int, cv);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                int up = __builtin_amdgcn_update_dpp(ci, __builtin_bit_cast(int, s), 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                s = __builtin_bit_cast(float, up) + t;
+            }
+        }
+    }
+    return s;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap) { return ((size_t) rx_cap + 3 * (size_t) rs_cap) * sizeof(float); }
+
+// One wave per channel.  Reference src/dsp/dc_blocker.c:56-64,105-119: four cascaded length-L boxcars
+// (y = (u - u[-L]) + y_prev; out y/L) and out = x[n - 2(L-1)] - y4.  Delay lines live in LDS rings that persist in
+// the channel's DC state between calls; the slot of stream sample n is n & mask.
+template <int MODE>
+__global__ __launch_bounds__(64) void k2_dc(DeviceBatch b) {
+    extern __shared__ __attribute__((aligned(16))) float k2_lds[];
+    const int c = blockIdx.x;
+    const sdrm_chan_params p = b.params[c];
+    if (p.dc_len == 0) {
+        return;
+    }
+    const sdrm_chunk_ctl ctl = b.ctl[c];
+    const int lane = threadIdx.x;
+    float *rx = k2_lds;
+    float *r0 = rx + b.rx_cap;
+    float *r1 = r0 + b.rs_cap;
+    float *r2 = r1 + b.rs_cap;
+    const uint32_t mx = p.rx_mask, ms = p.rs_mask;
+    float *st = b.dc_state + p.dc_state_off;
+    float *st_rx = st, *st_r0 = st_rx + (mx + 1), *st_r1 = st_r0 + (ms + 1), *st_r2 = st_r1 + (ms + 1);
+    float *st_acc = st_r2 + (ms + 1);
+    for (uint32_t k = lane; k <= mx; k += 64) {
+        rx[k] = st_rx[k];
+    }
+    for (uint32_t k = lane; k <= ms; k += 64) {
+        r0[k] = st_r0[k];
+        r1[k] = st_r1[k];
+        r2[k] = st_r2[k];
+    }
+    float a0 = st_acc[0], a1 = st_acc[1], a2 = st_acc[2], a3 = st_acc[3];
+    __syncthreads();
+
+    const float *z = b.z + (size_t) c * b.z_stride;
+    float *out = b.dcout + (size_t) c * b.z_stride;
+    const uint32_t L = p.dc_len;
+    const float Lf = p.dc_len_f;
+    const uint32_t nz = ctl.nz;
+    for (uint32_t n0 = 0; n0 < nz; n0 += 64) {
+        const uint32_t n = n0 + lane;
+        const bool valid = n < nz;
+        const int last = (int) ((nz - n0 < 64u ? nz - n0 : 64u) - 1u);
+        const uint32_t pos = ctl.zbase + n;  // stream index (mod 2^32; ring sizes divide 2^32)
+        const float x = valid ? z[n] : 0.0f;
+        if (valid) {
+            rx[pos & mx] = x;
+        }
+        __builtin_amdgcn_wave_barrier();  // keep the ring write ahead of the delayed reads (same wave: LDS is in order)
+        const float xd = rx[(pos - L) & mx];
+        const float xdd = rx[(pos - 2 * (L - 1)) & mx];
+        // stage 0
+        float t = valid ? sdrm_boxcar_term(x, xd) : 0.0f;
+        float s = wave_inorder_sum<MODE>(t, a0);
+        a0 = lane_bcast(s, last);
+        float v = sdrm_boxcar_out(s, Lf);
+        if (valid) {
+            r0[pos & ms] = v;
+        }
+        __builtin_amdgcn_wave_barrier();  // keep the ring write ahead of the delayed reads (same wave: LDS is in order)
+        float vd = r0[(pos - L) & ms];
+        // stage 1
+        t = valid ? sdrm_boxcar_term(v, vd) : 0.0f;
+        s = wave_inorder_sum<MODE>(t, a1);
+        a1 = lane_bcast(s, last);
+        v = sdrm_boxcar_out(s, Lf);
+        if (valid) {
+            r1[pos & ms] = v;
+        }
+        __builtin_amdgcn_wave_barrier();  // keep the ring write ahead of the delayed reads (same wave: LDS is in order)
+        vd = r1[(pos - L) & ms];
+        // stage 2
+        t = valid ? sdrm_boxcar_term(v, vd) : 0.0f;
+        s = wave_inorder_sum<MODE>(t, a2);
+        a2 = lane_bcast(s, last);
+        v = sdrm_boxcar_out(s, Lf);
+        if (valid) {
+            r2[pos & ms] = v;
+        }
+        __builtin_amdgcn_wave_barrier();  // keep the ring write ahead of the delayed reads (same wave: LDS is in order)
+        vd = r2[(pos - L) & ms];
+        // stage 3
+        t = valid ? sdrm_boxcar_term(v, vd) : 0.0f;
+        s = wave_inorder_sum<MODE>(t, a3);
+        a3 = lane_bcast(s, last);
+        v = sdrm_boxcar_out(s, Lf);
+        if (valid) {
+            out[n] = xdd - v;
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = lane; k <= mx; k += 64) {
+        st_rx[k] = rx[k];
+    }
+    for (uint32_t k = lane; k <= ms; k += 64) {
+        st_r0[k] = r0[k];
+        st_r1[k] = r1[k];
+        st_r2[k] = r2[k];
+    }
+    if (lane == 0) {
+        st_acc[0] = a0;
+        st_acc[1] = a1;
+        st_acc[2] = a2;
+        st_acc[3] = a3;
+    }
+}
+
+static int g_scan_mode = 0;
+
+void launch_dc(const DeviceBatch &b, hipStream_t s) {
+    if (!b.any_dc) {
+        return;
+    }
+    size_t lds = k2_lds_bytes(b.rx_cap, b.rs_cap);
+    static size_t granted0 = 0, granted1 = 0;
+    allow_lds(k2_dc<0>, lds, &granted0);
+    allow_lds(k2_dc<1>, lds, &granted1);
+    if (g_scan_mode == 0) {
+        hipLaunchKernelGGL(k2_dc<0>, dim3((unsigned) b.n_channels), dim3(64), lds, s, b);
+    } else {
+        hipLaunchKernelGGL(k2_dc<1>, dim3((unsigned) b.n_channels), dim3(64), lds, s, b);
+    }
+}
+
+// ================================================================================================ K3
+
+// One lane per channel, 64 channels per wave.  Per step the wave stages the next SDRM_K3_BLOCK samples of each of
+// its 64 channels into an LDS ring (coalesced row reads), then every lane runs its own Mueller&Mueller loop
+// (reference src/dsp/clock_recovery_mm.c:78-139) until it runs out of staged samples.
+__global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
+    __shared__ float ring[SDRM_K3_LANES * SDRM_K3_ROW];
+    __shared__ __attribute__((aligned(16))) float bank[129 * 8];
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * SDRM_K3_LANES;
+    const int c = c0 + lane;
+    const bool active = c < b.n_channels;
+    for (int k = lane; k < 129 * 8; k += 64) {
+        bank[k] = b.mmse_bank[k];
+    }
+    sdrm_k3_lane L;
+    L.kept = 0;
+    L.nz = 0;
+    L.oo = 0;
+    L.cap = 0;
+    L.st.mu = 0.0f;
+    L.st.omega = 0.0f;
+    L.st.last = 0.0f;
+    L.st.ii = 0;
+    L.st.prev = 0;
+    L.k.omega_mid = L.k.omega_lim = L.k.gain_omega = L.k.gain_mu = 0.0f;
+    float *my_ring = ring + lane * SDRM_K3_ROW;
+    sdrm_clock_state *cs = b.clock_state + (active ? c : 0);
+    if (active) {
+        const sdrm_chan_params p = b.params[c];
+        L.k.omega_mid = p.omega_mid;
+        L.k.omega_lim = p.omega_lim;
+        L.k.gain_omega = p.gain_omega;
+        L.k.gain_mu = p.gain_mu;
+        L.cap = p.max_len;
+        L.nz = (int) b.ctl[c].nz;
+        L.kept = (int) cs->kept;
+        L.st.mu = cs->mu;
+        L.st.omega = cs->omega;
+        L.st.last = cs->last;
+        for (int j = 0; j < L.kept; j++) {
+            my_ring[(j - L.kept) & (SDRM_K3_RING - 1)] = cs->hist[j];
+        }
+    }
+    int max_nz = 0;
+    for (int r = 0; r < SDRM_K3_LANES; r++) {
+        int v = __builtin_amdgcn_readlane(L.nz, r);
+        max_nz = v > max_nz ? v : max_nz;
+    }
+    __syncthreads();
+
+    int8_t *o8 = b.out_i8 + (size_t) (active ? c : 0) * b.out_stride;
+    float *of = b.out_f32 ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
+
+    const int nblocks = (max_nz + SDRM_K3_BLOCK - 1) / SDRM_K3_BLOCK;
+    for (int k = 0; k <= nblocks; k++) {
+        // k == nblocks: no staging, only drains what the carried history alone allows (nz == 0 case)
+        if (k < nblocks) {
+            for (int r = 0; r < SDRM_K3_LANES; r++) {
+                const int cr = c0 + r;
+                if (cr >= b.n_channels) {
+                    break;
+                }
+                const int nz_r = __builtin_amdgcn_readlane(L.nz, r);
+                const float *src = (b.params[cr].dc_len ? b.dcout : b.z) + (size_t) cr * b.z_stride;
+                float *row = ring + r * SDRM_K3_ROW;
+#pragma unroll
+                for (int h = 0; h < SDRM_K3_BLOCK / 64; h++) {
+                    const int n = k * SDRM_K3_BLOCK + h * 64 + lane;
+                    if (n < nz_r) {
+                        row[n & (SDRM_K3_RING - 1)] = src[n];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        int avail = (k + 1) * SDRM_K3_BLOCK;
+        avail = avail < L.nz ? avail : L.nz;
+        while (true) {
+            const bool can = active && sdrm_k3_can_step(L, avail);
+            if (!__any(can)) {
+                break;
+            }
+            if (can) {
+                const float soft = sdrm_k3_step(L, my_ring, bank);
+                o8[L.oo] = sdrm_soft_to_i8(soft);
+                if (of) {
+                    of[L.oo] = soft;
+                }
+                L.oo++;
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        int from_n, new_kept;
+        sdrm_k3_finish(L, &from_n, &new_kept);
+        for (int j = 0; j < new_kept; j++) {
+            cs->hist[j] = my_ring[(from_n + j) & (SDRM_K3_RING - 1)];
+        }
+        cs->kept = (uint32_t) new_kept;
+        cs->mu = L.st.mu;
+        cs->omega = L.st.omega;
+        cs->last = L.st.last;
+        b.out_len[c] = L.oo;
+    }
+}
+
+void launch_clock(const DeviceBatch &b, hipStream_t s) {
+    unsigned blocks = (unsigned) ((b.n_channels + SDRM_K3_LANES - 1) / SDRM_K3_LANES);
+    hipLaunchKernelGGL(k3_clock, dim3(blocks), dim3(64), 0, s, b);
+}
+
+// ================================================================================================ probes
+
+__global__ void probe_atan2(const float *y, const float *x, const float *tab, float *out, size_t n) {
+    __shared__ float t[260];
+    for (int k = threadIdx.x; k < 257; k += blockDim.x) {
+        t[k] = tab[k];
+    }
+    __syncthreads();
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[i] = sdrm_fast_atan2f(y[i], x[i], t);
+    }
+}
+
+template <int MODE>
+__global__ void probe_scan(const float *terms, float carry, float *out, size_t n) {
+    const int lane = threadIdx.x;
+    for (size_t n0 = 0; n0 < n; n0 += 64) {
+        const size_t i = n0 + lane;
+        const bool valid = i < n;
+        const int last = (int) ((n - n0 < 64 ? n - n0 : 64) - 1);
+        float t = valid ? terms[i] : 0.0f;
+        float s = wave_inorder_sum<MODE>(t, carry);
+        carry = lane_bcast(s, last);
+        if (valid) {
+            out[i] = s;
+        }
+    }
+}
+
+void launch_probe_atan2(const float *d_y, const float *d_x, const float *d_tab, float *d_out, size_t n, hipStream_t s) {
+    unsigned blocks = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(probe_atan2, dim3(blocks ? blocks : 1), dim3(256), 0, s, d_y, d_x, d_tab, d_out, n);
+}
+
+void launch_probe_scan(const float *d_terms, float carry, float *d_out, size_t n, int mode, hipStream_t s) {
+    if (mode == 0) {
+        hipLaunchKernelGGL(probe_scan<0>, dim3(1), dim3(64), 0, s, d_terms, carry, d_out, n);
+    } else {
+        hipLaunchKernelGGL(probe_scan<1>, dim3(1), dim3(64), 0, s, d_terms, carry, d_out, n);
+    }
+}
+
+void set_scan_mode(int mode) { g_scan_mode = mode; }
+
+}  // namespace sdrm

@@ -1,0 +1,53 @@
+// sdrm_launch.h -- host-callable launchers of the gfx950 kernels (defined in sdrm_kernels.hip).
+#ifndef SDRM_LAUNCH_H
+#define SDRM_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sdrm_kernels.h"
+
+namespace sdrm {
+
+// device-resident, batch-wide pointers and strides
+struct DeviceBatch {
+    int n_channels;
+    const sdrm_chan_params *params;  // [C]
+    const sdrm_chunk_ctl *ctl;       // [C] for the call being launched
+    const float *tap_pool;           // reversed taps of all channels
+    const float *atan_tab;           // [257]
+    const float *mmse_bank;          // [129*8]
+    sdrm_f2 *raw_hist;               // [C][2][hist_stride]
+    uint32_t hist_stride;
+    float *z;                        // [C][z_stride]   LPF2 output
+    float *dcout;                    // [C][z_stride]   DC-blocker output
+    uint32_t z_stride;
+    float *dc_state;                 // pool, per-channel offsets in params
+    sdrm_clock_state *clock_state;   // [C]
+    int8_t *out_i8;                  // [C][out_stride]
+    float *out_f32;                  // [C][out_stride] or nullptr
+    uint32_t *out_len;               // [C]
+    uint32_t out_stride;
+    // launch geometry (host-computed maxima over the batch)
+    uint32_t max_tiles;              // K1 grid.x for this call
+    uint32_t t1_max;                 // sizes K1's LDS
+    uint32_t rx_cap, rs_cap;         // DC ring capacities (floats) sizing K2's LDS
+    int any_dc;
+};
+
+size_t k1_lds_bytes(uint32_t t1_max);
+size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap);
+
+void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
+void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
+void launch_dc(const DeviceBatch &b, hipStream_t s);
+void launch_clock(const DeviceBatch &b, hipStream_t s);
+
+// test probes
+void launch_probe_atan2(const float *d_y, const float *d_x, const float *d_tab, float *d_out, size_t n, hipStream_t s);
+void launch_probe_scan(const float *d_terms, float carry, float *d_out, size_t n, int mode, hipStream_t s);
+
+}  // namespace sdrm
+
+#endif

@@ -1,0 +1,131 @@
+// sdrm_plan.cpp -- see sdrm_plan.h
+#include "sdrm_plan.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace sdrm {
+
+static uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+static uint32_t pow2_at_least(uint32_t v) {
+    uint32_t p = 64;
+    while (p < v) {
+        p <<= 1;
+    }
+    return p;
+}
+
+int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
+    plan.design.resize(n);
+    for (size_t c = 0; c < n; c++) {
+        int code = design_channel(cfgs[c], plan.design[c]);
+        if (code != 0) {
+            return code;
+        }
+    }
+    plan.params.resize(n);
+    plan.phase.assign(n, 0);
+    plan.parity.assign(n, 0);
+    plan.zbase.assign(n, 0);
+    uint32_t h_max = 0, maxlen_max = 0;
+    size_t last_distinct = 0;
+    for (size_t c = 0; c < n; c++) {
+        const ChannelDesign &d = plan.design[c];
+        sdrm_chan_params &p = plan.params[c];
+        memset(&p, 0, sizeof(p));
+        p.T1 = (uint32_t) d.taps1.size();
+        p.T2 = (uint32_t) d.taps2.size();
+        p.decim = d.cfg.decimation;
+        p.dc_len = d.dc_length;
+        // channels with the same filters share one copy of the taps (batches are mostly a few distinct configs)
+        bool shared = false;
+        const size_t probes[2] = {last_distinct, c ? c - 1 : 0};
+        for (size_t e : probes) {
+            if (c > 0 && e < c && plan.design[e].taps1 == d.taps1 && plan.design[e].taps2 == d.taps2) {
+                p.taps1_off = plan.params[e].taps1_off;
+                p.taps2_off = plan.params[e].taps2_off;
+                shared = true;
+                break;
+            }
+        }
+        if (!shared) {
+            last_distinct = c;
+            p.taps1_off = (uint32_t) plan.tap_pool.size();
+            plan.tap_pool.insert(plan.tap_pool.end(), d.taps1.rbegin(), d.taps1.rend());  // reversed: fir_filter.c:25-28
+            while (plan.tap_pool.size() % 8) {
+                plan.tap_pool.push_back(0.0f);
+            }
+            p.taps2_off = (uint32_t) plan.tap_pool.size();
+            plan.tap_pool.insert(plan.tap_pool.end(), d.taps2.rbegin(), d.taps2.rend());
+            while (plan.tap_pool.size() % 8) {
+                plan.tap_pool.push_back(0.0f);
+            }
+        }
+        p.hist_len = p.T1 + p.T2 - 1;
+        if (p.T2 + 2 > (uint32_t) SDRM_K1_NY) {
+            fprintf(stderr, "<3>low-pass filter of %u taps does not fit a tile\n", p.T2);
+            return -ENOTSUP;
+        }
+        // a tile computes SDRM_K1_NY LPF1 positions: (m-1)*d + T2 + 1 of them are needed for m outputs
+        uint32_t by_halo = (uint32_t) ((SDRM_K1_NY - 1 - (int) p.T2) / (int) p.decim + 1);
+        p.tile_m = std::min<uint32_t>((uint32_t) (SDRM_K1_THREADS * SDRM_K1_RZ), by_halo);
+        p.max_len = d.cfg.max_input_buffer_length;
+        p.quad_gain = d.quad_gain;
+        p.omega_mid = d.sps;
+        p.omega_lim = d.omega_lim;
+        p.gain_omega = d.gain_omega;
+        p.gain_mu = d.gain_mu;
+        if (p.dc_len) {
+            plan.any_dc = 1;
+            p.dc_len_f = (float) p.dc_len;
+            const uint32_t rs = pow2_at_least(p.dc_len + 64), rx = pow2_at_least(2 * (p.dc_len - 1) + 64);
+            p.rs_mask = rs - 1;
+            p.rx_mask = rx - 1;
+            p.dc_state_off = (uint32_t) plan.dc_state_floats;
+            plan.dc_state_floats += (size_t) rx + 3 * (size_t) rs + 8;
+            plan.rx_cap = std::max(plan.rx_cap, rx);
+            plan.rs_cap = std::max(plan.rs_cap, rs);
+        }
+        plan.t1_max = std::max(plan.t1_max, p.T1);
+        h_max = std::max(h_max, p.hist_len);
+        maxlen_max = std::max(maxlen_max, p.max_len);
+    }
+    plan.hist_stride = round_up_u32(h_max, 8);
+    plan.z_stride = round_up_u32(maxlen_max + 64, 64);
+    plan.out_stride = round_up_u32(maxlen_max + 64, 64);
+    plan.in_stride = round_up_u32(std::max<uint32_t>(maxlen_max, 1), 64);
+    return 0;
+}
+
+uint32_t plan_call(BatchPlan &plan, const size_t *lens, sdrm_chunk_ctl *ctl) {
+    uint32_t max_tiles = 0;
+    const size_t n_ch = plan.params.size();
+    for (size_t c = 0; c < n_ch; c++) {
+        const sdrm_chan_params &p = plan.params[c];
+        size_t n = lens ? lens[c] : 0;
+        if (n > p.max_len) {
+            fprintf(stderr, "<3>requested buffer %zu is more than max: %zu\n", n, (size_t) p.max_len);
+            n = 0;
+        }
+        sdrm_chunk_ctl &k = ctl[c];
+        k.n_in = (uint32_t) n;
+        k.i0 = plan.phase[c];
+        // LPF2 emits at stream positions that are multiples of d (fir_filter.c:100-107 carries the phase in
+        // history_offset); i0 is where the next one falls inside this call's input
+        k.nz = (k.n_in > k.i0) ? (k.n_in - k.i0 + p.decim - 1) / p.decim : 0;
+        k.tiles = (k.nz + p.tile_m - 1) / p.tile_m;
+        k.parity = plan.parity[c];
+        k.zbase = plan.zbase[c];
+        plan.phase[c] = k.i0 + k.nz * p.decim - k.n_in;
+        plan.parity[c] ^= 1u;
+        plan.zbase[c] += k.nz;
+        max_tiles = std::max(max_tiles, k.tiles);
+    }
+    return max_tiles;
+}
+
+}  // namespace sdrm

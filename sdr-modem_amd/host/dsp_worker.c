@@ -1,0 +1,180 @@
+/*
+ * dsp_worker.c -- per-client DSP thread: pulls IQ buffers from its queue, optionally dumps them, demodulates
+ * them on the GPU through fsk_demod_process(), and pushes the soft bits to a file and/or the client socket.
+ *
+ * Mirror of the reference's src/dsp_worker.{h,c} (public API src/dsp_worker.h:14-22, thread body
+ * src/dsp_worker.c:44-106, construction :108-197, teardown :199-227) with the protobuf RxRequest and the
+ * libconfig server_config replaced by the plain sdrm_worker_config (those headers need protobuf-c / libiio,
+ * which are outside this path).  Same call order, same file names (rx.sdr2demod.<id>.cf32,
+ * rx.demod2client.<id>.s8), same error returns and "<3>" messages.  Doppler pre-correction (src/dsp/doppler.c)
+ * is the next row of the scope table and is not wired yet.
+ */
+#include <errno.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "../../include/sdrmodem_hip.h"
+
+enum { DEST_FILE = 0, DEST_SOCKET = 1, DEST_BOTH = 2 }; /* api.proto DemodDestination */
+
+struct dsp_worker_t {
+    uint32_t id;
+    int client_socket;
+    fsk_demod *demod;
+    queue *inbox;
+    pthread_t thread;
+    bool thread_started;
+    FILE *iq_dump;
+    FILE *soft_dump;
+    int destination;
+};
+
+bool dsp_worker_find_by_id(void *id, void *data) {
+    const dsp_worker *w = (const dsp_worker *) data;
+    return w->id == *(uint32_t *) id;
+}
+
+void dsp_worker_put(sdrm_cf32 *output, size_t output_len, dsp_worker *worker) {
+    queue_put(output, output_len, worker->inbox);
+}
+
+void dsp_worker_shutdown(void *arg, void *data) {
+    (void) arg;
+    dsp_worker *w = (dsp_worker *) data;
+    interrupt_waiting_the_data(w->inbox);
+}
+
+/* reference src/tcp_utils.c:7-17 */
+static int write_fully(const uint8_t *bytes, size_t n, int fd) {
+    size_t done = 0;
+    while (done < n) {
+        ssize_t w = write(fd, bytes + done, n - done);
+        if (w < 0) {
+            return -1;
+        }
+        done += (size_t) w;
+    }
+    return 0;
+}
+
+static void *worker_main(void *arg) {
+    dsp_worker *w = (dsp_worker *) arg;
+    fprintf(stdout, "[%d] dsp_worker is starting\n", w->id);
+    for (;;) {
+        sdrm_cf32 *iq = NULL;
+        size_t iq_len = 0;
+        take_buffer_for_processing(&iq, &iq_len, w->inbox);
+        if (iq == NULL) {
+            break; /* poison pill */
+        }
+        if (w->iq_dump != NULL && fwrite(iq, sizeof(sdrm_cf32), iq_len, w->iq_dump) < iq_len) {
+            complete_buffer_processing(w->inbox);
+            fprintf(stderr, "<3>[%d] unable to write sdr data\n", w->id);
+            break;
+        }
+        int8_t *soft = NULL;
+        size_t soft_len = 0;
+        if (w->demod != NULL) {
+            fsk_demod_process(iq, iq_len, &soft, &soft_len, w->demod);
+        }
+        if (soft == NULL) {
+            complete_buffer_processing(w->inbox);
+            continue;
+        }
+        if (w->soft_dump != NULL && fwrite(soft, sizeof(int8_t), soft_len, w->soft_dump) < soft_len) {
+            complete_buffer_processing(w->inbox);
+            fprintf(stderr, "<3>[%d] unable to write demod data\n", w->id);
+            break;
+        }
+        int code = 0;
+        if (w->destination == DEST_SOCKET || w->destination == DEST_BOTH) {
+            code = write_fully((const uint8_t *) soft, soft_len, w->client_socket);
+        }
+        complete_buffer_processing(w->inbox);
+        if (code != 0) {
+            break;
+        }
+    }
+    printf("[%d] dsp_worker stopped\n", w->id);
+    return NULL;
+}
+
+int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *cfg, dsp_worker **result) {
+    dsp_worker *w = calloc(1, sizeof(*w));
+    if (w == NULL) {
+        return -ENOMEM;
+    }
+    w->id = id;
+    w->client_socket = client_socket;
+    int code = fsk_demod_create(cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
+                                (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
+                                cfg->demod_fsk_use_dc_block, cfg->buffer_size, &w->demod);
+    if (code != 0) {
+        fprintf(stderr, "<3>[%d] unable to create demodulator\n", w->id);
+        dsp_worker_destroy(w);
+        return code;
+    }
+    char path[4096];
+    if (cfg->rx_dump_file) {
+        snprintf(path, sizeof(path), "%s/rx.sdr2demod.%d.cf32", cfg->base_path, id);
+        w->iq_dump = fopen(path, "wb");
+        if (w->iq_dump == NULL) {
+            fprintf(stderr, "<3>[%d] unable to open file for sdr input: %s\n", w->id, path);
+            dsp_worker_destroy(w);
+            return -1;
+        }
+    }
+    w->destination = cfg->demod_destination;
+    if (cfg->demod_destination == DEST_FILE || cfg->demod_destination == DEST_BOTH) {
+        snprintf(path, sizeof(path), "%s/rx.demod2client.%d.s8", cfg->base_path, id);
+        w->soft_dump = fopen(path, "wb");
+        if (w->soft_dump == NULL) {
+            fprintf(stderr, "<3>[%d] unable to open file for demod output: %s\n", w->id, path);
+            dsp_worker_destroy(w);
+            return -1;
+        }
+    }
+    /* a file source must not lose data => blocking queue (src/dsp_worker.c:176-179) */
+    code = create_queue(cfg->buffer_size, cfg->queue_size, cfg->rx_file_source, &w->inbox);
+    if (code != 0) {
+        dsp_worker_destroy(w);
+        return code;
+    }
+    if (pthread_create(&w->thread, NULL, worker_main, w) != 0) {
+        dsp_worker_destroy(w);
+        return -1;
+    }
+    w->thread_started = true;
+    *result = w;
+    return 0;
+}
+
+void dsp_worker_destroy(void *data) {
+    if (data == NULL) {
+        return;
+    }
+    dsp_worker *w = (dsp_worker *) data;
+    fprintf(stdout, "[%d] dsp_worker is stopping\n", w->id);
+    if (w->inbox != NULL) {
+        interrupt_waiting_the_data(w->inbox);
+    }
+    if (w->thread_started) {
+        pthread_join(w->thread, NULL);
+    }
+    if (w->inbox != NULL) {
+        destroy_queue(w->inbox);
+    }
+    if (w->iq_dump != NULL) {
+        fclose(w->iq_dump);
+    }
+    if (w->soft_dump != NULL) {
+        fclose(w->soft_dump);
+    }
+    if (w->demod != NULL) {
+        fsk_demod_destroy(w->demod);
+    }
+    free(w);
+}

@@ -1,0 +1,236 @@
+// sdrm_emu.cpp -- TEST INFRASTRUCTURE: drives the per-thread kernel bodies of sdr-modem_amd/csrc/sdrm_kernels.h on
+// the host, thread by thread and phase by phase (a __syncthreads() becomes the end of a loop over thread ids), with
+// the same planning code the C-ABI uses (sdrm_plan.cpp).  It lets the CPU-only test suite check tiling, history
+// hand-off, decimation phase, ring indexing and the clock loop's block-wise execution against the oracle without
+// a GPU.  It is NOT a fallback: the product library never links or loads this file.
+//
+// K2 (DC blocker) is wave-level code on the GPU (DPP chain); here the same ring layout and block structure are
+// walked with a plain sequential running sum.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../sdr-modem_amd/csrc/sdrm_plan.h"
+#include "../../sdr-modem_amd/csrc/sdrm_tables.h"
+
+using namespace sdrm;
+
+struct EmuBatch {
+    BatchPlan plan;
+    std::vector<sdrm_f2> hist;
+    std::vector<float> z, dcout, dcstate;
+    std::vector<sdrm_clock_state> clock;
+    std::vector<int8_t> out8;
+    std::vector<float> outf;
+    std::vector<uint32_t> outlen;
+    std::vector<sdrm_chunk_ctl> ctl;
+};
+
+extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out) {
+    EmuBatch *b = new EmuBatch();
+    int code = plan_batch(cfgs, n, b->plan);
+    if (code != 0) {
+        delete b;
+        return code;
+    }
+    const BatchPlan &pl = b->plan;
+    b->hist.assign(n * 2 * (size_t) pl.hist_stride, sdrm_f2{0.0f, 0.0f});
+    b->z.assign(n * (size_t) pl.z_stride, 0.0f);
+    b->dcout.assign(n * (size_t) pl.z_stride, 0.0f);
+    b->dcstate.assign(pl.dc_state_floats + 8, 0.0f);
+    b->clock.resize(n);
+    for (size_t c = 0; c < n; c++) {
+        memset(&b->clock[c], 0, sizeof(sdrm_clock_state));
+        b->clock[c].mu = 0.5f;
+        b->clock[c].omega = pl.design[c].sps;
+    }
+    b->out8.assign(n * (size_t) pl.out_stride, 0);
+    b->outf.assign(n * (size_t) pl.out_stride, 0.0f);
+    b->outlen.assign(n, 0);
+    b->ctl.resize(n);
+    *out = b;
+    return 0;
+}
+
+extern "C" void emu_destroy(EmuBatch *b) { delete b; }
+
+static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
+    const BatchPlan &pl = b->plan;
+    const size_t C = pl.params.size();
+    std::vector<sdrm_f2> xs(SDRM_K1_NY + pl.t1_max);
+    std::vector<float> qs(SDRM_K1_NY + SDRM_K1_QPAD);
+    std::vector<sdrm_f2> bnd(SDRM_K1_THREADS);
+    std::vector<float> tab(260);
+    std::vector<sdrm_k1_regs> regs(SDRM_K1_THREADS);
+    for (size_t c = 0; c < C; c++) {
+        const sdrm_chan_params &p = pl.params[c];
+        const sdrm_chunk_ctl &ctl = b->ctl[c];
+        const sdrm_f2 *in = inputs[c];
+        const sdrm_f2 *hist = b->hist.data() + (c * 2 + ctl.parity) * pl.hist_stride;
+        for (uint32_t tile = 0; tile < ctl.tiles; tile++) {
+            // poison the "LDS" so that any read of a slot the kernel did not write shows up as NaN in the outputs
+            for (auto &v : xs) v = sdrm_f2{NAN, NAN};
+            for (auto &v : qs) v = NAN;
+            const sdrm_k1_tile t = sdrm_k1_tile_setup(p, ctl, (int) tile);
+            for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
+                sdrm_k1_phase_load(tid, t, in, hist, (int) p.hist_len, sdrm_atan_tab, xs.data(), tab.data());
+            for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
+                sdrm_k1_phase_lpf1(tid, t, p, pl.tap_pool.data() + p.taps1_off, xs.data(), bnd.data(), regs[tid]);
+            for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
+                sdrm_k1_phase_quad(tid, t, p, tab.data(), bnd.data(), regs[tid], qs.data());
+            for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
+                sdrm_k1_phase_lpf2(tid, t, p, pl.tap_pool.data() + p.taps2_off, qs.data(), b->z.data() + c * pl.z_stride);
+        }
+        sdrm_f2 *next = b->hist.data() + (c * 2 + (ctl.parity ^ 1u)) * pl.hist_stride;
+        for (int tid = 0; tid < 256; tid++) sdrm_hist_roll(tid, 256, p, ctl, in, hist, next);
+    }
+}
+
+static void emu_dc(EmuBatch *b) {
+    const BatchPlan &pl = b->plan;
+    for (size_t c = 0; c < pl.params.size(); c++) {
+        const sdrm_chan_params &p = pl.params[c];
+        if (p.dc_len == 0) continue;
+        const sdrm_chunk_ctl &ctl = b->ctl[c];
+        const uint32_t mx = p.rx_mask, ms = p.rs_mask, L = p.dc_len;
+        float *st = b->dcstate.data() + p.dc_state_off;
+        float *rx = st, *r[3] = {rx + (mx + 1), rx + (mx + 1) + (ms + 1), rx + (mx + 1) + 2 * (ms + 1)};
+        float *acc = rx + (mx + 1) + 3 * (ms + 1);
+        const float *z = b->z.data() + c * pl.z_stride;
+        float *out = b->dcout.data() + c * pl.z_stride;
+        for (uint32_t n0 = 0; n0 < ctl.nz; n0 += 64) {
+            const uint32_t cnt = ctl.nz - n0 < 64 ? ctl.nz - n0 : 64;
+            float u[64], xdd[64];
+            for (uint32_t l = 0; l < cnt; l++) {
+                u[l] = z[n0 + l];
+                rx[(ctl.zbase + n0 + l) & mx] = u[l];
+            }
+            for (uint32_t l = 0; l < cnt; l++) xdd[l] = rx[(ctl.zbase + n0 + l - 2 * (L - 1)) & mx];
+            for (int s = 0; s < 4; s++) {
+                float *ring_in = (s == 0) ? rx : r[s - 1];
+                const uint32_t m_in = (s == 0) ? mx : ms;
+                float t[64];
+                for (uint32_t l = 0; l < cnt; l++) t[l] = sdrm_boxcar_term(u[l], ring_in[(ctl.zbase + n0 + l - L) & m_in]);
+                float run = acc[s];
+                for (uint32_t l = 0; l < cnt; l++) {
+                    run = run + t[l];
+                    u[l] = sdrm_boxcar_out(run, p.dc_len_f);
+                }
+                acc[s] = run;
+                if (s < 3)
+                    for (uint32_t l = 0; l < cnt; l++) r[s][(ctl.zbase + n0 + l) & ms] = u[l];
+            }
+            for (uint32_t l = 0; l < cnt; l++) out[n0 + l] = xdd[l] - u[l];
+        }
+    }
+}
+
+static void emu_clock(EmuBatch *b) {
+    const BatchPlan &pl = b->plan;
+    const int C = (int) pl.params.size();
+    std::vector<float> ring(SDRM_K3_LANES * SDRM_K3_ROW);
+    for (int c0 = 0; c0 < C; c0 += SDRM_K3_LANES) {
+        for (auto &v : ring) v = NAN;
+        sdrm_k3_lane lanes[SDRM_K3_LANES];
+        int max_nz = 0;
+        const int nl = C - c0 < SDRM_K3_LANES ? C - c0 : SDRM_K3_LANES;
+        for (int l = 0; l < nl; l++) {
+            const int c = c0 + l;
+            const sdrm_chan_params &p = pl.params[c];
+            sdrm_clock_state &cs = b->clock[c];
+            sdrm_k3_lane &L = lanes[l];
+            L.k = sdrm_mm_consts{p.omega_mid, p.omega_lim, p.gain_omega, p.gain_mu};
+            L.cap = p.max_len;
+            L.nz = (int) b->ctl[c].nz;
+            L.kept = (int) cs.kept;
+            L.oo = 0;
+            L.st.mu = cs.mu;
+            L.st.omega = cs.omega;
+            L.st.last = cs.last;
+            L.st.ii = 0;
+            L.st.prev = 0;
+            float *row = ring.data() + l * SDRM_K3_ROW;
+            for (int j = 0; j < L.kept; j++) row[(j - L.kept) & (SDRM_K3_RING - 1)] = cs.hist[j];
+            max_nz = L.nz > max_nz ? L.nz : max_nz;
+        }
+        const int nblocks = (max_nz + SDRM_K3_BLOCK - 1) / SDRM_K3_BLOCK;
+        for (int k = 0; k <= nblocks; k++) {
+            if (k < nblocks) {
+                for (int r = 0; r < nl; r++) {
+                    const int cr = c0 + r;
+                    const float *src = (pl.params[cr].dc_len ? b->dcout.data() : b->z.data()) + (size_t) cr * pl.z_stride;
+                    float *row = ring.data() + r * SDRM_K3_ROW;
+                    for (int n = k * SDRM_K3_BLOCK; n < (k + 1) * SDRM_K3_BLOCK && n < lanes[r].nz; n++)
+                        row[n & (SDRM_K3_RING - 1)] = src[n];
+                }
+            }
+            for (int l = 0; l < nl; l++) {
+                sdrm_k3_lane &L = lanes[l];
+                int avail = (k + 1) * SDRM_K3_BLOCK;
+                avail = avail < L.nz ? avail : L.nz;
+                const int c = c0 + l;
+                while (sdrm_k3_can_step(L, avail)) {
+                    const float soft = sdrm_k3_step(L, ring.data() + l * SDRM_K3_ROW, &sdrm_mmse_bank[0][0]);
+                    b->out8[(size_t) c * pl.out_stride + L.oo] = sdrm_soft_to_i8(soft);
+                    b->outf[(size_t) c * pl.out_stride + L.oo] = soft;
+                    L.oo++;
+                }
+            }
+        }
+        for (int l = 0; l < nl; l++) {
+            const int c = c0 + l;
+            sdrm_k3_lane &L = lanes[l];
+            sdrm_clock_state &cs = b->clock[c];
+            int from_n, new_kept;
+            sdrm_k3_finish(L, &from_n, &new_kept);
+            const float *row = ring.data() + l * SDRM_K3_ROW;
+            float tmp[SDRM_CLOCK_HCAP];
+            for (int j = 0; j < new_kept; j++) tmp[j] = row[(from_n + j) & (SDRM_K3_RING - 1)];
+            for (int j = 0; j < new_kept; j++) cs.hist[j] = tmp[j];
+            cs.kept = (uint32_t) new_kept;
+            cs.mu = L.st.mu;
+            cs.omega = L.st.omega;
+            cs.last = L.st.last;
+            b->outlen[c] = L.oo;
+        }
+    }
+}
+
+// inputs[c]: interleaved cf32, lens[c] samples.  Outputs: per channel pointers into emu-owned memory.
+extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t *lens, const int8_t **out8,
+                           const float **outf, size_t *outlens) {
+    const size_t C = b->plan.params.size();
+    plan_call(b->plan, lens, b->ctl.data());
+    std::vector<const sdrm_f2 *> ins(C);
+    for (size_t c = 0; c < C; c++) ins[c] = reinterpret_cast<const sdrm_f2 *>(inputs[c]);
+    emu_front(b, ins.data());
+    emu_dc(b);
+    emu_clock(b);
+    for (size_t c = 0; c < C; c++) {
+        out8[c] = b->out8.data() + c * b->plan.out_stride;
+        outf[c] = b->outf.data() + c * b->plan.out_stride;
+        outlens[c] = b->outlen[c];
+    }
+    return 0;
+}
+
+// stage taps for inspection
+extern "C" size_t emu_taps(EmuBatch *b, size_t c, int stage, float *dst, size_t cap) {
+    const std::vector<float> &t = stage == 2 ? b->plan.design[c].taps2 : b->plan.design[c].taps1;
+    for (size_t i = 0; i < t.size() && i < cap; i++) dst[i] = t[i];
+    return t.size();
+}
+
+extern "C" void emu_info(EmuBatch *b, size_t c, sdrm_fsk_info *info) {
+    const ChannelDesign &d = b->plan.design[c];
+    info->taps1_len = (uint32_t) d.taps1.size();
+    info->taps2_len = (uint32_t) d.taps2.size();
+    info->dc_length = d.dc_length;
+    info->quad_gain = d.quad_gain;
+    info->sps = d.sps;
+    info->gain_omega = d.gain_omega;
+    info->gain_mu = d.gain_mu;
+    info->omega_lim = d.omega_lim;
+}

@@ -1,0 +1,74 @@
+"""ctypes view of tests/emu/libsdrm_emu.so: the kernel bodies of the HIP path driven thread-by-thread on the host.
+TEST INFRASTRUCTURE (CPU-only suite); never used by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import sdrm_pkg
+
+sdrm_pkg.load()
+from sdr_modem_amd.binding import FskConfig, FskInfo, make_configs  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-s", "-C", EMU_DIR], stdout=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(EMU_DIR, "libsdrm_emu.so"))
+        L.emu_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.POINTER(C.c_void_p)]
+        L.emu_destroy.argtypes = [C.c_void_p]
+        L.emu_destroy.restype = None
+        L.emu_process.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.emu_taps.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.emu_taps.restype = C.c_size_t
+        L.emu_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FskInfo)]
+        L.emu_info.restype = None
+        _LIB = L
+    return _LIB
+
+
+class EmuBatch:
+    def __init__(self, cfgs):
+        self.n = len(cfgs)
+        self._cfgs = make_configs(list(cfgs))
+        self.h = C.c_void_p()
+        self.code = lib().emu_create(self._cfgs, self.n, C.byref(self.h))
+
+    def process(self, inputs):
+        """inputs: list of complex64 arrays. Returns (list of int8 arrays, list of float32 arrays)."""
+        keep = [np.ascontiguousarray(x).view(np.float32) if x is not None else np.zeros(0, np.float32) for x in inputs]
+        dummy = np.zeros(2, np.float32)
+        ptrs = (C.c_void_p * self.n)(*[(k.ctypes.data if len(k) else dummy.ctypes.data) for k in keep])
+        lens = (C.c_size_t * self.n)(*[len(k) // 2 for k in keep])
+        o8 = (C.c_void_p * self.n)()
+        of = (C.c_void_p * self.n)()
+        ol = (C.c_size_t * self.n)()
+        lib().emu_process(self.h, ptrs, lens, o8, of, ol)
+        r8, rf = [], []
+        for c in range(self.n):
+            n = ol[c]
+            r8.append(np.ctypeslib.as_array(C.cast(o8[c], C.POINTER(C.c_int8)), shape=(n,)).copy() if n else np.zeros(0, np.int8))
+            rf.append(np.ctypeslib.as_array(C.cast(of[c], C.POINTER(C.c_float)), shape=(n,)).copy() if n else np.zeros(0, np.float32))
+        return r8, rf
+
+    def taps(self, c, stage):
+        n = lib().emu_taps(self.h, c, stage, None, 0)
+        out = np.zeros(n, np.float32)
+        lib().emu_taps(self.h, c, stage, out.ctypes.data, n)
+        return out
+
+    def info(self, c):
+        inf = FskInfo()
+        lib().emu_info(self.h, c, C.byref(inf))
+        return inf
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().emu_destroy(self.h)

@@ -1,0 +1,275 @@
+"""`-m gpu`: the HIP path, called through the C-ABI (libsdrmodem_hip.so), against the CPU oracle.
+
+Bar (BASELINE.json north_star): float soft bits within 1e-4 RMS of the CPU reference.  The exact-mode kernels are
+built to be BIT-IDENTICAL (tolerance 0 on the fp32 soft bits and on the int8 output), which is what these tests
+assert; the RMS figure is checked as well so the stated tolerance is visible in the test."""
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import orc
+import sdrm_pkg
+
+sdrm_pkg.load()
+from sdr_modem_amd import binding, siggen  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RMS_TOL = 1e-4  # north_star tolerance on the float soft bits
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    L = binding.load()
+    assert L.sdrm_device_count() > 0, "these tests need an MI355X; the library has no CPU path"
+
+
+def assert_same(of, gf, o8, g8, where=""):
+    assert len(of) == len(gf) and len(o8) == len(g8), (where, len(of), len(gf))
+    if len(of):
+        rms = float(np.sqrt(np.mean((of.astype(np.float64) - gf.astype(np.float64)) ** 2)))
+        assert rms <= RMS_TOL, (where, rms)
+    assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)), (where, "float soft bits differ")
+    assert np.array_equal(o8, g8), (where, "int8 soft bits differ")
+
+
+def run_stream(cfg, iq, chunks, maxlen):
+    o = orc.Fsk(*cfg, maxlen)
+    g = binding.Batch([cfg + (maxlen,)], keep_soft=True)
+    assert o.code == 0 and g.code == 0
+    pos = 0
+    total = 0
+    for n in chunks:
+        part = iq[pos:pos + n]
+        pos += n
+        o8, of = o.process(part)
+        g8 = g.process([part])[0]
+        gf = g.last_soft(0)
+        assert_same(of, gf, o8, g8, where="pos %d" % pos)
+        total += len(o8)
+    g.close()
+    return total
+
+
+# ---------------------------------------------------------------- stage probes
+
+def test_probe_fast_atan2_bit_exact():
+    rng = np.random.default_rng(3)
+    y = np.concatenate([rng.standard_normal(100000), [0, 0, 1, -1, 1e-3, -1e-9, 0.0, -0.0, np.inf, np.nan, 1e-42, 3e38, 1e-39]])
+    x = np.concatenate([rng.standard_normal(100000), [0, -1, 1, -1, 1, -1, -0.0, 0.0, 1.0, 1.0, 1e-40, 3e38, 3e-39]])
+    k = np.arange(1, 256, dtype=np.float64) / 255.0
+    y = np.concatenate([y, k, k * (1 + 1e-7), k * (1 - 1e-7), [0.003921569, 0.0039215689, 0.00392157]]).astype(np.float32)
+    x = np.concatenate([x, np.ones(3 * 255 + 3)]).astype(np.float32)
+    out = np.zeros(len(y), np.float32)
+    assert binding.load().sdrm_probe_atan2(y.ctypes.data, x.ctypes.data, out.ctypes.data, len(y)) == 0
+    want = np.array([orc.lib().orc_fast_atan2f(a, b) for a, b in zip(y, x)], dtype=np.float32)
+    both_nan = np.isnan(out) & np.isnan(want)
+    assert np.array_equal(out.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_probe_inorder_wave_scan_is_the_sequential_fp32_sum(mode):
+    L = binding.load()
+    L.sdrm_set_scan_mode(mode)
+    rng = np.random.default_rng(mode)
+    for n in (1, 63, 64, 65, 1000, 4096 + 17):
+        t = (rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)).astype(np.float32)
+        t[n // 2] = 1e-41  # denormal term must not be flushed
+        out = np.zeros(n, np.float32)
+        carry = np.float32(0.37)
+        assert L.sdrm_probe_wave_scan(t.ctypes.data, carry, out.ctypes.data, n) == 0
+        want = np.zeros(n, np.float32)
+        acc = carry
+        for i in range(n):
+            acc = np.float32(t[i] + acc)
+            want[i] = acc
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (mode, n)
+    L.sdrm_set_scan_mode(0)
+
+
+def test_design_parameters_match_oracle():
+    cfg = (48000, 9600, 5000, 1, 2000, True)
+    g = binding.Batch([cfg + (4096,)])
+    o = orc.Fsk(*cfg, 4096)
+    inf, t1, t2 = o.info()
+    ginf = g.info(0)
+    for f in ("taps1_len", "taps2_len", "dc_length", "quad_gain", "sps", "gain_omega", "gain_mu", "omega_lim"):
+        assert getattr(inf, f) == getattr(ginf, f), f
+    assert np.array_equal(t1.view(np.uint32), g.taps(0, 1).view(np.uint32))
+    assert np.array_equal(t2.view(np.uint32), g.taps(0, 2).view(np.uint32))
+    g.close()
+
+
+# ---------------------------------------------------------------- the reference's own fixtures (test/test_fsk_demod.c)
+
+E2E = [
+    ("lucky7", (48000, 4800, 5000, 2, 2000, True), "lucky7.expected.cf32", "lucky7.expected.s8"),
+    ("lucky7_nodc", (48000, 4800, 5000, 2, 2000, False), "lucky7.expected.cf32", "lucky7.expected.nodc.s8"),
+    ("nusat", (192000, 40000, 5000, 1, 2000, True), "nusat.cf32", "processed.s8"),
+    ("nan", (240000, 9600, 5000, 1, 2000, True), "inputnan.cf32", "nan.s8"),
+]
+
+
+@pytest.mark.parametrize("name,cfg,inp,exp", E2E, ids=[e[0] for e in E2E])
+def test_reference_fixtures_through_fsk_demod_api(name, cfg, inp, exp):
+    """Reads like test/test_fsk_demod.c:22-50: 4096-sample buffers through fsk_demod_process, +-2 LSB vs the golden
+    file (the reference's tolerance) -- and, stronger, identical to the oracle."""
+    iq = np.fromfile(os.path.join(GOLDEN, inp), dtype=np.complex64)
+    want = np.fromfile(os.path.join(GOLDEN, exp), dtype=np.int8)
+    d = binding.FskDemod(*cfg, 4096)
+    assert d.code == 0
+    got = np.concatenate([d.process(iq[o:o + 4096]) for o in range(0, len(iq), 4096)])
+    d.close()
+    assert len(got) == len(want)
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 2
+    oracle8, _ = orc.demod_stream(cfg, iq, 4096)
+    assert np.array_equal(got, oracle8)
+
+
+# ---------------------------------------------------------------- config 2 of BASELINE.json + chunking edge cases
+
+def test_single_channel_48k_9600_vs_cpu_soft_bits():
+    iq = siggen.gmsk_channel(0, 4 * 131072)
+    n = run_stream((48000, 9600, 5000, 1, 2000, True), iq, [131072] * 4, 131072)
+    assert n > 4 * 26000
+
+
+def test_lucky7_float_soft_bits_all_configs():
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    for cfg in [(48000, 9600, 5000, 1, 2000, True), (48000, 9600, 5000, 1, 2000, False),
+                (48000, 4800, 5000, 2, 2000, True), (48000, 4800, 5000, 3, 2000, True)]:
+        run_stream(cfg, iq, [4096] * 23 + [96000 - 23 * 4096], 4096)
+
+
+def test_ragged_chunks():
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    chunks = [0, 1, 1, 1, 7, 0, 100, 3839, 3840, 3841, 5000, 9000, 1, 2, 8191, 12000, 64, 63, 65, 1]
+    for cfg in [(48000, 9600, 5000, 1, 2000, True), (48000, 4800, 5000, 2, 2000, True)]:
+        run_stream(cfg, iq, chunks, 12000)
+
+
+def test_mixed_rate_configs():
+    for cfg, fs, baud in [((240000, 19200, 5000, 5, 2000, True), 240000, 19200),
+                          ((48000, 1200, 5000, 8, 2000, True), 48000, 1200),
+                          ((48000, 1200, 5000, 1, 2000, True), 48000, 1200),  # sps 40: tail quirk, chunk-faithful
+                          ((240000, 19200, 5000, 1, 2000, True), 240000, 19200)]:
+        iq = siggen.gmsk_channel(3, 40000, fs=fs, baud=baud)
+        run_stream(cfg, iq, [16384, 5, 16384, 7227], 16384)
+
+
+def test_nan_inf_denormal_inputs():
+    iq = siggen.gmsk_channel(7, 20000)
+    iq[5000] = np.nan
+    iq[9000] = np.inf + 0j
+    iq[9001] = 1e-41 + 1e-42j
+    iq[12000:12100] *= np.float32(1e-38)  # denormal region
+    run_stream((48000, 9600, 5000, 1, 2000, False), iq, [4096] * 4, 4096)
+    run_stream((48000, 9600, 5000, 1, 2000, True), iq[10000:], [4096, 4096], 4096)
+
+
+def test_oversize_input_gives_no_output(capfd):
+    d = binding.FskDemod(48000, 9600, 5000, 1, 2000, True, 100)
+    assert len(d.process(siggen.gmsk_channel(1, 101))) == 0
+    d.close()
+    assert "<3>requested buffer 101 is more than max: 100" in capfd.readouterr().err
+
+
+# ---------------------------------------------------------------- batches (configs 3 and 5 shapes, scaled to seconds)
+
+def test_batch_256_channels_bit_exact_and_independent():
+    C_, N = 256, 16384
+    cfg = (48000, 9600, 5000, 1, 2000, True)
+    sig = siggen.gmsk_batch(C_, 2 * N)
+    g = binding.Batch([cfg + (N,)] * C_, keep_soft=True)
+    assert g.code == 0
+    outs = [g.process([sig[c, k * N:(k + 1) * N] for c in range(C_)]) for k in range(2)]
+    for c in list(range(0, C_, 37)) + [63, 64, 255]:
+        o8a, _ = orc.demod_stream(cfg, sig[c], N)
+        got = np.concatenate([outs[0][c], outs[1][c]])
+        assert np.array_equal(got, o8a), c
+    # size-independent property: every channel produced ~N*baud/fs symbols
+    lens = np.array([len(outs[1][c]) for c in range(C_)])
+    assert np.all(np.abs(lens - N / 5) < 40)
+    g.close()
+
+
+def test_mixed_batch_with_ragged_lengths():
+    cfgs = [(48000, 9600, 5000, 1, 2000, True, 8192), (48000, 4800, 5000, 2, 2000, False, 8192),
+            (240000, 19200, 5000, 5, 2000, True, 8192)] * 23
+    sigs = [siggen.gmsk_channel(i, 9000, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    g = binding.Batch(cfgs, keep_soft=True)
+    assert g.code == 0
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    for lo, hi in [(0, 5000), (5000, 5003), (5003, 9000)]:
+        lens = [(hi - lo) if i % 7 else max(0, hi - lo - 17) for i in range(len(cfgs))]
+        parts = [s[lo:lo + n] for s, n in zip(sigs, lens)]
+        g8 = g.process(parts)
+        for i, o in enumerate(oracles):
+            o8, of = o.process(parts[i])
+            assert_same(of, g.last_soft(i), o8, g8[i], where="ch %d" % i)
+    g.close()
+
+
+def test_full_size_chunk_properties_131072():
+    """BASELINE chunk size (config.conf:11 buffer_size 131072): spot-check channels against the oracle and check the
+    size-independent property that splitting the stream differently gives the same symbols (sps < 8)."""
+    N = 131072
+    cfg = (48000, 9600, 5000, 1, 2000, True)
+    sig = siggen.gmsk_batch(8, N)
+    a = binding.Batch([cfg + (N,)] * 8)
+    b = binding.Batch([cfg + (N,)] * 8)
+    whole = a.process([sig[c] for c in range(8)])
+    halves = [b.process([sig[c, :50000] for c in range(8)]), b.process([sig[c, 50000:] for c in range(8)])]
+    for c in range(8):
+        assert np.array_equal(whole[c], np.concatenate([halves[0][c], halves[1][c]]))
+    o8, _ = orc.demod_stream(cfg, sig[5], N)
+    assert np.array_equal(whole[5], o8)
+    a.close()
+    b.close()
+
+
+# ---------------------------------------------------------------- device-resident path + worker surface
+
+def test_device_resident_call_matches_host_call():
+    torch = pytest.importorskip("torch")
+    C_, N = 64, 8192
+    cfg = (48000, 9600, 5000, 1, 2000, True)
+    sig = siggen.gmsk_batch(C_, N)
+    g = binding.Batch([cfg + (N,)] * C_)
+    h = binding.Batch([cfg + (N,)] * C_)
+    t = torch.from_numpy(sig.view(np.float32).reshape(C_, 2 * N)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    g.process_device(t.data_ptr(), N, [N] * C_, stream)
+    torch.cuda.synchronize()
+    data, lens = g.fetch(N)
+    ref = h.process([sig[c] for c in range(C_)])
+    for c in range(C_):
+        assert lens[c] == len(ref[c]) and np.array_equal(data[c, :lens[c]], ref[c])
+    g.close()
+    h.close()
+
+
+def test_dsp_worker_file_sink_matches_oracle():
+    """dsp_worker push/pull surface (src/dsp_worker.c:44-106): put IQ buffers, get rx.demod2client.<id>.s8."""
+    L = binding.load()
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = binding.WorkerConfig(48000, 4800, 5000, 2, 2000, True, True, 0, 4096, 4, True, tmp.encode())
+        w = C.c_void_p()
+        assert L.dsp_worker_create(7, -1, C.byref(cfg), C.byref(w)) == 0
+        wid = C.c_uint32(7)
+        assert L.dsp_worker_find_by_id(C.byref(wid), w)
+        for off in range(0, len(iq), 4096):
+            part = np.ascontiguousarray(iq[off:off + 4096]).view(np.float32)
+            L.dsp_worker_put(part.ctypes.data, len(part) // 2, w)
+        L.dsp_worker_destroy(w)  # poison pill is delivered after the queued buffers (blocking queue)
+        got = np.fromfile(os.path.join(tmp, "rx.demod2client.7.s8"), dtype=np.int8)
+        dump = np.fromfile(os.path.join(tmp, "rx.sdr2demod.7.cf32"), dtype=np.complex64)
+    want, _ = orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq, 4096)
+    assert np.array_equal(dump, iq)
+    assert np.array_equal(got, want)
+    golden = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.s8"), dtype=np.int8)
+    assert np.abs(got.astype(np.int32) - golden.astype(np.int32)).max() <= 2

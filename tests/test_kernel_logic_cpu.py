@@ -1,0 +1,142 @@
+"""CPU-only checks of the HIP path's LOGIC: the per-thread kernel bodies (sdrm_kernels.h) and the host planning
+(sdrm_plan.cpp, sdrm_design.cpp) are driven on the host by tests/emu and must reproduce the oracle bit for bit --
+same tiling, history hand-off, decimation phase, DC rings and block-wise clock loop the GPU will execute.
+(The arithmetic itself -- no FMA, IEEE divide, denormals on gfx950 -- is what the `-m gpu` tests check.)"""
+import os
+
+import numpy as np
+import pytest
+
+import emu_api
+import orc
+import sdrm_pkg
+
+sdrm_pkg.load()
+from sdr_modem_amd import siggen  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run_both(cfg, iq, chunks, maxlen):
+    """cfg = (fs, baud, dev, decim, tw, dc). chunks = list of chunk lengths. Returns per-call (oracle, emu) outputs."""
+    o = orc.Fsk(*cfg, maxlen)
+    e = emu_api.EmuBatch([cfg + (maxlen,)])
+    assert o.code == 0 and e.code == 0
+    pos = 0
+    for n in chunks:
+        part = iq[pos:pos + n]
+        pos += n
+        o8, of = o.process(part)
+        e8, ef = e.process([part])
+        assert len(o8) == len(e8[0]), (pos, len(o8), len(e8[0]))
+        assert np.array_equal(of.view(np.uint32), ef[0].view(np.uint32)), (pos, np.abs(of - ef[0]).max())
+        assert np.array_equal(o8, e8[0])
+    return pos
+
+
+CONFIGS = [
+    (48000, 9600, 5000, 1, 2000, True),
+    (48000, 9600, 5000, 1, 2000, False),
+    (48000, 4800, 5000, 2, 2000, True),
+    (48000, 4800, 5000, 2, 2000, False),
+    (240000, 19200, 5000, 5, 2000, True),
+    (48000, 1200, 5000, 8, 2000, True),
+    (192000, 40000, 5000, 1, 2000, True),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c) for c in CONFIGS])
+def test_design_matches_oracle(cfg):
+    o = orc.Fsk(*cfg, 4096)
+    e = emu_api.EmuBatch([cfg + (4096,)])
+    inf, t1, t2 = o.info()
+    einf = e.info(0)
+    for f in ("taps1_len", "taps2_len", "dc_length", "quad_gain", "sps", "gain_omega", "gain_mu", "omega_lim"):
+        assert getattr(inf, f) == getattr(einf, f), f
+    assert np.array_equal(t1.view(np.uint32), e.taps(0, 1).view(np.uint32))
+    assert np.array_equal(t2.view(np.uint32), e.taps(0, 2).view(np.uint32))
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:4], ids=[str(c) for c in CONFIGS[:4]])
+def test_lucky7_stream_bit_exact(cfg):
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    run_both(cfg, iq, [4096] * 23 + [96000 - 23 * 4096], 4096)
+
+
+def test_ragged_chunks_cross_tiles_and_phases():
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    chunks = [0, 1, 1, 1, 7, 0, 100, 3839, 3840, 3841, 5000, 9000, 1, 2, 8191, 12000, 64, 63, 65, 1]
+    for cfg in [(48000, 9600, 5000, 1, 2000, True), (48000, 4800, 5000, 2, 2000, True), (48000, 4800, 5000, 3, 2000, True)]:
+        assert run_both(cfg, iq, chunks, 12000) <= len(iq)
+
+
+def test_synthetic_gmsk_large_chunk():
+    iq = siggen.gmsk_channel(0, 70000)
+    run_both((48000, 9600, 5000, 1, 2000, True), iq, [65536, 4464], 65536)
+
+
+def test_mixed_rate_configs_with_decimation():
+    for cfg, fs, baud in [((240000, 19200, 5000, 5, 2000, True), 240000, 19200),
+                          ((48000, 1200, 5000, 8, 2000, True), 48000, 1200)]:
+        iq = siggen.gmsk_channel(3, 30000, fs=fs, baud=baud)
+        run_both(cfg, iq, [10000, 5, 19995], 20000)
+
+
+@pytest.mark.parametrize("cfg,name", [((192000, 40000, 5000, 1, 2000, True), "nusat.cf32"),
+                                      ((240000, 9600, 5000, 1, 2000, True), "inputnan.cf32")])
+def test_reference_fixtures_nusat_and_nan(cfg, name):
+    iq = np.fromfile(os.path.join(GOLDEN, name), dtype=np.complex64)
+    n = len(iq)
+    chunks = [4096] * (n // 4096) + ([n % 4096] if n % 4096 else [])
+    run_both(cfg, iq, chunks, 4096)
+
+
+def test_sps_ge_8_tail_quirk_is_chunk_faithful():
+    """48 kHz / 1200 baud / decim 1 => sps 40: the reference re-emits a symbol at chunk edges (SURVEY finding 3)."""
+    iq = siggen.gmsk_channel(5, 40000, fs=48000, baud=1200)
+    cfg = (48000, 1200, 5000, 1, 2000, True)
+    run_both(cfg, iq, [4096] * 9, 4096)
+    run_both(cfg, iq, [1000] * 30, 4096)
+
+
+def test_nan_and_inf_inputs_no_dc():
+    rng = np.random.default_rng(11)
+    iq = siggen.gmsk_channel(7, 20000)
+    iq[5000] = np.nan
+    iq[9000] = np.inf + 0j
+    iq[9001] = 1e-41 + 1e-42j
+    run_both((48000, 9600, 5000, 1, 2000, False), iq, [4096] * 4, 4096)
+
+
+def test_batch_of_mixed_channels_is_independent():
+    cfgs = [(48000, 9600, 5000, 1, 2000, True, 8192), (48000, 4800, 5000, 2, 2000, False, 8192),
+            (240000, 19200, 5000, 5, 2000, True, 8192)] * 23  # 69 channels: two K3 waves, one partial
+    sigs = [siggen.gmsk_channel(i, 9000, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    e = emu_api.EmuBatch(cfgs)
+    assert e.code == 0
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    for lo, hi in [(0, 5000), (5000, 5003), (5003, 9000)]:
+        lens = [(hi - lo) if i % 7 else max(0, hi - lo - 17) for i in range(len(cfgs))]  # ragged per channel
+        parts = [s[lo:lo + n] for s, n in zip(sigs, lens)]
+        e8, ef = e.process(parts)
+        for i, o in enumerate(oracles):
+            o8, of = o.process(parts[i])
+            assert np.array_equal(o8, e8[i]), i
+            assert np.array_equal(of.view(np.uint32), ef[i].view(np.uint32)), i
+
+
+def test_oversize_input_is_dropped(capfd):
+    e = emu_api.EmuBatch([(48000, 9600, 5000, 1, 2000, True, 100)])
+    o = orc.Fsk(48000, 9600, 5000, 1, 2000, True, 100)
+    iq = siggen.gmsk_channel(1, 300)
+    for part in (iq[:100], iq[100:201], iq[201:300]):
+        o8, of = o.process(part)
+        e8, ef = e.process([part])
+        assert np.array_equal(o8, e8[0])
+    assert "more than max: 100" in capfd.readouterr().err
+
+
+def test_create_errors_match_reference():
+    assert emu_api.EmuBatch([(48000, 48000, 5000, 1, 2000, True, 4096)]).code == -1  # cutoff > fs/2
+    assert emu_api.EmuBatch([(0, 4800, 5000, 1, 2000, True, 4096)]).code == -1
+    assert emu_api.EmuBatch([(48000, 4800, 5000, 1, 0, True, 4096)]).code == -1
