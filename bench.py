@@ -41,6 +41,25 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """threads this process may really run at once: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.999)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, (quota + period - 1) // period))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def main():
     args = parse()
     import torch
@@ -183,7 +202,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import orc
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             row = x[0].cpu().numpy().view(np.complex64)[:2 * N]
             one, _, _ = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), 1, min(2.0, args.cpu_seconds))
             allc, secs, smp = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), cores, args.cpu_seconds)

@@ -105,7 +105,8 @@ int sdrm_batch_timing_read(sdrm_batch *batch, int which, double *total_ms, uint6
  * stage is). Return 0 on success. */
 int sdrm_probe_atan2(const float *y, const float *x, float *out, size_t n);
 int sdrm_probe_wave_scan(const float *terms, float carry_in, float *out, size_t n); /* in-order fp32 running sum */
-/* in-order scan flavour used by the probe and the DC kernel: 0 = DPP wave_shr, 1 = DPP row_shr + readlane */
+/* in-order scan flavour used by the probe and the DC kernel: 0 = hand-placed v_add_f32_dpp chain (default),
+ * 1 = the same wave_shr data flow through the compiler's update_dpp builtin */
 void sdrm_set_scan_mode(int mode);
 
 const char *sdrm_version(void);

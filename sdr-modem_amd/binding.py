@@ -55,6 +55,13 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64; if torch is going to be used in this
+    # process (bench.py, the device-resident test) it must be the copy that gets loaded, so import it first and let
+    # our library's libamdhip64.so dependency resolve to the already-loaded one.  Without torch we use /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libsdrmodem_hip.so is not built (run __graft_entry__.build() or make -C sdr-modem_amd/csrc); "
                            "there is no CPU fallback")

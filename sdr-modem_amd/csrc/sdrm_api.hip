@@ -52,6 +52,7 @@ struct sdrm_batch_t {
     int8_t *d_out8 = nullptr;
     float *d_outf = nullptr;
     uint32_t *d_outlen = nullptr;
+    uint32_t *d_flags = nullptr;  // [SLOTS][C] non-finite flags, one set per control slot
     sdrm_f2 *d_in = nullptr;  // staging for the host-buffer API (lazy)
     // host (pinned) mirrors
     sdrm_chunk_ctl *h_ctl = nullptr;  // [SLOTS][C]
@@ -103,7 +104,7 @@ static void batch_free(sdrm_batch_t *b) {
         }
     }
     void *dev_ptrs[] = {b->d_params, b->d_ctl, b->d_taps, b->d_atan, b->d_bank, b->d_hist, b->d_z, b->d_dcout,
-                        b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in};
+                        b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in, b->d_flags};
     for (void *p : dev_ptrs) {
         if (p) {
             (void) hipFree(p);
@@ -194,6 +195,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         code = code ? code : dev_alloc_zero(&b->d_outf, C * (size_t) out_stride);
     }
     code = code ? code : dev_alloc_zero(&b->d_outlen, C);
+    code = code ? code : dev_alloc_zero(&b->d_flags, C * SDRM_CTL_SLOTS);
     if (code != 0) {
         batch_free(b);
         return code;
@@ -362,6 +364,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, s));
     sdrm::DeviceBatch d = b->dev;
     d.ctl = d_ctl;
+    d.nonfinite = b->d_flags + (size_t) slot * C;
     d.max_tiles = max_tiles;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (b->timing) {
@@ -615,6 +618,26 @@ extern "C" int sdrm_probe_wave_scan(const float *terms, float carry_in, float *o
     (void) hipFree(dt);
     (void) hipFree(dout);
     return 0;
+}
+
+// diagnostics: allocate (once) and return the device buffer K3 writes its per-wave cycle stamps into; enable != 0
+// turns stamping on for subsequent calls.  Copies the stamps of the last call to `out` (4 x uint64 per wave).
+extern "C" int sdrm_batch_k3_stamps(sdrm_batch *b, int enable, unsigned long long *out, size_t max_waves) {
+    if (b == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t waves = (b->plan.params.size() + 63) / 64;
+    if (b->dev.k3_stamps == nullptr && enable) {
+        HIP_TRY(hipMalloc((void **) &b->dev.k3_stamps, waves * 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(b->dev.k3_stamps, 0, waves * 4 * sizeof(unsigned long long)));
+    }
+    if (out != nullptr && b->dev.k3_stamps != nullptr) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, b->dev.k3_stamps, std::min(waves, max_waves) * 4 * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost));
+    }
+    return (int) waves;
 }
 
 // selects the in-order scan flavour (0 = wave_shr DPP, 1 = row_shr DPP + readlane) for the probe and the DC kernel

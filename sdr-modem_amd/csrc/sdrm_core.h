@@ -31,10 +31,8 @@ struct sdrm_f2 {
 // float -> int32 with the x86-64 cvttss2si result for out-of-range / NaN (INT_MIN); the reference relies on
 // that behaviour at src/math/fast_atan2f.c:112 and src/dsp/clock_recovery_mm.c:110,122.
 SDRM_HD int sdrm_cvt_i32(float v) {
-    if (v >= -2147483648.0f && v < 2147483648.0f) {
-        return (int) v;
-    }
-    return SDRM_INT_MIN;
+    // |v| < 2^31 also rejects NaN; -2^31 itself converts to INT_MIN either way
+    return (fabsf(v) < 2147483648.0f) ? (int) v : SDRM_INT_MIN;
 }
 
 // reference src/math/fast_atan2f.c:87-157; tab = 257-entry arctan table (sdrm_tables.h)
@@ -84,12 +82,9 @@ SDRM_HD float sdrm_boxcar_out(float running, float len_f) { return running / len
 // reference src/dsp/fsk_demod.c:106 (VOLK generic volk_32f_s32f_convert_8i, scale 127)
 SDRM_HD int8_t sdrm_soft_to_i8(float v) {
     float r = v * 127.0f;
-    if (r > 127.0f) {
-        return 127;
-    }
-    if (r < -128.0f) {
-        return -128;
-    }
+    // clamp-then-round == the generic kernel's compare-then-round for every non-NaN r (NaN symbols never get here:
+    // the clock stage emits 0 for them)
+    r = fminf(fmaxf(r, -128.0f), 127.0f);
     return (int8_t) (int) rintf(r);
 }
 
@@ -103,59 +98,5 @@ struct sdrm_mm_state {
 struct sdrm_mm_consts {
     float omega_mid, omega_lim, gain_omega, gain_mu;
 };
-
-// MMSE bank row for a fractional delay (reference src/dsp/mmse_fir_interpolator.c:189); -1 = invalid (mu is NaN)
-SDRM_HD int sdrm_mmse_row(float mu) {
-    float scaled = mu * (float) SDRM_MMSE_STEPS;
-    int imu = sdrm_cvt_i32(rintf(scaled));  // rint((double)f) == rintf(f) for every float
-    if (imu < 0 || imu > SDRM_MMSE_STEPS) {
-        return -1;
-    }
-    return imu;
-}
-
-// 8-tap interpolation, reference src/dsp/mmse_fir_interpolator.c:188-191 + src/dsp/fir_filter.c:116-121.
-// w[0..7] = samples at ii..ii+7; lead[0..2] = samples at ii-3..ii-1 (only the last `nlead` = ii & 3 of them are
-// touched: the reference's 16-byte aligned dot product multiplies them by zero taps first).
-// row = bank row (8 taps, listing order); applied reversed.
-SDRM_HD float sdrm_mmse_dot(const float *w, const float *lead, int nlead, const float *row) {
-    float acc = 0.0f;
-    if (nlead >= 3) acc = acc + lead[0] * 0.0f;
-    if (nlead >= 2) acc = acc + lead[1] * 0.0f;
-    if (nlead >= 1) acc = acc + lead[2] * 0.0f;
-    acc = acc + w[0] * row[7];
-    acc = acc + w[1] * row[6];
-    acc = acc + w[2] * row[5];
-    acc = acc + w[3] * row[4];
-    acc = acc + w[4] * row[3];
-    acc = acc + w[5] * row[2];
-    acc = acc + w[6] * row[1];
-    acc = acc + w[7] * row[0];
-    return acc;
-}
-
-// One symbol of the loop (reference src/dsp/clock_recovery_mm.c:103-125).  `o` is the interpolator output for
-// the current (ii, mu).  Returns the soft value to emit and advances the state.
-SDRM_HD float sdrm_mm_advance(sdrm_mm_state &s, const sdrm_mm_consts &k, float o) {
-    if (isnan(o)) {
-        s.prev = s.ii;
-        s.ii = (int) ((uint32_t) s.ii + (uint32_t) sdrm_cvt_i32(floorf(s.omega)));
-        return 0.0f;
-    }
-    float s_last = (s.last < 0.0f) ? -1.0f : 1.0f;
-    float s_o = (o < 0.0f) ? -1.0f : 1.0f;
-    float mm = s_last * o - s_o * s.last;
-    s.last = o;
-    s.prev = s.ii;
-    s.omega = s.omega + k.gain_omega * mm;
-    float dev = s.omega - k.omega_mid;
-    float clipped = 0.5f * (fabsf(dev + k.omega_lim) - fabsf(dev - k.omega_lim));
-    s.omega = k.omega_mid + clipped;
-    s.mu = s.mu + s.omega + k.gain_mu * mm;
-    float whole = floorf(s.mu);
-    s.ii = (int) ((uint32_t) s.ii + (uint32_t) sdrm_cvt_i32(whole));
-    s.mu = s.mu - whole;
-    return o;
-}
 
 #endif  // SDRM_CORE_H

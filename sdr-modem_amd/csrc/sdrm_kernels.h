@@ -26,7 +26,7 @@
 
 #define SDRM_K3_LANES 64
 #define SDRM_K3_RING 256    // per-channel sample ring in LDS (power of two)
-#define SDRM_K3_ROW (SDRM_K3_RING + 1)
+#define SDRM_K3_PITCH 65    // floats between consecutive slots (64 channels + 1: conflict-free transposing writes)
 #define SDRM_K3_BLOCK 128   // samples staged per channel per step
 
 // immutable per-channel parameters (device array, one per channel)
@@ -56,7 +56,9 @@ struct sdrm_chunk_ctl {
 // mutable clock-recovery state (device array, one per channel)
 struct sdrm_clock_state {
     float mu, omega, last;
-    uint32_t kept;  // samples carried in hist[] (< SDRM_CLOCK_HCAP)
+    uint32_t kept;    // samples carried in hist[] (< SDRM_CLOCK_HCAP)
+    uint32_t poison;  // the carried samples may contain NaN/Inf (previous call saw some): no fast path
+    uint32_t pad[3];
     float hist[SDRM_CLOCK_HCAP];
 };
 
@@ -199,7 +201,7 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
 
 // phase 3: LPF2 with decimation (reference src/dsp/fir_filter.c:93-114), results to global z
 SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps2_rev,
-                                const float *qs, float *z_out) {
+                                const float *qs, float *z_out, uint32_t *nonfinite_flag) {
     const int base = tid * SDRM_K1_RZ;
     if (base >= t.m) {
         return;
@@ -223,11 +225,16 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
             }
         }
     }
+    bool odd = false;
 #pragma unroll
     for (int r = 0; r < SDRM_K1_RZ; r++) {
         if (base + r < t.m) {
             z_out[t.o_lo + base + r] = acc[r];
+            odd |= !(fabsf(acc[r]) < INFINITY);
         }
+    }
+    if (odd) {
+        *nonfinite_flag = 1u;  // tells the clock stage to take its general (NaN-aware) path for this channel
     }
 }
 
@@ -242,8 +249,8 @@ SDRM_HD void sdrm_hist_roll(int tid, int nthreads, const sdrm_chan_params &p, co
 
 // ------------------------------------------------------------------------------------------------ K3
 
-// per-lane context of the clock-recovery kernel; ring = this channel's row of the LDS sample ring.
-// Ring slot of chunk-relative sample n (n < 0: carried history) is n & (SDRM_K3_RING-1).
+// per-lane context of the clock-recovery kernel; ring = this channel's column of the LDS sample ring.
+// Ring slot of chunk-relative sample n (n < 0: carried history) is n & (SDRM_K3_RING-1); ring[slot][channel].
 struct sdrm_k3_lane {
     sdrm_mm_state st;
     sdrm_mm_consts k;
@@ -253,38 +260,126 @@ struct sdrm_k3_lane {
     uint32_t cap;      // max symbols per call (= max_input_buffer_length, clock_recovery_mm.c:103)
 };
 
-SDRM_HD float sdrm_k3_ring_get(const float *ring, int n) { return ring[n & (SDRM_K3_RING - 1)]; }
+SDRM_HD void sdrm_k3_ring_put(float *col, int n, float v) { col[(n & (SDRM_K3_RING - 1)) * SDRM_K3_PITCH] = v; }
+SDRM_HD float sdrm_k3_ring_get(const float *col, int n) { return col[(n & (SDRM_K3_RING - 1)) * SDRM_K3_PITCH]; }
 
 // can this lane produce its next symbol with `avail` chunk samples staged?  Mirrors the loop condition
-// `ii < working_len - 7 && oo < output_len` (clock_recovery_mm.c:103) with ii compared as size_t.
+// `ii < working_len - 7 && oo < output_len` (clock_recovery_mm.c:103) with ii compared as size_t (negative => stop).
 SDRM_HD bool sdrm_k3_can_step(const sdrm_k3_lane &L, int avail) {
-    if (L.st.ii < 0 || L.oo >= L.cap) {
-        return false;
-    }
-    // chunk-relative index of the first of the 8 samples is ii - kept; need +7 < avail
-    return (int64_t) L.st.ii - L.kept + 7 < (int64_t) avail;
+    // chunk-relative index of the first of the 8 samples is ii - kept; the window needs +7 < avail
+    return (L.st.ii >= 0) & (L.st.ii - L.kept + 7 < avail) & (L.oo < L.cap);
 }
 
-// one symbol; bank = MMSE table [129][8]; returns the float soft value
-SDRM_HD float sdrm_k3_step(sdrm_k3_lane &L, const float *ring, const float *bank) {
+// does the 11-sample neighbourhood [n-3, n+7] of this lane's window wrap around the ring?
+SDRM_HD bool sdrm_k3_wraps(const sdrm_k3_lane &L) {
+    const unsigned slot = (unsigned) (L.st.ii - L.kept) & (SDRM_K3_RING - 1);
+    return (slot - 3u) > (unsigned) (SDRM_K3_RING - 11);
+}
+
+// fetch the 8 window samples and the 3 samples in front of them.  CONTIG: one base address + constant offsets.
+template <bool CONTIG>
+SDRM_HD void sdrm_k3_window(const sdrm_k3_lane &L, const float *col, float (&w)[8], float (&lead)[3]) {
     const int n = L.st.ii - L.kept;
-    float w[8], lead[3];
+    if (CONTIG) {
+        const float *base = col + (n & (SDRM_K3_RING - 1)) * SDRM_K3_PITCH;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        w[j] = sdrm_k3_ring_get(ring, n + j);
-    }
+        for (int j = 0; j < 8; j++) {
+            w[j] = base[j * SDRM_K3_PITCH];
+        }
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        lead[j] = sdrm_k3_ring_get(ring, n - 3 + j);
-    }
-    const int row = sdrm_mmse_row(L.st.mu);
-    float o;
-    if (row < 0) {
-        o = NAN;
+        for (int j = 0; j < 3; j++) {
+            lead[j] = base[(j - 3) * SDRM_K3_PITCH];
+        }
     } else {
-        o = sdrm_mmse_dot(w, lead, L.st.ii & 3, bank + row * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            w[j] = sdrm_k3_ring_get(col, n + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            lead[j] = sdrm_k3_ring_get(col, n - 3 + j);
+        }
     }
-    return sdrm_mm_advance(L.st, L.k, o);
+}
+
+// The exact form of the reference's 16-byte aligned dot product (src/dsp/fir_filter.c:116-121): the `nlead` = ii & 3
+// samples in front of the window are multiplied by zero taps and summed first.
+SDRM_HD float sdrm_k3_lead_exact(const float *lead, int nlead) {
+    float acc = 0.0f;
+    if (nlead >= 3) acc = acc + lead[0] * 0.0f;
+    if (nlead >= 2) acc = acc + lead[1] * 0.0f;
+    if (nlead >= 1) acc = acc + lead[2] * 0.0f;
+    return acc;
+}
+
+// One symbol (reference src/dsp/clock_recovery_mm.c:103-125 with mmse_fir_interpolator.c:188-191 inlined).
+// bank_rev = MMSE table [129][8] with every row already reversed (the FIR applies the listed taps reversed,
+// fir_filter.c:25-28), so tap j multiplies window sample j.
+// FINITE: the caller guarantees every sample this lane can touch and the loop state are finite (no NaN/Inf entered
+// the stream): then the interpolator output is finite, the NaN branch and the zero-tap lead samples cannot matter,
+// mu stays in [0,1) and the float->int conversions are in range -- the same values with fewer instructions.
+template <bool FINITE>
+SDRM_HD float sdrm_k3_step(sdrm_k3_lane &L, const float (&w)[8], const float (&lead)[3], const float *bank_rev) {
+    const int ii = L.st.ii;
+    const float mu = L.st.mu;
+    const float scaled = mu * (float) SDRM_MMSE_STEPS;
+    int imu;
+    bool row_ok = true;
+    if (FINITE) {
+        imu = (int) rintf(scaled);  // rint((double)f) == rintf(f); half-to-even
+    } else {
+        row_ok = (scaled >= 0.0f) & (scaled <= (float) SDRM_MMSE_STEPS);  // false for NaN
+        imu = row_ok ? (int) rintf(scaled) : 0;
+    }
+    const float *row = bank_rev + imu * 8;
+    float acc = 0.0f;
+    if (!FINITE) {
+        // leading zero-tap samples only matter when one of them is NaN/Inf (x*0 = NaN); test all three at once
+        float probe = lead[0] * 0.0f;
+        probe = probe + lead[1] * 0.0f;
+        probe = probe + lead[2] * 0.0f;
+        if (probe != probe) {
+            acc = sdrm_k3_lead_exact(lead, ii & 3);
+        }
+    }
+    acc = acc + w[0] * row[0];
+    acc = acc + w[1] * row[1];
+    acc = acc + w[2] * row[2];
+    acc = acc + w[3] * row[3];
+    acc = acc + w[4] * row[4];
+    acc = acc + w[5] * row[5];
+    acc = acc + w[6] * row[6];
+    acc = acc + w[7] * row[7];
+    // the reference indexes out of bounds when mu is NaN; defined as a NaN symbol here
+    const float o = (FINITE || row_ok) ? acc : NAN;
+    // regular symbol (clock_recovery_mm.c:115-123)
+    const float last = L.st.last;
+    const float a = (last < 0.0f) ? -o : o;        // slice(last) * o
+    const float bneg = (o < 0.0f) ? -last : last;  // slice(o) * last
+    const float mm = a - bneg;
+    float om = L.st.omega + L.k.gain_omega * mm;
+    const float dev = om - L.k.omega_mid;
+    const float clipped = 0.5f * (fabsf(dev + L.k.omega_lim) - fabsf(dev - L.k.omega_lim));
+    om = L.k.omega_mid + clipped;
+    const float m2 = L.st.mu + om + L.k.gain_mu * mm;
+    const float whole = floorf(m2);
+    L.st.prev = ii;
+    if (FINITE) {
+        L.st.omega = om;
+        L.st.mu = m2 - whole;
+        L.st.last = o;
+        L.st.ii = ii + (int) whole;
+        return o;
+    }
+    // NaN symbol (:107-113): emit 0, skip floor(omega) samples, leave the loop state alone
+    const bool bad = o != o;
+    const float skip = floorf(L.st.omega);
+    const int step = bad ? sdrm_cvt_i32(skip) : sdrm_cvt_i32(whole);
+    L.st.omega = bad ? L.st.omega : om;
+    L.st.mu = bad ? mu : m2 - whole;
+    L.st.last = bad ? last : o;
+    L.st.ii = (int) ((uint32_t) ii + (uint32_t) step);
+    return bad ? 0.0f : o;
 }
 
 // after the last block: decide what to carry (clock_recovery_mm.c:127-135). Returns the chunk-relative index of

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS) void k1_front(DeviceBatch b, const
     __syncthreads();
     sdrm_k1_phase_quad(tid, t, p, tab, bnd, regs, qs);
     __syncthreads();
-    sdrm_k1_phase_lpf2(tid, t, p, b.tap_pool + p.taps2_off, qs, b.z + (size_t) c * b.z_stride);
+    sdrm_k1_phase_lpf2(tid, t, p, b.tap_pool + p.taps2_off, qs, b.z + (size_t) c * b.z_stride, b.nonfinite + c);
 }
 
 __global__ __launch_bounds__(256) void k1_hist_roll(DeviceBatch b, const sdrm_f2 *__restrict__ d_in, size_t in_stride) {
@@ -82,33 +82,29 @@ void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_strid
 // ================================================================================================ K2
 
 // In-order fp32 running sum across the 64 lanes of a wave: s[i] = fl(s[i-1] + t[i]), s[-1] = carry.
-// fp32 addition is not associative, so this is a chain of 63 dependent adds; each step moves the partial sums
-// one lane up with a DPP shift (no LDS).  Lanes whose predecessor is already final compute their final value,
-// finished lanes recompute the same value, unfinished lanes hold scratch.
-// MODE 0: wave_shr:1 (one shift across the whole wave).  MODE 1: row_shr:1 in 16-lane rows + readlane carries.
+// fp32 addition is not associative, so this is a chain of 63 dependent adds ("wavefront-prefix handoff"): each step
+// is ONE instruction, v_add_f32 with a DPP wave_shr:1 on its first source -- lane i adds its term to lane i-1's
+// partial sum; lane 0 has no source lane and (bound_ctrl off) keeps its value, which is already final.  After step k
+// lanes 0..k are final; finished lanes recompute the same value, unfinished lanes hold scratch.
+// MODE 0: hand-placed instruction chain (s_nop 1 = the 2 wait states a DPP read of a just-written VGPR needs).
+// MODE 1: the same data flow through the update_dpp builtin, scheduled by the compiler (v_mov + v_mov_dpp + v_add).
 template <int MODE>
 __device__ __forceinline__ float wave_inorder_sum(float t, float carry) {
-    float s = carry + t;  // lane 0 is final; the DPP below leaves lane 0's operand = carry
+    float s = carry + t;  // lane 0 is final
     if (MODE == 0) {
+        asm volatile(
+            ".rept 63\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            ".endr"
+            : "+v"(s)
+            : "v"(t));
+    } else {
         const int ci = __builtin_bit_cast(int, carry);
 #pragma unroll
         for (int k = 1; k < 64; k++) {
             int up = __builtin_amdgcn_update_dpp(ci, __builtin_bit_cast(int, s), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             s = __builtin_bit_cast(float, up) + t;
-        }
-    } else {
-#pragma unroll
-        for (int row = 0; row < 4; row++) {
-            float cv = carry;
-            if (row > 0) {
-                cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16 * row - 1));
-            }
-            const int ci = __builtin_bit_cast(int, cv);
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                int up = __builtin_amdgcn_update_dpp(ci, __builtin_bit_cast(int, s), 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-                s = __builtin_bit_cast(float, up) + t;
-            }
         }
     }
     return s;
@@ -157,6 +153,7 @@ __global__ __launch_bounds__(64) void k2_dc(DeviceBatch b) {
     const uint32_t L = p.dc_len;
     const float Lf = p.dc_len_f;
     const uint32_t nz = ctl.nz;
+    bool odd = false;
     for (uint32_t n0 = 0; n0 < nz; n0 += 64) {
         const uint32_t n = n0 + lane;
         const bool valid = n < nz;
@@ -205,8 +202,13 @@ __global__ __launch_bounds__(64) void k2_dc(DeviceBatch b) {
         a3 = lane_bcast(s, last);
         v = sdrm_boxcar_out(s, Lf);
         if (valid) {
-            out[n] = xdd - v;
+            const float o = xdd - v;
+            out[n] = o;
+            odd |= !(fabsf(o) < INFINITY);
         }
+    }
+    if (odd) {
+        b.nonfinite[c] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
     }
     __syncthreads();
     for (uint32_t k = lane; k <= mx; k += 64) {
@@ -244,18 +246,23 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 
 // ================================================================================================ K3
 
-// One lane per channel, 64 channels per wave.  Per step the wave stages the next SDRM_K3_BLOCK samples of each of
-// its 64 channels into an LDS ring (coalesced row reads), then every lane runs its own Mueller&Mueller loop
-// (reference src/dsp/clock_recovery_mm.c:78-139) until it runs out of staged samples.
+// One lane per channel, 64 channels per wave (reference src/dsp/clock_recovery_mm.c:78-139 per lane).
+// The wave stages SDRM_K3_BLOCK samples of each of its 64 channels per step into an LDS ring, slot-major
+// (ring[slot][channel], pitch 65 floats): row reads from global are coalesced (lane = time), the transposing LDS
+// writes spread over the banks, and a lane's window reads (lane = channel) are one base address plus constant
+// offsets whenever the window does not wrap around the ring.  The next step's rows are prefetched into registers
+// before the current step's symbols are computed.  Symbols are computed by the short FINITE form of the loop body
+// unless a producer kernel flagged NaN/Inf in one of this wave's channels.
 __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
-    __shared__ float ring[SDRM_K3_LANES * SDRM_K3_ROW];
-    __shared__ __attribute__((aligned(16))) float bank[129 * 8];
+    __shared__ float ring[SDRM_K3_RING * SDRM_K3_PITCH];
+    __shared__ __attribute__((aligned(16))) float bank_rev[129 * 8];
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * SDRM_K3_LANES;
     const int c = c0 + lane;
     const bool active = c < b.n_channels;
+    const int nrows = b.n_channels - c0 < SDRM_K3_LANES ? b.n_channels - c0 : SDRM_K3_LANES;
     for (int k = lane; k < 129 * 8; k += 64) {
-        bank[k] = b.mmse_bank[k];
+        bank_rev[k] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];  // rows reversed once: tap j meets window sample j
     }
     sdrm_k3_lane L;
     L.kept = 0;
@@ -268,8 +275,11 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
     L.st.ii = 0;
     L.st.prev = 0;
     L.k.omega_mid = L.k.omega_lim = L.k.gain_omega = L.k.gain_mu = 0.0f;
-    float *my_ring = ring + lane * SDRM_K3_ROW;
+    float *my_col = ring + lane;  // this channel's column
     sdrm_clock_state *cs = b.clock_state + (active ? c : 0);
+    int uses_dc = 0;
+    bool clean = true;
+    uint32_t flagged = 0;
     if (active) {
         const sdrm_chan_params p = b.params[c];
         L.k.omega_mid = p.omega_mid;
@@ -282,70 +292,143 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
         L.st.mu = cs->mu;
         L.st.omega = cs->omega;
         L.st.last = cs->last;
+        uses_dc = p.dc_len != 0;
+        flagged = b.nonfinite[c];
+        clean = (flagged == 0) & (cs->poison == 0);
         for (int j = 0; j < L.kept; j++) {
-            my_ring[(j - L.kept) & (SDRM_K3_RING - 1)] = cs->hist[j];
+            sdrm_k3_ring_put(my_col, j - L.kept, cs->hist[j]);
         }
     }
-    int max_nz = 0;
-    for (int r = 0; r < SDRM_K3_LANES; r++) {
+    const bool wave_clean = __all(clean);
+    int max_nz = 0, min_nz = 0x7fffffff;
+    for (int r = 0; r < nrows; r++) {
         int v = __builtin_amdgcn_readlane(L.nz, r);
         max_nz = v > max_nz ? v : max_nz;
+        min_nz = v < min_nz ? v : min_nz;
     }
     __syncthreads();
 
     int8_t *o8 = b.out_i8 + (size_t) (active ? c : 0) * b.out_stride;
     float *of = b.out_f32 ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
+    const float *src_dc = b.dcout;
+    const float *src_z = b.z;
 
     const int nblocks = (max_nz + SDRM_K3_BLOCK - 1) / SDRM_K3_BLOCK;
+    float2 pre[SDRM_K3_LANES];  // prefetched row segments: pre[r] = samples (2*lane, 2*lane+1) of channel c0+r's block
+    // rows of one wave are z_stride apart; a full step (every row has the whole block) needs no per-row predicate
+#define K3_ROW_SRC(r) ((__builtin_amdgcn_readlane(uses_dc, (r)) ? src_dc : src_z) + (size_t) (c0 + (r)) * b.z_stride)
+#define K3_ISSUE(k)                                                                                          \
+    {                                                                                                        \
+        const int n_ = (k) * SDRM_K3_BLOCK + 2 * lane;                                                        \
+        if (((k) + 1) * SDRM_K3_BLOCK <= min_nz && nrows == SDRM_K3_LANES) {                                  \
+            _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
+                pre[r] = *reinterpret_cast<const float2 *>(K3_ROW_SRC(r) + n_);                               \
+            }                                                                                                \
+        } else {                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
+                pre[r] = make_float2(0.0f, 0.0f);                                                             \
+                if (r < nrows && n_ < __builtin_amdgcn_readlane(L.nz, r)) {                                   \
+                    pre[r] = *reinterpret_cast<const float2 *>(K3_ROW_SRC(r) + n_);                           \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+#define K3_COMMIT(k)                                                                                         \
+    {                                                                                                        \
+        const int n_ = (k) * SDRM_K3_BLOCK + 2 * lane;                                                        \
+        float *slot_ = ring + (n_ & (SDRM_K3_RING - 1)) * SDRM_K3_PITCH; /* n_ even: n_+1 is the next slot */ \
+        if (((k) + 1) * SDRM_K3_BLOCK <= min_nz && nrows == SDRM_K3_LANES) {                                  \
+            _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
+                slot_[r] = pre[r].x;                                                                          \
+                slot_[r + SDRM_K3_PITCH] = pre[r].y;                                                          \
+            }                                                                                                \
+        } else {                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
+                const int nz_r = r < nrows ? __builtin_amdgcn_readlane(L.nz, r) : 0;                          \
+                if (n_ < nz_r) {                                                                              \
+                    slot_[r] = pre[r].x;                                                                      \
+                }                                                                                            \
+                if (n_ + 1 < nz_r) {                                                                          \
+                    slot_[r + SDRM_K3_PITCH] = pre[r].y;                                                      \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+    // run every lane's loop as far as the staged samples allow
+#define K3_DRAIN(FIN)                                                                                        \
+    while (true) {                                                                                           \
+        const bool can = active && sdrm_k3_can_step(L, avail);                                                \
+        if (!__any(can)) {                                                                                    \
+            break;                                                                                           \
+        }                                                                                                    \
+        n_iter++;                                                                                            \
+        const bool wrap = can && sdrm_k3_wraps(L);                                                            \
+        if (can) {                                                                                            \
+            float w[8], lead[3];                                                                              \
+            if (__any(wrap)) {                                                                                \
+                sdrm_k3_window<false>(L, my_col, w, lead);                                                    \
+            } else {                                                                                         \
+                sdrm_k3_window<true>(L, my_col, w, lead);                                                     \
+            }                                                                                                \
+            const float soft = sdrm_k3_step<FIN>(L, w, lead, bank_rev);                                       \
+            o8[L.oo] = sdrm_soft_to_i8(soft);                                                                 \
+            if (of) {                                                                                         \
+                of[L.oo] = soft;                                                                              \
+            }                                                                                                \
+            L.oo++;                                                                                           \
+        }                                                                                                    \
+    }
+    if (nblocks > 0) {
+        K3_ISSUE(0)
+    }
+    unsigned long long t_stage = 0, t_drain = 0, n_iter = 0;
     for (int k = 0; k <= nblocks; k++) {
         // k == nblocks: no staging, only drains what the carried history alone allows (nz == 0 case)
+        unsigned long long t0 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         if (k < nblocks) {
-            for (int r = 0; r < SDRM_K3_LANES; r++) {
-                const int cr = c0 + r;
-                if (cr >= b.n_channels) {
-                    break;
-                }
-                const int nz_r = __builtin_amdgcn_readlane(L.nz, r);
-                const float *src = (b.params[cr].dc_len ? b.dcout : b.z) + (size_t) cr * b.z_stride;
-                float *row = ring + r * SDRM_K3_ROW;
-#pragma unroll
-                for (int h = 0; h < SDRM_K3_BLOCK / 64; h++) {
-                    const int n = k * SDRM_K3_BLOCK + h * 64 + lane;
-                    if (n < nz_r) {
-                        row[n & (SDRM_K3_RING - 1)] = src[n];
-                    }
-                }
+            K3_COMMIT(k)
+            if (k + 1 < nblocks) {
+                K3_ISSUE(k + 1)
             }
         }
         __syncthreads();
+        unsigned long long t1 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         int avail = (k + 1) * SDRM_K3_BLOCK;
         avail = avail < L.nz ? avail : L.nz;
-        while (true) {
-            const bool can = active && sdrm_k3_can_step(L, avail);
-            if (!__any(can)) {
-                break;
-            }
-            if (can) {
-                const float soft = sdrm_k3_step(L, my_ring, bank);
-                o8[L.oo] = sdrm_soft_to_i8(soft);
-                if (of) {
-                    of[L.oo] = soft;
-                }
-                L.oo++;
-            }
+        if (wave_clean) {
+            K3_DRAIN(true)
+        } else {
+            K3_DRAIN(false)
         }
         __syncthreads();
+        if (b.k3_stamps) {
+            unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            t_stage += t1 - t0;
+            t_drain += t2 - t1;
+        }
     }
+    if (b.k3_stamps && lane == 0) {  // diagnostic only: cycles spent staging vs in the symbol loops, per wave
+        b.k3_stamps[blockIdx.x * 4 + 0] = t_stage;
+        b.k3_stamps[blockIdx.x * 4 + 1] = t_drain;
+        b.k3_stamps[blockIdx.x * 4 + 2] = (unsigned long long) nblocks;
+        b.k3_stamps[blockIdx.x * 4 + 3] = n_iter;
+    }
+#undef K3_ISSUE
+#undef K3_COMMIT
+#undef K3_DRAIN
+#undef K3_ROW_SRC
     if (active) {
         int from_n, new_kept;
         sdrm_k3_finish(L, &from_n, &new_kept);
         for (int j = 0; j < new_kept; j++) {
-            cs->hist[j] = my_ring[(from_n + j) & (SDRM_K3_RING - 1)];
+            cs->hist[j] = sdrm_k3_ring_get(my_col, from_n + j);
         }
         cs->kept = (uint32_t) new_kept;
         cs->mu = L.st.mu;
         cs->omega = L.st.omega;
         cs->last = L.st.last;
+        cs->poison = flagged;      // the carried samples come from this call's stream
+        b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
         b.out_len[c] = L.oo;
     }
 }

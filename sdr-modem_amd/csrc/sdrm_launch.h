@@ -28,7 +28,9 @@ struct DeviceBatch {
     int8_t *out_i8;                  // [C][out_stride]
     float *out_f32;                  // [C][out_stride] or nullptr
     uint32_t *out_len;               // [C]
+    uint32_t *nonfinite;             // [C] of the call's control slot: set by K1/K2 when NaN/Inf reaches the clock stage
     uint32_t out_stride;
+    unsigned long long *k3_stamps;   // diagnostics (normally null): per K3 wave {staging cycles, loop cycles, steps, iterations}
     // launch geometry (host-computed maxima over the batch)
     uint32_t max_tiles;              // K1 grid.x for this call
     uint32_t t1_max;                 // sizes K1's LDS

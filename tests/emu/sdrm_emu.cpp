@@ -26,6 +26,7 @@ struct EmuBatch {
     std::vector<float> outf;
     std::vector<uint32_t> outlen;
     std::vector<sdrm_chunk_ctl> ctl;
+    std::vector<uint32_t> nonfinite;
 };
 
 extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out) {
@@ -50,6 +51,7 @@ extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out)
     b->outf.assign(n * (size_t) pl.out_stride, 0.0f);
     b->outlen.assign(n, 0);
     b->ctl.resize(n);
+    b->nonfinite.assign(n, 0);
     *out = b;
     return 0;
 }
@@ -81,7 +83,8 @@ static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
                 sdrm_k1_phase_quad(tid, t, p, tab.data(), bnd.data(), regs[tid], qs.data());
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
-                sdrm_k1_phase_lpf2(tid, t, p, pl.tap_pool.data() + p.taps2_off, qs.data(), b->z.data() + c * pl.z_stride);
+                sdrm_k1_phase_lpf2(tid, t, p, pl.tap_pool.data() + p.taps2_off, qs.data(), b->z.data() + c * pl.z_stride,
+                                   &b->nonfinite[c]);
         }
         sdrm_f2 *next = b->hist.data() + (c * 2 + (ctl.parity ^ 1u)) * pl.hist_stride;
         for (int tid = 0; tid < 256; tid++) sdrm_hist_roll(tid, 256, p, ctl, in, hist, next);
@@ -122,7 +125,10 @@ static void emu_dc(EmuBatch *b) {
                 if (s < 3)
                     for (uint32_t l = 0; l < cnt; l++) r[s][(ctl.zbase + n0 + l) & ms] = u[l];
             }
-            for (uint32_t l = 0; l < cnt; l++) out[n0 + l] = xdd[l] - u[l];
+            for (uint32_t l = 0; l < cnt; l++) {
+                out[n0 + l] = xdd[l] - u[l];
+                if (!(fabsf(out[n0 + l]) < INFINITY)) b->nonfinite[c] = 1u;
+            }
         }
     }
 }
@@ -130,10 +136,14 @@ static void emu_dc(EmuBatch *b) {
 static void emu_clock(EmuBatch *b) {
     const BatchPlan &pl = b->plan;
     const int C = (int) pl.params.size();
-    std::vector<float> ring(SDRM_K3_LANES * SDRM_K3_ROW);
+    std::vector<float> ring(SDRM_K3_RING * SDRM_K3_PITCH);
+    float bank_rev[129 * 8];
+    for (int k = 0; k < 129 * 8; k++) bank_rev[k] = (&sdrm_mmse_bank[0][0])[(k & ~7) + 7 - (k & 7)];
     for (int c0 = 0; c0 < C; c0 += SDRM_K3_LANES) {
         for (auto &v : ring) v = NAN;
         sdrm_k3_lane lanes[SDRM_K3_LANES];
+        bool clean[SDRM_K3_LANES];
+        uint32_t flagged[SDRM_K3_LANES];
         int max_nz = 0;
         const int nl = C - c0 < SDRM_K3_LANES ? C - c0 : SDRM_K3_LANES;
         for (int l = 0; l < nl; l++) {
@@ -151,8 +161,10 @@ static void emu_clock(EmuBatch *b) {
             L.st.last = cs.last;
             L.st.ii = 0;
             L.st.prev = 0;
-            float *row = ring.data() + l * SDRM_K3_ROW;
-            for (int j = 0; j < L.kept; j++) row[(j - L.kept) & (SDRM_K3_RING - 1)] = cs.hist[j];
+            flagged[l] = b->nonfinite[c];
+            clean[l] = flagged[l] == 0 && cs.poison == 0;
+            float *col = ring.data() + l;
+            for (int j = 0; j < L.kept; j++) sdrm_k3_ring_put(col, j - L.kept, cs.hist[j]);
             max_nz = L.nz > max_nz ? L.nz : max_nz;
         }
         const int nblocks = (max_nz + SDRM_K3_BLOCK - 1) / SDRM_K3_BLOCK;
@@ -161,9 +173,9 @@ static void emu_clock(EmuBatch *b) {
                 for (int r = 0; r < nl; r++) {
                     const int cr = c0 + r;
                     const float *src = (pl.params[cr].dc_len ? b->dcout.data() : b->z.data()) + (size_t) cr * pl.z_stride;
-                    float *row = ring.data() + r * SDRM_K3_ROW;
+                    float *col = ring.data() + r;
                     for (int n = k * SDRM_K3_BLOCK; n < (k + 1) * SDRM_K3_BLOCK && n < lanes[r].nz; n++)
-                        row[n & (SDRM_K3_RING - 1)] = src[n];
+                        sdrm_k3_ring_put(col, n, src[n]);
                 }
             }
             for (int l = 0; l < nl; l++) {
@@ -171,8 +183,15 @@ static void emu_clock(EmuBatch *b) {
                 int avail = (k + 1) * SDRM_K3_BLOCK;
                 avail = avail < L.nz ? avail : L.nz;
                 const int c = c0 + l;
+                const float *col = ring.data() + l;
                 while (sdrm_k3_can_step(L, avail)) {
-                    const float soft = sdrm_k3_step(L, ring.data() + l * SDRM_K3_ROW, &sdrm_mmse_bank[0][0]);
+                    // the GPU picks the window/step flavour per wave; every flavour must give the same values, so the
+                    // emulation lets each lane take the cheapest one its own state allows
+                    float w[8], lead[3];
+                    if (sdrm_k3_wraps(L)) sdrm_k3_window<false>(L, col, w, lead);
+                    else sdrm_k3_window<true>(L, col, w, lead);
+                    const float soft = clean[l] ? sdrm_k3_step<true>(L, w, lead, bank_rev)
+                                                : sdrm_k3_step<false>(L, w, lead, bank_rev);
                     b->out8[(size_t) c * pl.out_stride + L.oo] = sdrm_soft_to_i8(soft);
                     b->outf[(size_t) c * pl.out_stride + L.oo] = soft;
                     L.oo++;
@@ -185,14 +204,16 @@ static void emu_clock(EmuBatch *b) {
             sdrm_clock_state &cs = b->clock[c];
             int from_n, new_kept;
             sdrm_k3_finish(L, &from_n, &new_kept);
-            const float *row = ring.data() + l * SDRM_K3_ROW;
+            const float *col = ring.data() + l;
             float tmp[SDRM_CLOCK_HCAP];
-            for (int j = 0; j < new_kept; j++) tmp[j] = row[(from_n + j) & (SDRM_K3_RING - 1)];
+            for (int j = 0; j < new_kept; j++) tmp[j] = sdrm_k3_ring_get(col, from_n + j);
             for (int j = 0; j < new_kept; j++) cs.hist[j] = tmp[j];
             cs.kept = (uint32_t) new_kept;
             cs.mu = L.st.mu;
             cs.omega = L.st.omega;
             cs.last = L.st.last;
+            cs.poison = flagged[l];
+            b->nonfinite[c] = 0;
             b->outlen[c] = L.oo;
         }
     }

@@ -72,6 +72,7 @@ def test_probe_fast_atan2_bit_exact():
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_probe_inorder_wave_scan_is_the_sequential_fp32_sum(mode):
+    """mode 0 = hand-placed v_add_f32_dpp chain, mode 1 = the same data flow through the update_dpp builtin"""
     L = binding.load()
     L.sdrm_set_scan_mode(mode)
     rng = np.random.default_rng(mode)

@@ -1,0 +1,27 @@
+"""Diagnostic: where do K3's cycles go (staging vs symbol loops)?  python tools/k3_probe.py [channels]"""
+import ctypes as C, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sdrm_pkg; sdrm_pkg.load()
+from sdr_modem_amd import binding, siggen
+Cn = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+N = 131072
+cfg = (48000, 9600, 5000, 1, 2000, True, N)
+base = np.stack([siggen.gmsk_channel(i, 2 * N) for i in range(8)])
+x = torch.from_numpy(np.tile(base, (Cn // 8, 1)).view(np.float32)).cuda()
+b = binding.Batch([cfg] * Cn)
+L = binding.load()
+L.sdrm_batch_k3_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+L.sdrm_batch_k3_stamps(b.h, 1, None, 0)
+st = torch.cuda.current_stream().cuda_stream
+for i in range(4):
+    b.process_device(x.data_ptr() + (i % 2) * N * 8, 2 * N, [N] * Cn, st)
+torch.cuda.synchronize()
+waves = (Cn + 63) // 64
+out = np.zeros((waves, 4), dtype=np.uint64)
+L.sdrm_batch_k3_stamps(b.h, 1, out.ctypes.data, waves)
+for w in range(min(waves, 4)):
+    stg, drn, nb, it = [int(v) for v in out[w]]
+    print("wave %d: staging %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration" % (
+        w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1)))

@@ -1,0 +1,65 @@
+// ubench_chain.hip -- latency of the dependent chains the sequential stages are made of, and the clock the chip holds
+// while only a few waves are resident.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+// MODE 0: 1024 dependent v_add_f32.  MODE 1: 1024 dependent v_add_f32_dpp wave_shr:1 (+ s_nop 1).
+// MODE 2: 1024 dependent v_add_f32_dpp row_shr:1.  MODE 3: 256 dependent LDS round trips (ds_read_b32, address from data)
+template <int MODE>
+__global__ __launch_bounds__(64) void k(float *out, unsigned long long *stamps, int reps) {
+    __shared__ int lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = (i * 7 + 3) & 1023;
+    __syncthreads();
+    float s = threadIdx.x * 0.001f, t = 1.0f + threadIdx.x * 1e-6f;
+    int idx = threadIdx.x;
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int r = 0; r < reps; r++) {
+        if (MODE == 0) {
+            asm volatile(".rept 1024\n\tv_add_f32 %0, %0, %1\n\t.endr" : "+v"(s) : "v"(t));
+        } else if (MODE == 1) {
+            asm volatile(".rept 1024\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(s) : "v"(t));
+        } else if (MODE == 2) {
+            asm volatile(".rept 1024\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(s) : "v"(t));
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < 256; i++) idx = lds[idx];
+        }
+    }
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * 64 + threadIdx.x] = s + idx;
+    if (threadIdx.x == 0) {
+        stamps[2 * blockIdx.x] = c1 - c0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+template <int MODE>
+static void run(const char *name, int blocks, int reps, int steps_per_rep) {
+    float *d;
+    unsigned long long *st, *h = (unsigned long long *) malloc(16 * blocks);
+    hipMalloc(&d, 256 * blocks);
+    hipMalloc(&st, 16 * blocks);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, st, reps);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, st, reps);
+    hipDeviceSynchronize();
+    hipMemcpy(h, st, 16 * blocks, hipMemcpyDeviceToHost);
+    double cyc = 0, rt = 0;
+    for (int i = 0; i < blocks; i++) { cyc += h[2 * i]; rt += h[2 * i + 1]; }
+    cyc /= blocks; rt /= blocks;
+    double steps = (double) reps * steps_per_rep;
+    printf("%-22s waves %5d: %7.2f shader-cycles/step, %7.2f ns/step, clock %.0f MHz\n", name, blocks, cyc / steps,
+           rt * 10.0 / steps, cyc / (rt * 10.0) * 1000.0);
+    hipFree(d); hipFree(st); free(h);
+}
+
+int main() {
+    for (int blocks : {4, 256, 4096}) {
+        run<0>("dependent v_add_f32", blocks, 200, 1024);
+        run<1>("dpp wave_shr chain", blocks, 200, 1024);
+        run<2>("dpp row_shr chain", blocks, 200, 1024);
+        run<3>("dependent ds_read_b32", blocks, 200, 256);
+    }
+    return 0;
+}

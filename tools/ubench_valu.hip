@@ -30,8 +30,12 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
             } else if (MODE == 2) {  // packed fma
                 acc[i] = __builtin_elementwise_fma(x[i], t, acc[i]);
             } else {  // scalar fma
-                acc[i].x = __builtin_fmaf(x[i].x, t.x, acc[i].x);
-                acc[i].y = __builtin_fmaf(x[i].y, t.x, acc[i].y);
+                float f0 = __builtin_fmaf(x[i].x, t.x, acc[i].x);
+                asm volatile("" : "+v"(f0));
+                float f1 = __builtin_fmaf(x[i].y, t.x, acc[i].y);
+                asm volatile("" : "+v"(f1));
+                acc[i].x = f0;
+                acc[i].y = f1;
             }
         }
 #pragma unroll
