@@ -82,13 +82,10 @@ def main():
     total_ch = C * world
 
     # --- configuration fan-out: rank 0 owns the channel table; RCCL broadcast (the only collective on this path)
-    cfg_table = torch.zeros((total_ch, 7), dtype=torch.int64, device=dev)
-    if rank == 0:
-        cfg_table[:] = torch.tensor([FS, BAUD, DEV, DECIM, TW, int(DC), N], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.broadcast(cfg_table, src=0)
-    mine = cfg_table[rank * C:(rank + 1) * C].cpu().numpy()
-    cfgs = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), bool(r[5]), int(r[6])) for r in mine]
+    from sdr_modem_amd import shard
+    table0 = [(FS, BAUD, DEV, DECIM, TW, DC, N)] * total_ch if rank == 0 else None
+    cfgs, lo, hi = shard.fanout_configs(table0, total_ch, device=dev)
+    assert hi - lo == C
 
     # --- synthetic input, resident in HBM: [C][R*N] complex64
     n_total = R * N
