@@ -26,7 +26,10 @@
 
 #define SDRM_K3_LANES 64
 #define SDRM_K3_RING 256    // per-channel sample ring in LDS (power of two)
-#define SDRM_K3_PITCH 65    // floats between consecutive slots (64 channels + 1: conflict-free transposing writes)
+#define SDRM_K3_PRE 3       // mirror rows below slot 0 (a symbol reads up to 3 samples before its window)
+#define SDRM_K3_POST 8      // mirror rows above slot RING-1 (a window is 8 samples)
+#define SDRM_K3_ROWS (SDRM_K3_PRE + SDRM_K3_RING + SDRM_K3_POST)
+#define SDRM_K3_PITCH 65    // floats between consecutive rows (64 channels + 1: conflict-free transposing writes)
 #define SDRM_K3_BLOCK 128   // samples staged per channel per step
 
 // immutable per-channel parameters (device array, one per channel)
@@ -260,8 +263,23 @@ struct sdrm_k3_lane {
     uint32_t cap;      // max symbols per call (= max_input_buffer_length, clock_recovery_mm.c:103)
 };
 
-SDRM_HD void sdrm_k3_ring_put(float *col, int n, float v) { col[(n & (SDRM_K3_RING - 1)) * SDRM_K3_PITCH] = v; }
-SDRM_HD float sdrm_k3_ring_get(const float *col, int n) { return col[(n & (SDRM_K3_RING - 1)) * SDRM_K3_PITCH]; }
+// `col` = this channel's column of the row-major ring (ring + channel).  Sample n lives in slot n & (RING-1), row
+// slot + PRE.  Slots < POST are mirrored above the ring and slots >= RING-PRE below it, so the 11 rows
+// [slot-3, slot+7] around any slot are contiguous: a symbol's samples are one base address plus constant offsets.
+SDRM_HD void sdrm_k3_ring_put(float *col, int n, float v) {
+    const int slot = n & (SDRM_K3_RING - 1);
+    col[(slot + SDRM_K3_PRE) * SDRM_K3_PITCH] = v;
+    if (slot < SDRM_K3_POST) {
+        col[(slot + SDRM_K3_RING + SDRM_K3_PRE) * SDRM_K3_PITCH] = v;
+    }
+    if (slot >= SDRM_K3_RING - SDRM_K3_PRE) {
+        col[(slot - SDRM_K3_RING + SDRM_K3_PRE) * SDRM_K3_PITCH] = v;
+    }
+}
+
+SDRM_HD float sdrm_k3_ring_get(const float *col, int n) {
+    return col[((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) * SDRM_K3_PITCH];
+}
 
 // can this lane produce its next symbol with `avail` chunk samples staged?  Mirrors the loop condition
 // `ii < working_len - 7 && oo < output_len` (clock_recovery_mm.c:103) with ii compared as size_t (negative => stop).
@@ -270,35 +288,17 @@ SDRM_HD bool sdrm_k3_can_step(const sdrm_k3_lane &L, int avail) {
     return (L.st.ii >= 0) & (L.st.ii - L.kept + 7 < avail) & (L.oo < L.cap);
 }
 
-// does the 11-sample neighbourhood [n-3, n+7] of this lane's window wrap around the ring?
-SDRM_HD bool sdrm_k3_wraps(const sdrm_k3_lane &L) {
-    const unsigned slot = (unsigned) (L.st.ii - L.kept) & (SDRM_K3_RING - 1);
-    return (slot - 3u) > (unsigned) (SDRM_K3_RING - 11);
-}
-
-// fetch the 8 window samples and the 3 samples in front of them.  CONTIG: one base address + constant offsets.
-template <bool CONTIG>
+// fetch the 8 window samples and the 3 samples in front of them: one base address + constant offsets
 SDRM_HD void sdrm_k3_window(const sdrm_k3_lane &L, const float *col, float (&w)[8], float (&lead)[3]) {
     const int n = L.st.ii - L.kept;
-    if (CONTIG) {
-        const float *base = col + (n & (SDRM_K3_RING - 1)) * SDRM_K3_PITCH;
+    const float *base = col + ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) * SDRM_K3_PITCH;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            w[j] = base[j * SDRM_K3_PITCH];
-        }
+    for (int j = 0; j < 8; j++) {
+        w[j] = base[j * SDRM_K3_PITCH];
+    }
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            lead[j] = base[(j - 3) * SDRM_K3_PITCH];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            w[j] = sdrm_k3_ring_get(col, n + j);
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            lead[j] = sdrm_k3_ring_get(col, n - 3 + j);
-        }
+    for (int j = 0; j < 3; j++) {
+        lead[j] = base[(j - 3) * SDRM_K3_PITCH];
     }
 }
 

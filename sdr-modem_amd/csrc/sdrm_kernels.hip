@@ -247,14 +247,15 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // ================================================================================================ K3
 
 // One lane per channel, 64 channels per wave (reference src/dsp/clock_recovery_mm.c:78-139 per lane).
-// The wave stages SDRM_K3_BLOCK samples of each of its 64 channels per step into an LDS ring, slot-major
-// (ring[slot][channel], pitch 65 floats): row reads from global are coalesced (lane = time), the transposing LDS
-// writes spread over the banks, and a lane's window reads (lane = channel) are one base address plus constant
-// offsets whenever the window does not wrap around the ring.  The next step's rows are prefetched into registers
-// before the current step's symbols are computed.  Symbols are computed by the short FINITE form of the loop body
-// unless a producer kernel flagged NaN/Inf in one of this wave's channels.
+// The wave stages SDRM_K3_BLOCK samples of each of its 64 channels per step into an LDS ring, row-major
+// (ring[row][channel], pitch 65 floats): row reads from global are coalesced (lane = time), the transposing LDS
+// writes spread over the banks, and a lane's 11 window samples (lane = channel) are one base address plus constant
+// offsets (mirror rows at both ends of the ring keep every window contiguous).  The next step's rows are prefetched
+// into registers before the current step's symbols are computed.  Symbols are computed by the short FINITE form of the
+// loop body unless a producer kernel flagged NaN/Inf in one of this wave's channels.
+template <bool SOFT>
 __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
-    __shared__ float ring[SDRM_K3_RING * SDRM_K3_PITCH];
+    __shared__ float ring[SDRM_K3_ROWS * SDRM_K3_PITCH];
     __shared__ __attribute__((aligned(16))) float bank_rev[129 * 8];
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * SDRM_K3_LANES;
@@ -300,29 +301,33 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
         }
     }
     const bool wave_clean = __all(clean);
+    // a wave whose 64 channels all read the same stream (all with / all without DC blocker) and all have a full block
+    // takes the unpredicated staging path: one base pointer, rows z_stride apart
+    const bool same_src = __all(!active || uses_dc) || __all(!active || !uses_dc);
     int max_nz = 0, min_nz = 0x7fffffff;
     for (int r = 0; r < nrows; r++) {
         int v = __builtin_amdgcn_readlane(L.nz, r);
         max_nz = v > max_nz ? v : max_nz;
         min_nz = v < min_nz ? v : min_nz;
     }
+    const bool uniform = same_src && nrows == SDRM_K3_LANES;
+    const float *row0 = (__builtin_amdgcn_readfirstlane(uses_dc) ? b.dcout : b.z) + (size_t) c0 * b.z_stride;
     __syncthreads();
 
     int8_t *o8 = b.out_i8 + (size_t) (active ? c : 0) * b.out_stride;
-    float *of = b.out_f32 ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
-    const float *src_dc = b.dcout;
-    const float *src_z = b.z;
+    float *of = SOFT ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
 
     const int nblocks = (max_nz + SDRM_K3_BLOCK - 1) / SDRM_K3_BLOCK;
     float2 pre[SDRM_K3_LANES];  // prefetched row segments: pre[r] = samples (2*lane, 2*lane+1) of channel c0+r's block
-    // rows of one wave are z_stride apart; a full step (every row has the whole block) needs no per-row predicate
-#define K3_ROW_SRC(r) ((__builtin_amdgcn_readlane(uses_dc, (r)) ? src_dc : src_z) + (size_t) (c0 + (r)) * b.z_stride)
+#define K3_ROW_SRC(r) ((__builtin_amdgcn_readlane(uses_dc, (r)) ? b.dcout : b.z) + (size_t) (c0 + (r)) * b.z_stride)
 #define K3_ISSUE(k)                                                                                          \
     {                                                                                                        \
         const int n_ = (k) * SDRM_K3_BLOCK + 2 * lane;                                                        \
-        if (((k) + 1) * SDRM_K3_BLOCK <= min_nz && nrows == SDRM_K3_LANES) {                                  \
+        if (uniform && ((k) + 1) * SDRM_K3_BLOCK <= min_nz) {                                                 \
+            const float *p_ = row0 + n_;                                                                      \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                pre[r] = *reinterpret_cast<const float2 *>(K3_ROW_SRC(r) + n_);                               \
+                pre[r] = *reinterpret_cast<const float2 *>(p_);                                               \
+                p_ += b.z_stride;                                                                             \
             }                                                                                                \
         } else {                                                                                             \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
@@ -333,23 +338,36 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
             }                                                                                                \
         }                                                                                                    \
     }
+    // transpose the prefetched rows into the ring; the full-block path writes rows directly and refreshes the mirror
+    // rows with a small copy pass, the ragged path goes element by element through sdrm_k3_ring_put
 #define K3_COMMIT(k)                                                                                         \
     {                                                                                                        \
         const int n_ = (k) * SDRM_K3_BLOCK + 2 * lane;                                                        \
-        float *slot_ = ring + (n_ & (SDRM_K3_RING - 1)) * SDRM_K3_PITCH; /* n_ even: n_+1 is the next slot */ \
-        if (((k) + 1) * SDRM_K3_BLOCK <= min_nz && nrows == SDRM_K3_LANES) {                                  \
+        if (uniform && ((k) + 1) * SDRM_K3_BLOCK <= min_nz) {                                                 \
+            float *row_ = ring + ((n_ & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) * SDRM_K3_PITCH;                   \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                slot_[r] = pre[r].x;                                                                          \
-                slot_[r + SDRM_K3_PITCH] = pre[r].y;                                                          \
+                row_[r] = pre[r].x;                                                                           \
+                row_[r + SDRM_K3_PITCH] = pre[r].y;                                                           \
+            }                                                                                                \
+            __builtin_amdgcn_wave_barrier();                                                                  \
+            if ((((k) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                          \
+                _Pragma("unroll") for (int j = 0; j < SDRM_K3_POST; j++) {                                    \
+                    my_col[(j + SDRM_K3_RING + SDRM_K3_PRE) * SDRM_K3_PITCH] = my_col[(j + SDRM_K3_PRE) * SDRM_K3_PITCH]; \
+                }                                                                                            \
+            }                                                                                                \
+            if (((((k) + 1) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                    \
+                _Pragma("unroll") for (int j = 0; j < SDRM_K3_PRE; j++) {                                     \
+                    my_col[j * SDRM_K3_PITCH] = my_col[(j + SDRM_K3_RING) * SDRM_K3_PITCH];                   \
+                }                                                                                            \
             }                                                                                                \
         } else {                                                                                             \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
                 const int nz_r = r < nrows ? __builtin_amdgcn_readlane(L.nz, r) : 0;                          \
                 if (n_ < nz_r) {                                                                              \
-                    slot_[r] = pre[r].x;                                                                      \
+                    sdrm_k3_ring_put(ring + r, n_, pre[r].x);                                                 \
                 }                                                                                            \
                 if (n_ + 1 < nz_r) {                                                                          \
-                    slot_[r + SDRM_K3_PITCH] = pre[r].y;                                                      \
+                    sdrm_k3_ring_put(ring + r, n_ + 1, pre[r].y);                                             \
                 }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
@@ -362,17 +380,12 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
             break;                                                                                           \
         }                                                                                                    \
         n_iter++;                                                                                            \
-        const bool wrap = can && sdrm_k3_wraps(L);                                                            \
         if (can) {                                                                                            \
             float w[8], lead[3];                                                                              \
-            if (__any(wrap)) {                                                                                \
-                sdrm_k3_window<false>(L, my_col, w, lead);                                                    \
-            } else {                                                                                         \
-                sdrm_k3_window<true>(L, my_col, w, lead);                                                     \
-            }                                                                                                \
+            sdrm_k3_window(L, my_col, w, lead);                                                               \
             const float soft = sdrm_k3_step<FIN>(L, w, lead, bank_rev);                                       \
             o8[L.oo] = sdrm_soft_to_i8(soft);                                                                 \
-            if (of) {                                                                                         \
+            if (SOFT) {                                                                                       \
                 of[L.oo] = soft;                                                                              \
             }                                                                                                \
             L.oo++;                                                                                           \
@@ -435,7 +448,11 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
 
 void launch_clock(const DeviceBatch &b, hipStream_t s) {
     unsigned blocks = (unsigned) ((b.n_channels + SDRM_K3_LANES - 1) / SDRM_K3_LANES);
-    hipLaunchKernelGGL(k3_clock, dim3(blocks), dim3(64), 0, s, b);
+    if (b.out_f32) {
+        hipLaunchKernelGGL(k3_clock<true>, dim3(blocks), dim3(64), 0, s, b);
+    } else {
+        hipLaunchKernelGGL(k3_clock<false>, dim3(blocks), dim3(64), 0, s, b);
+    }
 }
 
 // ================================================================================================ probes

@@ -136,7 +136,7 @@ static void emu_dc(EmuBatch *b) {
 static void emu_clock(EmuBatch *b) {
     const BatchPlan &pl = b->plan;
     const int C = (int) pl.params.size();
-    std::vector<float> ring(SDRM_K3_RING * SDRM_K3_PITCH);
+    std::vector<float> ring(SDRM_K3_ROWS * SDRM_K3_PITCH);
     float bank_rev[129 * 8];
     for (int k = 0; k < 129 * 8; k++) bank_rev[k] = (&sdrm_mmse_bank[0][0])[(k & ~7) + 7 - (k & 7)];
     for (int c0 = 0; c0 < C; c0 += SDRM_K3_LANES) {
@@ -188,8 +188,7 @@ static void emu_clock(EmuBatch *b) {
                     // the GPU picks the window/step flavour per wave; every flavour must give the same values, so the
                     // emulation lets each lane take the cheapest one its own state allows
                     float w[8], lead[3];
-                    if (sdrm_k3_wraps(L)) sdrm_k3_window<false>(L, col, w, lead);
-                    else sdrm_k3_window<true>(L, col, w, lead);
+                    sdrm_k3_window(L, col, w, lead);
                     const float soft = clean[l] ? sdrm_k3_step<true>(L, w, lead, bank_rev)
                                                 : sdrm_k3_step<false>(L, w, lead, bank_rev);
                     b->out8[(size_t) c * pl.out_stride + L.oo] = sdrm_soft_to_i8(soft);
