@@ -88,6 +88,11 @@ int sdrm_batch_process(sdrm_batch *batch, const sdrm_cf32 *const *inputs, const 
  * returns without synchronising.  Results stay on the device: see sdrm_batch_device_outputs(). */
 int sdrm_batch_process_device(sdrm_batch *batch, const void *d_input, size_t in_stride, const size_t *input_lens,
                               void *stream);
+/* Stages of consecutive device-resident calls overlap on the batch's own streams; `stream` only marks when the input
+ * is ready.  sdrm_batch_wait makes a stream wait (on the device) for the latest call's results; sdrm_batch_sync blocks
+ * the host until they are there. */
+int sdrm_batch_wait(sdrm_batch *batch, void *stream);
+int sdrm_batch_sync(sdrm_batch *batch);
 /* device pointers: int8 soft bits [C][out_stride], per-channel counts uint32[C], float soft bits or NULL */
 int sdrm_batch_device_outputs(sdrm_batch *batch, void **d_out_i8, size_t *out_stride, void **d_out_len,
                               void **d_out_f32);

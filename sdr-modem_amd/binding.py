@@ -43,7 +43,7 @@ EXPORTS = [
     "fsk_demod_create", "fsk_demod_process", "fsk_demod_destroy",
     "sdrm_batch_create", "sdrm_batch_destroy", "sdrm_batch_channels", "sdrm_batch_info", "sdrm_batch_taps",
     "sdrm_batch_process", "sdrm_batch_process_device", "sdrm_batch_device_outputs", "sdrm_batch_last_soft",
-    "sdrm_batch_fetch", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
+    "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
     "sdrm_probe_atan2", "sdrm_probe_wave_scan", "sdrm_set_scan_mode", "sdrm_version", "sdrm_device_count",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
     "interrupt_waiting_the_data", "destroy_queue",
@@ -82,6 +82,8 @@ def load():
     L.sdrm_batch_device_outputs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(vp)]
     L.sdrm_batch_last_soft.argtypes = [vp, C.c_size_t, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdrm_batch_fetch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdrm_batch_wait.argtypes = [vp, vp]
+    L.sdrm_batch_sync.argtypes = [vp]
     L.sdrm_batch_timing_enable.argtypes = [vp, C.c_int]
     L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sdrm_probe_atan2.argtypes = [vp, vp, vp, C.c_size_t]
@@ -187,6 +189,10 @@ class Batch:
         code = self.L.sdrm_batch_process_device(self.h, C.c_void_p(d_ptr), in_stride, arr, C.c_void_p(stream or 0))
         if code != 0:
             raise RuntimeError("sdrm_batch_process_device failed: %d" % code)
+
+    def sync(self):
+        if self.L.sdrm_batch_sync(self.h) != 0:
+            raise RuntimeError("sdrm_batch_sync failed")
 
     def last_soft(self, c):
         n = C.c_size_t()

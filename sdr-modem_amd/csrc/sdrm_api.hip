@@ -58,9 +58,18 @@ struct sdrm_batch_t {
     sdrm_chunk_ctl *h_ctl = nullptr;  // [SLOTS][C]
     uint32_t *h_outlen = nullptr;
     int8_t *h_out8 = nullptr;  // lazy
-    hipEvent_t slot_done[SDRM_CTL_SLOTS] = {};
+    hipEvent_t slot_done[SDRM_CTL_SLOTS] = {};   // clock stage of the call that used the slot has finished
+    hipEvent_t ev_in[SDRM_CTL_SLOTS] = {};       // caller's stream position when the call was made (input ready)
+    hipEvent_t ev_front[SDRM_CTL_SLOTS] = {};    // front-end (K1 + history roll) finished
+    hipEvent_t ev_dc[SDRM_CTL_SLOTS] = {};       // DC blocker finished
     bool slot_used[SDRM_CTL_SLOTS] = {};
+    // The three stages of consecutive calls overlap: each stage has its own stream, the stage-to-stage buffers
+    // (z, dcout) are double buffered, and events order producer -> consumer and buffer reuse.
+    hipStream_t s_front = nullptr, s_dc = nullptr, s_clock = nullptr;
+    float *d_z2 = nullptr, *d_dcout2 = nullptr;
+    bool any_nodc = false;
     uint64_t calls = 0;
+    int last_slot = -1;
     hipStream_t stream = nullptr;  // private stream of the host-buffer API
     sdrm::DeviceBatch dev = {};
     uint32_t in_stride = 0;  // staging stride (samples)
@@ -99,12 +108,21 @@ static void batch_free(sdrm_batch_t *b) {
         }
     }
     for (int i = 0; i < SDRM_CTL_SLOTS; i++) {
-        if (b->slot_done[i]) {
-            (void) hipEventDestroy(b->slot_done[i]);
+        hipEvent_t evs[4] = {b->slot_done[i], b->ev_in[i], b->ev_front[i], b->ev_dc[i]};
+        for (hipEvent_t e : evs) {
+            if (e) {
+                (void) hipEventDestroy(e);
+            }
+        }
+    }
+    hipStream_t streams[3] = {b->s_front, b->s_dc, b->s_clock};
+    for (hipStream_t st : streams) {
+        if (st) {
+            (void) hipStreamDestroy(st);
         }
     }
     void *dev_ptrs[] = {b->d_params, b->d_ctl, b->d_taps, b->d_atan, b->d_bank, b->d_hist, b->d_z, b->d_dcout,
-                        b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in, b->d_flags};
+                        b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in, b->d_flags, b->d_z2, b->d_dcout2};
     for (void *p : dev_ptrs) {
         if (p) {
             (void) hipFree(p);
@@ -185,8 +203,10 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     code = code ? code : dev_alloc_zero(&b->d_bank, 129 * 8);
     code = code ? code : dev_alloc_zero(&b->d_hist, C * 2 * (size_t) hist_stride);
     code = code ? code : dev_alloc_zero(&b->d_z, C * (size_t) z_stride);
+    code = code ? code : dev_alloc_zero(&b->d_z2, C * (size_t) z_stride);
     if (any_dc) {
         code = code ? code : dev_alloc_zero(&b->d_dcout, C * (size_t) z_stride);
+        code = code ? code : dev_alloc_zero(&b->d_dcout2, C * (size_t) z_stride);
         code = code ? code : dev_alloc_zero(&b->d_dcstate, dc_floats);
     }
     code = code ? code : dev_alloc_zero(&b->d_clock, C);
@@ -221,8 +241,23 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     e = e ? e : hipMemcpy(b->d_bank, sdrm_mmse_bank, sizeof(float) * 129 * 8, hipMemcpyHostToDevice);
     e = e ? e : hipMemcpy(b->d_clock, cs.data(), sizeof(sdrm_clock_state) * C, hipMemcpyHostToDevice);
     e = e ? e : hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    // HIP multiplexes streams onto a few hardware queues, and two streams on one queue run back to back.  Streams of
+    // different priority never share a queue, so give each stage its own level: the clock stage (the longest
+    // dependent chain, a handful of waves) highest, the wide front-end lowest.
+    int prio_low = 0, prio_high = 0;
+    e = e ? e : hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    const int prio_mid = (prio_low + prio_high) / 2;
+    e = e ? e : hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, prio_low);
+    e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
+    e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
     for (int i = 0; i < SDRM_CTL_SLOTS && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
+        e = e ? e : hipEventCreateWithFlags(&b->ev_in[i], hipEventDisableTiming);
+        e = e ? e : hipEventCreateWithFlags(&b->ev_front[i], hipEventDisableTiming);
+        e = e ? e : hipEventCreateWithFlags(&b->ev_dc[i], hipEventDisableTiming);
+    }
+    for (size_t c = 0; c < C; c++) {
+        b->any_nodc = b->any_nodc || pl.params[c].dc_len == 0;
     }
     if (e != hipSuccess) {
         fprintf(stderr, "<3>sdrmodem_hip: device initialisation failed: %s\n", hipGetErrorString(e));
@@ -352,47 +387,106 @@ extern "C" int sdrm_batch_timing_read(sdrm_batch *b, int which, double *total_ms
 
 // --- the call ------------------------------------------------------------------------------------
 
-static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t s) {
+// Enqueue one call.  `caller` is the stream on which the caller's input becomes ready; the stages run on the
+// batch's own streams so that the front-end of call i+1, the DC blocker of call i and the clock recovery of call i-1
+// can be resident together (the sequential stages only occupy a few waves).  Nothing waits on the host.
+static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller) {
     const size_t C = b->plan.design.size();
-    const int slot = (int) (b->calls % SDRM_CTL_SLOTS);
+    const uint64_t i = b->calls;
+    const int slot = (int) (i % SDRM_CTL_SLOTS);
     if (b->slot_used[slot]) {
         HIP_TRY(hipEventSynchronize(b->slot_done[slot]));  // that call's kernels have consumed the slot
     }
     sdrm_chunk_ctl *h = b->h_ctl + (size_t) slot * C;
     const uint32_t max_tiles = sdrm::plan_call(b->plan, lens, h);
     sdrm_chunk_ctl *d_ctl = b->d_ctl + (size_t) slot * C;
-    HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, s));
     sdrm::DeviceBatch d = b->dev;
     d.ctl = d_ctl;
     d.nonfinite = b->d_flags + (size_t) slot * C;
     d.max_tiles = max_tiles;
+    d.z = (i & 1) ? b->d_z2 : b->d_z;
+    d.dcout = (i & 1) ? b->d_dcout2 : b->d_dcout;
+    const int prev2 = (int) ((i + SDRM_CTL_SLOTS - 2) % SDRM_CTL_SLOTS);  // the call that last used these buffers
+    const bool have_prev2 = i >= 2;
+
+    // ---- front-end: needs the input, and z[i&1] released by its readers of call i-2
+    HIP_TRY(hipEventRecord(b->ev_in[slot], caller));
+    HIP_TRY(hipStreamWaitEvent(b->s_front, b->ev_in[slot], 0));
+    if (have_prev2) {
+        HIP_TRY(hipStreamWaitEvent(b->s_front, d.any_dc ? b->ev_dc[prev2] : b->slot_done[prev2], 0));
+        if (d.any_dc && b->any_nodc) {
+            HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[prev2], 0));  // channels without DC: K3 reads z
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, b->s_front));
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (b->timing) {
-        timing_begin(b, 0, s, &ev);
+        timing_begin(b, 0, b->s_front, &ev);
     }
-    sdrm::launch_front(d, d_in, in_stride, s);
+    sdrm::launch_front(d, d_in, in_stride, b->s_front);
     if (b->timing) {
-        timing_end(b, 0, s, ev);
+        timing_end(b, 0, b->s_front, ev);
     }
-    sdrm::launch_hist_roll(d, d_in, in_stride, s);
-    if (b->timing) {
-        timing_begin(b, 1, s, &ev);
+    sdrm::launch_hist_roll(d, d_in, in_stride, b->s_front);
+    HIP_TRY(hipEventRecord(b->ev_front[slot], b->s_front));
+
+    // ---- DC blocker: needs z of this call, and dcout[i&1] released by the clock stage of call i-2
+    if (d.any_dc) {
+        HIP_TRY(hipStreamWaitEvent(b->s_dc, b->ev_front[slot], 0));
+        if (have_prev2) {
+            HIP_TRY(hipStreamWaitEvent(b->s_dc, b->slot_done[prev2], 0));
+        }
+        if (b->timing) {
+            timing_begin(b, 1, b->s_dc, &ev);
+        }
+        sdrm::launch_dc(d, b->s_dc);
+        if (b->timing) {
+            timing_end(b, 1, b->s_dc, ev);
+        }
+        HIP_TRY(hipEventRecord(b->ev_dc[slot], b->s_dc));
     }
-    sdrm::launch_dc(d, s);
-    if (b->timing) {
-        timing_end(b, 1, s, ev);
-        timing_begin(b, 2, s, &ev);
+
+    // ---- clock recovery + int8
+    HIP_TRY(hipStreamWaitEvent(b->s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
+    if (d.any_dc && b->any_nodc) {
+        HIP_TRY(hipStreamWaitEvent(b->s_clock, b->ev_front[slot], 0));
     }
-    sdrm::launch_clock(d, s);
     if (b->timing) {
-        timing_end(b, 2, s, ev);
+        timing_begin(b, 2, b->s_clock, &ev);
+    }
+    sdrm::launch_clock(d, b->s_clock);
+    if (b->timing) {
+        timing_end(b, 2, b->s_clock, ev);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->slot_done[slot], s));
+    HIP_TRY(hipEventRecord(b->slot_done[slot], b->s_clock));
     b->slot_used[slot] = true;
+    b->last_slot = slot;
     b->calls++;
     if (b->timing && b->lanes[0].pending.size() > 4096) {
         timing_collect(b);
+    }
+    return 0;
+}
+
+// make `stream` wait for the results of the most recent call (device-side dependency, no host wait)
+extern "C" int sdrm_batch_wait(sdrm_batch *b, void *stream) {
+    if (b == nullptr) {
+        return -1;
+    }
+    if (b->last_slot >= 0) {
+        HIP_TRY(hipStreamWaitEvent((hipStream_t) stream, b->slot_done[b->last_slot], 0));
+    }
+    return 0;
+}
+
+// block the host until every enqueued call has finished
+extern "C" int sdrm_batch_sync(sdrm_batch *b) {
+    if (b == nullptr) {
+        return -1;
+    }
+    if (b->last_slot >= 0) {
+        HIP_TRY(hipEventSynchronize(b->slot_done[b->last_slot]));
     }
     return 0;
 }
@@ -466,6 +560,7 @@ extern "C" int sdrm_batch_process(sdrm_batch *b, const sdrm_cf32 *const *inputs,
     if (code != 0) {
         return code;
     }
+    HIP_TRY(hipStreamWaitEvent(b->stream, b->slot_done[b->last_slot], 0));
     HIP_TRY(hipMemcpyAsync(b->h_outlen, b->d_outlen, sizeof(uint32_t) * C, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     for (size_t c = 0; c < C; c++) {

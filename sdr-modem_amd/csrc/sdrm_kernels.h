@@ -288,17 +288,43 @@ SDRM_HD bool sdrm_k3_can_step(const sdrm_k3_lane &L, int avail) {
     return (L.st.ii >= 0) & (L.st.ii - L.kept + 7 < avail) & (L.oo < L.cap);
 }
 
-// fetch the 8 window samples and the 3 samples in front of them: one base address + constant offsets
-SDRM_HD void sdrm_k3_window(const sdrm_k3_lane &L, const float *col, float (&w)[8], float (&lead)[3]) {
+// everything one symbol reads from LDS: fetched for the lane's current (ii, mu) BEFORE the symbol is computed, so
+// that the fetch for the next symbol can be issued while the current one is still being quantised and stored
+struct sdrm_k3_operands {
+    float w[8];     // window samples ii .. ii+7
+    float lead[3];  // samples ii-3 .. ii-1 (only the general form looks at them)
+    float tap[8];   // MMSE bank row for mu, reversed: tap[j] multiplies w[j]
+    bool row_ok;    // false when mu is NaN (the reference indexes out of bounds there)
+};
+
+// reference src/dsp/mmse_fir_interpolator.c:189: row = rint(mu * 128) (mu*128 in fp32, half-to-even)
+template <bool FINITE>
+SDRM_HD void sdrm_k3_fetch(const sdrm_k3_lane &L, const float *col, const float *bank_rev, sdrm_k3_operands &F) {
     const int n = L.st.ii - L.kept;
     const float *base = col + ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) * SDRM_K3_PITCH;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        w[j] = base[j * SDRM_K3_PITCH];
+        F.w[j] = base[j * SDRM_K3_PITCH];
     }
+    if (!FINITE) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        lead[j] = base[(j - 3) * SDRM_K3_PITCH];
+        for (int j = 0; j < 3; j++) {
+            F.lead[j] = base[(j - 3) * SDRM_K3_PITCH];
+        }
+    }
+    const float scaled = L.st.mu * (float) SDRM_MMSE_STEPS;
+    int imu;
+    F.row_ok = true;
+    if (FINITE) {
+        imu = (int) rintf(scaled) & 0xff;  // mu in [0,1) => 0..128; the mask only keeps a stray lane inside the table
+    } else {
+        F.row_ok = (scaled >= 0.0f) & (scaled <= (float) SDRM_MMSE_STEPS);  // false for NaN
+        imu = F.row_ok ? (int) rintf(scaled) : 0;
+    }
+    const float *row = bank_rev + imu * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        F.tap[j] = row[j];
     }
 }
 
@@ -312,46 +338,35 @@ SDRM_HD float sdrm_k3_lead_exact(const float *lead, int nlead) {
     return acc;
 }
 
-// One symbol (reference src/dsp/clock_recovery_mm.c:103-125 with mmse_fir_interpolator.c:188-191 inlined).
-// bank_rev = MMSE table [129][8] with every row already reversed (the FIR applies the listed taps reversed,
-// fir_filter.c:25-28), so tap j multiplies window sample j.
+// One symbol (reference src/dsp/clock_recovery_mm.c:103-125 with mmse_fir_interpolator.c:188-191 inlined) from
+// operands fetched by sdrm_k3_fetch for the lane's current state.
 // FINITE: the caller guarantees every sample this lane can touch and the loop state are finite (no NaN/Inf entered
 // the stream): then the interpolator output is finite, the NaN branch and the zero-tap lead samples cannot matter,
 // mu stays in [0,1) and the float->int conversions are in range -- the same values with fewer instructions.
 template <bool FINITE>
-SDRM_HD float sdrm_k3_step(sdrm_k3_lane &L, const float (&w)[8], const float (&lead)[3], const float *bank_rev) {
+SDRM_HD float sdrm_k3_step(sdrm_k3_lane &L, const sdrm_k3_operands &F) {
     const int ii = L.st.ii;
     const float mu = L.st.mu;
-    const float scaled = mu * (float) SDRM_MMSE_STEPS;
-    int imu;
-    bool row_ok = true;
-    if (FINITE) {
-        imu = (int) rintf(scaled);  // rint((double)f) == rintf(f); half-to-even
-    } else {
-        row_ok = (scaled >= 0.0f) & (scaled <= (float) SDRM_MMSE_STEPS);  // false for NaN
-        imu = row_ok ? (int) rintf(scaled) : 0;
-    }
-    const float *row = bank_rev + imu * 8;
     float acc = 0.0f;
     if (!FINITE) {
         // leading zero-tap samples only matter when one of them is NaN/Inf (x*0 = NaN); test all three at once
-        float probe = lead[0] * 0.0f;
-        probe = probe + lead[1] * 0.0f;
-        probe = probe + lead[2] * 0.0f;
+        float probe = F.lead[0] * 0.0f;
+        probe = probe + F.lead[1] * 0.0f;
+        probe = probe + F.lead[2] * 0.0f;
         if (probe != probe) {
-            acc = sdrm_k3_lead_exact(lead, ii & 3);
+            acc = sdrm_k3_lead_exact(F.lead, ii & 3);
         }
     }
-    acc = acc + w[0] * row[0];
-    acc = acc + w[1] * row[1];
-    acc = acc + w[2] * row[2];
-    acc = acc + w[3] * row[3];
-    acc = acc + w[4] * row[4];
-    acc = acc + w[5] * row[5];
-    acc = acc + w[6] * row[6];
-    acc = acc + w[7] * row[7];
+    acc = acc + F.w[0] * F.tap[0];
+    acc = acc + F.w[1] * F.tap[1];
+    acc = acc + F.w[2] * F.tap[2];
+    acc = acc + F.w[3] * F.tap[3];
+    acc = acc + F.w[4] * F.tap[4];
+    acc = acc + F.w[5] * F.tap[5];
+    acc = acc + F.w[6] * F.tap[6];
+    acc = acc + F.w[7] * F.tap[7];
     // the reference indexes out of bounds when mu is NaN; defined as a NaN symbol here
-    const float o = (FINITE || row_ok) ? acc : NAN;
+    const float o = (FINITE || F.row_ok) ? acc : NAN;
     // regular symbol (clock_recovery_mm.c:115-123)
     const float last = L.st.last;
     const float a = (last < 0.0f) ? -o : o;        // slice(last) * o

@@ -374,21 +374,29 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
     }
     // run every lane's loop as far as the staged samples allow
 #define K3_DRAIN(FIN)                                                                                        \
-    while (true) {                                                                                           \
-        const bool can = active && sdrm_k3_can_step(L, avail);                                                \
-        if (!__any(can)) {                                                                                    \
-            break;                                                                                           \
-        }                                                                                                    \
-        n_iter++;                                                                                            \
-        if (can) {                                                                                            \
-            float w[8], lead[3];                                                                              \
-            sdrm_k3_window(L, my_col, w, lead);                                                               \
-            const float soft = sdrm_k3_step<FIN>(L, w, lead, bank_rev);                                       \
-            o8[L.oo] = sdrm_soft_to_i8(soft);                                                                 \
-            if (SOFT) {                                                                                       \
-                of[L.oo] = soft;                                                                              \
+    {                                                                                                        \
+        sdrm_k3_operands F;                                                                                   \
+        sdrm_k3_fetch<FIN>(L, my_col, bank_rev, F);                                                           \
+        while (true) {                                                                                       \
+            const bool can = active && sdrm_k3_can_step(L, avail);                                            \
+            if (!__any(can)) {                                                                                \
+                break;                                                                                       \
             }                                                                                                \
-            L.oo++;                                                                                           \
+            n_iter++;                                                                                        \
+            float soft = 0.0f;                                                                                \
+            if (can) {                                                                                        \
+                soft = sdrm_k3_step<FIN>(L, F);                                                               \
+            }                                                                                                \
+            /* operands of the NEXT symbol: issued before this one is quantised/stored so the LDS latency */ \
+            /* hides behind that work (lanes that cannot step again read rows they will simply re-read)   */ \
+            sdrm_k3_fetch<FIN>(L, my_col, bank_rev, F);                                                       \
+            if (can) {                                                                                        \
+                o8[L.oo] = sdrm_soft_to_i8(soft);                                                             \
+                if (SOFT) {                                                                                   \
+                    of[L.oo] = soft;                                                                          \
+                }                                                                                            \
+                L.oo++;                                                                                       \
+            }                                                                                                \
         }                                                                                                    \
     }
     if (nblocks > 0) {

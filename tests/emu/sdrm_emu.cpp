@@ -187,10 +187,15 @@ static void emu_clock(EmuBatch *b) {
                 while (sdrm_k3_can_step(L, avail)) {
                     // the GPU picks the window/step flavour per wave; every flavour must give the same values, so the
                     // emulation lets each lane take the cheapest one its own state allows
-                    float w[8], lead[3];
-                    sdrm_k3_window(L, col, w, lead);
-                    const float soft = clean[l] ? sdrm_k3_step<true>(L, w, lead, bank_rev)
-                                                : sdrm_k3_step<false>(L, w, lead, bank_rev);
+                    sdrm_k3_operands F;
+                    float soft;
+                    if (clean[l]) {
+                        sdrm_k3_fetch<true>(L, col, bank_rev, F);
+                        soft = sdrm_k3_step<true>(L, F);
+                    } else {
+                        sdrm_k3_fetch<false>(L, col, bank_rev, F);
+                        soft = sdrm_k3_step<false>(L, F);
+                    }
                     b->out8[(size_t) c * pl.out_stride + L.oo] = sdrm_soft_to_i8(soft);
                     b->outf[(size_t) c * pl.out_stride + L.oo] = soft;
                     L.oo++;
