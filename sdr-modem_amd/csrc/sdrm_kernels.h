@@ -25,7 +25,7 @@
 #define SDRM_K1_QPAD 16
 
 #define SDRM_K3_LANES 64
-#define SDRM_K3_RING 256    // per-channel sample ring in LDS (power of two)
+#define SDRM_K3_RING 512    // per-channel sample ring in LDS (power of two): 4 staging blocks
 #define SDRM_K3_PRE 3       // mirror rows below slot 0 (a symbol reads up to 3 samples before its window)
 #define SDRM_K3_POST 8      // mirror rows above slot RING-1 (a window is 8 samples)
 #define SDRM_K3_ROWS (SDRM_K3_PRE + SDRM_K3_RING + SDRM_K3_POST)

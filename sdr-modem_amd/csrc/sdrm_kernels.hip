@@ -246,23 +246,31 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 
 // ================================================================================================ K3
 
-// One lane per channel, 64 channels per wave (reference src/dsp/clock_recovery_mm.c:78-139 per lane).
-// The wave stages SDRM_K3_BLOCK samples of each of its 64 channels per step into an LDS ring, row-major
-// (ring[row][channel], pitch 65 floats): row reads from global are coalesced (lane = time), the transposing LDS
-// writes spread over the banks, and a lane's 11 window samples (lane = channel) are one base address plus constant
-// offsets (mirror rows at both ends of the ring keep every window contiguous).  The next step's rows are prefetched
-// into registers before the current step's symbols are computed.  Symbols are computed by the short FINITE form of the
-// loop body unless a producer kernel flagged NaN/Inf in one of this wave's channels.
+// One lane per channel, 64 channels per CONSUMER wave (reference src/dsp/clock_recovery_mm.c:78-139 per lane); a second
+// PRODUCER wave of the same workgroup stages the samples, so the two overlap.
+// Producer: per step, SDRM_K3_BLOCK samples of each of the 64 channels go from global memory (coalesced row reads,
+// lane = time, prefetched one step ahead into registers) into an LDS ring, row-major (ring[row][channel], pitch 65
+// floats => the transposing writes spread over the banks).  The ring holds 4 steps; mirror rows at both ends keep every
+// window contiguous.  Consumer: each lane runs its own loop while staged samples last; a symbol's 8 window samples are
+// one base address plus constant offsets, and the next symbol's operands are fetched before the current symbol is
+// quantised and stored.  The short FINITE form of the loop body is used unless a producer kernel flagged NaN/Inf in
+// one of this workgroup's channels.  One barrier per step hands block k to the consumer while block k+1 is written.
+size_t k3_lds_bytes() { return (size_t) (SDRM_K3_ROWS * SDRM_K3_PITCH + 129 * 8 + 2 * SDRM_K3_LANES) * sizeof(float); }
+
 template <bool SOFT>
-__global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
-    __shared__ float ring[SDRM_K3_ROWS * SDRM_K3_PITCH];
-    __shared__ __attribute__((aligned(16))) float bank_rev[129 * 8];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
+    extern __shared__ __attribute__((aligned(16))) float k3_lds[];
+    float *bank_rev = k3_lds;                       // [129*8], 16-byte aligned
+    float *ring = bank_rev + 129 * 8;               // [ROWS][PITCH]
+    int *nz_sh = reinterpret_cast<int *>(ring + SDRM_K3_ROWS * SDRM_K3_PITCH);  // [64] samples per channel
+    int *dc_sh = nz_sh + SDRM_K3_LANES;                                          // [64] reads dcout (1) or z (0)
+    const int lane = threadIdx.x & 63;
+    const bool producer = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) != 0;
     const int c0 = blockIdx.x * SDRM_K3_LANES;
     const int c = c0 + lane;
     const bool active = c < b.n_channels;
     const int nrows = b.n_channels - c0 < SDRM_K3_LANES ? b.n_channels - c0 : SDRM_K3_LANES;
-    for (int k = lane; k < 129 * 8; k += 64) {
+    for (int k = threadIdx.x; k < 129 * 8; k += 128) {
         bank_rev[k] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];  // rows reversed once: tap j meets window sample j
     }
     sdrm_k3_lane L;
@@ -278,48 +286,51 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
     L.k.omega_mid = L.k.omega_lim = L.k.gain_omega = L.k.gain_mu = 0.0f;
     float *my_col = ring + lane;  // this channel's column
     sdrm_clock_state *cs = b.clock_state + (active ? c : 0);
-    int uses_dc = 0;
     bool clean = true;
     uint32_t flagged = 0;
-    if (active) {
-        const sdrm_chan_params p = b.params[c];
-        L.k.omega_mid = p.omega_mid;
-        L.k.omega_lim = p.omega_lim;
-        L.k.gain_omega = p.gain_omega;
-        L.k.gain_mu = p.gain_mu;
-        L.cap = p.max_len;
-        L.nz = (int) b.ctl[c].nz;
-        L.kept = (int) cs->kept;
-        L.st.mu = cs->mu;
-        L.st.omega = cs->omega;
-        L.st.last = cs->last;
-        uses_dc = p.dc_len != 0;
-        flagged = b.nonfinite[c];
-        clean = (flagged == 0) & (cs->poison == 0);
-        for (int j = 0; j < L.kept; j++) {
-            sdrm_k3_ring_put(my_col, j - L.kept, cs->hist[j]);
+    if (!producer) {
+        int uses_dc = 0;
+        if (active) {
+            const sdrm_chan_params p = b.params[c];
+            L.k.omega_mid = p.omega_mid;
+            L.k.omega_lim = p.omega_lim;
+            L.k.gain_omega = p.gain_omega;
+            L.k.gain_mu = p.gain_mu;
+            L.cap = p.max_len;
+            L.nz = (int) b.ctl[c].nz;
+            L.kept = (int) cs->kept;
+            L.st.mu = cs->mu;
+            L.st.omega = cs->omega;
+            L.st.last = cs->last;
+            uses_dc = p.dc_len != 0;
+            flagged = b.nonfinite[c];
+            clean = (flagged == 0) & (cs->poison == 0);
+            for (int j = 0; j < L.kept; j++) {
+                sdrm_k3_ring_put(my_col, j - L.kept, cs->hist[j]);
+            }
         }
+        nz_sh[lane] = L.nz;
+        dc_sh[lane] = uses_dc;
     }
-    const bool wave_clean = __all(clean);
-    // a wave whose 64 channels all read the same stream (all with / all without DC blocker) and all have a full block
-    // takes the unpredicated staging path: one base pointer, rows z_stride apart
-    const bool same_src = __all(!active || uses_dc) || __all(!active || !uses_dc);
+    __syncthreads();
+    const int my_nz = nz_sh[lane];
+    const int my_dc = dc_sh[lane];
+    // a workgroup whose 64 channels all read the same stream (all with / all without DC blocker) and all have a full
+    // block takes the unpredicated staging path: one base pointer, rows z_stride apart
+    const bool same_src = __all(lane >= nrows || my_dc) || __all(lane >= nrows || !my_dc);
     int max_nz = 0, min_nz = 0x7fffffff;
     for (int r = 0; r < nrows; r++) {
-        int v = __builtin_amdgcn_readlane(L.nz, r);
+        int v = __builtin_amdgcn_readlane(my_nz, r);
         max_nz = v > max_nz ? v : max_nz;
         min_nz = v < min_nz ? v : min_nz;
     }
     const bool uniform = same_src && nrows == SDRM_K3_LANES;
-    const float *row0 = (__builtin_amdgcn_readfirstlane(uses_dc) ? b.dcout : b.z) + (size_t) c0 * b.z_stride;
-    __syncthreads();
-
-    int8_t *o8 = b.out_i8 + (size_t) (active ? c : 0) * b.out_stride;
-    float *of = SOFT ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
-
     const int nblocks = (max_nz + SDRM_K3_BLOCK - 1) / SDRM_K3_BLOCK;
-    float2 pre[SDRM_K3_LANES];  // prefetched row segments: pre[r] = samples (2*lane, 2*lane+1) of channel c0+r's block
-#define K3_ROW_SRC(r) ((__builtin_amdgcn_readlane(uses_dc, (r)) ? b.dcout : b.z) + (size_t) (c0 + (r)) * b.z_stride)
+
+    if (producer) {
+        const float *row0 = (__builtin_amdgcn_readfirstlane(my_dc) ? b.dcout : b.z) + (size_t) c0 * b.z_stride;
+        float2 pre[SDRM_K3_LANES];  // prefetched row segments: pre[r] = samples (2*lane, 2*lane+1) of channel c0+r
+#define K3_ROW_SRC(r) ((__builtin_amdgcn_readlane(my_dc, (r)) ? b.dcout : b.z) + (size_t) (c0 + (r)) * b.z_stride)
 #define K3_ISSUE(k)                                                                                          \
     {                                                                                                        \
         const int n_ = (k) * SDRM_K3_BLOCK + 2 * lane;                                                        \
@@ -332,14 +343,14 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
         } else {                                                                                             \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
                 pre[r] = make_float2(0.0f, 0.0f);                                                             \
-                if (r < nrows && n_ < __builtin_amdgcn_readlane(L.nz, r)) {                                   \
+                if (r < nrows && n_ < __builtin_amdgcn_readlane(my_nz, r)) {                                  \
                     pre[r] = *reinterpret_cast<const float2 *>(K3_ROW_SRC(r) + n_);                           \
                 }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
     }
-    // transpose the prefetched rows into the ring; the full-block path writes rows directly and refreshes the mirror
-    // rows with a small copy pass, the ragged path goes element by element through sdrm_k3_ring_put
+        // transpose the prefetched rows into the ring; the full-block path writes rows directly and refreshes the
+        // mirror rows with a small copy pass, the ragged path goes element by element through sdrm_k3_ring_put
 #define K3_COMMIT(k)                                                                                         \
     {                                                                                                        \
         const int n_ = (k) * SDRM_K3_BLOCK + 2 * lane;                                                        \
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
             }                                                                                                \
         } else {                                                                                             \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                const int nz_r = r < nrows ? __builtin_amdgcn_readlane(L.nz, r) : 0;                          \
+                const int nz_r = r < nrows ? __builtin_amdgcn_readlane(my_nz, r) : 0;                         \
                 if (n_ < nz_r) {                                                                              \
                     sdrm_k3_ring_put(ring + r, n_, pre[r].x);                                                 \
                 }                                                                                            \
@@ -372,6 +383,26 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
             }                                                                                                \
         }                                                                                                    \
     }
+        if (nblocks > 0) {
+            K3_ISSUE(0)
+        }
+        for (int k = 0; k < nblocks; k++) {
+            K3_COMMIT(k)
+            if (k + 1 < nblocks) {
+                K3_ISSUE(k + 1)
+            }
+            __syncthreads();  // block k is in the ring; the consumer works on it while block k+1 is written
+        }
+#undef K3_ISSUE
+#undef K3_COMMIT
+#undef K3_ROW_SRC
+        return;
+    }
+
+    // ------------------------------------------------------------------ consumer wave
+    int8_t *o8 = b.out_i8 + (size_t) (active ? c : 0) * b.out_stride;
+    float *of = SOFT ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
+    const bool wave_clean = __all(clean);
     // run every lane's loop as far as the staged samples allow
 #define K3_DRAIN(FIN)                                                                                        \
     {                                                                                                        \
@@ -379,7 +410,7 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
         sdrm_k3_fetch<FIN>(L, my_col, bank_rev, F);                                                           \
         while (true) {                                                                                       \
             const bool can = active && sdrm_k3_can_step(L, avail);                                            \
-            if (!__any(can)) {                                                                                \
+            if (__builtin_amdgcn_ballot_w64(can) == 0) {                                                      \
                 break;                                                                                       \
             }                                                                                                \
             n_iter++;                                                                                        \
@@ -399,20 +430,13 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
             }                                                                                                \
         }                                                                                                    \
     }
-    if (nblocks > 0) {
-        K3_ISSUE(0)
-    }
-    unsigned long long t_stage = 0, t_drain = 0, n_iter = 0;
+    unsigned long long t_wait = 0, t_drain = 0, n_iter = 0;
     for (int k = 0; k <= nblocks; k++) {
-        // k == nblocks: no staging, only drains what the carried history alone allows (nz == 0 case)
+        // k == nblocks: nothing new, only drains what the carried history alone allows (nz == 0 case)
         unsigned long long t0 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         if (k < nblocks) {
-            K3_COMMIT(k)
-            if (k + 1 < nblocks) {
-                K3_ISSUE(k + 1)
-            }
+            __syncthreads();  // block k staged
         }
-        __syncthreads();
         unsigned long long t1 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         int avail = (k + 1) * SDRM_K3_BLOCK;
         avail = avail < L.nz ? avail : L.nz;
@@ -421,23 +445,19 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
         } else {
             K3_DRAIN(false)
         }
-        __syncthreads();
         if (b.k3_stamps) {
             unsigned long long t2 = __builtin_amdgcn_s_memtime();
-            t_stage += t1 - t0;
+            t_wait += t1 - t0;
             t_drain += t2 - t1;
         }
     }
-    if (b.k3_stamps && lane == 0) {  // diagnostic only: cycles spent staging vs in the symbol loops, per wave
-        b.k3_stamps[blockIdx.x * 4 + 0] = t_stage;
+    if (b.k3_stamps && lane == 0) {  // diagnostic only: cycles waiting for the producer vs in the symbol loops
+        b.k3_stamps[blockIdx.x * 4 + 0] = t_wait;
         b.k3_stamps[blockIdx.x * 4 + 1] = t_drain;
         b.k3_stamps[blockIdx.x * 4 + 2] = (unsigned long long) nblocks;
         b.k3_stamps[blockIdx.x * 4 + 3] = n_iter;
     }
-#undef K3_ISSUE
-#undef K3_COMMIT
 #undef K3_DRAIN
-#undef K3_ROW_SRC
     if (active) {
         int from_n, new_kept;
         sdrm_k3_finish(L, &from_n, &new_kept);
@@ -456,10 +476,14 @@ __global__ __launch_bounds__(64) void k3_clock(DeviceBatch b) {
 
 void launch_clock(const DeviceBatch &b, hipStream_t s) {
     unsigned blocks = (unsigned) ((b.n_channels + SDRM_K3_LANES - 1) / SDRM_K3_LANES);
+    static size_t granted_t = 0, granted_f = 0;
+    const size_t lds = k3_lds_bytes();
     if (b.out_f32) {
-        hipLaunchKernelGGL(k3_clock<true>, dim3(blocks), dim3(64), 0, s, b);
+        allow_lds(k3_clock<true>, lds, &granted_t);
+        hipLaunchKernelGGL(k3_clock<true>, dim3(blocks), dim3(128), lds, s, b);
     } else {
-        hipLaunchKernelGGL(k3_clock<false>, dim3(blocks), dim3(64), 0, s, b);
+        allow_lds(k3_clock<false>, lds, &granted_f);
+        hipLaunchKernelGGL(k3_clock<false>, dim3(blocks), dim3(128), lds, s, b);
     }
 }
 

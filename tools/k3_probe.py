@@ -23,5 +23,5 @@ out = np.zeros((waves, 4), dtype=np.uint64)
 L.sdrm_batch_k3_stamps(b.h, 1, out.ctypes.data, waves)
 for w in range(min(waves, 4)):
     stg, drn, nb, it = [int(v) for v in out[w]]
-    print("wave %d: staging %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration" % (
+    print("wave %d: wait-for-producer %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration" % (
         w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1)))
