@@ -116,11 +116,15 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 
 size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap) { return ((size_t) rx_cap + 3 * (size_t) rs_cap) * sizeof(float); }
 
-// One wave per channel.  Reference src/dsp/dc_blocker.c:56-64,105-119: four cascaded length-L boxcars
-// (y = (u - u[-L]) + y_prev; out y/L) and out = x[n - 2(L-1)] - y4.  Delay lines live in LDS rings that persist in
-// the channel's DC state between calls; the slot of stream sample n is n & mask.
+// One workgroup of four waves per channel, one wave per boxcar stage (reference src/dsp/dc_blocker.c:56-64,105-119:
+// four cascaded length-L boxcars, y = (u - u[-L]) + y_prev, out y/L; result x[n - 2(L-1)] - y4).
+// The stages form a software pipeline over 64-sample blocks: in iteration `it`, wave s works on block it - s.  Within a
+// block the pointwise parts are lane-parallel (lane = sample) and the running sum is the in-order 64-lane chain above;
+// a stage hands its block to the next one through an LDS ring (which is also that stage's delay line), one barrier per
+// iteration.  Rings and running sums persist in the channel's DC state between calls; the slot of stream sample n is
+// n & mask.
 template <int MODE>
-__global__ __launch_bounds__(64) void k2_dc(DeviceBatch b) {
+__global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     extern __shared__ __attribute__((aligned(16))) float k2_lds[];
     const int c = blockIdx.x;
     const sdrm_chan_params p = b.params[c];
@@ -128,24 +132,23 @@ __global__ __launch_bounds__(64) void k2_dc(DeviceBatch b) {
         return;
     }
     const sdrm_chunk_ctl ctl = b.ctl[c];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int stage = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     float *rx = k2_lds;
-    float *r0 = rx + b.rx_cap;
-    float *r1 = r0 + b.rs_cap;
-    float *r2 = r1 + b.rs_cap;
+    float *rs[3] = {rx + b.rx_cap, rx + b.rx_cap + b.rs_cap, rx + b.rx_cap + 2 * b.rs_cap};
     const uint32_t mx = p.rx_mask, ms = p.rs_mask;
     float *st = b.dc_state + p.dc_state_off;
     float *st_rx = st, *st_r0 = st_rx + (mx + 1), *st_r1 = st_r0 + (ms + 1), *st_r2 = st_r1 + (ms + 1);
     float *st_acc = st_r2 + (ms + 1);
-    for (uint32_t k = lane; k <= mx; k += 64) {
+    for (uint32_t k = threadIdx.x; k <= mx; k += 256) {
         rx[k] = st_rx[k];
     }
-    for (uint32_t k = lane; k <= ms; k += 64) {
-        r0[k] = st_r0[k];
-        r1[k] = st_r1[k];
-        r2[k] = st_r2[k];
+    for (uint32_t k = threadIdx.x; k <= ms; k += 256) {
+        rs[0][k] = st_r0[k];
+        rs[1][k] = st_r1[k];
+        rs[2][k] = st_r2[k];
     }
-    float a0 = st_acc[0], a1 = st_acc[1], a2 = st_acc[2], a3 = st_acc[3];
+    float acc = st_acc[stage];
     __syncthreads();
 
     const float *z = b.z + (size_t) c * b.z_stride;
@@ -153,77 +156,81 @@ __global__ __launch_bounds__(64) void k2_dc(DeviceBatch b) {
     const uint32_t L = p.dc_len;
     const float Lf = p.dc_len_f;
     const uint32_t nz = ctl.nz;
+    const int nb = (int) ((nz + 63) / 64);
+    // this stage's input ring (the previous stage's output; the raw LPF2 stream for stage 0) and output ring, as
+    // offsets into the one LDS array (pointers picked at run time would degrade to flat addressing)
+    const uint32_t rin_off = stage == 0 ? 0u : b.rx_cap + (uint32_t) (stage - 1) * b.rs_cap;
+    const uint32_t min_ = stage == 0 ? mx : ms;
+    const uint32_t rout_off = b.rx_cap + (uint32_t) (stage < 3 ? stage : 0) * b.rs_cap;
     bool odd = false;
-    for (uint32_t n0 = 0; n0 < nz; n0 += 64) {
-        const uint32_t n = n0 + lane;
-        const bool valid = n < nz;
-        const int last = (int) ((nz - n0 < 64u ? nz - n0 : 64u) - 1u);
-        const uint32_t pos = ctl.zbase + n;  // stream index (mod 2^32; ring sizes divide 2^32)
-        const float x = valid ? z[n] : 0.0f;
-        if (valid) {
-            rx[pos & mx] = x;
-        }
-        __builtin_amdgcn_wave_barrier();  // keep the ring write ahead of the delayed reads (same wave: LDS is in order)
-        const float xd = rx[(pos - L) & mx];
-        const float xdd = rx[(pos - 2 * (L - 1)) & mx];
-        // stage 0
-        float t = valid ? sdrm_boxcar_term(x, xd) : 0.0f;
-        float s = wave_inorder_sum<MODE>(t, a0);
-        a0 = lane_bcast(s, last);
-        float v = sdrm_boxcar_out(s, Lf);
-        if (valid) {
-            r0[pos & ms] = v;
-        }
-        __builtin_amdgcn_wave_barrier();  // keep the ring write ahead of the delayed reads (same wave: LDS is in order)
-        float vd = r0[(pos - L) & ms];
-        // stage 1
-        t = valid ? sdrm_boxcar_term(v, vd) : 0.0f;
-        s = wave_inorder_sum<MODE>(t, a1);
-        a1 = lane_bcast(s, last);
-        v = sdrm_boxcar_out(s, Lf);
-        if (valid) {
-            r1[pos & ms] = v;
-        }
-        __builtin_amdgcn_wave_barrier();  // keep the ring write ahead of the delayed reads (same wave: LDS is in order)
-        vd = r1[(pos - L) & ms];
-        // stage 2
-        t = valid ? sdrm_boxcar_term(v, vd) : 0.0f;
-        s = wave_inorder_sum<MODE>(t, a2);
-        a2 = lane_bcast(s, last);
-        v = sdrm_boxcar_out(s, Lf);
-        if (valid) {
-            r2[pos & ms] = v;
-        }
-        __builtin_amdgcn_wave_barrier();  // keep the ring write ahead of the delayed reads (same wave: LDS is in order)
-        vd = r2[(pos - L) & ms];
-        // stage 3
-        t = valid ? sdrm_boxcar_term(v, vd) : 0.0f;
-        s = wave_inorder_sum<MODE>(t, a3);
-        a3 = lane_bcast(s, last);
-        v = sdrm_boxcar_out(s, Lf);
-        if (valid) {
-            const float o = xdd - v;
-            out[n] = o;
-            odd |= !(fabsf(o) < INFINITY);
-        }
+    // stage 0 keeps the next four blocks of the input in flight (a block is consumed faster than HBM answers)
+    float xq0 = 0.0f, xq1 = 0.0f, xq2 = 0.0f, xq3 = 0.0f;
+    if (stage == 0) {
+        xq0 = (uint32_t) lane < nz ? z[lane] : 0.0f;
+        xq1 = (uint32_t) lane + 64u < nz ? z[lane + 64] : 0.0f;
+        xq2 = (uint32_t) lane + 128u < nz ? z[lane + 128] : 0.0f;
+        xq3 = (uint32_t) lane + 192u < nz ? z[lane + 192] : 0.0f;
     }
+    // The iteration loop is unrolled by four so that each of stage 0's four in-flight input registers has a fixed
+    // name (rotating them would make the compiler wait for a load right after issuing it).
+#define K2_ITER(it_, XQ)                                                                                     \
+    if ((it_) < nb + 3) {                                                                                    \
+        const int blk = (it_) - stage;                                                                       \
+        if (blk >= 0 && blk < nb) {                                                                          \
+            const uint32_t n = (uint32_t) blk * 64u + lane;                                                   \
+            const bool valid = n < nz;                                                                        \
+            const int last = (int) ((nz - (uint32_t) blk * 64u < 64u ? nz - (uint32_t) blk * 64u : 64u) - 1u); \
+            const uint32_t pos = ctl.zbase + n; /* stream index (mod 2^32; ring sizes divide 2^32) */         \
+            float u;                                                                                          \
+            if (stage == 0) {                                                                                 \
+                u = XQ;                                                                                       \
+                if (valid) {                                                                                  \
+                    rx[pos & mx] = u;                                                                         \
+                }                                                                                            \
+                const uint32_t nn = n + 256u;                                                                 \
+                XQ = nn < nz ? z[nn] : 0.0f;                                                                  \
+                __builtin_amdgcn_wave_barrier(); /* ring write stays ahead of the delayed read (same wave) */ \
+            } else {                                                                                         \
+                u = k2_lds[rin_off + (pos & min_)];                                                           \
+            }                                                                                                \
+            const float ud = k2_lds[rin_off + ((pos - L) & min_)];                                            \
+            const float t = valid ? sdrm_boxcar_term(u, ud) : 0.0f;                                           \
+            const float s = wave_inorder_sum<MODE>(t, acc);                                                   \
+            acc = lane_bcast(s, last);                                                                        \
+            const float v = sdrm_boxcar_out(s, Lf);                                                           \
+            if (stage < 3) {                                                                                  \
+                if (valid) {                                                                                  \
+                    k2_lds[rout_off + (pos & ms)] = v;                                                        \
+                }                                                                                            \
+            } else if (valid) {                                                                               \
+                const float o = rx[(pos - 2 * (L - 1)) & mx] - v;                                             \
+                out[n] = o;                                                                                   \
+                odd |= !(fabsf(o) < INFINITY);                                                                \
+            }                                                                                                \
+        }                                                                                                    \
+        /* hand-off between stage waves goes through LDS only: wait for LDS, not for global prefetch/store */ \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                       \
+    }
+    for (int it = 0; it < nb + 3; it += 4) {
+        K2_ITER(it, xq0)
+        K2_ITER(it + 1, xq1)
+        K2_ITER(it + 2, xq2)
+        K2_ITER(it + 3, xq3)
+    }
+#undef K2_ITER
     if (odd) {
         b.nonfinite[c] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
     }
-    __syncthreads();
-    for (uint32_t k = lane; k <= mx; k += 64) {
+    for (uint32_t k = threadIdx.x; k <= mx; k += 256) {
         st_rx[k] = rx[k];
     }
-    for (uint32_t k = lane; k <= ms; k += 64) {
-        st_r0[k] = r0[k];
-        st_r1[k] = r1[k];
-        st_r2[k] = r2[k];
+    for (uint32_t k = threadIdx.x; k <= ms; k += 256) {
+        st_r0[k] = rs[0][k];
+        st_r1[k] = rs[1][k];
+        st_r2[k] = rs[2][k];
     }
     if (lane == 0) {
-        st_acc[0] = a0;
-        st_acc[1] = a1;
-        st_acc[2] = a2;
-        st_acc[3] = a3;
+        st_acc[stage] = acc;
     }
 }
 
@@ -238,9 +245,9 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
     allow_lds(k2_dc<0>, lds, &granted0);
     allow_lds(k2_dc<1>, lds, &granted1);
     if (g_scan_mode == 0) {
-        hipLaunchKernelGGL(k2_dc<0>, dim3((unsigned) b.n_channels), dim3(64), lds, s, b);
+        hipLaunchKernelGGL(k2_dc<0>, dim3((unsigned) b.n_channels), dim3(256), lds, s, b);
     } else {
-        hipLaunchKernelGGL(k2_dc<1>, dim3((unsigned) b.n_channels), dim3(64), lds, s, b);
+        hipLaunchKernelGGL(k2_dc<1>, dim3((unsigned) b.n_channels), dim3(256), lds, s, b);
     }
 }
 
