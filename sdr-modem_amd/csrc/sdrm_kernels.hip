@@ -8,16 +8,16 @@ namespace sdrm {
 // ================================================================================================ K1
 
 size_t k1_lds_bytes(uint32_t t1_max) {
+    // the quadrature-demod tile (NY + pad floats) reuses the raw-IQ tile's space: LPF1 is done with it by then
     size_t xs = (size_t) (SDRM_K1_NY + t1_max) * sizeof(sdrm_f2);
-    size_t qs = (size_t) (SDRM_K1_NY + SDRM_K1_QPAD) * sizeof(float);
     size_t bnd = (size_t) SDRM_K1_THREADS * sizeof(sdrm_f2);
     size_t tab = 260 * sizeof(float);
-    return xs + qs + bnd + tab;
+    return xs + bnd + tab;
 }
 
 // grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
 // per-thread boundary samples | arctan table.
-__global__ __launch_bounds__(SDRM_K1_THREADS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
+__global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
                                                             size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
     const int c = blockIdx.y;
@@ -27,8 +27,8 @@ __global__ __launch_bounds__(SDRM_K1_THREADS) void k1_front(DeviceBatch b, const
     }
     const sdrm_chan_params p = b.params[c];
     sdrm_f2 *xs = reinterpret_cast<sdrm_f2 *>(k1_lds);
-    float *qs = reinterpret_cast<float *>(xs + SDRM_K1_NY + b.t1_max);
-    sdrm_f2 *bnd = reinterpret_cast<sdrm_f2 *>(qs + SDRM_K1_NY + SDRM_K1_QPAD);
+    float *qs = reinterpret_cast<float *>(xs);  // aliases the raw tile: written only after every LPF1 read (barrier)
+    sdrm_f2 *bnd = reinterpret_cast<sdrm_f2 *>(xs + SDRM_K1_NY + b.t1_max);
     float *tab = reinterpret_cast<float *>(bnd + SDRM_K1_THREADS);
 
     const int tid = threadIdx.x;
