@@ -724,12 +724,12 @@ extern "C" int sdrm_batch_k3_stamps(sdrm_batch *b, int enable, unsigned long lon
     HIP_TRY(hipSetDevice(b->device));
     const size_t waves = (b->plan.params.size() + 63) / 64;
     if (b->dev.k3_stamps == nullptr && enable) {
-        HIP_TRY(hipMalloc((void **) &b->dev.k3_stamps, waves * 4 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(b->dev.k3_stamps, 0, waves * 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **) &b->dev.k3_stamps, (waves * 4 + 16) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(b->dev.k3_stamps, 0, (waves * 4 + 16) * sizeof(unsigned long long)));
     }
     if (out != nullptr && b->dev.k3_stamps != nullptr) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out, b->dev.k3_stamps, std::min(waves, max_waves) * 4 * sizeof(unsigned long long),
+        HIP_TRY(hipMemcpy(out, b->dev.k3_stamps, (std::min(waves, max_waves) * 4 + 8) * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost));
     }
     return (int) waves;

@@ -36,14 +36,28 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, co
     const sdrm_f2 *in = d_in + (size_t) c * in_stride;
     const sdrm_f2 *hist = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
 
+    const bool stamp = b.k3_stamps != nullptr;  // diagnostics: per-phase cycles, summed over workgroups
+    unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_load(tid, t, in, hist, (int) p.hist_len, b.atan_tab, xs, tab);
     __syncthreads();
+    unsigned long long t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_regs regs;
     sdrm_k1_phase_lpf1(tid, t, p, b.tap_pool + p.taps1_off, xs, bnd, regs);
     __syncthreads();
+    unsigned long long t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_quad(tid, t, p, tab, bnd, regs, qs);
     __syncthreads();
+    unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_lpf2(tid, t, p, b.tap_pool + p.taps2_off, qs, b.z + (size_t) c * b.z_stride, b.nonfinite + c);
+    if (stamp && tid == 0) {
+        unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        unsigned long long *k1s = b.k3_stamps + ((b.n_channels + 63) / 64) * 4;  // after the K3 per-wave records
+        atomicAdd(k1s + 0, t1 - t0);
+        atomicAdd(k1s + 1, t2 - t1);
+        atomicAdd(k1s + 2, t3 - t2);
+        atomicAdd(k1s + 3, t4 - t3);
+        atomicAdd(k1s + 4, 1ull);
+    }
 }
 
 __global__ __launch_bounds__(256) void k1_hist_roll(DeviceBatch b, const sdrm_f2 *__restrict__ d_in, size_t in_stride) {

@@ -17,6 +17,11 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
     }
     v2f t = (v2f){a, a};
     for (int it = 0; it < iters; it++) {
+        // keep the operands opaque: otherwise x*t is loop-invariant and the "mul+add" modes only time the adds
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            asm volatile("" : "+v"(x[i]));
+        }
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             if (MODE == 0) {  // packed mul + packed add (exact mode, complex sample x real tap)
