@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0)
     ap.add_argument("--verify", action="store_true", help="also check 2 channels of the last step against the oracle")
+    ap.add_argument("--sweep", type=str, default="1024,4096",
+                    help="extra channel counts measured briefly at N=1 (reported under 'channel_sweep'); '' to skip")
     return ap.parse_args()
 
 
@@ -191,8 +193,11 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": C * N * 8,
-                         "note": "8 B of IQ read per input sample (SURVEY 8d LPF-stage HBM-read term); exact mode is "
-                                 "fp32-VALU-bound: 2 ops per tap per component, no FMA"},
+                         "valu_exact_ceiling_frac": round(35.9e12 / 291.0 * 8.0 / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "8 B of IQ read per input sample (SURVEY 8d LPF-stage HBM-read term). The kernel is "
+                                 "fp32-VALU-bound: bit-exact parity needs a separately rounded multiply and add per tap "
+                                 "(v_pk_mul_f32 + v_pk_add_f32, measured 35.9 T component-MAC/s; 291 MAC per sample), "
+                                 "which caps it at valu_exact_ceiling_frac of the HBM peak"},
         }
         if verify is not None:
             out["verified_vs_oracle"] = verify
@@ -209,8 +214,49 @@ def main():
                 "sample": "oracle (plain-C restatement of the reference path, gcc -O2 -ffp-contract=off), one "
                           "independent channel per thread on %d threads, %d-sample chunks of channel 0 looped for "
                           "%.1f s wall (%.0f Msamples total)" % (cores, N, secs, smp / 1e6)}
+        if world == 1 and args.sweep:
+            # the named workload (256 channels) is bounded by the sequential clock-recovery chain of 4 waves; show how
+            # the same pipeline fills the GPU with more channels (short runs, 2 resident chunks)
+            batch.close()
+            batch = None
+            del x
+            torch.cuda.empty_cache()
+            sweep = {}
+            for c2 in [int(v) for v in args.sweep.split(",") if v.strip()]:
+                try:
+                    x2 = torch.empty((c2, 4 * N), dtype=torch.float32, device=dev)
+                    seed = torch.from_numpy(base[:, :2 * N].copy().view(np.float32).reshape(k, 4 * N)).to(dev)
+                    for c in range(c2):
+                        x2[c] = torch.roll(seed[c % k], shifts=2 * 977 * (c // k))
+                    del seed
+                    b2 = binding.Batch([(FS, BAUD, DEV, DECIM, TW, DC, N)] * c2, device=local_rank)
+                    if b2.code != 0:
+                        raise RuntimeError("create failed %d" % b2.code)
+                    ln = [N] * c2
+                    for i in range(2):
+                        b2.process_device(x2.data_ptr() + (i % 2) * N * 8, 2 * N, ln, stream)
+                    torch.cuda.synchronize()
+                    b2.timing_enable(True)
+                    t0 = time.perf_counter()
+                    for i in range(6):
+                        b2.process_device(x2.data_ptr() + (i % 2) * N * 8, 2 * N, ln, stream)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    km = [b2.timing_read(w) for w in range(3)]
+                    fr = km[0][0] / max(km[0][1], 1)
+                    sweep[str(c2)] = {"value": round(c2 * N * 6 / dt / 1e6, 1), "unit": "Msamples/s",
+                                      "ms_per_step": round(dt / 6 * 1e3, 3),
+                                      "kernel_ms": [round(m / max(n, 1), 3) for m, n in km],
+                                      "front_hbm_frac": round(c2 * N * 8.0 / (fr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    b2.close()
+                    del x2
+                    torch.cuda.empty_cache()
+                except Exception as exc:  # the sweep is informative only
+                    sweep[str(c2)] = {"error": str(exc)[:200]}
+            out["channel_sweep"] = sweep
         print(json.dumps(out), flush=True)
-    batch.close()
+    if batch is not None:
+        batch.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,12 +25,12 @@
 #define SDRM_K1_QPAD 16
 
 #define SDRM_K3_LANES 64
-#define SDRM_K3_RING 512    // per-channel sample ring in LDS (power of two): 4 staging blocks
+#define SDRM_K3_RING 256    // per-channel sample ring in LDS (power of two): 4 staging blocks
 #define SDRM_K3_PRE 3       // mirror rows below slot 0 (a symbol reads up to 3 samples before its window)
 #define SDRM_K3_POST 8      // mirror rows above slot RING-1 (a window is 8 samples)
 #define SDRM_K3_ROWS (SDRM_K3_PRE + SDRM_K3_RING + SDRM_K3_POST)
 #define SDRM_K3_PITCH 65    // floats between consecutive rows (64 channels + 1: conflict-free transposing writes)
-#define SDRM_K3_BLOCK 128   // samples staged per channel per step
+#define SDRM_K3_BLOCK 64    // samples staged per channel per step (one per producer lane)
 
 // immutable per-channel parameters (device array, one per channel)
 struct sdrm_chan_params {

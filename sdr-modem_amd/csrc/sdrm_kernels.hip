@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     }
     float acc = st_acc[stage];
     __syncthreads();
+    __builtin_amdgcn_s_setprio(2);  // latency-bound chains: issue ahead of the front-end's waves on a shared SIMD
 
     const float *z = b.z + (size_t) c * b.z_stride;
     float *out = b.dcout + (size_t) c * b.z_stride;
@@ -269,7 +270,7 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 
 // One lane per channel, 64 channels per CONSUMER wave (reference src/dsp/clock_recovery_mm.c:78-139 per lane); a second
 // PRODUCER wave of the same workgroup stages the samples, so the two overlap.
-// Producer: per step, SDRM_K3_BLOCK samples of each of the 64 channels go from global memory (coalesced row reads,
+// Producer: per step, SDRM_K3_BLOCK (= 64, one per lane) samples of each of the 64 channels go from global memory (coalesced row reads,
 // lane = time, prefetched one step ahead into registers) into an LDS ring, row-major (ring[row][channel], pitch 65
 // floats => the transposing writes spread over the banks).  The ring holds 4 steps; mirror rows at both ends keep every
 // window contiguous.  Consumer: each lane runs its own loop while staged samples last; a symbol's 8 window samples are
@@ -350,22 +351,22 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 
     if (producer) {
         const float *row0 = (__builtin_amdgcn_readfirstlane(my_dc) ? b.dcout : b.z) + (size_t) c0 * b.z_stride;
-        float2 pre[SDRM_K3_LANES];  // prefetched row segments: pre[r] = samples (2*lane, 2*lane+1) of channel c0+r
+        float pre[SDRM_K3_LANES];  // prefetched row segments: pre[r] = sample `lane` of channel c0+r's next block
 #define K3_ROW_SRC(r) ((__builtin_amdgcn_readlane(my_dc, (r)) ? b.dcout : b.z) + (size_t) (c0 + (r)) * b.z_stride)
 #define K3_ISSUE(k)                                                                                          \
     {                                                                                                        \
-        const int n_ = (k) * SDRM_K3_BLOCK + 2 * lane;                                                        \
+        const int n_ = (k) * SDRM_K3_BLOCK + lane;                                                            \
         if (uniform && ((k) + 1) * SDRM_K3_BLOCK <= min_nz) {                                                 \
             const float *p_ = row0 + n_;                                                                      \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                pre[r] = *reinterpret_cast<const float2 *>(p_);                                               \
+                pre[r] = *p_;                                                                                 \
                 p_ += b.z_stride;                                                                             \
             }                                                                                                \
         } else {                                                                                             \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                pre[r] = make_float2(0.0f, 0.0f);                                                             \
+                pre[r] = 0.0f;                                                                                \
                 if (r < nrows && n_ < __builtin_amdgcn_readlane(my_nz, r)) {                                  \
-                    pre[r] = *reinterpret_cast<const float2 *>(K3_ROW_SRC(r) + n_);                           \
+                    pre[r] = K3_ROW_SRC(r)[n_];                                                               \
                 }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
@@ -374,12 +375,11 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         // mirror rows with a small copy pass, the ragged path goes element by element through sdrm_k3_ring_put
 #define K3_COMMIT(k)                                                                                         \
     {                                                                                                        \
-        const int n_ = (k) * SDRM_K3_BLOCK + 2 * lane;                                                        \
+        const int n_ = (k) * SDRM_K3_BLOCK + lane;                                                            \
         if (uniform && ((k) + 1) * SDRM_K3_BLOCK <= min_nz) {                                                 \
             float *row_ = ring + ((n_ & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) * SDRM_K3_PITCH;                   \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                row_[r] = pre[r].x;                                                                           \
-                row_[r + SDRM_K3_PITCH] = pre[r].y;                                                           \
+                row_[r] = pre[r];                                                                             \
             }                                                                                                \
             __builtin_amdgcn_wave_barrier();                                                                  \
             if ((((k) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                          \
@@ -396,10 +396,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
                 const int nz_r = r < nrows ? __builtin_amdgcn_readlane(my_nz, r) : 0;                         \
                 if (n_ < nz_r) {                                                                              \
-                    sdrm_k3_ring_put(ring + r, n_, pre[r].x);                                                 \
-                }                                                                                            \
-                if (n_ + 1 < nz_r) {                                                                          \
-                    sdrm_k3_ring_put(ring + r, n_ + 1, pre[r].y);                                             \
+                    sdrm_k3_ring_put(ring + r, n_, pre[r]);                                                   \
                 }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
@@ -421,6 +418,8 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     }
 
     // ------------------------------------------------------------------ consumer wave
+    // a long dependent chain on one wave: let it win issue arbitration against the throughput kernels sharing the SIMD
+    __builtin_amdgcn_s_setprio(3);
     int8_t *o8 = b.out_i8 + (size_t) (active ? c : 0) * b.out_stride;
     float *of = SOFT ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
     const bool wave_clean = __all(clean);
