@@ -185,6 +185,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: %d concurrent 48 kHz / 9600 baud GMSK channels per GPU, "
                                    "fsk_demod(48000,9600,5000,1,2000,dc), %d-sample chunks" % (C, N),
                        "channels_per_gpu": C, "chunk_samples": N, "mode": "exact (bit-identical to CPU reference)",
+                       "stages": "serial" if os.environ.get("SDRM_SERIAL_STAGES") else "pipelined across calls",
                        "parallelism": "channel-sharded x%d, no data-path collective" % world},
             "channels_at_realtime": int(msps * 1e6 / FS),
             "kernel_ms": {"front_lpf1_quad_lpf2": round(k_ms[0], 4), "dc_blocker": round(k_ms[1], 4),

@@ -68,6 +68,7 @@ struct sdrm_batch_t {
     hipStream_t s_front = nullptr, s_dc = nullptr, s_clock = nullptr;
     float *d_z2 = nullptr, *d_dcout2 = nullptr;
     bool any_nodc = false;
+    bool serial = false;
     uint64_t calls = 0;
     int last_slot = -1;
     hipStream_t stream = nullptr;  // private stream of the host-buffer API
@@ -115,7 +116,7 @@ static void batch_free(sdrm_batch_t *b) {
             }
         }
     }
-    hipStream_t streams[3] = {b->s_front, b->s_dc, b->s_clock};
+    hipStream_t streams[3] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock};
     for (hipStream_t st : streams) {
         if (st) {
             (void) hipStreamDestroy(st);
@@ -248,8 +249,15 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     e = e ? e : hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     const int prio_mid = (prio_low + prio_high) / 2;
     e = e ? e : hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, prio_low);
-    e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
-    e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
+    if (getenv("SDRM_SERIAL_STAGES") != nullptr) {
+        // escape hatch: all stages on one stream (no overlap between consecutive calls); same kernels, same results
+        b->s_dc = b->s_front;
+        b->s_clock = b->s_front;
+        b->serial = true;
+    } else {
+        e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
+        e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
+    }
     for (int i = 0; i < SDRM_CTL_SLOTS && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
         e = e ? e : hipEventCreateWithFlags(&b->ev_in[i], hipEventDisableTiming);

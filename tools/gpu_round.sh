@@ -12,7 +12,7 @@ timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pyte
 echo "== ubench"
 timeout 300 tools/ubench_valu > gpurun_out/ubench_valu.log 2>&1; cat gpurun_out/ubench_valu.log
 echo "== bench"
-timeout 900 python bench.py --steps 8 --warmup 2 --verify > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench exit $?"; cat gpurun_out/bench.log; tail -5 gpurun_out/bench.err
+timeout 900 python bench.py --steps 16 --warmup 4 --verify > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench exit $?"; cat gpurun_out/bench.log; tail -5 gpurun_out/bench.err
 echo "== rocprof"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1; echo "rocprof exit $?"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --sweep "" > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1; echo "rocprof exit $?"
 cd $GRAFT_REPO_ROOT; find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do head -12 $f; done
