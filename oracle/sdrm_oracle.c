@@ -727,6 +727,126 @@ void orc_nco_destroy(orc_nco *s) {
     free(s);
 }
 
+/* ------------------------------------------------------------------ Doppler batching (next row f-1) */
+
+struct orc_doppler {
+    orc_nco *nco;
+    uint64_t interval;       /* update_interval_samples = sampling_freq (doppler.c:84) */
+    uint64_t in_interval;    /* current_samples, starts "expired" (doppler.c:85) */
+    double cur, next, slope; /* current / next second's shift and the per-sample slope between them */
+    const double *shifts;
+    size_t n_shifts, second; /* next per-second value to hand out */
+    uint32_t cap;
+    float *out;
+};
+
+int orc_doppler_create(uint64_t fs, const double *shifts, size_t n_shifts, uint32_t max_len, orc_doppler **out) {
+    orc_doppler *d = calloc(1, sizeof(*d));
+    if (d == NULL) {
+        return -ENOMEM;
+    }
+    d->interval = fs;
+    d->in_interval = fs;
+    d->cap = max_len;
+    double *copy = malloc(sizeof(double) * (n_shifts ? n_shifts : 1));
+    d->out = malloc(sizeof(float) * 2 * (size_t) max_len + 8);
+    if (copy == NULL || d->out == NULL || orc_nco_create(1.0f, fs, max_len, &d->nco) != 0) {
+        free(copy);
+        orc_doppler_destroy(d);
+        return -ENOMEM;
+    }
+    memcpy(copy, shifts, sizeof(double) * n_shifts);
+    d->shifts = copy;
+    d->n_shifts = n_shifts;
+    *out = d;
+    return 0;
+}
+
+static double doppler_shift_at(orc_doppler *d, size_t k) {
+    if (d->n_shifts == 0) {
+        return 0.0;
+    }
+    return d->shifts[k < d->n_shifts ? k : d->n_shifts - 1];
+}
+
+/* one batch of reference src/dsp/doppler.c:131-178: its length and its (truncated) frequency */
+static size_t doppler_next_batch(orc_doppler *d, size_t remaining, int64_t *freq) {
+    size_t batch;
+    if (d->interval < remaining + d->in_interval) {
+        if (d->in_interval >= d->interval) {
+            batch = d->interval < remaining ? (size_t) d->interval : remaining;
+        } else {
+            batch = (size_t) (d->interval - d->in_interval);
+        }
+    } else {
+        batch = remaining;
+    }
+    if (d->in_interval >= d->interval) {
+        d->in_interval = 0;
+        if (d->next == 0) {
+            d->cur = doppler_shift_at(d, d->second++);
+        } else {
+            d->cur = d->next;
+        }
+        d->next = doppler_shift_at(d, d->second++);
+        d->slope = (d->next - d->cur) / d->interval;
+    } else {
+        d->cur += d->slope * (double) batch;
+    }
+    d->in_interval += batch;
+    *freq = (int64_t) d->cur;
+    return batch;
+}
+
+size_t orc_doppler_plan(orc_doppler *d, size_t n, uint32_t *lens, int64_t *freqs, size_t cap) {
+    size_t done = 0, count = 0;
+    while (done < n && count < cap) {
+        int64_t f;
+        size_t b = doppler_next_batch(d, n - done, &f);
+        lens[count] = (uint32_t) b;
+        freqs[count] = f;
+        count++;
+        done += b;
+    }
+    return count;
+}
+
+void orc_doppler_process(orc_doppler *d, const float *iq, size_t n, float **iq_out, size_t *out_len) {
+    if (iq == NULL || n == 0) { /* doppler.c:117-121 */
+        *iq_out = NULL;
+        *out_len = 0;
+        return;
+    }
+    if (n > d->cap) {
+        fprintf(stderr, "<3>requested buffer %zu is more than max: %u\n", n, d->cap);
+        *iq_out = NULL;
+        *out_len = 0;
+        return;
+    }
+    size_t done = 0;
+    while (done < n) {
+        int64_t f;
+        size_t b = doppler_next_batch(d, n - done, &f);
+        float *part = NULL;
+        size_t m = 0;
+        orc_nco_multiply(d->nco, f, iq + 2 * done, b, &part, &m);
+        memcpy(d->out + 2 * done, part, sizeof(float) * 2 * m);
+        done += b;
+    }
+    *iq_out = d->out;
+    *out_len = done;
+}
+
+void orc_doppler_destroy(orc_doppler *d) {
+    if (d == NULL) {
+        return;
+    }
+    orc_nco_destroy(d->nco);
+    free((void *) d->shifts);
+    free(d->out);
+    free(d);
+}
+
 /* ------------------------------------------------------------------ CPU baseline timing */
 
 struct bench_job {

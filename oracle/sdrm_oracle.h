@@ -99,6 +99,16 @@ void orc_nco_process(orc_nco *s, int64_t freq, size_t n, float **iq_out, size_t 
 void orc_nco_multiply(orc_nco *s, int64_t freq, const float *iq_in, size_t n, float **iq_out, size_t *out_len);
 void orc_nco_destroy(orc_nco *s);
 
+/* ---- next row (f-1): Doppler pre-correction = batching of the NCO at one-second boundaries with a linearly
+ *      interpolated, integer-truncated shift (reference src/dsp/doppler.c:116-190).  The orbit model that produces the
+ *      per-second shifts (SGP4, doppler.c:31-42) stays outside: shifts[k] is the shift at second k of the pass. ---- */
+typedef struct orc_doppler orc_doppler;
+int orc_doppler_create(uint64_t sampling_freq, const double *shifts, size_t n_shifts, uint32_t max_len, orc_doppler **out);
+/* the (len, freq_hz) batches one call of doppler_process() would hand to sig_source_multiply(); returns the count */
+size_t orc_doppler_plan(orc_doppler *d, size_t input_len, uint32_t *lens, int64_t *freqs, size_t cap);
+void orc_doppler_process(orc_doppler *d, const float *iq, size_t input_len, float **iq_out, size_t *out_len);
+void orc_doppler_destroy(orc_doppler *d);
+
 /* ---- CPU baseline timing helper (bench.py cpu_baseline leg) ----
  * Runs `threads` independent demodulators (one per thread, like one dsp_worker per client,
  * reference src/dsp_worker.c:188) over the same cf32 buffer in chunks of `chunk` samples, looping over

@@ -73,6 +73,12 @@ def lib():
     L.orc_nco_multiply.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(f32p), C.POINTER(C.c_size_t)]
     L.orc_nco_multiply.restype = None
     L.orc_nco_destroy.argtypes = [C.c_void_p]
+    L.orc_doppler_create.argtypes = [C.c_uint64, C.POINTER(C.c_double), C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.orc_doppler_plan.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_int64), C.c_size_t]
+    L.orc_doppler_plan.restype = C.c_size_t
+    L.orc_doppler_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(f32p), C.POINTER(C.c_size_t)]
+    L.orc_doppler_process.restype = None
+    L.orc_doppler_destroy.argtypes = [C.c_void_p]
     L.orc_bench_fsk.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int64, C.c_uint8,
                                 C.c_uint32, C.c_bool, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.orc_bench_fsk.restype = C.c_double
@@ -275,6 +281,31 @@ class Nco:
     def __del__(self):
         if getattr(self, "h", None):
             lib().orc_nco_destroy(self.h)
+
+
+class Doppler:
+    """orc_doppler_*: the reference's Doppler batching (doppler.c:116-190) driven by per-second shifts."""
+
+    def __init__(self, fs, shifts, maxlen):
+        self.h = C.c_void_p()
+        arr = (C.c_double * len(shifts))(*shifts)
+        self.code = lib().orc_doppler_create(fs, arr, len(shifts), maxlen, C.byref(self.h))
+
+    def plan(self, n):
+        lens = (C.c_uint32 * 64)()
+        freqs = (C.c_int64 * 64)()
+        k = lib().orc_doppler_plan(self.h, n, lens, freqs, 64)
+        return [(int(lens[i]), int(freqs[i])) for i in range(k)]
+
+    def process(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        p, m = f32p(), C.c_size_t()
+        lib().orc_doppler_process(self.h, iq.ctypes.data if len(iq) else None, len(iq) // 2, C.byref(p), C.byref(m))
+        return _take(p, 2 * m.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_doppler_destroy(self.h)
 
 
 def demod_stream(cfg, iq, chunk):

@@ -196,6 +196,42 @@ def test_nco_known_answer():
     assert np.abs(got - want).max() < 1e-2
 
 
+# ---------------------------------------------------------------- next row f-1: Doppler batching + NCO (test/test_doppler.c)
+
+DOPPLER = json.load(open(os.path.join(GOLDEN, "doppler_shifts_lucky7.json")))
+
+
+@pytest.mark.parametrize("buflen", [2000, 47000, 95000])
+def test_doppler_rx_golden_file(buflen):
+    """test/test_doppler.c:37-76: lucky7.cf32 -> lucky7.expected.cf32 (the .47000/.95000 expected files are
+    byte-identical to it), fed in 2000-sample reads, tolerance 0.01 (test/utils.c:137)."""
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.float32)
+    want = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.float32)
+    d = orc.Doppler(DOPPLER["sampling_freq"], DOPPLER["shifts_hz"], buflen)
+    assert d.code == 0
+    got = np.concatenate([d.process(iq[2 * o: 2 * (o + 2000)]) for o in range(0, len(iq) // 2, 2000)])
+    assert len(got) == len(want)
+    assert np.abs(got - want).max() < 0.01
+    assert np.abs(got - want).max() < 2e-6  # in fact equal to float rounding of the stored file
+
+
+def test_doppler_batches_split_at_second_boundaries():
+    d = orc.Doppler(48000, DOPPLER["shifts_hz"], 131072)
+    plan = d.plan(131072)
+    assert [p[0] for p in plan] == [48000, 48000, 35072]
+    assert plan[0][1] == int(DOPPLER["shifts_hz"][0]) and plan[1][1] == int(DOPPLER["shifts_hz"][1])
+    # a call that ends inside a second: the next call first finishes that second with the interpolated shift
+    nxt = d.plan(20000)
+    assert [p[0] for p in nxt] == [12928, 7072]
+
+
+def test_doppler_invalid_arguments(capfd):
+    d = orc.Doppler(48000, DOPPLER["shifts_hz"], 2000)
+    assert len(d.process(np.zeros(0, np.float32))) == 0
+    assert len(d.process(np.zeros(2 * 2001, np.float32))) == 0
+    assert "more than max: 2000" in capfd.readouterr().err
+
+
 # ---------------------------------------------------------------- against the reference's own code (oracle/_ref)
 
 needs_ref = pytest.mark.skipif(orc.ref_lib() is None, reason="oracle/_ref not built (reference tree absent)")
