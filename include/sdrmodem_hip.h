@@ -101,6 +101,32 @@ int sdrm_batch_last_soft(sdrm_batch *batch, size_t channel, float *dst, size_t d
 /* copy the last call's int8 outputs of every channel to host: lens[C], data[C][stride] */
 int sdrm_batch_fetch(sdrm_batch *batch, int8_t *data, size_t stride, size_t *lens);
 
+/* ---- Doppler pre-correction / NCO (next scope row: reference src/dsp/doppler.c:116-190, src/dsp/sig_source.c:43-75).
+ * A segment mixes `len` consecutive input samples of `channel` with an oscillator at the integer frequency freq_hz
+ * (fp32 phase accumulator carried across segments and calls, cos/sin in double, exactly as sig_source does).
+ * Segments of one channel must be consecutive in the array and cover that channel's whole input of the call;
+ * channels without segments are demodulated uncorrected.  The _nco calls are the plain calls plus the mix in front. */
+typedef struct {
+    uint32_t channel;
+    uint32_t len;
+    int64_t freq_hz;
+} sdrm_nco_segment;
+int sdrm_batch_process_nco(sdrm_batch *batch, const sdrm_cf32 *const *inputs, const size_t *input_lens,
+                           const sdrm_nco_segment *segments, size_t n_segments, int8_t **outputs, size_t *output_lens);
+int sdrm_batch_process_device_nco(sdrm_batch *batch, const void *d_input, size_t in_stride, const size_t *input_lens,
+                                  const sdrm_nco_segment *segments, size_t n_segments, void *stream);
+/* diagnostics: copy channel c's mixed IQ of the last call (interleaved re,im) to host */
+int sdrm_batch_last_mixed(sdrm_batch *batch, size_t channel, float *dst, size_t dst_cap_samples, size_t *len);
+
+/* The reference's batching of the correction (doppler.c:128-180): batches end at one-second boundaries, the shift is
+ * evaluated once per second by `fn` (the orbit model -- SGP4 in the reference, doppler.c:31-42 -- stays with the
+ * caller), interpolated linearly inside the second and truncated to integer Hz.  One planner per channel. */
+typedef double (*sdrm_doppler_shift_fn)(void *user, uint64_t second);
+typedef struct sdrm_doppler_t sdrm_doppler;
+int sdrm_doppler_create(uint64_t sampling_freq, sdrm_doppler_shift_fn fn, void *user, sdrm_doppler **out);
+size_t sdrm_doppler_plan(sdrm_doppler *d, uint32_t channel, size_t input_len, sdrm_nco_segment *segments, size_t cap);
+void sdrm_doppler_destroy(sdrm_doppler *d);
+
 /* Per-kernel device time, measured with HIP events on the launch stream when enabled.
  * which: 0 = front-end (LPF1+quadrature demod+LPF2), 1 = DC blocker, 2 = clock recovery + int8. */
 int sdrm_batch_timing_enable(sdrm_batch *batch, int enable);

@@ -30,6 +30,13 @@ class FskInfo(C.Structure):
                 ("gain_mu", C.c_float), ("omega_lim", C.c_float)]
 
 
+class NcoSegment(C.Structure):
+    _fields_ = [("channel", C.c_uint32), ("len", C.c_uint32), ("freq_hz", C.c_int64)]
+
+
+SHIFT_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_uint64)
+
+
 class WorkerConfig(C.Structure):
     _fields_ = [("rx_sampling_freq", C.c_uint64), ("demod_baud_rate", C.c_uint32), ("demod_fsk_deviation", C.c_int64),
                 ("demod_decimation", C.c_uint32), ("demod_fsk_transition_width", C.c_uint32),
@@ -44,6 +51,8 @@ EXPORTS = [
     "sdrm_batch_create", "sdrm_batch_destroy", "sdrm_batch_channels", "sdrm_batch_info", "sdrm_batch_taps",
     "sdrm_batch_process", "sdrm_batch_process_device", "sdrm_batch_device_outputs", "sdrm_batch_last_soft",
     "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
+    "sdrm_batch_process_nco", "sdrm_batch_process_device_nco", "sdrm_batch_last_mixed",
+    "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_wave_scan", "sdrm_set_scan_mode", "sdrm_version", "sdrm_device_count",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
     "interrupt_waiting_the_data", "destroy_queue",
@@ -84,6 +93,15 @@ def load():
     L.sdrm_batch_fetch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdrm_batch_wait.argtypes = [vp, vp]
     L.sdrm_batch_sync.argtypes = [vp]
+    L.sdrm_batch_process_nco.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(NcoSegment), C.c_size_t,
+                                         C.POINTER(i8p), C.POINTER(C.c_size_t)]
+    L.sdrm_batch_process_device_nco.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(NcoSegment), C.c_size_t, vp]
+    L.sdrm_batch_last_mixed.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdrm_doppler_create.argtypes = [C.c_uint64, SHIFT_FN, vp, C.POINTER(vp)]
+    L.sdrm_doppler_plan.argtypes = [vp, C.c_uint32, C.c_size_t, C.POINTER(NcoSegment), C.c_size_t]
+    L.sdrm_doppler_plan.restype = C.c_size_t
+    L.sdrm_doppler_destroy.argtypes = [vp]
+    L.sdrm_doppler_destroy.restype = None
     L.sdrm_batch_timing_enable.argtypes = [vp, C.c_int]
     L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sdrm_probe_atan2.argtypes = [vp, vp, vp, C.c_size_t]
@@ -184,6 +202,29 @@ class Batch:
             res.append(np.ctypeslib.as_array(outs[c], shape=(n,)).copy() if n else np.zeros(0, np.int8))
         return res
 
+    def process_nco(self, inputs, segments):
+        """segments: list of (channel, len, freq_hz), grouped by channel, covering each corrected channel's input."""
+        keep = [None if x is None else _as_f32(x) for x in inputs]
+        ptrs = (C.c_void_p * self.n)(*[None if k is None or len(k) == 0 else k.ctypes.data for k in keep])
+        lens = (C.c_size_t * self.n)(*[0 if k is None else len(k) // 2 for k in keep])
+        segs = (NcoSegment * max(len(segments), 1))(*[NcoSegment(*s) for s in segments])
+        outs = (i8p * self.n)()
+        olens = (C.c_size_t * self.n)()
+        code = self.L.sdrm_batch_process_nco(self.h, ptrs, lens, segs, len(segments), outs, olens)
+        if code != 0:
+            raise RuntimeError("sdrm_batch_process_nco failed: %d" % code)
+        return [np.ctypeslib.as_array(outs[c], shape=(olens[c],)).copy() if olens[c] else np.zeros(0, np.int8)
+                for c in range(self.n)]
+
+    def last_mixed(self, c):
+        n = C.c_size_t()
+        if self.L.sdrm_batch_last_mixed(self.h, c, None, 0, C.byref(n)) != 0:
+            raise RuntimeError("sdrm_batch_last_mixed failed")
+        out = np.zeros(2 * n.value, dtype=np.float32)
+        if n.value:
+            self.L.sdrm_batch_last_mixed(self.h, c, out.ctypes.data, n.value, C.byref(n))
+        return out
+
     def process_device(self, d_ptr, in_stride, lens, stream=None):
         arr = (C.c_size_t * self.n)(*[int(x) for x in lens])
         code = self.L.sdrm_batch_process_device(self.h, C.c_void_p(d_ptr), in_stride, arr, C.c_void_p(stream or 0))
@@ -219,6 +260,25 @@ class Batch:
         ms, n = C.c_double(), C.c_uint64()
         self.L.sdrm_batch_timing_read(self.h, which, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+
+class DopplerPlanner:
+    """sdrm_doppler_*: the reference's batching of the correction (doppler.c:128-180); shift_fn(second) -> Hz."""
+
+    def __init__(self, fs, shift_fn):
+        self.L = load()
+        self._cb = SHIFT_FN(lambda user, k: float(shift_fn(int(k))))
+        self.h = C.c_void_p()
+        self.code = self.L.sdrm_doppler_create(fs, self._cb, None, C.byref(self.h))
+
+    def plan(self, channel, n):
+        segs = (NcoSegment * 64)()
+        k = self.L.sdrm_doppler_plan(self.h, channel, n, segs, 64)
+        return [(int(segs[i].channel), int(segs[i].len), int(segs[i].freq_hz)) for i in range(k)]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.sdrm_doppler_destroy(self.h)
 
 
 class FskDemod:

@@ -53,6 +53,12 @@ struct sdrm_batch_t {
     float *d_outf = nullptr;
     uint32_t *d_outlen = nullptr;
     uint32_t *d_flags = nullptr;  // [SLOTS][C] non-finite flags, one set per control slot
+    // NCO pre-mix (allocated on first use)
+    sdrm_nco_seg *d_nco_segs = nullptr, *h_nco_segs = nullptr;  // [SLOTS][nco_seg_cap]
+    size_t nco_seg_cap = 0;
+    float *d_nco_state = nullptr, *d_nco_phase = nullptr;
+    sdrm_f2 *d_nco_out = nullptr;
+    std::vector<sdrm_nco_seg> nco_table;
     sdrm_f2 *d_in = nullptr;  // staging for the host-buffer API (lazy)
     // host (pinned) mirrors
     sdrm_chunk_ctl *h_ctl = nullptr;  // [SLOTS][C]
@@ -123,7 +129,8 @@ static void batch_free(sdrm_batch_t *b) {
         }
     }
     void *dev_ptrs[] = {b->d_params, b->d_ctl, b->d_taps, b->d_atan, b->d_bank, b->d_hist, b->d_z, b->d_dcout,
-                        b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in, b->d_flags, b->d_z2, b->d_dcout2};
+                        b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in, b->d_flags, b->d_z2, b->d_dcout2,
+                        b->d_nco_segs, b->d_nco_state, b->d_nco_phase, b->d_nco_out};
     for (void *p : dev_ptrs) {
         if (p) {
             (void) hipFree(p);
@@ -137,6 +144,9 @@ static void batch_free(sdrm_batch_t *b) {
     }
     if (b->h_out8) {
         (void) hipHostFree(b->h_out8);
+    }
+    if (b->h_nco_segs) {
+        (void) hipHostFree(b->h_nco_segs);
     }
     if (b->stream) {
         (void) hipStreamDestroy(b->stream);
@@ -398,7 +408,25 @@ extern "C" int sdrm_batch_timing_read(sdrm_batch *b, int which, double *total_ms
 // Enqueue one call.  `caller` is the stream on which the caller's input becomes ready; the stages run on the
 // batch's own streams so that the front-end of call i+1, the DC blocker of call i and the clock recovery of call i-1
 // can be resident together (the sequential stages only occupy a few waves).  Nothing waits on the host.
-static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller) {
+static int ensure_nco(sdrm_batch_t *b) {
+    if (b->d_nco_out != nullptr) {
+        return 0;
+    }
+    const size_t C = b->plan.design.size();
+    b->nco_seg_cap = 8 * C + 64;
+    int code = 0;
+    code = code ? code : dev_alloc_zero(&b->d_nco_segs, b->nco_seg_cap * SDRM_CTL_SLOTS);
+    code = code ? code : dev_alloc_zero(&b->d_nco_state, C);
+    code = code ? code : dev_alloc_zero(&b->d_nco_phase, C * (size_t) b->in_stride);
+    code = code ? code : dev_alloc_zero(&b->d_nco_out, C * (size_t) b->in_stride);
+    if (code == 0 && hipHostMalloc((void **) &b->h_nco_segs, sizeof(sdrm_nco_seg) * b->nco_seg_cap * SDRM_CTL_SLOTS) != hipSuccess) {
+        code = -ENOMEM;
+    }
+    return code;
+}
+
+static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
+                        const sdrm_nco_segment *segs = nullptr, size_t n_segs = 0) {
     const size_t C = b->plan.design.size();
     const uint64_t i = b->calls;
     const int slot = (int) (i % SDRM_CTL_SLOTS);
@@ -409,6 +437,35 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     const uint32_t max_tiles = sdrm::plan_call(b->plan, lens, h);
     sdrm_chunk_ctl *d_ctl = b->d_ctl + (size_t) slot * C;
     sdrm::DeviceBatch d = b->dev;
+    bool with_nco = false;
+    uint32_t nco_max_len = 0;
+    if (segs != nullptr && n_segs > 0) {
+        int code = ensure_nco(b);
+        if (code != 0) {
+            return code;
+        }
+        if (sdrm::plan_nco(b->plan, segs, n_segs, h, b->nco_table) != 0 || b->nco_table.size() > b->nco_seg_cap) {
+            // the bookkeeping of plan_call already advanced: an invalid table is a caller bug, keep the stream alive
+            // by running the call without correction
+            fprintf(stderr, "<3>sdrmodem_hip: invalid NCO segment table, call runs uncorrected\n");
+            for (size_t c = 0; c < C; c++) {
+                h[c].nco_cnt = 0;
+            }
+        } else if (!b->nco_table.empty()) {
+            with_nco = true;
+            memcpy(b->h_nco_segs + (size_t) slot * b->nco_seg_cap, b->nco_table.data(), sizeof(sdrm_nco_seg) * b->nco_table.size());
+            for (size_t c = 0; c < C; c++) {
+                if (h[c].nco_cnt) {
+                    nco_max_len = std::max(nco_max_len, h[c].n_in);
+                }
+            }
+        }
+    }
+    d.nco_segs = with_nco ? b->d_nco_segs + (size_t) slot * b->nco_seg_cap : nullptr;
+    d.nco_phase_state = b->d_nco_state;
+    d.nco_phase = b->d_nco_phase;
+    d.nco_out = b->d_nco_out;
+    d.nco_stride = b->in_stride;
     d.ctl = d_ctl;
     d.nonfinite = b->d_flags + (size_t) slot * C;
     d.max_tiles = max_tiles;
@@ -427,6 +484,11 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         }
     }
     HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, b->s_front));
+    if (with_nco) {
+        HIP_TRY(hipMemcpyAsync(b->d_nco_segs + (size_t) slot * b->nco_seg_cap, b->h_nco_segs + (size_t) slot * b->nco_seg_cap,
+                               sizeof(sdrm_nco_seg) * b->nco_table.size(), hipMemcpyHostToDevice, b->s_front));
+        sdrm::launch_nco(d, d_in, in_stride, nco_max_len, b->s_front);
+    }
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (b->timing) {
         timing_begin(b, 0, b->s_front, &ev);
@@ -509,6 +571,58 @@ extern "C" int sdrm_batch_process_device(sdrm_batch *b, const void *d_input, siz
     return enqueue_call(b, (const sdrm_f2 *) d_input, in_stride, input_lens, (hipStream_t) stream);
 }
 
+extern "C" int sdrm_batch_process_device_nco(sdrm_batch *b, const void *d_input, size_t in_stride, const size_t *input_lens,
+                                             const sdrm_nco_segment *segments, size_t n_segments, void *stream) {
+    if (b == nullptr || input_lens == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    return enqueue_call(b, (const sdrm_f2 *) d_input, in_stride, input_lens, (hipStream_t) stream, segments, n_segments);
+}
+
+extern "C" int sdrm_batch_last_mixed(sdrm_batch *b, size_t c, float *dst, size_t cap, size_t *len) {
+    if (b == nullptr || c >= b->plan.design.size() || b->d_nco_out == nullptr || b->last_slot < 0) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const sdrm_chunk_ctl &k = b->h_ctl[(size_t) b->last_slot * b->plan.design.size() + c];
+    const size_t n = k.nco_cnt ? k.n_in : 0;
+    if (len) {
+        *len = n;
+    }
+    if (dst != nullptr && n > 0) {
+        HIP_TRY(hipMemcpy(dst, b->d_nco_out + c * (size_t) b->in_stride, sizeof(sdrm_f2) * std::min(n, cap), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+struct sdrm_doppler_t {
+    sdrm::DopplerPlanner planner;
+};
+
+extern "C" int sdrm_doppler_create(uint64_t sampling_freq, sdrm_doppler_shift_fn fn, void *user, sdrm_doppler **out) {
+    if (sampling_freq == 0 || fn == nullptr || out == nullptr) {
+        return -1;
+    }
+    sdrm_doppler_t *d = new sdrm_doppler_t();
+    d->planner.interval = sampling_freq;     // one update per second (doppler.c:84)
+    d->planner.in_interval = sampling_freq;  // "expired": the first batch evaluates the shift (doppler.c:85)
+    d->planner.fn = fn;
+    d->planner.user = user;
+    *out = d;
+    return 0;
+}
+
+extern "C" size_t sdrm_doppler_plan(sdrm_doppler *d, uint32_t channel, size_t input_len, sdrm_nco_segment *segments, size_t cap) {
+    if (d == nullptr || segments == nullptr) {
+        return 0;
+    }
+    return d->planner.plan(channel, input_len, segments, cap);
+}
+
+extern "C" void sdrm_doppler_destroy(sdrm_doppler *d) { delete d; }
+
 extern "C" int sdrm_batch_device_outputs(sdrm_batch *b, void **d_out_i8, size_t *out_stride, void **d_out_len,
                                          void **d_out_f32) {
     if (b == nullptr) {
@@ -545,8 +659,22 @@ static int ensure_host_staging(sdrm_batch_t *b) {
     return 0;
 }
 
+static int process_host(sdrm_batch *b, const sdrm_cf32 *const *inputs, const size_t *input_lens, int8_t **outputs,
+                        size_t *output_lens, const sdrm_nco_segment *segs, size_t n_segs);
+
 extern "C" int sdrm_batch_process(sdrm_batch *b, const sdrm_cf32 *const *inputs, const size_t *input_lens,
                                   int8_t **outputs, size_t *output_lens) {
+    return process_host(b, inputs, input_lens, outputs, output_lens, nullptr, 0);
+}
+
+extern "C" int sdrm_batch_process_nco(sdrm_batch *b, const sdrm_cf32 *const *inputs, const size_t *input_lens,
+                                      const sdrm_nco_segment *segments, size_t n_segments, int8_t **outputs,
+                                      size_t *output_lens) {
+    return process_host(b, inputs, input_lens, outputs, output_lens, segments, n_segments);
+}
+
+static int process_host(sdrm_batch *b, const sdrm_cf32 *const *inputs, const size_t *input_lens, int8_t **outputs,
+                        size_t *output_lens, const sdrm_nco_segment *segs, size_t n_segs) {
     if (b == nullptr || input_lens == nullptr || outputs == nullptr || output_lens == nullptr) {
         return -1;
     }
@@ -564,7 +692,7 @@ extern "C" int sdrm_batch_process(sdrm_batch *b, const sdrm_cf32 *const *inputs,
         HIP_TRY(hipMemcpyAsync(b->d_in + c * (size_t) b->in_stride, inputs[c], n * sizeof(sdrm_f2), hipMemcpyHostToDevice,
                                b->stream));
     }
-    code = enqueue_call(b, b->d_in, b->in_stride, input_lens, b->stream);
+    code = enqueue_call(b, b->d_in, b->in_stride, input_lens, b->stream, segs, n_segs);
     if (code != 0) {
         return code;
     }

@@ -99,4 +99,34 @@ struct sdrm_mm_consts {
     float omega_mid, omega_lim, gain_omega, gain_mu;
 };
 
+// ---- NCO (next scope row f-1; reference src/dsp/sig_source.c:43-58) ----
+// the oscillator sample for an fp32 phase: cos/sin evaluated in double on it, rounded to fp32 (amplitude 1)
+SDRM_HD sdrm_f2 sdrm_nco_sample(float phase) {
+    sdrm_f2 s;
+    s.x = (float) cos((double) phase);
+    s.y = (float) sin((double) phase);
+    return s;
+}
+
+// fp32 phase accumulator with a one-turn wrap when it leaves [-2pi, 2pi] (sig_source.c:47-53)
+SDRM_HD float sdrm_nco_advance(float phase, float step) {
+    const float two_pi = 6.28318530717958647692f;  // (float)(2 * M_PI)
+    phase = phase + step;
+    if (phase < -two_pi) {
+        phase = phase + two_pi;
+    }
+    if (phase > two_pi) {
+        phase = phase - two_pi;
+    }
+    return phase;
+}
+
+// input sample times oscillator sample: C complex multiply as VOLK generic volk_32fc_x2_multiply_32fc (sig_source.c:71)
+SDRM_HD sdrm_f2 sdrm_nco_mix(sdrm_f2 in, sdrm_f2 osc) {
+    sdrm_f2 o;
+    o.x = in.x * osc.x - in.y * osc.y;
+    o.y = in.x * osc.y + in.y * osc.x;
+    return o;
+}
+
 #endif  // SDRM_CORE_H

@@ -54,6 +54,14 @@ struct sdrm_chunk_ctl {
     uint32_t tiles;   // K1 tiles for this channel
     uint32_t parity;  // which of the two raw-history buffers is current
     uint32_t zbase;   // LPF2 outputs produced by earlier calls (mod 2^32): DC ring phase
+    uint32_t nco_off, nco_cnt;  // this call's NCO segments of the channel in the segment table (cnt 0: no NCO)
+};
+
+// one batch of the Doppler pre-correction: `len` samples mixed with an oscillator advancing `step` radians per sample
+// (reference src/dsp/doppler.c:180 -> sig_source.c:44: step = fl(fl(2pi_f * (float)freq_hz) / fs), computed on the host)
+struct sdrm_nco_seg {
+    uint32_t len;
+    float step;
 };
 
 // mutable clock-recovery state (device array, one per channel)

@@ -5,6 +5,78 @@
 
 namespace sdrm {
 
+// ================================================================================================ K0 (NCO, row f-1)
+
+// Phase accumulator, one lane per channel: the fp32 recursion phase += step with its wrap is sequential
+// (reference src/dsp/sig_source.c:43-58).  Writes the phase of every sample (4 samples per 16-byte store).
+__global__ __launch_bounds__(64) void k0_nco_phase(DeviceBatch b) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= b.n_channels) {
+        return;
+    }
+    const sdrm_chunk_ctl ctl = b.ctl[c];
+    if (ctl.nco_cnt == 0) {
+        return;
+    }
+    float phase = b.nco_phase_state[c];
+    float *out = b.nco_phase + (size_t) c * b.nco_stride;
+    const sdrm_nco_seg *seg = b.nco_segs + ctl.nco_off;
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < ctl.nco_cnt; k++) {
+        const float step = seg[k].step;
+        uint32_t left = seg[k].len;
+        // peel to a 4-sample boundary, then whole float4 stores
+        while (left > 0 && (n & 3u)) {
+            out[n++] = phase;
+            phase = sdrm_nco_advance(phase, step);
+            left--;
+        }
+        for (; left >= 4; left -= 4) {
+            float4 v;
+            v.x = phase;
+            phase = sdrm_nco_advance(phase, step);
+            v.y = phase;
+            phase = sdrm_nco_advance(phase, step);
+            v.z = phase;
+            phase = sdrm_nco_advance(phase, step);
+            v.w = phase;
+            phase = sdrm_nco_advance(phase, step);
+            *reinterpret_cast<float4 *>(out + n) = v;
+            n += 4;
+        }
+        while (left > 0) {
+            out[n++] = phase;
+            phase = sdrm_nco_advance(phase, step);
+            left--;
+        }
+    }
+    b.nco_phase_state[c] = phase;
+}
+
+// mix: out[n] = in[n] * (cos, sin)(phase[n]), cos/sin in double on the fp32 phase (sig_source.c:46, :71)
+__global__ __launch_bounds__(256) void k0_nco_mix(DeviceBatch b, const sdrm_f2 *__restrict__ d_in, size_t in_stride) {
+    const int c = blockIdx.y;
+    const sdrm_chunk_ctl ctl = b.ctl[c];
+    if (ctl.nco_cnt == 0) {
+        return;
+    }
+    const sdrm_f2 *in = d_in + (size_t) c * in_stride;
+    const float *ph = b.nco_phase + (size_t) c * b.nco_stride;
+    sdrm_f2 *out = b.nco_out + (size_t) c * b.nco_stride;
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < ctl.n_in; n += gridDim.x * blockDim.x) {
+        out[n] = sdrm_nco_mix(in[n], sdrm_nco_sample(ph[n]));
+    }
+}
+
+void launch_nco(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s) {
+    if (b.nco_segs == nullptr || max_len == 0) {
+        return;
+    }
+    hipLaunchKernelGGL(k0_nco_phase, dim3((unsigned) ((b.n_channels + 63) / 64)), dim3(64), 0, s, b);
+    unsigned gx = (max_len + 1023) / 1024;
+    hipLaunchKernelGGL(k0_nco_mix, dim3(gx ? gx : 1, (unsigned) b.n_channels), dim3(256), 0, s, b, d_in, in_stride);
+}
+
 // ================================================================================================ K1
 
 size_t k1_lds_bytes(uint32_t t1_max) {
@@ -33,7 +105,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, co
 
     const int tid = threadIdx.x;
     const sdrm_k1_tile t = sdrm_k1_tile_setup(p, ctl, (int) blockIdx.x);
-    const sdrm_f2 *in = d_in + (size_t) c * in_stride;
+    const sdrm_f2 *in = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
     const sdrm_f2 *hist = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
 
     const bool stamp = b.k3_stamps != nullptr;  // diagnostics: per-phase cycles, summed over workgroups
@@ -66,7 +138,8 @@ __global__ __launch_bounds__(256) void k1_hist_roll(DeviceBatch b, const sdrm_f2
     const sdrm_chan_params p = b.params[c];
     const sdrm_f2 *cur = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
     sdrm_f2 *next = b.raw_hist + ((size_t) c * 2 + (ctl.parity ^ 1u)) * b.hist_stride;
-    sdrm_hist_roll((int) threadIdx.x, (int) blockDim.x, p, ctl, d_in + (size_t) c * in_stride, cur, next);
+    const sdrm_f2 *in = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
+    sdrm_hist_roll((int) threadIdx.x, (int) blockDim.x, p, ctl, in, cur, next);
 }
 
 // dynamic LDS above the 64 KiB default has to be requested per kernel (up to the CU's 160 KiB)

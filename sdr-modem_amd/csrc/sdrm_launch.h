@@ -31,6 +31,12 @@ struct DeviceBatch {
     uint32_t *nonfinite;             // [C] of the call's control slot: set by K1/K2 when NaN/Inf reaches the clock stage
     uint32_t out_stride;
     unsigned long long *k3_stamps;   // diagnostics (normally null): per K3 wave {staging cycles, loop cycles, steps, iterations}
+    // NCO pre-mix (optional): per-call segment table, per-channel fp32 phase, phase scratch and mixed-IQ buffer
+    const sdrm_nco_seg *nco_segs;
+    float *nco_phase_state;          // [C]
+    float *nco_phase;                // [C][nco_stride] phase of every sample of the call
+    sdrm_f2 *nco_out;                // [C][nco_stride] input after the mix (what K1 reads for NCO channels)
+    uint32_t nco_stride;
     // launch geometry (host-computed maxima over the batch)
     uint32_t max_tiles;              // K1 grid.x for this call
     uint32_t t1_max;                 // sizes K1's LDS
@@ -41,6 +47,7 @@ struct DeviceBatch {
 size_t k1_lds_bytes(uint32_t t1_max);
 size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap);
 
+void launch_nco(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);
 void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
 void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
 void launch_dc(const DeviceBatch &b, hipStream_t s);

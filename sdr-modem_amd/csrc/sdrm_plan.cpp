@@ -121,12 +121,86 @@ uint32_t plan_call(BatchPlan &plan, const size_t *lens, sdrm_chunk_ctl *ctl) {
         k.tiles = (k.nz + p.tile_m - 1) / p.tile_m;
         k.parity = plan.parity[c];
         k.zbase = plan.zbase[c];
+        k.nco_off = 0;
+        k.nco_cnt = 0;
         plan.phase[c] = k.i0 + k.nz * p.decim - k.n_in;
         plan.parity[c] ^= 1u;
         plan.zbase[c] += k.nz;
         max_tiles = std::max(max_tiles, k.tiles);
     }
     return max_tiles;
+}
+
+int plan_nco(const BatchPlan &plan, const sdrm_nco_segment *segs, size_t n_segs, sdrm_chunk_ctl *ctl,
+             std::vector<sdrm_nco_seg> &table) {
+    table.clear();
+    const size_t n_ch = plan.params.size();
+    size_t i = 0;
+    while (i < n_segs) {
+        const uint32_t c = segs[i].channel;
+        if (c >= n_ch || ctl[c].nco_cnt != 0) {
+            fprintf(stderr, "<3>nco segments must be grouped by channel (segment %zu, channel %u)\n", i, c);
+            return -1;
+        }
+        const uint64_t fs = plan.design[c].cfg.sampling_freq;
+        uint64_t total = 0;
+        ctl[c].nco_off = (uint32_t) table.size();
+        while (i < n_segs && segs[i].channel == c) {
+            sdrm_nco_seg s;
+            s.len = segs[i].len;
+            // reference src/dsp/sig_source.c:44: `M_2PI * (float) freq / source->rx_sampling_freq` in fp32
+            const float two_pi = (float) (2 * 3.14159265358979323846);
+            s.step = two_pi * (float) segs[i].freq_hz / fs;
+            table.push_back(s);
+            total += s.len;
+            i++;
+        }
+        ctl[c].nco_cnt = (uint32_t) (table.size() - ctl[c].nco_off);
+        if (total != ctl[c].n_in) {
+            if (ctl[c].n_in == 0) {  // oversize / empty input was dropped: so is its correction
+                table.resize(ctl[c].nco_off);
+                ctl[c].nco_cnt = 0;
+                continue;
+            }
+            fprintf(stderr, "<3>nco segments of channel %u cover %llu samples, input has %u\n", c,
+                    (unsigned long long) total, ctl[c].n_in);
+            return -1;
+        }
+    }
+    return 0;
+}
+
+// reference src/dsp/doppler.c:128-180, one batch per loop turn
+size_t DopplerPlanner::plan(uint32_t channel, size_t input_len, sdrm_nco_segment *out, size_t cap) {
+    size_t done = 0, count = 0;
+    while (done < input_len && count < cap) {
+        const size_t remaining = input_len - done;
+        size_t batch;
+        if (interval < remaining + in_interval) {
+            if (in_interval >= interval) {
+                batch = interval < remaining ? (size_t) interval : remaining;
+            } else {
+                batch = (size_t) (interval - in_interval);
+            }
+        } else {
+            batch = remaining;
+        }
+        if (in_interval >= interval) {
+            in_interval = 0;
+            cur = (next == 0) ? fn(user, second++) : next;  // :147-160 (0 doubles as "not evaluated yet")
+            next = fn(user, second++);
+            slope = (next - cur) / interval;                 // :166 linear interpolation inside the second
+        } else {
+            cur += slope * (double) batch;                   // :168
+        }
+        in_interval += batch;
+        out[count].channel = channel;
+        out[count].len = (uint32_t) batch;
+        out[count].freq_hz = (int64_t) cur;                  // :180 truncation to integer Hz
+        count++;
+        done += batch;
+    }
+    return count;
 }
 
 }  // namespace sdrm

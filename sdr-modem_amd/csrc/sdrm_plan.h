@@ -35,6 +35,23 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan);
 // (src/dsp/fir_filter.c:147-152) and is treated as an empty input.  Returns the largest tile count.
 uint32_t plan_call(BatchPlan &plan, const size_t *lens, sdrm_chunk_ctl *ctl);
 
+// Turn the caller's NCO segments (grouped by channel, consecutive, covering the channel's whole input of this call)
+// into the device table and fill ctl[c].nco_off / nco_cnt.  Channels without segments get no NCO.  Returns 0, or -1
+// when a channel's segments do not add up to its input length / are not grouped.
+int plan_nco(const BatchPlan &plan, const sdrm_nco_segment *segs, size_t n_segs, sdrm_chunk_ctl *ctl,
+             std::vector<sdrm_nco_seg> &table);
+
+// Doppler batching of the reference (src/dsp/doppler.c:116-190) without its orbit model: the per-second shifts come
+// from the caller (SGP4 stays on the host side of the boundary).
+struct DopplerPlanner {
+    uint64_t interval = 0, in_interval = 0;
+    double cur = 0.0, next = 0.0, slope = 0.0;
+    uint64_t second = 0;
+    sdrm_doppler_shift_fn fn = nullptr;
+    void *user = nullptr;
+    size_t plan(uint32_t channel, size_t input_len, sdrm_nco_segment *out, size_t cap);
+};
+
 }  // namespace sdrm
 
 #endif

@@ -27,6 +27,9 @@ struct EmuBatch {
     std::vector<uint32_t> outlen;
     std::vector<sdrm_chunk_ctl> ctl;
     std::vector<uint32_t> nonfinite;
+    std::vector<float> nco_state;
+    std::vector<std::vector<sdrm_f2>> mixed;
+    std::vector<sdrm_nco_seg> nco_table;
 };
 
 extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out) {
@@ -52,6 +55,8 @@ extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out)
     b->outlen.assign(n, 0);
     b->ctl.resize(n);
     b->nonfinite.assign(n, 0);
+    b->nco_state.assign(n, 0.0f);
+    b->mixed.resize(n);
     *out = b;
     return 0;
 }
@@ -239,6 +244,82 @@ extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t
         outlens[c] = b->outlen[c];
     }
     return 0;
+}
+
+// same call with the NCO pre-mix in front (K0: lane-per-channel phase chain, then the pointwise mix)
+extern "C" int emu_process_nco(EmuBatch *b, const float *const *inputs, const size_t *lens, const sdrm_nco_segment *segs,
+                               size_t n_segs, const int8_t **out8, const float **outf, size_t *outlens) {
+    const size_t C = b->plan.params.size();
+    plan_call(b->plan, lens, b->ctl.data());
+    if (plan_nco(b->plan, segs, n_segs, b->ctl.data(), b->nco_table) != 0) {
+        return -1;
+    }
+    std::vector<const sdrm_f2 *> ins(C);
+    for (size_t c = 0; c < C; c++) {
+        const sdrm_chunk_ctl &k = b->ctl[c];
+        const sdrm_f2 *in = reinterpret_cast<const sdrm_f2 *>(inputs[c]);
+        if (k.nco_cnt == 0) {
+            ins[c] = in;
+            continue;
+        }
+        std::vector<sdrm_f2> &m = b->mixed[c];
+        m.resize(k.n_in);
+        float phase = b->nco_state[c];
+        uint32_t n = 0;
+        for (uint32_t s = 0; s < k.nco_cnt; s++) {
+            const sdrm_nco_seg &sg = b->nco_table[k.nco_off + s];
+            for (uint32_t i = 0; i < sg.len; i++, n++) {
+                m[n] = sdrm_nco_mix(in[n], sdrm_nco_sample(phase));
+                phase = sdrm_nco_advance(phase, sg.step);
+            }
+        }
+        b->nco_state[c] = phase;
+        ins[c] = m.data();
+    }
+    emu_front(b, ins.data());
+    emu_dc(b);
+    emu_clock(b);
+    for (size_t c = 0; c < C; c++) {
+        out8[c] = b->out8.data() + c * b->plan.out_stride;
+        outf[c] = b->outf.data() + c * b->plan.out_stride;
+        outlens[c] = b->outlen[c];
+    }
+    return 0;
+}
+
+extern "C" size_t emu_mixed(EmuBatch *b, size_t c, float *dst, size_t cap) {
+    const std::vector<sdrm_f2> &m = b->mixed[c];
+    for (size_t i = 0; i < m.size() && i < cap; i++) {
+        dst[2 * i] = m[i].x;
+        dst[2 * i + 1] = m[i].y;
+    }
+    return m.size();
+}
+
+// the Doppler planner (host code of the product) for CPU tests
+struct EmuShift {
+    const double *v;
+    size_t n;
+};
+static double emu_shift_cb(void *user, uint64_t k) {
+    EmuShift *s = (EmuShift *) user;
+    return s->n ? s->v[k < s->n ? k : s->n - 1] : 0.0;
+}
+extern "C" size_t emu_doppler_plan_stream(uint64_t fs, const double *shifts, size_t n_shifts, const size_t *call_lens,
+                                          size_t n_calls, sdrm_nco_segment *out, size_t cap, size_t *per_call_counts) {
+    EmuShift sh{shifts, n_shifts};
+    DopplerPlanner p;
+    p.interval = fs;
+    p.in_interval = fs;
+    p.fn = emu_shift_cb;
+    p.user = &sh;
+    size_t total = 0;
+    for (size_t i = 0; i < n_calls; i++) {
+        size_t k = p.plan(0, call_lens[i], out + total, cap - total);
+        per_call_counts[i] = k;
+        total += k;
+    }
+    return total;
 }
 
 // stage taps for inspection

@@ -9,7 +9,7 @@ import numpy as np
 import sdrm_pkg
 
 sdrm_pkg.load()
-from sdr_modem_amd.binding import FskConfig, FskInfo, make_configs  # noqa: E402
+from sdr_modem_amd.binding import FskConfig, FskInfo, NcoSegment, make_configs  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_DIR = os.path.join(HERE, "emu")
@@ -26,6 +26,13 @@ def lib():
         L.emu_destroy.restype = None
         L.emu_process.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.emu_process_nco.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(NcoSegment),
+                                      C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.emu_mixed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.emu_mixed.restype = C.c_size_t
+        L.emu_doppler_plan_stream.argtypes = [C.c_uint64, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_size_t),
+                                              C.c_size_t, C.POINTER(NcoSegment), C.c_size_t, C.POINTER(C.c_size_t)]
+        L.emu_doppler_plan_stream.restype = C.c_size_t
         L.emu_taps.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
         L.emu_taps.restype = C.c_size_t
         L.emu_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FskInfo)]
@@ -41,8 +48,9 @@ class EmuBatch:
         self.h = C.c_void_p()
         self.code = lib().emu_create(self._cfgs, self.n, C.byref(self.h))
 
-    def process(self, inputs):
-        """inputs: list of complex64 arrays. Returns (list of int8 arrays, list of float32 arrays)."""
+    def process(self, inputs, segments=None):
+        """inputs: list of complex64 arrays. Returns (list of int8 arrays, list of float32 arrays).
+        segments: optional list of (channel, len, freq_hz) NCO batches."""
         keep = [np.ascontiguousarray(x).view(np.float32) if x is not None else np.zeros(0, np.float32) for x in inputs]
         dummy = np.zeros(2, np.float32)
         ptrs = (C.c_void_p * self.n)(*[(k.ctypes.data if len(k) else dummy.ctypes.data) for k in keep])
@@ -50,13 +58,23 @@ class EmuBatch:
         o8 = (C.c_void_p * self.n)()
         of = (C.c_void_p * self.n)()
         ol = (C.c_size_t * self.n)()
-        lib().emu_process(self.h, ptrs, lens, o8, of, ol)
+        if segments is None:
+            lib().emu_process(self.h, ptrs, lens, o8, of, ol)
+        else:
+            segs = (NcoSegment * max(len(segments), 1))(*[NcoSegment(*s) for s in segments])
+            assert lib().emu_process_nco(self.h, ptrs, lens, segs, len(segments), o8, of, ol) == 0
         r8, rf = [], []
         for c in range(self.n):
             n = ol[c]
             r8.append(np.ctypeslib.as_array(C.cast(o8[c], C.POINTER(C.c_int8)), shape=(n,)).copy() if n else np.zeros(0, np.int8))
             rf.append(np.ctypeslib.as_array(C.cast(of[c], C.POINTER(C.c_float)), shape=(n,)).copy() if n else np.zeros(0, np.float32))
         return r8, rf
+
+    def mixed(self, c):
+        n = lib().emu_mixed(self.h, c, None, 0)
+        out = np.zeros(2 * n, np.float32)
+        lib().emu_mixed(self.h, c, out.ctypes.data, n)
+        return out
 
     def taps(self, c, stage):
         n = lib().emu_taps(self.h, c, stage, None, 0)
@@ -72,3 +90,17 @@ class EmuBatch:
     def __del__(self):
         if getattr(self, "h", None):
             lib().emu_destroy(self.h)
+
+
+def doppler_plan_stream(fs, shifts, call_lens):
+    """the product's Doppler planner over consecutive calls: list (per call) of [(len, freq_hz), ...]"""
+    sh = (C.c_double * len(shifts))(*shifts)
+    cl = (C.c_size_t * len(call_lens))(*call_lens)
+    segs = (NcoSegment * (16 * len(call_lens) + 16))()
+    counts = (C.c_size_t * len(call_lens))()
+    lib().emu_doppler_plan_stream(fs, sh, len(shifts), cl, len(call_lens), segs, len(segs), counts)
+    out, pos = [], 0
+    for k in counts:
+        out.append([(int(segs[pos + i].len), int(segs[pos + i].freq_hz)) for i in range(k)])
+        pos += k
+    return out

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(ROOT, "include", "sdrmodem_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"typedef[^;{]*\(\s*\*\s*\w+\s*\)[^;]*;", "", text)  # function-pointer typedefs are not exports
     names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{}]*\)\s*;", text)
     return sorted(set(n for n in names if n not in ("defined",)))
 

@@ -274,3 +274,89 @@ def test_dsp_worker_file_sink_matches_oracle():
     assert np.array_equal(got, want)
     golden = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.s8"), dtype=np.int8)
     assert np.abs(got.astype(np.int32) - golden.astype(np.int32)).max() <= 2
+
+
+# ---------------------------------------------------------------- next row f-1: Doppler planner + NCO (doppler.c, sig_source.c)
+
+import json  # noqa: E402
+
+DOPPLER = json.load(open(os.path.join(GOLDEN, "doppler_shifts_lucky7.json")))
+NCO_TOL = 0.01  # the reference's own tolerance for the corrected IQ (test/utils.c:137 via test/test_doppler.c:60)
+
+
+def test_doppler_corrected_iq_matches_reference_golden_file():
+    """test/test_doppler.c:37-76 through the device NCO: lucky7.cf32 -> lucky7.expected.cf32.  cos/sin come from the
+    device's double-precision math library instead of glibc: tolerance 0.01 as in the reference; we also require the
+    values to be bit-identical to the oracle for at least 99.99 % of the samples."""
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.complex64)
+    want = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.float32)
+    chunk = 2000  # the reference harness reads 2000 samples at a time; the interpolated shift advances per call
+    g = binding.Batch([(48000, 4800, 5000, 2, 2000, True, chunk)])
+    planner = binding.DopplerPlanner(48000, lambda k: DOPPLER["shifts_hz"][min(k, len(DOPPLER["shifts_hz"]) - 1)])
+    o = orc.Doppler(48000, DOPPLER["shifts_hz"], chunk)
+    got, ref = [], []
+    for off in range(0, len(iq), chunk):
+        part = iq[off:off + chunk]
+        segs = planner.plan(0, len(part))
+        g.process_nco([part], segs)
+        got.append(g.last_mixed(0))
+        ref.append(o.process(part.view(np.float32)))
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    assert len(got) == len(want)
+    assert np.abs(got - want).max() < NCO_TOL
+    assert np.abs(got - ref).max() < 1e-6
+    same = np.mean(got.view(np.uint32) == ref.view(np.uint32))
+    assert same > 0.9999, same
+    g.close()
+
+
+def test_doppler_then_demod_soft_bits_match_oracle():
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.complex64)
+    cfg = (48000, 4800, 5000, 2, 2000, True)
+    chunk = 20000
+    g = binding.Batch([cfg + (chunk,)], keep_soft=True)
+    planner = binding.DopplerPlanner(48000, lambda k: DOPPLER["shifts_hz"][min(k, len(DOPPLER["shifts_hz"]) - 1)])
+    o = orc.Fsk(*cfg, chunk)
+    d = orc.Doppler(48000, DOPPLER["shifts_hz"], chunk)
+    for off in range(0, len(iq), chunk):
+        part = iq[off:off + chunk]
+        o8, of = o.process(d.process(part.view(np.float32)))
+        g8 = g.process_nco([part], planner.plan(0, len(part)))[0]
+        gf = g.last_soft(0)
+        assert len(of) == len(gf)
+        rms = float(np.sqrt(np.mean((of.astype(np.float64) - gf) ** 2))) if len(of) else 0.0
+        assert rms <= RMS_TOL, rms
+        assert np.abs(o8.astype(np.int32) - g8.astype(np.int32)).max() <= 2  # reference tolerance, test_fsk_demod.c:47
+    g.close()
+
+
+def test_mixed_rate_batch_with_per_channel_doppler_ramp():
+    """BASELINE config 5 in miniature: 240 kHz / 19200 baud and 48 kHz / 1200 baud channels (decimated to sps < 8), each
+    with its own linear Doppler ramp (+-10 kHz over the run, piecewise-constant per <= 1 s batch), some uncorrected."""
+    cfgs = ([(240000, 19200, 5000, 5, 2000, True, 60000)] * 3 + [(48000, 1200, 5000, 8, 2000, True, 60000)] * 3) * 2
+    n_calls, n = 3, 60000
+    sigs = [siggen.gmsk_channel(i, n_calls * n, fs=c[0], baud=c[1], carrier_offset_hz=0.0) for i, c in enumerate(cfgs)]
+    ramps = [(lambda k, i=i: -10000.0 + 2500.0 * k + 37.0 * i) if i % 3 else None for i in range(len(cfgs))]
+    g = binding.Batch(cfgs, keep_soft=True)
+    assert g.code == 0
+    planners = [binding.DopplerPlanner(c[0], r) if r else None for c, r in zip(cfgs, ramps)]
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    odops = [orc.Doppler(c[0], [r(k) for k in range(8)], n) if r else None for c, r in zip(cfgs, ramps)]
+    for call in range(n_calls):
+        parts = [s[call * n:(call + 1) * n] for s in sigs]
+        segs = []
+        for i, p in enumerate(planners):
+            if p is not None:
+                segs += p.plan(i, n)
+        g8 = g.process_nco(parts, segs)
+        for i, o in enumerate(oracles):
+            x = parts[i].view(np.float32)
+            if odops[i] is not None:
+                x = odops[i].process(x)
+            o8, of = o.process(x)
+            gf = g.last_soft(i)
+            assert len(of) == len(gf), i
+            if len(of):
+                assert float(np.sqrt(np.mean((of.astype(np.float64) - gf) ** 2))) <= RMS_TOL, i
+            assert np.abs(o8.astype(np.int32) - g8[i].astype(np.int32)).max(initial=0) <= 2, i
+    g.close()

@@ -140,3 +140,40 @@ def test_create_errors_match_reference():
     assert emu_api.EmuBatch([(48000, 48000, 5000, 1, 2000, True, 4096)]).code == -1  # cutoff > fs/2
     assert emu_api.EmuBatch([(0, 4800, 5000, 1, 2000, True, 4096)]).code == -1
     assert emu_api.EmuBatch([(48000, 4800, 5000, 1, 0, True, 4096)]).code == -1
+
+
+# ---------------------------------------------------------------- next row f-1: Doppler planner + NCO in front of the path
+
+import json  # noqa: E402
+
+DOPPLER = json.load(open(os.path.join(GOLDEN, "doppler_shifts_lucky7.json")))
+
+
+def test_doppler_planner_matches_oracle_batching():
+    lens = [2000] * 30 + [47000, 1, 95000, 48000, 7]
+    ours = emu_api.doppler_plan_stream(48000, DOPPLER["shifts_hz"], lens)
+    d = orc.Doppler(48000, DOPPLER["shifts_hz"], 100000)
+    for n, got in zip(lens, ours):
+        assert got == d.plan(n), n
+
+
+def test_nco_then_demod_matches_oracle_doppler_then_demod():
+    """lucky7.cf32 is the uncorrected recording of the reference's Doppler test: correct + demodulate."""
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.complex64)
+    cfg = (48000, 4800, 5000, 2, 2000, True)
+    chunk = 20000
+    e = emu_api.EmuBatch([cfg + (chunk,)])
+    o = orc.Fsk(*cfg, chunk)
+    d = orc.Doppler(48000, DOPPLER["shifts_hz"], chunk)
+    calls = [chunk] * 4 + [len(iq) - 4 * chunk]
+    plans = emu_api.doppler_plan_stream(48000, DOPPLER["shifts_hz"], calls)
+    pos = 0
+    for n, plan in zip(calls, plans):
+        part = iq[pos:pos + n]
+        pos += n
+        mixed = d.process(part.view(np.float32))
+        o8, of = o.process(mixed)
+        e8, ef = e.process([part], [(0, ln, f) for ln, f in plan])
+        assert np.array_equal(e.mixed(0).view(np.uint32), mixed.view(np.uint32))
+        assert np.array_equal(of.view(np.uint32), ef[0].view(np.uint32))
+        assert np.array_equal(o8, e8[0])
