@@ -173,6 +173,10 @@ typedef struct {
     uint16_t queue_size;
     bool rx_file_source;    /* rx_sdr_type == RX_SDR_TYPE_FILE => blocking queue */
     const char *base_path;
+    /* optional Doppler pre-correction (RxRequest.doppler in the reference, src/dsp_worker.c:120-136): the per-second
+     * shift in Hz; NULL = none.  The orbit model behind it (SGP4 from the TLE) stays with the caller. */
+    sdrm_doppler_shift_fn doppler_shift;
+    void *doppler_user;
 } sdrm_worker_config;
 
 typedef struct dsp_worker_t dsp_worker;

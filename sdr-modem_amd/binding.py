@@ -42,7 +42,7 @@ class WorkerConfig(C.Structure):
                 ("demod_decimation", C.c_uint32), ("demod_fsk_transition_width", C.c_uint32),
                 ("demod_fsk_use_dc_block", C.c_bool), ("rx_dump_file", C.c_bool), ("demod_destination", C.c_int),
                 ("buffer_size", C.c_uint32), ("queue_size", C.c_uint16), ("rx_file_source", C.c_bool),
-                ("base_path", C.c_char_p)]
+                ("base_path", C.c_char_p), ("doppler_shift", C.c_void_p), ("doppler_user", C.c_void_p)]
 
 
 # every symbol include/sdrmodem_hip.h declares

@@ -6,8 +6,9 @@
  * src/dsp_worker.c:44-106, construction :108-197, teardown :199-227) with the protobuf RxRequest and the
  * libconfig server_config replaced by the plain sdrm_worker_config (those headers need protobuf-c / libiio,
  * which are outside this path).  Same call order, same file names (rx.sdr2demod.<id>.cf32,
- * rx.demod2client.<id>.s8), same error returns and "<3>" messages.  Doppler pre-correction (src/dsp/doppler.c)
- * is the next row of the scope table and is not wired yet.
+ * rx.demod2client.<id>.s8), same error returns and "<3>" messages.  Doppler pre-correction (src/dsp/doppler.c) is
+ * driven by a per-second shift callback (the SGP4 orbit model stays with the caller) and runs on the GPU in front of
+ * the demodulator.
  */
 #include <errno.h>
 #include <pthread.h>
@@ -24,6 +25,8 @@ struct dsp_worker_t {
     uint32_t id;
     int client_socket;
     fsk_demod *demod;
+    sdrm_batch *corrected; /* batch of one channel, used instead of `demod` when Doppler pre-correction is on */
+    sdrm_doppler *doppler;
     queue *inbox;
     pthread_t thread;
     bool thread_started;
@@ -77,7 +80,22 @@ static void *worker_main(void *arg) {
         }
         int8_t *soft = NULL;
         size_t soft_len = 0;
-        if (w->demod != NULL) {
+        if (w->corrected != NULL) {
+            /* reference order: doppler_process_rx, then fsk_demod_process (src/dsp_worker.c:65-76); here one call */
+            sdrm_nco_segment segs[64];
+            size_t n_segs = sdrm_doppler_plan(w->doppler, 0, iq_len, segs, 64);
+            const sdrm_cf32 *ins[1] = {iq};
+            size_t lens[1] = {iq_len};
+            int8_t *outs[1] = {NULL};
+            size_t olens[1] = {0};
+            if (sdrm_batch_process_nco(w->corrected, ins, lens, segs, n_segs, outs, olens) != 0) {
+                complete_buffer_processing(w->inbox);
+                fprintf(stderr, "<3>[%d] demodulation failed on the device\n", w->id);
+                break;
+            }
+            soft = outs[0];
+            soft_len = olens[0];
+        } else if (w->demod != NULL) {
             fsk_demod_process(iq, iq_len, &soft, &soft_len, w->demod);
         }
         if (soft == NULL) {
@@ -109,9 +127,23 @@ int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *
     }
     w->id = id;
     w->client_socket = client_socket;
-    int code = fsk_demod_create(cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
+    int code;
+    if (cfg->doppler_shift != NULL) {
+        sdrm_fsk_config fc = {cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
+                              (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
+                              cfg->demod_fsk_use_dc_block, cfg->buffer_size};
+        code = sdrm_doppler_create(cfg->rx_sampling_freq, cfg->doppler_shift, cfg->doppler_user, &w->doppler);
+        if (code != 0) {
+            fprintf(stderr, "<3>[%d] unable to create doppler correction block\n", w->id);
+            dsp_worker_destroy(w);
+            return code;
+        }
+        code = sdrm_batch_create(&fc, 1, -1, 0, &w->corrected);
+    } else {
+        code = fsk_demod_create(cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
                                 (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
                                 cfg->demod_fsk_use_dc_block, cfg->buffer_size, &w->demod);
+    }
     if (code != 0) {
         fprintf(stderr, "<3>[%d] unable to create demodulator\n", w->id);
         dsp_worker_destroy(w);
@@ -175,6 +207,12 @@ void dsp_worker_destroy(void *data) {
     }
     if (w->demod != NULL) {
         fsk_demod_destroy(w->demod);
+    }
+    if (w->corrected != NULL) {
+        sdrm_batch_destroy(w->corrected);
+    }
+    if (w->doppler != NULL) {
+        sdrm_doppler_destroy(w->doppler);
     }
     free(w);
 }

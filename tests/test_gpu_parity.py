@@ -360,3 +360,27 @@ def test_mixed_rate_batch_with_per_channel_doppler_ramp():
                 assert float(np.sqrt(np.mean((of.astype(np.float64) - gf) ** 2))) <= RMS_TOL, i
             assert np.abs(o8.astype(np.int32) - g8[i].astype(np.int32)).max(initial=0) <= 2, i
     g.close()
+
+
+def test_dsp_worker_with_doppler_callback():
+    """the worker's Doppler leg (reference src/dsp_worker.c:65-71): shifts come from a per-second callback"""
+    L = binding.load()
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.complex64)
+    shifts = DOPPLER["shifts_hz"]
+    cb = binding.SHIFT_FN(lambda user, k: float(shifts[min(int(k), len(shifts) - 1)]))
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = binding.WorkerConfig(48000, 4800, 5000, 2, 2000, True, False, 0, 4096, 4, True, tmp.encode(),
+                                   C.cast(cb, C.c_void_p), None)
+        w = C.c_void_p()
+        assert L.dsp_worker_create(9, -1, C.byref(cfg), C.byref(w)) == 0
+        for off in range(0, len(iq), 4096):
+            part = np.ascontiguousarray(iq[off:off + 4096]).view(np.float32)
+            L.dsp_worker_put(part.ctypes.data, len(part) // 2, w)
+        L.dsp_worker_destroy(w)
+        got = np.fromfile(os.path.join(tmp, "rx.demod2client.9.s8"), dtype=np.int8)
+    o = orc.Fsk(48000, 4800, 5000, 2, 2000, True, 4096)
+    d = orc.Doppler(48000, shifts, 4096)
+    want = np.concatenate([o.process(d.process(iq[off:off + 4096].view(np.float32)))[0] for off in range(0, len(iq), 4096)])
+    assert len(got) == len(want)
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 2
+    assert np.mean(got == want) > 0.999
