@@ -88,11 +88,22 @@ SDRM_HD int8_t sdrm_soft_to_i8(float v) {
     return (int8_t) (int) rintf(r);
 }
 
+// the same for a value known to be finite: one median instead of max+min on the device
+SDRM_HD int8_t sdrm_soft_to_i8_finite(float v) {
+    float r = v * 127.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r = __builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+#else
+    r = fminf(fmaxf(r, -128.0f), 127.0f);
+#endif
+    return (int8_t) (int) rintf(r);
+}
+
 // Mueller & Mueller loop state of one channel (reference struct clock_mm_t, clock_recovery_mm.c:9-26)
 struct sdrm_mm_state {
     float mu, omega, last;
     int ii;    // position in the call's working buffer (history + input), as in the reference
-    int prev;  // position of the last produced symbol
+    int inc;   // advance of the last produced symbol (its position was ii - inc)
 };
 
 struct sdrm_mm_consts {

@@ -26,10 +26,10 @@
 
 #define SDRM_K3_LANES 64
 #define SDRM_K3_RING 256    // per-channel sample ring in LDS (power of two): 4 staging blocks
-#define SDRM_K3_PRE 3       // mirror rows below slot 0 (a symbol reads up to 3 samples before its window)
-#define SDRM_K3_POST 8      // mirror rows above slot RING-1 (a window is 8 samples)
+#define SDRM_K3_PRE 3       // mirror slots below slot 0 (a symbol reads up to 3 samples before its window)
+#define SDRM_K3_POST 8      // mirror slots above slot RING-1 (a window is 8 samples)
 #define SDRM_K3_ROWS (SDRM_K3_PRE + SDRM_K3_RING + SDRM_K3_POST)
-#define SDRM_K3_PITCH 65    // floats between consecutive rows (64 channels + 1: conflict-free transposing writes)
+#define SDRM_K3_CPITCH SDRM_K3_ROWS  // floats between two channels' rings (267, odd: lane-per-channel accesses spread over the banks)
 #define SDRM_K3_BLOCK 64    // samples staged per channel per step (one per producer lane)
 
 // immutable per-channel parameters (device array, one per channel)
@@ -260,8 +260,8 @@ SDRM_HD void sdrm_hist_roll(int tid, int nthreads, const sdrm_chan_params &p, co
 
 // ------------------------------------------------------------------------------------------------ K3
 
-// per-lane context of the clock-recovery kernel; ring = this channel's column of the LDS sample ring.
-// Ring slot of chunk-relative sample n (n < 0: carried history) is n & (SDRM_K3_RING-1); ring[slot][channel].
+// per-lane context of the clock-recovery kernel; col = this channel's sample ring in LDS (ring[channel][slot]).
+// Ring slot of chunk-relative sample n (n < 0: carried history) is n & (SDRM_K3_RING-1).
 struct sdrm_k3_lane {
     sdrm_mm_state st;
     sdrm_mm_consts k;
@@ -271,29 +271,33 @@ struct sdrm_k3_lane {
     uint32_t cap;      // max symbols per call (= max_input_buffer_length, clock_recovery_mm.c:103)
 };
 
-// `col` = this channel's column of the row-major ring (ring + channel).  Sample n lives in slot n & (RING-1), row
-// slot + PRE.  Slots < POST are mirrored above the ring and slots >= RING-PRE below it, so the 11 rows
-// [slot-3, slot+7] around any slot are contiguous: a symbol's samples are one base address plus constant offsets.
+// `col` = this channel's ring (ring + channel * CPITCH).  Sample n lives at col[slot + PRE], slot = n & (RING-1).
+// Slots < POST are mirrored above the ring and slots >= RING-PRE below it, so the 11 entries [slot-3, slot+7] around
+// any slot are contiguous: a symbol's samples are one base address plus constant offsets.
 SDRM_HD void sdrm_k3_ring_put(float *col, int n, float v) {
     const int slot = n & (SDRM_K3_RING - 1);
-    col[(slot + SDRM_K3_PRE) * SDRM_K3_PITCH] = v;
+    col[slot + SDRM_K3_PRE] = v;
     if (slot < SDRM_K3_POST) {
-        col[(slot + SDRM_K3_RING + SDRM_K3_PRE) * SDRM_K3_PITCH] = v;
+        col[slot + SDRM_K3_RING + SDRM_K3_PRE] = v;
     }
     if (slot >= SDRM_K3_RING - SDRM_K3_PRE) {
-        col[(slot - SDRM_K3_RING + SDRM_K3_PRE) * SDRM_K3_PITCH] = v;
+        col[slot - SDRM_K3_RING + SDRM_K3_PRE] = v;
     }
 }
 
-SDRM_HD float sdrm_k3_ring_get(const float *col, int n) {
-    return col[((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) * SDRM_K3_PITCH];
+SDRM_HD float sdrm_k3_ring_get(const float *col, int n) { return col[(n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE]; }
+
+// The loop condition `ii < working_len - 7` (clock_recovery_mm.c:103, ii compared as size_t: negative => stop) with
+// `avail` chunk samples staged, as ONE unsigned compare against a per-block limit: the window starts at chunk-relative
+// ii - kept and needs +7 < avail, i.e. 0 <= ii < avail + kept - 7.
+SDRM_HD uint32_t sdrm_k3_limit(const sdrm_k3_lane &L, int avail) {
+    const int lim = avail + L.kept - 7;
+    return lim > 0 ? (uint32_t) lim : 0u;
 }
 
-// can this lane produce its next symbol with `avail` chunk samples staged?  Mirrors the loop condition
-// `ii < working_len - 7 && oo < output_len` (clock_recovery_mm.c:103) with ii compared as size_t (negative => stop).
-SDRM_HD bool sdrm_k3_can_step(const sdrm_k3_lane &L, int avail) {
-    // chunk-relative index of the first of the 8 samples is ii - kept; the window needs +7 < avail
-    return (L.st.ii >= 0) & (L.st.ii - L.kept + 7 < avail) & (L.oo < L.cap);
+// can this lane produce its next symbol?  (`&& oo < output_len` of the same loop condition)
+SDRM_HD bool sdrm_k3_can_step(const sdrm_k3_lane &L, uint32_t limit) {
+    return ((uint32_t) L.st.ii < limit) & (L.oo < L.cap);
 }
 
 // everything one symbol reads from LDS: fetched for the lane's current (ii, mu) BEFORE the symbol is computed, so
@@ -306,30 +310,31 @@ struct sdrm_k3_operands {
 };
 
 // reference src/dsp/mmse_fir_interpolator.c:189: row = rint(mu * 128) (mu*128 in fp32, half-to-even)
-template <bool FINITE>
-SDRM_HD void sdrm_k3_fetch(const sdrm_k3_lane &L, const float *col, const float *bank_rev, sdrm_k3_operands &F) {
+// (RingPtr / BankPtr: plain `const float *` on the host, LDS-address-space pointers in the kernel)
+template <bool FINITE, typename RingPtr, typename BankPtr>
+SDRM_HD void sdrm_k3_fetch(const sdrm_k3_lane &L, RingPtr col, BankPtr bank_rev, sdrm_k3_operands &F) {
     const int n = L.st.ii - L.kept;
-    const float *base = col + ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) * SDRM_K3_PITCH;
+    const RingPtr base = col + ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        F.w[j] = base[j * SDRM_K3_PITCH];
+        F.w[j] = base[j];
     }
     if (!FINITE) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            F.lead[j] = base[(j - 3) * SDRM_K3_PITCH];
+            F.lead[j] = base[j - 3];
         }
     }
     const float scaled = L.st.mu * (float) SDRM_MMSE_STEPS;
     int imu;
     F.row_ok = true;
     if (FINITE) {
-        imu = (int) rintf(scaled) & 0xff;  // mu in [0,1) => 0..128; the mask only keeps a stray lane inside the table
+        imu = (int) rintf(scaled);  // mu in [0,1] => 0..128
     } else {
         F.row_ok = (scaled >= 0.0f) & (scaled <= (float) SDRM_MMSE_STEPS);  // false for NaN
         imu = F.row_ok ? (int) rintf(scaled) : 0;
     }
-    const float *row = bank_rev + imu * 8;
+    const BankPtr row = bank_rev + imu * 8;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         F.tap[j] = row[j];
@@ -386,12 +391,12 @@ SDRM_HD float sdrm_k3_step(sdrm_k3_lane &L, const sdrm_k3_operands &F) {
     om = L.k.omega_mid + clipped;
     const float m2 = L.st.mu + om + L.k.gain_mu * mm;
     const float whole = floorf(m2);
-    L.st.prev = ii;
     if (FINITE) {
         L.st.omega = om;
         L.st.mu = m2 - whole;
         L.st.last = o;
-        L.st.ii = ii + (int) whole;
+        L.st.inc = (int) whole;
+        L.st.ii = ii + L.st.inc;
         return o;
     }
     // NaN symbol (:107-113): emit 0, skip floor(omega) samples, leave the loop state alone
@@ -401,6 +406,7 @@ SDRM_HD float sdrm_k3_step(sdrm_k3_lane &L, const sdrm_k3_operands &F) {
     L.st.omega = bad ? L.st.omega : om;
     L.st.mu = bad ? mu : m2 - whole;
     L.st.last = bad ? last : o;
+    L.st.inc = step;
     L.st.ii = (int) ((uint32_t) ii + (uint32_t) step);
     return bad ? 0.0f : o;
 }
@@ -414,7 +420,8 @@ SDRM_HD void sdrm_k3_finish(const sdrm_k3_lane &L, int *from_n, int *new_kept) {
         from = 0;  // :94-99 keep everything, no symbols
     } else {
         const bool past = (L.st.ii < 0) || ((int64_t) L.st.ii > len);  // `ii > working_len` as size_t
-        from = past ? (int64_t) L.st.prev : (int64_t) L.st.ii;
+        const int prev = (int) ((uint32_t) L.st.ii - (uint32_t) L.st.inc);  // position of the last produced symbol
+        from = past ? (int64_t) prev : (int64_t) L.st.ii;
     }
     int64_t keep = len - from;
     if (keep > SDRM_CLOCK_HCAP - 1) {  // bounded where the reference overruns its buffer

@@ -343,21 +343,22 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 
 // One lane per channel, 64 channels per CONSUMER wave (reference src/dsp/clock_recovery_mm.c:78-139 per lane); a second
 // PRODUCER wave of the same workgroup stages the samples, so the two overlap.
-// Producer: per step, SDRM_K3_BLOCK (= 64, one per lane) samples of each of the 64 channels go from global memory (coalesced row reads,
-// lane = time, prefetched one step ahead into registers) into an LDS ring, row-major (ring[row][channel], pitch 65
-// floats => the transposing writes spread over the banks).  The ring holds 4 steps; mirror rows at both ends keep every
-// window contiguous.  Consumer: each lane runs its own loop while staged samples last; a symbol's 8 window samples are
-// one base address plus constant offsets, and the next symbol's operands are fetched before the current symbol is
-// quantised and stored.  The short FINITE form of the loop body is used unless a producer kernel flagged NaN/Inf in
+// Producer: per step, SDRM_K3_BLOCK (= 64, one per lane) samples of each of the 64 channels go from global memory
+// (coalesced row reads, lane = time, prefetched one step ahead into registers) into per-channel LDS rings
+// (ring[channel][slot], channel pitch 267 floats: the producer's lane = time writes are contiguous, the consumer's
+// lane = channel reads spread over the banks).  A ring holds 4 steps; mirror slots at both ends keep every window
+// contiguous.  Consumer: each lane runs its own loop while staged samples last (lanes drop out of the exec mask as
+// they run out); a symbol's 8 window samples are one base address plus constant offsets, and the next symbol's
+// operands are fetched before the current symbol is quantised and stored.  The short FINITE form of the loop body is used unless a producer kernel flagged NaN/Inf in
 // one of this workgroup's channels.  One barrier per step hands block k to the consumer while block k+1 is written.
-size_t k3_lds_bytes() { return (size_t) (SDRM_K3_ROWS * SDRM_K3_PITCH + 129 * 8 + 2 * SDRM_K3_LANES) * sizeof(float); }
+size_t k3_lds_bytes() { return (size_t) (SDRM_K3_LANES * SDRM_K3_CPITCH + 129 * 8 + 2 * SDRM_K3_LANES) * sizeof(float); }
 
 template <bool SOFT>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     extern __shared__ __attribute__((aligned(16))) float k3_lds[];
-    float *bank_rev = k3_lds;                       // [129*8], 16-byte aligned
-    float *ring = bank_rev + 129 * 8;               // [ROWS][PITCH]
-    int *nz_sh = reinterpret_cast<int *>(ring + SDRM_K3_ROWS * SDRM_K3_PITCH);  // [64] samples per channel
+    float *bank_rev = k3_lds;                       // [129*8] at LDS offset 0: a row is two aligned ds_read_b128
+    float *ring = bank_rev + 129 * 8;               // [LANES][CPITCH]
+    int *nz_sh = reinterpret_cast<int *>(ring + SDRM_K3_LANES * SDRM_K3_CPITCH);  // [64] samples per channel
     int *dc_sh = nz_sh + SDRM_K3_LANES;                                          // [64] reads dcout (1) or z (0)
     const int lane = threadIdx.x & 63;
     const bool producer = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) != 0;
@@ -377,9 +378,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     L.st.omega = 0.0f;
     L.st.last = 0.0f;
     L.st.ii = 0;
-    L.st.prev = 0;
+    L.st.inc = 0;
     L.k.omega_mid = L.k.omega_lim = L.k.gain_omega = L.k.gain_mu = 0.0f;
-    float *my_col = ring + lane;  // this channel's column
+    float *my_col = ring + lane * SDRM_K3_CPITCH;  // this channel's ring
     sdrm_clock_state *cs = b.clock_state + (active ? c : 0);
     bool clean = true;
     uint32_t flagged = 0;
@@ -450,26 +451,26 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     {                                                                                                        \
         const int n_ = (k) * SDRM_K3_BLOCK + lane;                                                            \
         if (uniform && ((k) + 1) * SDRM_K3_BLOCK <= min_nz) {                                                 \
-            float *row_ = ring + ((n_ & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) * SDRM_K3_PITCH;                   \
+            float *row_ = ring + ((n_ & (SDRM_K3_RING - 1)) + SDRM_K3_PRE);                                   \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                row_[r] = pre[r];                                                                             \
+                row_[r * SDRM_K3_CPITCH] = pre[r];                                                            \
             }                                                                                                \
             __builtin_amdgcn_wave_barrier();                                                                  \
             if ((((k) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                          \
                 _Pragma("unroll") for (int j = 0; j < SDRM_K3_POST; j++) {                                    \
-                    my_col[(j + SDRM_K3_RING + SDRM_K3_PRE) * SDRM_K3_PITCH] = my_col[(j + SDRM_K3_PRE) * SDRM_K3_PITCH]; \
+                    my_col[j + SDRM_K3_RING + SDRM_K3_PRE] = my_col[j + SDRM_K3_PRE];                         \
                 }                                                                                            \
             }                                                                                                \
             if (((((k) + 1) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                    \
                 _Pragma("unroll") for (int j = 0; j < SDRM_K3_PRE; j++) {                                     \
-                    my_col[j * SDRM_K3_PITCH] = my_col[(j + SDRM_K3_RING) * SDRM_K3_PITCH];                   \
+                    my_col[j] = my_col[j + SDRM_K3_RING];                                                     \
                 }                                                                                            \
             }                                                                                                \
         } else {                                                                                             \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
                 const int nz_r = r < nrows ? __builtin_amdgcn_readlane(my_nz, r) : 0;                         \
                 if (n_ < nz_r) {                                                                              \
-                    sdrm_k3_ring_put(ring + r, n_, pre[r]);                                                   \
+                    sdrm_k3_ring_put(ring + r * SDRM_K3_CPITCH, n_, pre[r]);                                  \
                 }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
@@ -496,32 +497,31 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     int8_t *o8 = b.out_i8 + (size_t) (active ? c : 0) * b.out_stride;
     float *of = SOFT ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
     const bool wave_clean = __all(clean);
-    // run every lane's loop as far as the staged samples allow
+    // Run every lane's loop as far as the staged samples allow.  A lane that cannot step now cannot step later in
+    // the same block either, so the loop only ever shrinks the exec mask.  The operands of the NEXT symbol are issued
+    // before the current one is quantised and stored, so part of the LDS latency hides behind that work.
+    int8_t *p8 = o8;
+    float *pf = of;
+    const uint32_t end_lo = (uint32_t) (uintptr_t) (o8 + L.cap);
+    // LDS-typed, opaque copy of this lane's ring address: the compiler then keeps it in one register and reaches the
+    // window through the ds_read2 immediate offsets instead of re-adding the ring's LDS offset per symbol
+    typedef const __attribute__((address_space(3))) float *lds_cf;
+    lds_cf col_l = (lds_cf) my_col;
+    asm volatile("" : "+v"(col_l));
 #define K3_DRAIN(FIN)                                                                                        \
-    {                                                                                                        \
+    if (sdrm_k3_can_step(L, lim)) {                                                                          \
         sdrm_k3_operands F;                                                                                   \
-        sdrm_k3_fetch<FIN>(L, my_col, bank_rev, F);                                                           \
-        while (true) {                                                                                       \
-            const bool can = active && sdrm_k3_can_step(L, avail);                                            \
-            if (__builtin_amdgcn_ballot_w64(can) == 0) {                                                      \
-                break;                                                                                       \
+        sdrm_k3_fetch<FIN>(L, col_l, bank_rev, F);                                                            \
+        do {                                                                                                 \
+            const float soft = sdrm_k3_step<FIN>(L, F);                                                       \
+            sdrm_k3_fetch<FIN>(L, col_l, bank_rev, F);                                                        \
+            *p8++ = FIN ? sdrm_soft_to_i8_finite(soft) : sdrm_soft_to_i8(soft);                               \
+            if (SOFT) {                                                                                       \
+                *pf++ = soft;                                                                                 \
             }                                                                                                \
-            n_iter++;                                                                                        \
-            float soft = 0.0f;                                                                                \
-            if (can) {                                                                                        \
-                soft = sdrm_k3_step<FIN>(L, F);                                                               \
-            }                                                                                                \
-            /* operands of the NEXT symbol: issued before this one is quantised/stored so the LDS latency */ \
-            /* hides behind that work (lanes that cannot step again read rows they will simply re-read)   */ \
-            sdrm_k3_fetch<FIN>(L, my_col, bank_rev, F);                                                       \
-            if (can) {                                                                                        \
-                o8[L.oo] = sdrm_soft_to_i8(soft);                                                             \
-                if (SOFT) {                                                                                   \
-                    of[L.oo] = soft;                                                                          \
-                }                                                                                            \
-                L.oo++;                                                                                       \
-            }                                                                                                \
-        }                                                                                                    \
+            /* `oo < output_len`: the output pointer stands in for the symbol count (low words suffice) */    \
+        } while (((uint32_t) L.st.ii < lim) & ((uint32_t) (uintptr_t) p8 != end_lo));                        \
+        L.oo = (uint32_t) (p8 - o8);                                                                          \
     }
     unsigned long long t_wait = 0, t_drain = 0, n_iter = 0;
     for (int k = 0; k <= nblocks; k++) {
@@ -533,6 +533,8 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         unsigned long long t1 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         int avail = (k + 1) * SDRM_K3_BLOCK;
         avail = avail < L.nz ? avail : L.nz;
+        const uint32_t lim = active ? sdrm_k3_limit(L, avail) : 0u;
+        const uint32_t oo0 = L.oo;
         if (wave_clean) {
             K3_DRAIN(true)
         } else {
@@ -542,6 +544,12 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             unsigned long long t2 = __builtin_amdgcn_s_memtime();
             t_wait += t1 - t0;
             t_drain += t2 - t1;
+            uint32_t most = 0;  // loop iterations of this block = the most symbols any lane produced in it
+            for (int r = 0; r < SDRM_K3_LANES; r++) {
+                const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) (L.oo - oo0), r);
+                most = v > most ? v : most;
+            }
+            n_iter += most;
         }
     }
     if (b.k3_stamps && lane == 0) {  // diagnostic only: cycles waiting for the producer vs in the symbol loops

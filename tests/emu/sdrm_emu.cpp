@@ -141,7 +141,7 @@ static void emu_dc(EmuBatch *b) {
 static void emu_clock(EmuBatch *b) {
     const BatchPlan &pl = b->plan;
     const int C = (int) pl.params.size();
-    std::vector<float> ring(SDRM_K3_ROWS * SDRM_K3_PITCH);
+    std::vector<float> ring(SDRM_K3_LANES * SDRM_K3_CPITCH);
     float bank_rev[129 * 8];
     for (int k = 0; k < 129 * 8; k++) bank_rev[k] = (&sdrm_mmse_bank[0][0])[(k & ~7) + 7 - (k & 7)];
     for (int c0 = 0; c0 < C; c0 += SDRM_K3_LANES) {
@@ -165,10 +165,10 @@ static void emu_clock(EmuBatch *b) {
             L.st.omega = cs.omega;
             L.st.last = cs.last;
             L.st.ii = 0;
-            L.st.prev = 0;
+            L.st.inc = 0;
             flagged[l] = b->nonfinite[c];
             clean[l] = flagged[l] == 0 && cs.poison == 0;
-            float *col = ring.data() + l;
+            float *col = ring.data() + l * SDRM_K3_CPITCH;
             for (int j = 0; j < L.kept; j++) sdrm_k3_ring_put(col, j - L.kept, cs.hist[j]);
             max_nz = L.nz > max_nz ? L.nz : max_nz;
         }
@@ -178,7 +178,7 @@ static void emu_clock(EmuBatch *b) {
                 for (int r = 0; r < nl; r++) {
                     const int cr = c0 + r;
                     const float *src = (pl.params[cr].dc_len ? b->dcout.data() : b->z.data()) + (size_t) cr * pl.z_stride;
-                    float *col = ring.data() + r;
+                    float *col = ring.data() + r * SDRM_K3_CPITCH;
                     for (int n = k * SDRM_K3_BLOCK; n < (k + 1) * SDRM_K3_BLOCK && n < lanes[r].nz; n++)
                         sdrm_k3_ring_put(col, n, src[n]);
                 }
@@ -188,8 +188,9 @@ static void emu_clock(EmuBatch *b) {
                 int avail = (k + 1) * SDRM_K3_BLOCK;
                 avail = avail < L.nz ? avail : L.nz;
                 const int c = c0 + l;
-                const float *col = ring.data() + l;
-                while (sdrm_k3_can_step(L, avail)) {
+                const float *col = ring.data() + l * SDRM_K3_CPITCH;
+                const uint32_t lim = sdrm_k3_limit(L, avail);
+                while (sdrm_k3_can_step(L, lim)) {
                     // the GPU picks the window/step flavour per wave; every flavour must give the same values, so the
                     // emulation lets each lane take the cheapest one its own state allows
                     sdrm_k3_operands F;
@@ -201,7 +202,7 @@ static void emu_clock(EmuBatch *b) {
                         sdrm_k3_fetch<false>(L, col, bank_rev, F);
                         soft = sdrm_k3_step<false>(L, F);
                     }
-                    b->out8[(size_t) c * pl.out_stride + L.oo] = sdrm_soft_to_i8(soft);
+                    b->out8[(size_t) c * pl.out_stride + L.oo] = clean[l] ? sdrm_soft_to_i8_finite(soft) : sdrm_soft_to_i8(soft);
                     b->outf[(size_t) c * pl.out_stride + L.oo] = soft;
                     L.oo++;
                 }
@@ -213,7 +214,7 @@ static void emu_clock(EmuBatch *b) {
             sdrm_clock_state &cs = b->clock[c];
             int from_n, new_kept;
             sdrm_k3_finish(L, &from_n, &new_kept);
-            const float *col = ring.data() + l;
+            const float *col = ring.data() + l * SDRM_K3_CPITCH;
             float tmp[SDRM_CLOCK_HCAP];
             for (int j = 0; j < new_kept; j++) tmp[j] = sdrm_k3_ring_get(col, from_n + j);
             for (int j = 0; j < new_kept; j++) cs.hist[j] = tmp[j];
