@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libsdrmodem_hip.so")
+LIB_PATH = os.environ.get("SDRM_LIB_PATH") or os.path.join(HERE, "csrc", "libsdrmodem_hip.so")  # override: A/B builds
 _LIB = None
 
 f32p = C.POINTER(C.c_float)

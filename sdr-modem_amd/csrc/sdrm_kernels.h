@@ -23,6 +23,12 @@
 #define SDRM_K1_U 4    // taps per unrolled step
 #define SDRM_K1_NY (SDRM_K1_THREADS * SDRM_K1_R)
 #define SDRM_K1_QPAD 16
+// bytes of the K1 tile area in LDS: raw IQ tile + halo, later reused by the demodulated samples with the tile's LPF2
+// outputs staged behind them
+#define SDRM_K1_XS_BYTES(t1_max)                                                     \
+    (((size_t) (SDRM_K1_NY + (t1_max)) * 8 > (size_t) (2 * SDRM_K1_NY + SDRM_K1_QPAD) * 4) \
+         ? (size_t) (SDRM_K1_NY + (t1_max)) * 8                                      \
+         : (size_t) (2 * SDRM_K1_NY + SDRM_K1_QPAD) * 4)
 
 #define SDRM_K3_LANES 64
 #define SDRM_K3_RING 256    // per-channel sample ring in LDS (power of two): 4 staging blocks
@@ -30,6 +36,9 @@
 #define SDRM_K3_POST 8      // mirror slots above slot RING-1 (a window is 8 samples)
 #define SDRM_K3_ROWS (SDRM_K3_PRE + SDRM_K3_RING + SDRM_K3_POST)
 #define SDRM_K3_CPITCH SDRM_K3_ROWS  // floats between two channels' rings (267, odd: lane-per-channel accesses spread over the banks)
+#ifndef SDRM_K3_BANKPITCH
+#define SDRM_K3_BANKPITCH 8  // floats between two rows of the MMSE bank copy in LDS
+#endif
 #define SDRM_K3_BLOCK 64    // samples staged per channel per step (one per producer lane)
 
 // immutable per-channel parameters (device array, one per channel)
@@ -212,7 +221,7 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
 
 // phase 3: LPF2 with decimation (reference src/dsp/fir_filter.c:93-114), results to global z
 SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps2_rev,
-                                const float *qs, float *z_out, uint32_t *nonfinite_flag) {
+                                const float *qs, float *zs, uint32_t *nonfinite_flag) {
     const int base = tid * SDRM_K1_RZ;
     if (base >= t.m) {
         return;
@@ -236,16 +245,24 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
             }
         }
     }
+    // results go to the tile's staging area (lane stride 15 floats: conflict-free) and leave in sdrm_k1_phase_store
     bool odd = false;
 #pragma unroll
     for (int r = 0; r < SDRM_K1_RZ; r++) {
         if (base + r < t.m) {
-            z_out[t.o_lo + base + r] = acc[r];
+            zs[base + r] = acc[r];
             odd |= !(fabsf(acc[r]) < INFINITY);
         }
     }
     if (odd) {
         *nonfinite_flag = 1u;  // tells the clock stage to take its general (NaN-aware) path for this channel
+    }
+}
+
+// the tile's LPF2 outputs, staged by sdrm_k1_phase_lpf2, written with consecutive lanes on consecutive samples
+SDRM_HD void sdrm_k1_phase_store(int tid, const sdrm_k1_tile &t, const float *zs, float *z_out) {
+    for (int i = tid; i < t.m; i += SDRM_K1_THREADS) {
+        z_out[t.o_lo + i] = zs[i];
     }
 }
 
@@ -334,7 +351,7 @@ SDRM_HD void sdrm_k3_fetch(const sdrm_k3_lane &L, RingPtr col, BankPtr bank_rev,
         F.row_ok = (scaled >= 0.0f) & (scaled <= (float) SDRM_MMSE_STEPS);  // false for NaN
         imu = F.row_ok ? (int) rintf(scaled) : 0;
     }
-    const BankPtr row = bank_rev + imu * 8;
+    const BankPtr row = bank_rev + imu * SDRM_K3_BANKPITCH;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         F.tap[j] = row[j];

@@ -81,7 +81,7 @@ void launch_nco(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uin
 
 size_t k1_lds_bytes(uint32_t t1_max) {
     // the quadrature-demod tile (NY + pad floats) reuses the raw-IQ tile's space: LPF1 is done with it by then
-    size_t xs = (size_t) (SDRM_K1_NY + t1_max) * sizeof(sdrm_f2);
+    size_t xs = SDRM_K1_XS_BYTES(t1_max);
     size_t bnd = (size_t) SDRM_K1_THREADS * sizeof(sdrm_f2);
     size_t tab = 260 * sizeof(float);
     return xs + bnd + tab;
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, co
     const sdrm_chan_params p = b.params[c];
     sdrm_f2 *xs = reinterpret_cast<sdrm_f2 *>(k1_lds);
     float *qs = reinterpret_cast<float *>(xs);  // aliases the raw tile: written only after every LPF1 read (barrier)
-    sdrm_f2 *bnd = reinterpret_cast<sdrm_f2 *>(xs + SDRM_K1_NY + b.t1_max);
+    float *zs = qs + SDRM_K1_NY + SDRM_K1_QPAD;  // LPF2 outputs of the tile, behind the demodulated samples
+    sdrm_f2 *bnd = reinterpret_cast<sdrm_f2 *>(k1_lds + SDRM_K1_XS_BYTES(b.t1_max));
     float *tab = reinterpret_cast<float *>(bnd + SDRM_K1_THREADS);
 
     const int tid = threadIdx.x;
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, co
     sdrm_k1_phase_quad(tid, t, p, tab, bnd, regs, qs);
     __syncthreads();
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    sdrm_k1_phase_lpf2(tid, t, p, b.tap_pool + p.taps2_off, qs, b.z + (size_t) c * b.z_stride, b.nonfinite + c);
+    sdrm_k1_phase_lpf2(tid, t, p, b.tap_pool + p.taps2_off, qs, zs, b.nonfinite + c);
+    __syncthreads();
+    sdrm_k1_phase_store(tid, t, zs, b.z + (size_t) c * b.z_stride);
     if (stamp && tid == 0) {
         unsigned long long t4 = __builtin_amdgcn_s_memtime();
         unsigned long long *k1s = b.k3_stamps + ((b.n_channels + 63) / 64) * 4;  // after the K3 per-wave records
@@ -251,17 +254,40 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     const uint32_t min_ = stage == 0 ? mx : ms;
     const uint32_t rout_off = b.rx_cap + (uint32_t) (stage < 3 ? stage : 0) * b.rs_cap;
     bool odd = false;
-    // stage 0 keeps the next four blocks of the input in flight (a block is consumed faster than HBM answers)
-    float xq0 = 0.0f, xq1 = 0.0f, xq2 = 0.0f, xq3 = 0.0f;
-    if (stage == 0) {
-        xq0 = (uint32_t) lane < nz ? z[lane] : 0.0f;
-        xq1 = (uint32_t) lane + 64u < nz ? z[lane + 64] : 0.0f;
-        xq2 = (uint32_t) lane + 128u < nz ? z[lane + 128] : 0.0f;
-        xq3 = (uint32_t) lane + 192u < nz ? z[lane + 192] : 0.0f;
+    // Stage 0 also feeds the input ring: every fourth iteration it commits four blocks that it loaded four iterations
+    // earlier (one float4 per lane) and issues the load of the four blocks after those, so a load has four iterations
+    // to land and the wait in front of the commit costs nothing.  Blocks it+4 .. it+7 are committed in iteration it;
+    // every stage reads its block's samples from LDS.
+    typedef float k2_f4 __attribute__((ext_vector_type(4)));
+    const k2_f4 *z4 = reinterpret_cast<const k2_f4 *>(z);  // rows start 256-byte aligned (z_stride % 64 == 0)
+    k2_f4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
+#define K2_COMMIT(first_block, V)                                                       \
+    {                                                                                   \
+        const uint32_t n4 = (uint32_t) (first_block) * 64u + 4u * (uint32_t) lane;      \
+        const uint32_t pos4 = ctl.zbase + n4;                                           \
+        if (n4 < nz) rx[pos4 & mx] = (V).x;                                             \
+        if (n4 + 1u < nz) rx[(pos4 + 1u) & mx] = (V).y;                                 \
+        if (n4 + 2u < nz) rx[(pos4 + 2u) & mx] = (V).z;                                 \
+        if (n4 + 3u < nz) rx[(pos4 + 3u) & mx] = (V).w;                                 \
     }
-    // The iteration loop is unrolled by four so that each of stage 0's four in-flight input registers has a fixed
-    // name (rotating them would make the compiler wait for a load right after issuing it).
-#define K2_ITER(it_, XQ)                                                                                     \
+    if (stage == 0) {
+        if (4u * (uint32_t) lane < nz) {
+            const k2_f4 first = z4[lane];
+            K2_COMMIT(0, first)
+        }
+        if (256u + 4u * (uint32_t) lane < nz) {
+            xq = z4[64 + lane];
+        }
+    }
+#define K2_FEED(it_)                                                                    \
+    if (stage == 0 && (it_) < nb) {                                                     \
+        K2_COMMIT((it_) + 4, xq)                                                        \
+        const uint32_t nn = ((uint32_t) (it_) + 8u) * 64u + 4u * (uint32_t) lane;       \
+        if (nn < nz) {                                                                  \
+            xq = z4[((it_) + 8) * 16 + lane];                                           \
+        }                                                                               \
+    }
+#define K2_ITER(it_)                                                                                         \
     if ((it_) < nb + 3) {                                                                                    \
         const int blk = (it_) - stage;                                                                       \
         if (blk >= 0 && blk < nb) {                                                                          \
@@ -269,18 +295,7 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
             const bool valid = n < nz;                                                                        \
             const int last = (int) ((nz - (uint32_t) blk * 64u < 64u ? nz - (uint32_t) blk * 64u : 64u) - 1u); \
             const uint32_t pos = ctl.zbase + n; /* stream index (mod 2^32; ring sizes divide 2^32) */         \
-            float u;                                                                                          \
-            if (stage == 0) {                                                                                 \
-                u = XQ;                                                                                       \
-                if (valid) {                                                                                  \
-                    rx[pos & mx] = u;                                                                         \
-                }                                                                                            \
-                const uint32_t nn = n + 256u;                                                                 \
-                XQ = nn < nz ? z[nn] : 0.0f;                                                                  \
-                __builtin_amdgcn_wave_barrier(); /* ring write stays ahead of the delayed read (same wave) */ \
-            } else {                                                                                         \
-                u = k2_lds[rin_off + (pos & min_)];                                                           \
-            }                                                                                                \
+            const float u = k2_lds[rin_off + (pos & min_)];                                                   \
             const float ud = k2_lds[rin_off + ((pos - L) & min_)];                                            \
             const float t = valid ? sdrm_boxcar_term(u, ud) : 0.0f;                                           \
             const float s = wave_inorder_sum<MODE>(t, acc);                                                   \
@@ -300,11 +315,14 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                       \
     }
     for (int it = 0; it < nb + 3; it += 4) {
-        K2_ITER(it, xq0)
-        K2_ITER(it + 1, xq1)
-        K2_ITER(it + 2, xq2)
-        K2_ITER(it + 3, xq3)
+        K2_FEED(it)
+        K2_ITER(it)
+        K2_ITER(it + 1)
+        K2_ITER(it + 2)
+        K2_ITER(it + 3)
     }
+#undef K2_FEED
+#undef K2_COMMIT
 #undef K2_ITER
     if (odd) {
         b.nonfinite[c] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
@@ -351,13 +369,13 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // they run out); a symbol's 8 window samples are one base address plus constant offsets, and the next symbol's
 // operands are fetched before the current symbol is quantised and stored.  The short FINITE form of the loop body is used unless a producer kernel flagged NaN/Inf in
 // one of this workgroup's channels.  One barrier per step hands block k to the consumer while block k+1 is written.
-size_t k3_lds_bytes() { return (size_t) (SDRM_K3_LANES * SDRM_K3_CPITCH + 129 * 8 + 2 * SDRM_K3_LANES) * sizeof(float); }
+size_t k3_lds_bytes() { return (size_t) (SDRM_K3_LANES * SDRM_K3_CPITCH + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_LANES) * sizeof(float); }
 
 template <bool SOFT>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     extern __shared__ __attribute__((aligned(16))) float k3_lds[];
     float *bank_rev = k3_lds;                       // [129*8] at LDS offset 0: a row is two aligned ds_read_b128
-    float *ring = bank_rev + 129 * 8;               // [LANES][CPITCH]
+    float *ring = bank_rev + ((129 * SDRM_K3_BANKPITCH + 3) & ~3);  // [LANES][CPITCH]
     int *nz_sh = reinterpret_cast<int *>(ring + SDRM_K3_LANES * SDRM_K3_CPITCH);  // [64] samples per channel
     int *dc_sh = nz_sh + SDRM_K3_LANES;                                          // [64] reads dcout (1) or z (0)
     const int lane = threadIdx.x & 63;
@@ -367,7 +385,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     const bool active = c < b.n_channels;
     const int nrows = b.n_channels - c0 < SDRM_K3_LANES ? b.n_channels - c0 : SDRM_K3_LANES;
     for (int k = threadIdx.x; k < 129 * 8; k += 128) {
-        bank_rev[k] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];  // rows reversed once: tap j meets window sample j
+        bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];  // rows reversed once: tap j meets window sample j
     }
     sdrm_k3_lane L;
     L.kept = 0;

@@ -67,7 +67,7 @@ static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
     const BatchPlan &pl = b->plan;
     const size_t C = pl.params.size();
     std::vector<sdrm_f2> xs(SDRM_K1_NY + pl.t1_max);
-    std::vector<float> qs(SDRM_K1_NY + SDRM_K1_QPAD);
+    std::vector<float> qs(SDRM_K1_NY + SDRM_K1_QPAD), zs(SDRM_K1_NY);
     std::vector<sdrm_f2> bnd(SDRM_K1_THREADS);
     std::vector<float> tab(260);
     std::vector<sdrm_k1_regs> regs(SDRM_K1_THREADS);
@@ -80,6 +80,7 @@ static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
             // poison the "LDS" so that any read of a slot the kernel did not write shows up as NaN in the outputs
             for (auto &v : xs) v = sdrm_f2{NAN, NAN};
             for (auto &v : qs) v = NAN;
+            for (auto &v : zs) v = NAN;
             const sdrm_k1_tile t = sdrm_k1_tile_setup(p, ctl, (int) tile);
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
                 sdrm_k1_phase_load(tid, t, in, hist, (int) p.hist_len, sdrm_atan_tab, xs.data(), tab.data());
@@ -88,8 +89,9 @@ static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
                 sdrm_k1_phase_quad(tid, t, p, tab.data(), bnd.data(), regs[tid], qs.data());
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
-                sdrm_k1_phase_lpf2(tid, t, p, pl.tap_pool.data() + p.taps2_off, qs.data(), b->z.data() + c * pl.z_stride,
-                                   &b->nonfinite[c]);
+                sdrm_k1_phase_lpf2(tid, t, p, pl.tap_pool.data() + p.taps2_off, qs.data(), zs.data(), &b->nonfinite[c]);
+            for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
+                sdrm_k1_phase_store(tid, t, zs.data(), b->z.data() + c * pl.z_stride);
         }
         sdrm_f2 *next = b->hist.data() + (c * 2 + (ctl.parity ^ 1u)) * pl.hist_stride;
         for (int tid = 0; tid < 256; tid++) sdrm_hist_roll(tid, 256, p, ctl, in, hist, next);
@@ -142,8 +144,8 @@ static void emu_clock(EmuBatch *b) {
     const BatchPlan &pl = b->plan;
     const int C = (int) pl.params.size();
     std::vector<float> ring(SDRM_K3_LANES * SDRM_K3_CPITCH);
-    float bank_rev[129 * 8];
-    for (int k = 0; k < 129 * 8; k++) bank_rev[k] = (&sdrm_mmse_bank[0][0])[(k & ~7) + 7 - (k & 7)];
+    float bank_rev[129 * SDRM_K3_BANKPITCH];
+    for (int k = 0; k < 129 * 8; k++) bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = (&sdrm_mmse_bank[0][0])[(k & ~7) + 7 - (k & 7)];
     for (int c0 = 0; c0 < C; c0 += SDRM_K3_LANES) {
         for (auto &v : ring) v = NAN;
         sdrm_k3_lane lanes[SDRM_K3_LANES];

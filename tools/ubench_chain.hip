@@ -13,6 +13,9 @@ __global__ __launch_bounds__(64) void k(float *out, unsigned long long *stamps, 
     __syncthreads();
     float s = threadIdx.x * 0.001f, t = 1.0f + threadIdx.x * 1e-6f;
     int idx = threadIdx.x;
+    float t2 = 0.5f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 pk = {s, t}, pk1 = {1.0f, 1.0f};
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int r = 0; r < reps; r++) {
         if (MODE == 0) {
@@ -21,13 +24,23 @@ __global__ __launch_bounds__(64) void k(float *out, unsigned long long *stamps, 
             asm volatile(".rept 1024\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(s) : "v"(t));
         } else if (MODE == 2) {
             asm volatile(".rept 1024\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(s) : "v"(t));
-        } else {
+        } else if (MODE == 3) {
 #pragma unroll 1
             for (int i = 0; i < 256; i++) idx = lds[idx];
+        } else if (MODE == 4) {  // same chain with only lanes 0..31 enabled: does a half-empty wave issue faster?
+            asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b64 exec, 0xffffffff\n\t.rept 1024\n\tv_add_f32 %0, %0, %1\n\t.endr\n\ts_mov_b64 exec, s[20:21]" : "+v"(s) : "v"(t) : "s20", "s21");
+        } else if (MODE == 5) {  // lanes 0..15 only
+            asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b64 exec, 0xffff\n\t.rept 1024\n\tv_add_f32 %0, %0, %1\n\t.endr\n\ts_mov_b64 exec, s[20:21]" : "+v"(s) : "v"(t) : "s20", "s21");
+        } else if (MODE == 6) {  // two independent chains interleaved: issue rate of one wave
+            asm volatile(".rept 512\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\t.endr" : "+v"(s), "+v"(t2) : "v"(t));
+        } else if (MODE == 7) {  // dependent v_pk_mul_f32
+            asm volatile(".rept 1024\n\tv_pk_mul_f32 %0, %0, %1\n\t.endr" : "+v"(pk) : "v"(pk1));
+        } else if (MODE == 8) {  // v_cmp -> v_cndmask dependent pair (+ the add closing the chain)
+            asm volatile(".rept 512\n\tv_cmp_gt_f32 vcc, 0, %0\n\tv_cndmask_b32 %0, %0, %1, vcc\n\t.endr" : "+v"(s) : "v"(t) : "vcc");
         }
     }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    out[blockIdx.x * 64 + threadIdx.x] = s + idx;
+    out[blockIdx.x * 64 + threadIdx.x] = s + idx + t2 + pk.x + pk.y;
     if (threadIdx.x == 0) {
         stamps[2 * blockIdx.x] = c1 - c0;
         stamps[2 * blockIdx.x + 1] = r1 - r0;
@@ -60,6 +73,11 @@ int main() {
         run<1>("dpp wave_shr chain", blocks, 200, 1024);
         run<2>("dpp row_shr chain", blocks, 200, 1024);
         run<3>("dependent ds_read_b32", blocks, 200, 256);
+        run<4>("v_add chain, 32 lanes", blocks, 200, 1024);
+        run<5>("v_add chain, 16 lanes", blocks, 200, 1024);
+        run<6>("2 indep v_add chains", blocks, 200, 1024);
+        run<7>("dependent v_pk_mul_f32", blocks, 200, 1024);
+        run<8>("v_cmp+v_cndmask chain", blocks, 200, 1024);
     }
     return 0;
 }
