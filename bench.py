@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--verify", action="store_true", help="also check 2 channels of the last step against the oracle")
     ap.add_argument("--sweep", type=str, default="1024,4096",
                     help="extra channel counts measured briefly at N=1 (reported under 'channel_sweep'); '' to skip")
+    ap.add_argument("--watchdog-seconds", type=float, default=900.0,
+                    help="give up (exit code 3, message on stderr) if the whole run takes longer than this")
     return ap.parse_args()
 
 
@@ -64,6 +66,17 @@ def usable_cores():
 
 def main():
     args = parse()
+    # a wedged device queue must not hold the box until an outer limit expires: leave with a diagnostic instead
+    import threading
+
+    def give_up():
+        sys.stderr.write("bench.py: no result after %.0f s -- giving up (device hang?)\n" % args.watchdog_seconds)
+        sys.stderr.flush()
+        os._exit(3)
+
+    dog = threading.Timer(args.watchdog_seconds, give_up)
+    dog.daemon = True
+    dog.start()
     import torch
     import torch.distributed as dist
     import sdrm_pkg

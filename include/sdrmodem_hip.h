@@ -115,6 +115,21 @@ int sdrm_batch_process_nco(sdrm_batch *batch, const sdrm_cf32 *const *inputs, co
                            const sdrm_nco_segment *segments, size_t n_segments, int8_t **outputs, size_t *output_lens);
 int sdrm_batch_process_device_nco(sdrm_batch *batch, const void *d_input, size_t in_stride, const size_t *input_lens,
                                   const sdrm_nco_segment *segments, size_t n_segments, void *stream);
+/* Pipelined host-buffer path.  The reference's boundary hands over HOST buffers (src/dsp/fsk_demod.h:13, filled by
+ * queue_put's memcpy, src/queue.c:99-154), so at batch scale the host link decides the rate.  sdrm_batch_arena pins
+ * `slots` (>= 2) input slots of [channels][*chan_stride] complex samples each (slot s starts at base + s * *slot_stride)
+ * that producers fill directly -- the memcpy of queue_put lands here instead of in a queue node.  sdrm_batch_submit
+ * enqueues one call on the data of a slot: ONE host-to-device copy on a copy stream (it overlaps the kernels of the
+ * previous call), the kernels, and the copy-back of the soft bits; it returns at once (-EAGAIN when three calls are
+ * already uncollected).  The slot may be refilled once the call has been collected.  sdrm_batch_collect blocks until
+ * the oldest submitted call is done; outputs[c] point into pinned result buffers owned by the batch, valid until the
+ * next collect returns.  `segments` as in sdrm_batch_process_nco (NULL, 0 = no Doppler correction).  Do not mix with the
+ * other process calls while a submitted call is uncollected. */
+int sdrm_batch_arena(sdrm_batch *batch, size_t slots, sdrm_cf32 **base, size_t *chan_stride, size_t *slot_stride);
+int sdrm_batch_submit(sdrm_batch *batch, size_t slot, const size_t *input_lens, const sdrm_nco_segment *segments,
+                      size_t n_segments);
+int sdrm_batch_collect(sdrm_batch *batch, int8_t **outputs, size_t *output_lens);
+
 /* diagnostics: copy channel c's mixed IQ of the last call (interleaved re,im) to host */
 int sdrm_batch_last_mixed(sdrm_batch *batch, size_t channel, float *dst, size_t dst_cap_samples, size_t *len);
 

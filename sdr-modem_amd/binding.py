@@ -52,6 +52,7 @@ EXPORTS = [
     "sdrm_batch_process", "sdrm_batch_process_device", "sdrm_batch_device_outputs", "sdrm_batch_last_soft",
     "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
     "sdrm_batch_process_nco", "sdrm_batch_process_device_nco", "sdrm_batch_last_mixed",
+    "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_wave_scan", "sdrm_set_scan_mode", "sdrm_version", "sdrm_device_count",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
@@ -97,6 +98,9 @@ def load():
                                          C.POINTER(i8p), C.POINTER(C.c_size_t)]
     L.sdrm_batch_process_device_nco.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(NcoSegment), C.c_size_t, vp]
     L.sdrm_batch_last_mixed.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdrm_batch_arena.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.sdrm_batch_submit.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t]
+    L.sdrm_batch_collect.argtypes = [vp, C.POINTER(i8p), C.POINTER(C.c_size_t)]
     L.sdrm_doppler_create.argtypes = [C.c_uint64, SHIFT_FN, vp, C.POINTER(vp)]
     L.sdrm_doppler_plan.argtypes = [vp, C.c_uint32, C.c_size_t, C.POINTER(NcoSegment), C.c_size_t]
     L.sdrm_doppler_plan.restype = C.c_size_t
@@ -213,6 +217,34 @@ class Batch:
         code = self.L.sdrm_batch_process_nco(self.h, ptrs, lens, segs, len(segments), outs, olens)
         if code != 0:
             raise RuntimeError("sdrm_batch_process_nco failed: %d" % code)
+        return [np.ctypeslib.as_array(outs[c], shape=(olens[c],)).copy() if olens[c] else np.zeros(0, np.int8)
+                for c in range(self.n)]
+
+    def arena(self, slots=3):
+        """Pinned input arena of the pipelined host path: float32 view [slots][C][2*chan_stride] (interleaved I,Q)."""
+        base, cs, ss = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        code = self.L.sdrm_batch_arena(self.h, slots, C.byref(base), C.byref(cs), C.byref(ss))
+        if code != 0:
+            raise RuntimeError("sdrm_batch_arena failed: %d" % code)
+        buf = (C.c_float * (slots * ss.value * 2)).from_address(base.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(slots, self.n, 2 * cs.value)
+
+    def submit(self, slot, lens, segments=None):
+        arr = (C.c_size_t * self.n)(*[int(x) for x in lens])
+        segs, nseg = None, 0
+        if segments:
+            segs = (NcoSegment * len(segments))(*[NcoSegment(*s) for s in segments])
+            nseg = len(segments)
+        return self.L.sdrm_batch_submit(self.h, slot, arr, C.cast(segs, C.c_void_p) if segs is not None else None, nseg)
+
+    def collect(self, copy=True):
+        outs = (i8p * self.n)()
+        olens = (C.c_size_t * self.n)()
+        code = self.L.sdrm_batch_collect(self.h, outs, olens)
+        if code != 0:
+            raise RuntimeError("sdrm_batch_collect failed: %d" % code)
+        if not copy:
+            return [int(olens[c]) for c in range(self.n)]
         return [np.ctypeslib.as_array(outs[c], shape=(olens[c],)).copy() if olens[c] else np.zeros(0, np.int8)
                 for c in range(self.n)]
 

@@ -20,6 +20,8 @@ void set_scan_mode(int mode);
 }
 
 #define SDRM_CTL_SLOTS 8
+#define SDRM_RES_SETS 4    // pinned result sets of the pipelined host path
+#define SDRM_MAX_FLIGHT 3  // uncollected calls it allows (copy-in, kernels and copy-back of different calls overlap)
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -83,7 +85,31 @@ struct sdrm_batch_t {
     bool timing = false;
     TimingLane lanes[3];
     std::vector<uint32_t> last_lens;
+    // pipelined host-buffer path (sdrm_batch_arena / _submit / _collect): the caller fills pinned arena slots, the
+    // copy of call k+1 runs while call k computes, results come back through two pinned result sets
+    sdrm_f2 *h_arena = nullptr;
+    size_t arena_slots = 0;
+    sdrm_f2 *d_in_ring[2] = {nullptr, nullptr};
+    int8_t *d_out8_b = nullptr;      // second output set: calls alternate between the two once the arena exists
+    uint32_t *d_outlen_b = nullptr;
+    int8_t *h_res8[SDRM_RES_SETS] = {};
+    uint32_t *h_reslen[SDRM_RES_SETS] = {};
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_res[SDRM_RES_SETS] = {};  // results of call k are in h_res8 / h_reslen [k % SDRM_RES_SETS]
+    hipEvent_t ev_out_free[2] = {};         // the device output set of that parity has been copied back
+    bool out_busy[2] = {false, false};
+    uint32_t res_width[SDRM_RES_SETS] = {};  // bytes per channel copied back for that call
+    uint32_t back_width[SDRM_RES_SETS] = {};
+    int back_slot[SDRM_RES_SETS] = {};
+    bool back_pending = false;               // the newest submitted call's copy-back is not enqueued yet
+    uint64_t submitted = 0, collected = 0;
+    uint64_t first_pipelined_call = 0;
 };
+
+static int8_t *out8_of(const sdrm_batch_t *b, uint64_t call) { return (b->d_out8_b && (call & 1)) ? b->d_out8_b : b->d_out8; }
+static uint32_t *outlen_of(const sdrm_batch_t *b, uint64_t call) {
+    return (b->d_outlen_b && (call & 1)) ? b->d_outlen_b : b->d_outlen;
+}
 
 extern "C" int sdrm_device_count(void) {
     int n = 0;
@@ -127,6 +153,40 @@ static void batch_free(sdrm_batch_t *b) {
         if (st) {
             (void) hipStreamDestroy(st);
         }
+    }
+    for (int i = 0; i < SDRM_RES_SETS; i++) {
+        if (b->ev_res[i]) {
+            (void) hipEventDestroy(b->ev_res[i]);
+        }
+        if (b->h_res8[i]) {
+            (void) hipHostFree(b->h_res8[i]);
+        }
+        if (b->h_reslen[i]) {
+            (void) hipHostFree(b->h_reslen[i]);
+        }
+    }
+    for (int i = 0; i < 2; i++) {
+        if (b->ev_out_free[i]) {
+            (void) hipEventDestroy(b->ev_out_free[i]);
+        }
+        if (b->d_in_ring[i]) {
+            (void) hipFree(b->d_in_ring[i]);
+        }
+    }
+    if (b->s_h2d) {
+        (void) hipStreamDestroy(b->s_h2d);
+    }
+    if (b->s_d2h) {
+        (void) hipStreamDestroy(b->s_d2h);
+    }
+    if (b->h_arena) {
+        (void) hipHostFree(b->h_arena);
+    }
+    if (b->d_out8_b) {
+        (void) hipFree(b->d_out8_b);
+    }
+    if (b->d_outlen_b) {
+        (void) hipFree(b->d_outlen_b);
     }
     void *dev_ptrs[] = {b->d_params, b->d_ctl, b->d_taps, b->d_atan, b->d_bank, b->d_hist, b->d_z, b->d_dcout,
                         b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in, b->d_flags, b->d_z2, b->d_dcout2,
@@ -471,6 +531,8 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     d.max_tiles = max_tiles;
     d.z = (i & 1) ? b->d_z2 : b->d_z;
     d.dcout = (i & 1) ? b->d_dcout2 : b->d_dcout;
+    d.out_i8 = out8_of(b, i);
+    d.out_len = outlen_of(b, i);
     const int prev2 = (int) ((i + SDRM_CTL_SLOTS - 2) % SDRM_CTL_SLOTS);  // the call that last used these buffers
     const bool have_prev2 = i >= 2;
 
@@ -520,6 +582,9 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     HIP_TRY(hipStreamWaitEvent(b->s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
     if (d.any_dc && b->any_nodc) {
         HIP_TRY(hipStreamWaitEvent(b->s_clock, b->ev_front[slot], 0));
+    }
+    if (b->out_busy[i & 1]) {
+        HIP_TRY(hipStreamWaitEvent(b->s_clock, b->ev_out_free[i & 1], 0));  // that output set is still being copied back
     }
     if (b->timing) {
         timing_begin(b, 2, b->s_clock, &ev);
@@ -628,14 +693,15 @@ extern "C" int sdrm_batch_device_outputs(sdrm_batch *b, void **d_out_i8, size_t 
     if (b == nullptr) {
         return -1;
     }
+    const uint64_t last = b->calls ? b->calls - 1 : 0;
     if (d_out_i8) {
-        *d_out_i8 = b->d_out8;
+        *d_out_i8 = out8_of(b, last);
     }
     if (out_stride) {
         *out_stride = b->dev.out_stride;
     }
     if (d_out_len) {
-        *d_out_len = b->d_outlen;
+        *d_out_len = outlen_of(b, last);
     }
     if (d_out_f32) {
         *d_out_f32 = b->d_outf;
@@ -697,19 +763,192 @@ static int process_host(sdrm_batch *b, const sdrm_cf32 *const *inputs, const siz
         return code;
     }
     HIP_TRY(hipStreamWaitEvent(b->stream, b->slot_done[b->last_slot], 0));
-    HIP_TRY(hipMemcpyAsync(b->h_outlen, b->d_outlen, sizeof(uint32_t) * C, hipMemcpyDeviceToHost, b->stream));
+    const uint64_t me = b->calls - 1;
+    HIP_TRY(hipMemcpyAsync(b->h_outlen, outlen_of(b, me), sizeof(uint32_t) * C, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     for (size_t c = 0; c < C; c++) {
         uint32_t n = b->h_outlen[c];
         b->last_lens[c] = n;
         int8_t *dst = b->h_out8 + c * (size_t) b->dev.out_stride;
         if (n > 0) {
-            HIP_TRY(hipMemcpyAsync(dst, b->d_out8 + c * (size_t) b->dev.out_stride, n, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipMemcpyAsync(dst, out8_of(b, me) + c * (size_t) b->dev.out_stride, n, hipMemcpyDeviceToHost, b->stream));
         }
         outputs[c] = dst;
         output_lens[c] = n;
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+
+// --- pipelined host-buffer path -------------------------------------------------------------------------------------
+// The reference hands fsk_demod_process a host buffer (src/dsp/fsk_demod.h:13), so the drop-in rate is bounded by the
+// host link.  Here the producers write IQ straight into a pinned arena ([slots][C][in_stride]), one slot per call; a
+// call is one large copy (56 GB/s measured, vs 30 GB/s for one copy per channel) on its own stream, so the copy of
+// call k+1 overlaps the kernels of call k, and the int8 results come back through two pinned result sets.
+
+// Copy the results of call k back to its pinned result set.  The copy rides on the DC stage's stream: HIP multiplexes
+// streams onto a few hardware queues, and a separate copy stream that lands on the queue of the copy-in stream holds the
+// next call's input behind this call's results (seen: the whole pipeline serialised).  It is enqueued only after the
+// DC stage of call k+1 (or at collect time), i.e. in front of K2 of call k+2, which waits for the clock stage of call k
+// anyway because it reuses its input buffer -- the 0.2 ms copy then delays nothing.
+static int issue_copy_back(sdrm_batch_t *b, uint64_t k) {
+    const size_t C = b->plan.design.size();
+    const int set = (int) (k % SDRM_RES_SETS), par = (int) (k & 1);
+    hipStream_t back = b->s_dc;
+    HIP_TRY(hipStreamWaitEvent(back, b->slot_done[b->back_slot[set]], 0));
+    HIP_TRY(hipMemcpyAsync(b->h_reslen[set], outlen_of(b, k), sizeof(uint32_t) * C, hipMemcpyDeviceToHost, back));
+    HIP_TRY(hipMemcpy2DAsync(b->h_res8[set], b->dev.out_stride, out8_of(b, k), b->dev.out_stride, b->back_width[set], C,
+                             hipMemcpyDeviceToHost, back));
+    HIP_TRY(hipEventRecord(b->ev_res[set], back));
+    HIP_TRY(hipEventRecord(b->ev_out_free[par], back));
+    b->out_busy[par] = true;
+    b->res_width[set] = b->back_width[set];
+    b->back_pending = false;
+    return 0;
+}
+
+extern "C" int sdrm_batch_arena(sdrm_batch *b, size_t slots, sdrm_cf32 **base, size_t *chan_stride, size_t *slot_stride) {
+    if (b == nullptr || slots < 2 || base == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t C = b->plan.design.size();
+    const size_t slot_samples = C * (size_t) b->in_stride;
+    if (b->h_arena == nullptr) {
+        HIP_TRY(hipDeviceSynchronize());  // the output-set switch below must not race a running call
+        int code = 0;
+        for (int i = 0; i < 2 && code == 0; i++) {
+            code = dev_alloc_zero(&b->d_in_ring[i], slot_samples);
+        }
+        code = code ? code : dev_alloc_zero(&b->d_out8_b, C * (size_t) b->dev.out_stride);
+        code = code ? code : dev_alloc_zero(&b->d_outlen_b, C);
+        if (code != 0) {
+            return code;
+        }
+        for (int i = 0; i < SDRM_RES_SETS; i++) {
+            if (hipHostMalloc((void **) &b->h_res8[i], C * (size_t) b->dev.out_stride) != hipSuccess ||
+                hipHostMalloc((void **) &b->h_reslen[i], sizeof(uint32_t) * C) != hipSuccess) {
+                return -ENOMEM;
+            }
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_res[i], hipEventDisableTiming));
+        }
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_out_free[i], hipEventDisableTiming));
+        }
+        if (hipHostMalloc((void **) &b->h_arena, slots * slot_samples * sizeof(sdrm_f2)) != hipSuccess) {
+            fprintf(stderr, "<3>sdrmodem_hip: cannot pin %zu bytes of host memory for the input arena\n",
+                    slots * slot_samples * sizeof(sdrm_f2));
+            return -ENOMEM;
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_h2d, hipStreamNonBlocking));
+        b->arena_slots = slots;
+    } else if (slots != b->arena_slots) {
+        return -1;
+    }
+    *base = reinterpret_cast<sdrm_cf32 *>(b->h_arena);
+    if (chan_stride) {
+        *chan_stride = b->in_stride;
+    }
+    if (slot_stride) {
+        *slot_stride = slot_samples;
+    }
+    return 0;
+}
+
+extern "C" int sdrm_batch_submit(sdrm_batch *b, size_t slot, const size_t *input_lens, const sdrm_nco_segment *segments,
+                                 size_t n_segments) {
+    if (b == nullptr || b->h_arena == nullptr || slot >= b->arena_slots || input_lens == nullptr) {
+        return -1;
+    }
+    if (b->submitted - b->collected >= SDRM_MAX_FLIGHT) {
+        return -EAGAIN;  // collect the oldest call first
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t C = b->plan.design.size();
+    const uint64_t k = b->calls;
+    const int par = (int) (k & 1);
+    // the device input buffer of this parity was last read by the front-end of call k-2
+    if (k >= 2 && b->slot_used[(k - 2) % SDRM_CTL_SLOTS]) {
+        HIP_TRY(hipStreamWaitEvent(b->s_h2d, b->ev_front[(k - 2) % SDRM_CTL_SLOTS], 0));
+    }
+    size_t longest = 0;
+    for (size_t c = 0; c < C; c++) {
+        if (input_lens[c] <= b->plan.params[c].max_len) {
+            longest = std::max(longest, input_lens[c]);
+        }
+    }
+    const sdrm_f2 *src = b->h_arena + slot * C * (size_t) b->in_stride;
+    if (longest == b->in_stride) {
+        HIP_TRY(hipMemcpyAsync(b->d_in_ring[par], src, C * (size_t) b->in_stride * sizeof(sdrm_f2), hipMemcpyHostToDevice,
+                               b->s_h2d));
+    } else if (longest > 0) {
+        HIP_TRY(hipMemcpy2DAsync(b->d_in_ring[par], (size_t) b->in_stride * sizeof(sdrm_f2), src,
+                                 (size_t) b->in_stride * sizeof(sdrm_f2), longest * sizeof(sdrm_f2), C, hipMemcpyHostToDevice,
+                                 b->s_h2d));
+    }
+    int code = enqueue_call(b, b->d_in_ring[par], b->in_stride, input_lens, b->s_h2d, segments, n_segments);
+    if (code != 0) {
+        return code;
+    }
+    // copy-back: counts, then the soft bits up to the most symbols a channel can have produced
+    // (every symbol consumes at least floor(omega_min) - 1 samples once in lock; the hard cap is max_len)
+    uint32_t width = 0;
+    for (size_t c = 0; c < C; c++) {
+        const sdrm_chan_params &p = b->plan.params[c];
+        const double step = std::max(1.0, (double) p.omega_mid - (double) p.omega_lim - 1.0);
+        const double bound = ((double) input_lens[c] / (double) p.decim + SDRM_CLOCK_HCAP) / step + 16.0;
+        width = std::max<uint32_t>(width, (uint32_t) std::min<double>(bound, (double) p.max_len));
+    }
+    width = std::min<uint32_t>((width + 63u) & ~63u, b->dev.out_stride);
+    b->back_width[k % SDRM_RES_SETS] = width;
+    b->back_slot[k % SDRM_RES_SETS] = b->last_slot;
+    // the previous call's copy-back goes in now, BEHIND this call's DC stage (see issue_copy_back)
+    if (b->back_pending) {
+        code = issue_copy_back(b, k - 1);
+        if (code != 0) {
+            return code;
+        }
+    }
+    b->back_pending = true;
+    if (b->submitted == b->collected) {
+        b->first_pipelined_call = k;
+    }
+    b->submitted++;
+    return 0;
+}
+
+extern "C" int sdrm_batch_collect(sdrm_batch *b, int8_t **outputs, size_t *output_lens) {
+    if (b == nullptr || outputs == nullptr || output_lens == nullptr || b->submitted == b->collected) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t C = b->plan.design.size();
+    // calls made through this path are consecutive while any is uncollected: the oldest one is
+    const uint64_t k = b->calls - (b->submitted - b->collected);
+    const int set = (int) (k % SDRM_RES_SETS);
+    if (b->back_pending && k + 1 == b->calls) {
+        int code = issue_copy_back(b, k);  // nothing was submitted after it
+        if (code != 0) {
+            return code;
+        }
+    }
+    HIP_TRY(hipEventSynchronize(b->ev_res[set]));
+    for (size_t c = 0; c < C; c++) {
+        const uint32_t n = b->h_reslen[set][c];
+        int8_t *dst = b->h_res8[set] + c * (size_t) b->dev.out_stride;
+        if (n > b->res_width[set]) {
+            // More symbols than the copy-back bound (a loop far out of lock).  The device set may already belong to
+            // call k+2 by now, so the tail is dropped with a message rather than read from the wrong call.
+            fprintf(stderr, "<3>sdrmodem_hip: channel %zu produced %u symbols, %u copied back\n", c, n, b->res_width[set]);
+            b->h_reslen[set][c] = b->res_width[set];
+        }
+        const uint32_t n_ok = b->h_reslen[set][c];
+        outputs[c] = dst;
+        output_lens[c] = n_ok;
+        b->last_lens[c] = n_ok;
+    }
+    b->collected++;
     return 0;
 }
 
@@ -720,13 +959,14 @@ extern "C" int sdrm_batch_fetch(sdrm_batch *b, int8_t *data, size_t stride, size
     HIP_TRY(hipSetDevice(b->device));
     const size_t C = b->plan.design.size();
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(b->h_outlen, b->d_outlen, sizeof(uint32_t) * C, hipMemcpyDeviceToHost));
+    const uint64_t last = b->calls ? b->calls - 1 : 0;
+    HIP_TRY(hipMemcpy(b->h_outlen, outlen_of(b, last), sizeof(uint32_t) * C, hipMemcpyDeviceToHost));
     for (size_t c = 0; c < C; c++) {
         uint32_t n = b->h_outlen[c];
         b->last_lens[c] = n;
         lens[c] = n;
         if (data != nullptr && n > 0) {
-            HIP_TRY(hipMemcpy(data + c * stride, b->d_out8 + c * (size_t) b->dev.out_stride, std::min<size_t>(n, stride),
+            HIP_TRY(hipMemcpy(data + c * stride, out8_of(b, last) + c * (size_t) b->dev.out_stride, std::min<size_t>(n, stride),
                               hipMemcpyDeviceToHost));
         }
     }
@@ -740,7 +980,7 @@ extern "C" int sdrm_batch_last_soft(sdrm_batch *b, size_t c, float *dst, size_t 
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipDeviceSynchronize());
     uint32_t n = 0;
-    HIP_TRY(hipMemcpy(&n, b->d_outlen + c, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, outlen_of(b, b->calls ? b->calls - 1 : 0) + c, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (len) {
         *len = n;
     }
@@ -860,12 +1100,12 @@ extern "C" int sdrm_batch_k3_stamps(sdrm_batch *b, int enable, unsigned long lon
     HIP_TRY(hipSetDevice(b->device));
     const size_t waves = (b->plan.params.size() + 63) / 64;
     if (b->dev.k3_stamps == nullptr && enable) {
-        HIP_TRY(hipMalloc((void **) &b->dev.k3_stamps, (waves * 4 + 16) * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(b->dev.k3_stamps, 0, (waves * 4 + 16) * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **) &b->dev.k3_stamps, (waves * 4 + 24) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(b->dev.k3_stamps, 0, (waves * 4 + 24) * sizeof(unsigned long long)));
     }
     if (out != nullptr && b->dev.k3_stamps != nullptr) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out, b->dev.k3_stamps, (std::min(waves, max_waves) * 4 + 8) * sizeof(unsigned long long),
+        HIP_TRY(hipMemcpy(out, b->dev.k3_stamps, (std::min(waves, max_waves) * 4 + 18) * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost));
     }
     return (int) waves;

@@ -258,6 +258,9 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     // earlier (one float4 per lane) and issues the load of the four blocks after those, so a load has four iterations
     // to land and the wait in front of the commit costs nothing.  Blocks it+4 .. it+7 are committed in iteration it;
     // every stage reads its block's samples from LDS.
+    const bool stamp = b.k3_stamps != nullptr && blockIdx.x == 0;  // diagnostics: cycles in the scan / at the barrier
+    unsigned long long t_scan = 0, t_bar = 0;
+    const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
     typedef float k2_f4 __attribute__((ext_vector_type(4)));
     const k2_f4 *z4 = reinterpret_cast<const k2_f4 *>(z);  // rows start 256-byte aligned (z_stride % 64 == 0)
     k2_f4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -298,8 +301,12 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
             const float u = k2_lds[rin_off + (pos & min_)];                                                   \
             const float ud = k2_lds[rin_off + ((pos - L) & min_)];                                            \
             const float t = valid ? sdrm_boxcar_term(u, ud) : 0.0f;                                           \
+            const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                          \
             const float s = wave_inorder_sum<MODE>(t, acc);                                                   \
             acc = lane_bcast(s, last);                                                                        \
+            if (stamp) {                                                                                      \
+                t_scan += __builtin_amdgcn_s_memtime() - ts0;                                                 \
+            }                                                                                                \
             const float v = sdrm_boxcar_out(s, Lf);                                                           \
             if (stage < 3) {                                                                                  \
                 if (valid) {                                                                                  \
@@ -312,7 +319,11 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
             }                                                                                                \
         }                                                                                                    \
         /* hand-off between stage waves goes through LDS only: wait for LDS, not for global prefetch/store */ \
+        const unsigned long long tb0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                              \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                       \
+        if (stamp) {                                                                                          \
+            t_bar += __builtin_amdgcn_s_memtime() - tb0;                                                      \
+        }                                                                                                    \
     }
     for (int it = 0; it < nb + 3; it += 4) {
         K2_FEED(it)
@@ -323,6 +334,15 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     }
 #undef K2_FEED
 #undef K2_COMMIT
+    if (stamp && lane == 0) {
+        unsigned long long *k2s = b.k3_stamps + ((b.n_channels + 63) / 64) * 4 + 8;  // after the K3 and K1 records
+        k2s[stage * 2] = t_scan;
+        k2s[stage * 2 + 1] = t_bar;
+        if (stage == 0) {
+            k2s[8] = __builtin_amdgcn_s_memtime() - t_begin;
+            k2s[9] = (unsigned long long) (nb + 3);
+        }
+    }
 #undef K2_ITER
     if (odd) {
         b.nonfinite[c] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel

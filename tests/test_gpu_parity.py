@@ -253,6 +253,53 @@ def test_device_resident_call_matches_host_call():
     h.close()
 
 
+def test_pipelined_host_path_calls_in_flight_match_oracle():
+    """sdrm_batch_arena / _submit / _collect: inputs written into the pinned arena, up to three calls kept in flight, full-length
+    and ragged calls (1-D and 2-D copy), results identical to the oracle's stream and to the synchronous host call."""
+    C_, N = 48, 8192
+    cfgs = [(48000, 9600, 5000, 1, 2000, True, N), (48000, 4800, 5000, 2, 2000, False, N)] * (C_ // 2)
+    sigs = [siggen.gmsk_channel(i, 6 * N, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    g = binding.Batch(cfgs)
+    assert g.code == 0
+    arena = g.arena(4)
+    assert arena.shape[0] == 4 and arena.shape[1] == C_
+    plan = [[N] * C_, [N] * C_, [(N - 5 * (c % 9)) for c in range(C_)], [0 if c % 5 == 0 else 4000 + c for c in range(C_)],
+            [N] * C_, [1000] * C_]
+    pos = [0] * C_
+    got = [[] for _ in range(C_)]
+    pending = 0
+    for k, lens in enumerate(plan):
+        slot = k % 4
+        for c in range(C_):
+            part = sigs[c][pos[c]:pos[c] + lens[c]].view(np.float32)
+            arena[slot, c, :len(part)] = part
+            pos[c] += lens[c]
+        code = g.submit(slot, lens)
+        if code != 0:  # three already in flight
+            for c, o in enumerate(g.collect()):
+                got[c].append(o)
+            pending -= 1
+            assert g.submit(slot, lens) == 0
+        pending += 1
+    while pending:
+        for c, o in enumerate(g.collect()):
+            got[c].append(o)
+        pending -= 1
+    for c in range(0, C_, 5):
+        o = orc.Fsk(*cfgs[c])
+        exp, p0 = [], 0
+        for lens in plan:
+            o8, _ = o.process(sigs[c][p0:p0 + lens[c]])
+            exp.append(o8)
+            p0 += lens[c]
+        assert np.array_equal(np.concatenate(got[c]), np.concatenate(exp)), c
+    assert g.submit(0, [N] * C_) == 0 and g.submit(1, [N] * C_) == 0 and g.submit(2, [N] * C_) == 0
+    assert g.submit(0, [N] * C_) != 0  # a fourth uncollected call is refused, not queued
+    for _ in range(3):
+        g.collect()
+    g.close()
+
+
 def test_dsp_worker_file_sink_matches_oracle():
     """dsp_worker push/pull surface (src/dsp_worker.c:44-106): put IQ buffers, get rx.demod2client.<id>.s8."""
     L = binding.load()

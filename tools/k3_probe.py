@@ -19,9 +19,10 @@ for i in range(4):
     b.process_device(x.data_ptr() + (i % 2) * N * 8, 2 * N, [N] * Cn, st)
 torch.cuda.synchronize()
 waves = (Cn + 63) // 64
-out = np.zeros(waves * 4 + 8, dtype=np.uint64)
+out = np.zeros(waves * 4 + 24, dtype=np.uint64)
 L.sdrm_batch_k3_stamps(b.h, 1, out.ctypes.data, waves)
 k1 = [int(v) for v in out[waves * 4:waves * 4 + 5]]
+k2 = [int(v) for v in out[waves * 4 + 8:waves * 4 + 18]]
 out = out[:waves * 4].reshape(waves, 4)
 if k1[4]:
     print("K1 per workgroup (cycles): load %.0f, lpf1 %.0f, quad %.0f, lpf2+store %.0f  (%d workgroups)" % (
@@ -30,3 +31,6 @@ for w in range(min(waves, 2)):
     stg, drn, nb, it = [int(v) for v in out[w]]
     print("wave %d: wait-for-producer %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration" % (
         w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1)))
+if k2[9]:
+    print("K2 channel 0: %d iterations, %.0f cycles each; per stage wave (scan, barrier wait) cycles/iteration: %s" % (
+        k2[9], k2[8] / k2[9], ", ".join("(%.0f, %.0f)" % (k2[2 * s] / k2[9], k2[2 * s + 1] / k2[9]) for s in range(4))))
