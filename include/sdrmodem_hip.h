@@ -158,6 +158,37 @@ void sdrm_set_scan_mode(int mode);
 const char *sdrm_version(void);
 int sdrm_device_count(void);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Per-GPU batcher: the queue + worker surface of many clients in front of ONE batch.
+ * Channel c of the batcher plays the part of one client's queue and demodulator together: its producer thread calls
+ * sdrm_batcher_put (the memcpy of queue_put, src/queue.c:99-154, lands in the pinned input arena), its consumer thread
+ * calls sdrm_batcher_take / sdrm_batcher_complete (take_buffer_for_processing + fsk_demod_process +
+ * complete_buffer_processing of src/dsp_worker.c:58-97 in one step: what comes back are the soft bits).  A batcher
+ * thread launches one batched call per round -- when every open channel has delivered its buffer or max_wait_us after
+ * the round's first buffer -- keeps up to three rounds on the device and hands the results back in order per channel.
+ * Queue behaviour is the reference's: `blocking` producers (file source) wait while all `slots` rounds are taken, live
+ * producers overwrite their newest buffer that is not on the device yet and log "<3>queue is full";
+ * sdrm_batcher_interrupt is the poison pill (buffers put before it are still delivered, then take returns NULL).
+ * --------------------------------------------------------------------------------------------------- */
+typedef struct sdrm_batcher_t sdrm_batcher;
+typedef struct {
+    uint32_t slots;       /* rounds that can be filling / in flight / waiting for their consumers (>= 4) */
+    uint32_t max_wait_us; /* launch a partly filled round this long after its first buffer */
+    bool blocking;        /* true: file-source behaviour; false: live-source behaviour */
+} sdrm_batcher_config;
+int sdrm_batcher_create(const sdrm_fsk_config *configs, size_t n_channels, int device, const sdrm_batcher_config *config,
+                        sdrm_batcher **batcher); /* config NULL = {4, 2000, true}; -ENODEV without a HIP device */
+void sdrm_batcher_put(sdrm_batcher *batcher, size_t channel, const sdrm_cf32 *buffer, size_t len);
+void sdrm_batcher_take(sdrm_batcher *batcher, size_t channel, int8_t **output, size_t *output_len);
+void sdrm_batcher_complete(sdrm_batcher *batcher, size_t channel);
+void sdrm_batcher_interrupt(sdrm_batcher *batcher, size_t channel);
+/* Doppler pre-correction for one channel: `planner` (borrowed, see sdrm_doppler_create) is asked for the segments of
+ * every buffer of that channel when its round is launched; NULL switches it off */
+int sdrm_batcher_set_doppler(sdrm_batcher *batcher, size_t channel, sdrm_doppler *planner);
+size_t sdrm_batcher_channels(const sdrm_batcher *batcher);
+uint64_t sdrm_batcher_rounds(const sdrm_batcher *batcher); /* batched calls launched so far */
+void sdrm_batcher_destroy(sdrm_batcher *batcher);
+
 /* ------------------------------------------------------------------------------------------------
  * (3) Queue + worker surface (host side, C, pthreads).
  * Queue: same names/semantics as src/queue.h:10-18 (blocking put for file sources, overwrite-newest for
@@ -192,6 +223,12 @@ typedef struct {
      * shift in Hz; NULL = none.  The orbit model behind it (SGP4 from the TLE) stays with the caller. */
     sdrm_doppler_shift_fn doppler_shift;
     void *doppler_user;
+    /* optional: demodulate through channel `batcher_channel` of a shared per-GPU batcher instead of a private
+     * fsk_demod handle and queue (NULL = the reference's one-demodulator-per-worker layout).  The channel's
+     * configuration in the batcher must equal this worker's.  queue_size / rx_file_source are then properties of the
+     * batcher (its slots / blocking). */
+    sdrm_batcher *batcher;
+    size_t batcher_channel;
 } sdrm_worker_config;
 
 typedef struct dsp_worker_t dsp_worker;

@@ -42,7 +42,8 @@ class WorkerConfig(C.Structure):
                 ("demod_decimation", C.c_uint32), ("demod_fsk_transition_width", C.c_uint32),
                 ("demod_fsk_use_dc_block", C.c_bool), ("rx_dump_file", C.c_bool), ("demod_destination", C.c_int),
                 ("buffer_size", C.c_uint32), ("queue_size", C.c_uint16), ("rx_file_source", C.c_bool),
-                ("base_path", C.c_char_p), ("doppler_shift", C.c_void_p), ("doppler_user", C.c_void_p)]
+                ("base_path", C.c_char_p), ("doppler_shift", C.c_void_p), ("doppler_user", C.c_void_p),
+                ("batcher", C.c_void_p), ("batcher_channel", C.c_size_t)]
 
 
 # every symbol include/sdrmodem_hip.h declares
@@ -53,12 +54,37 @@ EXPORTS = [
     "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
     "sdrm_batch_process_nco", "sdrm_batch_process_device_nco", "sdrm_batch_last_mixed",
     "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect",
+    "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt",
+    "sdrm_batcher_set_doppler", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_wave_scan", "sdrm_set_scan_mode", "sdrm_version", "sdrm_device_count",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
     "interrupt_waiting_the_data", "destroy_queue",
     "dsp_worker_create", "dsp_worker_put", "dsp_worker_shutdown", "dsp_worker_find_by_id", "dsp_worker_destroy",
 ]
+
+
+class BatcherConfig(C.Structure):
+    _fields_ = [("slots", C.c_uint32), ("max_wait_us", C.c_uint32), ("blocking", C.c_bool)]
+
+
+def bind_batcher(L):
+    """argtypes of the batcher's per-channel calls (also used for the test suite's emulation-backed build)"""
+    vp = C.c_void_p
+    L.sdrm_batcher_put.argtypes = [vp, C.c_size_t, vp, C.c_size_t]
+    L.sdrm_batcher_put.restype = None
+    L.sdrm_batcher_take.argtypes = [vp, C.c_size_t, C.POINTER(C.POINTER(C.c_int8)), C.POINTER(C.c_size_t)]
+    L.sdrm_batcher_take.restype = None
+    L.sdrm_batcher_complete.argtypes = [vp, C.c_size_t]
+    L.sdrm_batcher_complete.restype = None
+    L.sdrm_batcher_interrupt.argtypes = [vp, C.c_size_t]
+    L.sdrm_batcher_interrupt.restype = None
+    L.sdrm_batcher_channels.argtypes = [vp]
+    L.sdrm_batcher_channels.restype = C.c_size_t
+    L.sdrm_batcher_rounds.argtypes = [vp]
+    L.sdrm_batcher_rounds.restype = C.c_uint64
+    L.sdrm_batcher_destroy.argtypes = [vp]
+    L.sdrm_batcher_destroy.restype = None
 
 
 def load():
@@ -98,6 +124,9 @@ def load():
                                          C.POINTER(i8p), C.POINTER(C.c_size_t)]
     L.sdrm_batch_process_device_nco.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(NcoSegment), C.c_size_t, vp]
     L.sdrm_batch_last_mixed.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    bind_batcher(L)
+    L.sdrm_batcher_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.c_int, C.POINTER(BatcherConfig), C.POINTER(vp)]
+    L.sdrm_batcher_set_doppler.argtypes = [vp, C.c_size_t, vp]
     L.sdrm_batch_arena.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.sdrm_batch_submit.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t]
     L.sdrm_batch_collect.argtypes = [vp, C.POINTER(i8p), C.POINTER(C.c_size_t)]
@@ -311,6 +340,58 @@ class DopplerPlanner:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.sdrm_doppler_destroy(self.h)
+
+
+class Batcher:
+    """sdrm_batcher_*: many per-client producer/consumer pairs in front of one batch (include/sdrmodem_hip.h).
+    `lib`/`handle` let the CPU test-suite wrap its emulation-backed build of the same host code."""
+
+    def __init__(self, cfgs, slots=4, max_wait_us=2000, blocking=True, device=-1, lib=None, handle=None):
+        self.n = len(cfgs)
+        if lib is not None:
+            self.L, self.h, self.code = lib, handle, 0
+            return
+        self.L = load()
+        self._cfgs = make_configs(list(cfgs))
+        self.h = C.c_void_p()
+        bc = BatcherConfig(slots, max_wait_us, blocking)
+        self.code = self.L.sdrm_batcher_create(self._cfgs, self.n, device, C.byref(bc), C.byref(self.h))
+        if self.code != 0:
+            self.h = C.c_void_p()
+
+    def put(self, channel, iq):
+        k = _as_f32(iq)
+        self.L.sdrm_batcher_put(self.h, channel, k.ctypes.data, len(k) // 2)
+
+    def take(self, channel):
+        """soft bits of the channel's oldest undelivered buffer (copied, then released), or None after the poison pill"""
+        out, n = i8p(), C.c_size_t()
+        self.L.sdrm_batcher_take(self.h, channel, C.byref(out), C.byref(n))
+        if not out:
+            return None
+        res = np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int8)
+        self.L.sdrm_batcher_complete(self.h, channel)
+        return res
+
+    def interrupt(self, channel):
+        self.L.sdrm_batcher_interrupt(self.h, channel)
+
+    def rounds(self):
+        return int(self.L.sdrm_batcher_rounds(self.h))
+
+    def set_doppler(self, channel, planner):
+        return self.L.sdrm_batcher_set_doppler(self.h, channel, planner.h if planner is not None else None)
+
+    def close(self):
+        if self.h:
+            self.L.sdrm_batcher_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FskDemod:

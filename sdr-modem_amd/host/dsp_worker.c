@@ -27,6 +27,8 @@ struct dsp_worker_t {
     fsk_demod *demod;
     sdrm_batch *corrected; /* batch of one channel, used instead of `demod` when Doppler pre-correction is on */
     sdrm_doppler *doppler;
+    sdrm_batcher *batcher; /* shared per-GPU batcher (borrowed) used instead of demod/corrected + inbox */
+    size_t channel;
     queue *inbox;
     pthread_t thread;
     bool thread_started;
@@ -41,12 +43,25 @@ bool dsp_worker_find_by_id(void *id, void *data) {
 }
 
 void dsp_worker_put(sdrm_cf32 *output, size_t output_len, dsp_worker *worker) {
+    if (worker->batcher != NULL) {
+        /* the IQ goes straight into the batcher's pinned arena; the dump the reference writes from its DSP thread
+         * (src/dsp_worker.c:59-64) is written here, by the source thread, because no other thread sees the samples */
+        if (worker->iq_dump != NULL && fwrite(output, sizeof(sdrm_cf32), output_len, worker->iq_dump) < output_len) {
+            fprintf(stderr, "<3>[%d] unable to write sdr data\n", worker->id);
+        }
+        sdrm_batcher_put(worker->batcher, worker->channel, output, output_len);
+        return;
+    }
     queue_put(output, output_len, worker->inbox);
 }
 
 void dsp_worker_shutdown(void *arg, void *data) {
     (void) arg;
     dsp_worker *w = (dsp_worker *) data;
+    if (w->batcher != NULL) {
+        sdrm_batcher_interrupt(w->batcher, w->channel);
+        return;
+    }
     interrupt_waiting_the_data(w->inbox);
 }
 
@@ -61,6 +76,35 @@ static int write_fully(const uint8_t *bytes, size_t n, int fd) {
         done += (size_t) w;
     }
     return 0;
+}
+
+/* thread body when the worker sits on a shared batcher: the soft bits arrive already demodulated */
+static void *batched_main(void *arg) {
+    dsp_worker *w = (dsp_worker *) arg;
+    fprintf(stdout, "[%d] dsp_worker is starting\n", w->id);
+    for (;;) {
+        int8_t *soft = NULL;
+        size_t soft_len = 0;
+        sdrm_batcher_take(w->batcher, w->channel, &soft, &soft_len);
+        if (soft == NULL) {
+            break; /* poison pill */
+        }
+        if (w->soft_dump != NULL && fwrite(soft, sizeof(int8_t), soft_len, w->soft_dump) < soft_len) {
+            sdrm_batcher_complete(w->batcher, w->channel);
+            fprintf(stderr, "<3>[%d] unable to write demod data\n", w->id);
+            break;
+        }
+        int code = 0;
+        if (w->destination == DEST_SOCKET || w->destination == DEST_BOTH) {
+            code = write_fully((const uint8_t *) soft, soft_len, w->client_socket);
+        }
+        sdrm_batcher_complete(w->batcher, w->channel);
+        if (code != 0) {
+            break;
+        }
+    }
+    printf("[%d] dsp_worker stopped\n", w->id);
+    return NULL;
 }
 
 static void *worker_main(void *arg) {
@@ -127,8 +171,22 @@ int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *
     }
     w->id = id;
     w->client_socket = client_socket;
-    int code;
-    if (cfg->doppler_shift != NULL) {
+    int code = 0;
+    if (cfg->batcher != NULL) {
+        if (cfg->batcher_channel >= sdrm_batcher_channels(cfg->batcher)) {
+            fprintf(stderr, "<3>[%d] batcher has no channel %zu\n", w->id, cfg->batcher_channel);
+            free(w);
+            return -1;
+        }
+        w->batcher = cfg->batcher;
+        w->channel = cfg->batcher_channel;
+        if (cfg->doppler_shift != NULL) {
+            code = sdrm_doppler_create(cfg->rx_sampling_freq, cfg->doppler_shift, cfg->doppler_user, &w->doppler);
+            if (code == 0) {
+                code = sdrm_batcher_set_doppler(w->batcher, w->channel, w->doppler);
+            }
+        }
+    } else if (cfg->doppler_shift != NULL) {
         sdrm_fsk_config fc = {cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
                               (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
                               cfg->demod_fsk_use_dc_block, cfg->buffer_size};
@@ -170,12 +228,14 @@ int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *
         }
     }
     /* a file source must not lose data => blocking queue (src/dsp_worker.c:176-179) */
-    code = create_queue(cfg->buffer_size, cfg->queue_size, cfg->rx_file_source, &w->inbox);
-    if (code != 0) {
-        dsp_worker_destroy(w);
-        return code;
+    if (w->batcher == NULL) {
+        code = create_queue(cfg->buffer_size, cfg->queue_size, cfg->rx_file_source, &w->inbox);
+        if (code != 0) {
+            dsp_worker_destroy(w);
+            return code;
+        }
     }
-    if (pthread_create(&w->thread, NULL, worker_main, w) != 0) {
+    if (pthread_create(&w->thread, NULL, w->batcher != NULL ? batched_main : worker_main, w) != 0) {
         dsp_worker_destroy(w);
         return -1;
     }
@@ -192,6 +252,9 @@ void dsp_worker_destroy(void *data) {
     fprintf(stdout, "[%d] dsp_worker is stopping\n", w->id);
     if (w->inbox != NULL) {
         interrupt_waiting_the_data(w->inbox);
+    }
+    if (w->batcher != NULL) {
+        sdrm_batcher_interrupt(w->batcher, w->channel);
     }
     if (w->thread_started) {
         pthread_join(w->thread, NULL);
@@ -210,6 +273,9 @@ void dsp_worker_destroy(void *data) {
     }
     if (w->corrected != NULL) {
         sdrm_batch_destroy(w->corrected);
+    }
+    if (w->batcher != NULL && w->doppler != NULL) {
+        sdrm_batcher_set_doppler(w->batcher, w->channel, NULL);
     }
     if (w->doppler != NULL) {
         sdrm_doppler_destroy(w->doppler);

@@ -1,0 +1,93 @@
+// emu_batcher.cpp -- TEST INFRASTRUCTURE: the product's batcher host logic (sdr-modem_amd/host/batcher.cpp) on top of
+// the kernel emulation, so that the CPU-only suite can exercise rounds, ordering, back-pressure, overwrite-newest and
+// the poison pill without a GPU.  The product library has no such backend.
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <deque>
+#include <vector>
+
+#include "../../sdr-modem_amd/host/batcher.h"
+
+struct EmuBatch;
+extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out);
+extern "C" void emu_destroy(EmuBatch *b);
+extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t *lens, const int8_t **out8,
+                           const float **outf, size_t *outlens);
+extern "C" int emu_process_nco(EmuBatch *b, const float *const *inputs, const size_t *lens, const sdrm_nco_segment *segs,
+                               size_t n_segs, const int8_t **out8, const float **outf, size_t *outlens);
+
+namespace {
+
+struct EmuBackend : sdrm::BatchBackend {
+    EmuBatch *emu = nullptr;
+    std::vector<uint32_t> maxlen;
+    std::vector<float> arena_mem;
+    size_t stride = 0, slots = 0;
+    unsigned delay_us = 0;
+    struct Result {
+        std::vector<std::vector<int8_t>> out;
+    };
+    std::deque<Result> done;
+    ~EmuBackend() override { emu_destroy(emu); }
+    size_t channels() const override { return maxlen.size(); }
+    uint32_t max_len(size_t c) const override { return maxlen[c]; }
+    int arena(size_t n_slots, sdrm_cf32 **base, size_t *cs, size_t *ss) override {
+        for (uint32_t m : maxlen) stride = stride > m ? stride : m;
+        slots = n_slots;
+        arena_mem.assign(2 * slots * maxlen.size() * stride, 0.0f);
+        *base = reinterpret_cast<sdrm_cf32 *>(arena_mem.data());
+        *cs = stride;
+        *ss = maxlen.size() * stride;
+        return 0;
+    }
+    int submit(size_t slot, const size_t *lens, const sdrm_nco_segment *segs, size_t n_segs) override {
+        if (done.size() >= 3) return -11;
+        const size_t C = maxlen.size();
+        std::vector<const float *> ins(C);
+        for (size_t c = 0; c < C; c++) ins[c] = arena_mem.data() + 2 * ((slot * C + c) * stride);
+        std::vector<const int8_t *> o8(C);
+        std::vector<const float *> of(C);
+        std::vector<size_t> ol(C);
+        int code = n_segs ? emu_process_nco(emu, ins.data(), lens, segs, n_segs, o8.data(), of.data(), ol.data())
+                          : emu_process(emu, ins.data(), lens, o8.data(), of.data(), ol.data());
+        if (code != 0) return code;
+        Result r;
+        r.out.resize(C);
+        for (size_t c = 0; c < C; c++) r.out[c].assign(o8[c], o8[c] + ol[c]);
+        done.push_back(std::move(r));
+        return 0;
+    }
+    std::vector<std::vector<int8_t>> last;
+    int collect(int8_t **outs, size_t *lens) override {
+        if (done.empty()) return -1;
+        if (delay_us) usleep(delay_us);
+        last = std::move(done.front().out);
+        done.pop_front();
+        for (size_t c = 0; c < last.size(); c++) {
+            outs[c] = last[c].data();
+            lens[c] = last[c].size();
+        }
+        return 0;
+    }
+};
+
+}  // namespace
+
+extern "C" int emu_batcher_create(const sdrm_fsk_config *cfgs, size_t n, uint32_t slots, uint32_t max_wait_us, int blocking,
+                                  unsigned device_delay_us, sdrm_batcher **out) {
+    std::unique_ptr<EmuBackend> be(new EmuBackend());
+    int code = emu_create(cfgs, n, &be->emu);
+    if (code != 0) return code;
+    for (size_t c = 0; c < n; c++) be->maxlen.push_back(cfgs[c].max_input_buffer_length);
+    be->delay_us = device_delay_us;
+    sdrm::Batcher *b = new sdrm::Batcher(std::move(be), slots, max_wait_us, blocking != 0);
+    code = b->init();
+    if (code != 0) {
+        delete b;
+        return code;
+    }
+    *out = reinterpret_cast<sdrm_batcher *>(b);
+    return 0;
+}

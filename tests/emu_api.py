@@ -37,8 +37,22 @@ def lib():
         L.emu_taps.restype = C.c_size_t
         L.emu_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FskInfo)]
         L.emu_info.restype = None
+        from sdr_modem_amd.binding import bind_batcher
+        bind_batcher(L)
+        L.emu_batcher_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, C.c_uint,
+                                         C.POINTER(C.c_void_p)]
         _LIB = L
     return _LIB
+
+
+def emu_batcher(cfgs, slots=4, max_wait_us=2000, blocking=True, device_delay_us=0):
+    """the product's batcher host code (sdr-modem_amd/host/batcher.cpp) over the kernel emulation"""
+    from sdr_modem_amd.binding import Batcher
+    arr = make_configs(list(cfgs))
+    h = C.c_void_p()
+    code = lib().emu_batcher_create(arr, len(cfgs), slots, max_wait_us, 1 if blocking else 0, device_delay_us, C.byref(h))
+    assert code == 0, code
+    return Batcher(cfgs, lib=lib(), handle=h)
 
 
 class EmuBatch:

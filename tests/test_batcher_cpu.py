@@ -1,0 +1,152 @@
+"""Host logic of the per-GPU batcher (sdr-modem_amd/host/batcher.cpp) without a GPU: the same C++ code,
+built over the kernel emulation (tests/emu), is driven by producer and consumer threads and compared with the oracle.
+Checks the reference queue's behaviours (src/queue.c) as they appear through the batcher: per-channel order, blocking
+put when all rounds are taken, overwrite-newest for live sources, buffers put before the poison pill still delivered."""
+import threading
+import time
+
+import numpy as np
+
+import emu_api
+import orc
+import sdrm_pkg
+
+sdrm_pkg.load()
+from sdr_modem_amd import siggen  # noqa: E402
+
+CFG_A = (48000, 9600, 5000, 1, 2000, True, 4096)
+CFG_B = (48000, 4800, 5000, 2, 2000, False, 4096)
+
+
+def oracle_stream(cfg, chunks):
+    o = orc.Fsk(*cfg)
+    return [o.process(c)[0] for c in chunks]
+
+
+def test_many_clients_one_batch_ordered_and_bit_exact():
+    cfgs = [CFG_A, CFG_B, CFG_A, CFG_A, CFG_B, CFG_A]
+    K = 5
+    sizes = [4096, 1000, 4096, 37, 2500]
+    sigs = [siggen.gmsk_channel(i, sum(sizes), fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    chunks = [[s[sum(sizes[:k]):sum(sizes[:k + 1])] for k in range(K)] for s in sigs]
+    bt = emu_api.emu_batcher(cfgs, slots=4, max_wait_us=200000, blocking=True)
+    got = [[] for _ in cfgs]
+    start = threading.Barrier(len(cfgs))
+
+    def producer(c):
+        start.wait()
+        for k in range(K):
+            bt.put(c, chunks[c][k])
+
+    def consumer(c):
+        for k in range(K):
+            got[c].append(bt.take(c))
+
+    th = [threading.Thread(target=f, args=(c,)) for c in range(len(cfgs)) for f in (producer, consumer)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+        assert not t.is_alive()
+    for c, cfg in enumerate(cfgs):
+        exp = oracle_stream(cfg, chunks[c])
+        for k in range(K):
+            assert np.array_equal(got[c][k], exp[k]), (c, k)
+    # one batched call per buffer index, not one per client buffer
+    assert bt.rounds() <= K + 2, bt.rounds()
+    bt.close()
+
+
+def test_blocking_producer_waits_for_consumers():
+    bt = emu_api.emu_batcher([CFG_A], slots=4, max_wait_us=100, blocking=True)
+    sig = siggen.gmsk_channel(1, 6 * 2048)
+    done = []
+
+    def producer():
+        for k in range(6):
+            bt.put(0, sig[k * 2048:(k + 1) * 2048])
+            done.append(k)
+
+    t = threading.Thread(target=producer)
+    t.start()
+    time.sleep(0.5)
+    assert t.is_alive() and len(done) == 4, done  # four rounds taken, nothing consumed: the fifth put blocks
+    outs = [bt.take(0) for _ in range(6)]
+    t.join(10)
+    assert not t.is_alive()
+    exp = oracle_stream(CFG_A, [sig[k * 2048:(k + 1) * 2048] for k in range(6)])
+    for k in range(6):
+        assert np.array_equal(outs[k], exp[k]), k
+    bt.close()
+
+
+def test_live_producer_overwrites_its_newest_pending_buffer(capfd):
+    # channel 1 never delivers, so with a long deadline channel 0's rounds stay un-launched ("filled, not yet taken")
+    bt = emu_api.emu_batcher([CFG_A, CFG_A], slots=4, max_wait_us=30_000_000, blocking=False)
+    sig = siggen.gmsk_channel(2, 6 * 1024)
+    parts = [sig[k * 1024:(k + 1) * 1024] for k in range(6)]
+    for k in range(5):
+        bt.put(0, parts[k])  # buffers 0..3 take the four rounds, buffer 4 replaces buffer 3
+    assert "queue is full" in capfd.readouterr().err
+    bt.interrupt(1)  # rounds stop waiting for the silent channel
+    outs = [bt.take(0) for _ in range(4)]
+    exp = oracle_stream(CFG_A, [parts[0], parts[1], parts[2], parts[4]])
+    for k in range(4):
+        assert np.array_equal(outs[k], exp[k]), k
+    bt.close()
+
+
+def test_live_producer_drops_when_everything_pending_is_on_the_device(capfd):
+    bt = emu_api.emu_batcher([CFG_A], slots=4, max_wait_us=10, blocking=False)
+    sig = siggen.gmsk_channel(3, 6 * 1024)
+    parts = [sig[k * 1024:(k + 1) * 1024] for k in range(6)]
+    for k in range(4):
+        bt.put(0, parts[k])
+    t0 = time.time()
+    while bt.rounds() < 4 and time.time() - t0 < 10:
+        time.sleep(0.01)
+    bt.put(0, parts[4])  # no free round, nothing left to overwrite
+    assert "queue is full" in capfd.readouterr().err
+    outs = [bt.take(0) for _ in range(4)]
+    exp = oracle_stream(CFG_A, parts[:4])
+    for k in range(4):
+        assert np.array_equal(outs[k], exp[k]), k
+    bt.put(0, parts[5])  # rounds were released by the consumer: accepted again
+    o = orc.Fsk(*CFG_A)
+    for p in parts[:4]:
+        o.process(p)
+    assert np.array_equal(bt.take(0), o.process(parts[5])[0])
+    bt.close()
+
+
+def test_poison_pill_delivers_pending_buffers_then_null():
+    bt = emu_api.emu_batcher([CFG_A, CFG_B], slots=4, max_wait_us=100, blocking=True)
+    sig = siggen.gmsk_channel(4, 2 * 3000)
+    bt.put(0, sig[:3000])
+    bt.put(0, sig[3000:])
+    bt.interrupt(0)
+    bt.put(0, sig[:100])  # ignored after the pill
+    exp = oracle_stream(CFG_A, [sig[:3000], sig[3000:]])
+    assert np.array_equal(bt.take(0), exp[0])
+    assert np.array_equal(bt.take(0), exp[1])
+    assert bt.take(0) is None
+    # a consumer blocked on an idle channel is released by the pill
+    res = []
+    t = threading.Thread(target=lambda: res.append(bt.take(1)))
+    t.start()
+    time.sleep(0.2)
+    assert t.is_alive()
+    bt.interrupt(1)
+    t.join(10)
+    assert res == [None]
+    bt.close()
+
+
+def test_oversize_buffer_is_refused_with_the_reference_message(capfd):
+    bt = emu_api.emu_batcher([CFG_A], slots=4, max_wait_us=100, blocking=True)
+    sig = siggen.gmsk_channel(5, 5000)
+    bt.put(0, sig)  # 5000 > max_input_buffer_length 4096
+    assert "is more than max" in capfd.readouterr().err
+    bt.put(0, sig[:4096])
+    assert np.array_equal(bt.take(0), oracle_stream(CFG_A, [sig[:4096]])[0])
+    bt.close()

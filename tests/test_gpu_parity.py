@@ -431,3 +431,97 @@ def test_dsp_worker_with_doppler_callback():
     assert len(got) == len(want)
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 2
     assert np.mean(got == want) > 0.999
+
+
+# ---------------------------------------------------------------- next row f-3: per-GPU batcher behind many clients
+
+import threading  # noqa: E402
+
+
+def test_batcher_many_clients_on_the_device_match_oracle():
+    """sdrm_batcher_*: 24 clients (mixed configurations, one with Doppler pre-correction), each with its own producer
+    and consumer thread, share one batch; every client's soft bits equal the oracle's for its own stream."""
+    cfgs = [(48000, 9600, 5000, 1, 2000, True, 8192), (48000, 4800, 5000, 2, 2000, False, 8192),
+            (240000, 19200, 5000, 5, 2000, True, 8192)] * 8
+    K, sizes = 5, [8192, 3000, 8192, 17, 8000]
+    sigs = [siggen.gmsk_channel(i, sum(sizes), fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    chunks = [[s[sum(sizes[:k]):sum(sizes[:k + 1])] for k in range(K)] for s in sigs]
+    bt = binding.Batcher(cfgs, slots=4, max_wait_us=50000, blocking=True)
+    assert bt.code == 0
+    shifts = [1500.0 - 400.0 * k for k in range(8)]
+    planner = binding.DopplerPlanner(48000, lambda k: shifts[min(k, 7)])
+    assert bt.set_doppler(1, planner) == 0
+    got = [[] for _ in cfgs]
+
+    def producer(c):
+        for k in range(K):
+            bt.put(c, chunks[c][k])
+
+    def consumer(c):
+        for k in range(K):
+            got[c].append(bt.take(c))
+
+    th = [threading.Thread(target=f, args=(c,)) for c in range(len(cfgs)) for f in (producer, consumer)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+        assert not t.is_alive()
+    for c, cfg in enumerate(cfgs):
+        o = orc.Fsk(*cfg)
+        d = orc.Doppler(48000, shifts, 8192) if c == 1 else None
+        for k in range(K):
+            x = chunks[c][k].view(np.float32)
+            want = o.process(d.process(x) if d else chunks[c][k])[0]
+            if d is None:
+                assert np.array_equal(got[c][k], want), (c, k)
+            else:  # device cos/sin vs glibc: the reference's own 2-LSB tolerance (test_fsk_demod.c:47)
+                assert len(got[c][k]) == len(want)
+                if len(want):
+                    assert np.abs(got[c][k].astype(np.int32) - want.astype(np.int32)).max() <= 2
+    assert bt.rounds() <= K + 3  # batched: about one device call per buffer index, not 24 * K
+    for c in range(len(cfgs)):
+        bt.interrupt(c)
+    assert bt.take(0) is None
+    bt.close()
+
+
+def test_dsp_workers_sharing_one_batcher_write_the_reference_files():
+    """dsp_worker surface on top of a shared batcher: 6 workers, file sinks byte-identical to the oracle's output."""
+    L = binding.load()
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    n_w = 6
+    cfg = (48000, 4800, 5000, 2, 2000, True, 4096)
+    bt = binding.Batcher([cfg] * n_w, slots=4, max_wait_us=20000, blocking=True)
+    assert bt.code == 0
+    with tempfile.TemporaryDirectory() as tmp:
+        ws = []
+        for i in range(n_w):
+            wc = binding.WorkerConfig(48000, 4800, 5000, 2, 2000, True, i == 0, 0, 4096, 4, True, tmp.encode())
+            wc.batcher = bt.h
+            wc.batcher_channel = i
+            w = C.c_void_p()
+            assert L.dsp_worker_create(20 + i, -1, C.byref(wc), C.byref(w)) == 0
+            ws.append(w)
+        shift = [37 * i for i in range(n_w)]  # every client sees the recording from a different offset
+
+        def feed(i):
+            x = iq[shift[i]:]
+            for off in range(0, len(x), 4096):
+                part = np.ascontiguousarray(x[off:off + 4096]).view(np.float32)
+                L.dsp_worker_put(part.ctypes.data, len(part) // 2, ws[i])
+
+        th = [threading.Thread(target=feed, args=(i,)) for i in range(n_w)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(120)
+        for w in ws:
+            L.dsp_worker_destroy(w)
+        for i in range(n_w):
+            got = np.fromfile(os.path.join(tmp, "rx.demod2client.%d.s8" % (20 + i)), dtype=np.int8)
+            want, _ = orc.demod_stream(cfg[:6], iq[shift[i]:], 4096)
+            assert np.array_equal(got, want), i
+        dump = np.fromfile(os.path.join(tmp, "rx.sdr2demod.20.cf32"), dtype=np.complex64)
+        assert np.array_equal(dump, iq)
+    bt.close()
