@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -27,6 +28,42 @@
 struct sdrm_f2 {
     float x, y;
 };
+
+// bit pattern of a float and back
+SDRM_HD uint32_t sdrm_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(uint32_t, f);
+#else
+    uint32_t u;
+    memcpy(&u, &f, sizeof(u));
+    return u;
+#endif
+}
+SDRM_HD float sdrm_from_bits(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(float, u);
+#else
+    float f;
+    memcpy(&f, &u, sizeof(f));
+    return f;
+#endif
+}
+
+// bit-field insert: mask ? a : b, bit by bit (one v_bfi_b32 on the device; the compiler does not form it by itself here)
+SDRM_HD uint32_t sdrm_bfi(uint32_t mask, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+#else
+    return (a & mask) | (b & ~mask);
+#endif
+}
+
+// x + 1.5 * 2^23 carries rint(x) (round half to even, the current rounding mode) in its low mantissa bits for
+// |x| < 2^22: one add instead of round + convert
+#define SDRM_RINT_MAGIC 12582912.0f
+#define SDRM_RINT_MAGIC_BITS 0x4B400000u
 
 // float -> int32 with the x86-64 cvttss2si result for out-of-range / NaN (INT_MIN); the reference relies on
 // that behaviour at src/math/fast_atan2f.c:112 and src/dsp/clock_recovery_mm.c:110,122.
@@ -96,7 +133,8 @@ SDRM_HD int8_t sdrm_soft_to_i8_finite(float v) {
 #else
     r = fminf(fmaxf(r, -128.0f), 127.0f);
 #endif
-    return (int8_t) (int) rintf(r);
+    // rint by the magic add; the low byte of the sum is the two's-complement int8 (the magic's low byte is zero)
+    return (int8_t) (uint8_t) (sdrm_bits(r + SDRM_RINT_MAGIC) & 0xffu);
 }
 
 // Mueller & Mueller loop state of one channel (reference struct clock_mm_t, clock_recovery_mm.c:9-26)

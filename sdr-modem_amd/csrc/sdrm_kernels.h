@@ -35,9 +35,12 @@
 #define SDRM_K3_PRE 3       // mirror slots below slot 0 (a symbol reads up to 3 samples before its window)
 #define SDRM_K3_POST 8      // mirror slots above slot RING-1 (a window is 8 samples)
 #define SDRM_K3_ROWS (SDRM_K3_PRE + SDRM_K3_RING + SDRM_K3_POST)
-#define SDRM_K3_CPITCH SDRM_K3_ROWS  // floats between two channels' rings (267, odd: lane-per-channel accesses spread over the banks)
+// A channel's ring holds PAIRS: element e = {x[e], x[e+1]} (8 bytes, 8-byte aligned), so that the 8 samples of a window
+// starting anywhere are elements s, s+2, s+4, s+6: two ds_read2_b64 instead of four ds_read2_b32 (an LDS instruction
+// costs a lone wave ~12 cycles of issue whatever its width, tools/ubench_chain.hip).
+#define SDRM_K3_CPITCH (2 * SDRM_K3_ROWS)  // floats between two channels' rings (534: 22 mod 64, conflict-free b64 reads)
 #ifndef SDRM_K3_BANKPITCH
-#define SDRM_K3_BANKPITCH 8  // floats between two rows of the MMSE bank copy in LDS
+#define SDRM_K3_BANKPITCH 12  // floats between two rows of the MMSE bank copy in LDS (48 B: rows start on 16 different bank offsets instead of 8)
 #endif
 #define SDRM_K3_BLOCK 64    // samples staged per channel per step (one per producer lane)
 
@@ -288,21 +291,26 @@ struct sdrm_k3_lane {
     uint32_t cap;      // max symbols per call (= max_input_buffer_length, clock_recovery_mm.c:103)
 };
 
-// `col` = this channel's ring (ring + channel * CPITCH).  Sample n lives at col[slot + PRE], slot = n & (RING-1).
-// Slots < POST are mirrored above the ring and slots >= RING-PRE below it, so the 11 entries [slot-3, slot+7] around
-// any slot are contiguous: a symbol's samples are one base address plus constant offsets.
-SDRM_HD void sdrm_k3_ring_put(float *col, int n, float v) {
-    const int slot = n & (SDRM_K3_RING - 1);
-    col[slot + SDRM_K3_PRE] = v;
+// `col` = this channel's ring (ring + channel * CPITCH).  Element e = {x[e], x[e+1]} lives at col[2 * (slot + PRE)],
+// slot = e & (RING-1).  Slots < POST are mirrored above the ring and slots >= RING-PRE below it, so the elements
+// [slot-3, slot+7] around any slot are contiguous: a symbol's samples are one base address plus constant offsets.
+SDRM_HD void sdrm_k3_elem_put(float *col, int slot, int half, float v) {
+    col[2 * (slot + SDRM_K3_PRE) + half] = v;
     if (slot < SDRM_K3_POST) {
-        col[slot + SDRM_K3_RING + SDRM_K3_PRE] = v;
+        col[2 * (slot + SDRM_K3_RING + SDRM_K3_PRE) + half] = v;
     }
     if (slot >= SDRM_K3_RING - SDRM_K3_PRE) {
-        col[slot - SDRM_K3_RING + SDRM_K3_PRE] = v;
+        col[2 * (slot - SDRM_K3_RING + SDRM_K3_PRE) + half] = v;
     }
 }
 
-SDRM_HD float sdrm_k3_ring_get(const float *col, int n) { return col[(n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE]; }
+// sample n is the first half of its own element and the second half of its predecessor's
+SDRM_HD void sdrm_k3_ring_put(float *col, int n, float v) {
+    sdrm_k3_elem_put(col, n & (SDRM_K3_RING - 1), 0, v);
+    sdrm_k3_elem_put(col, (n - 1) & (SDRM_K3_RING - 1), 1, v);
+}
+
+SDRM_HD float sdrm_k3_ring_get(const float *col, int n) { return col[2 * ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE)]; }
 
 // The loop condition `ii < working_len - 7` (clock_recovery_mm.c:103, ii compared as size_t: negative => stop) with
 // `avail` chunk samples staged, as ONE unsigned compare against a per-block limit: the window starts at chunk-relative
@@ -331,22 +339,24 @@ struct sdrm_k3_operands {
 template <bool FINITE, typename RingPtr, typename BankPtr>
 SDRM_HD void sdrm_k3_fetch(const sdrm_k3_lane &L, RingPtr col, BankPtr bank_rev, sdrm_k3_operands &F) {
     const int n = L.st.ii - L.kept;
-    const RingPtr base = col + ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE);
+    const RingPtr base = col + 2 * ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        F.w[j] = base[j];
+    for (int j = 0; j < 8; j += 2) {  // elements s, s+2, s+4, s+6
+        F.w[j] = base[2 * j];
+        F.w[j + 1] = base[2 * j + 1];
     }
     if (!FINITE) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            F.lead[j] = base[j - 3];
-        }
+        F.lead[0] = base[-6];  // x[s-3], x[s-2] = element s-3; x[s-1] = first half of element s-1
+        F.lead[1] = base[-5];
+        F.lead[2] = base[-2];
     }
     const float scaled = L.st.mu * (float) SDRM_MMSE_STEPS;
     int imu;
     F.row_ok = true;
     if (FINITE) {
-        imu = (int) rintf(scaled);  // mu in [0,1] => 0..128
+        // mu in [0,1] => 0..128.  mu * 128 is exact (power of two), so the explicit fused multiply-add rounds once,
+        // exactly where rint(mu * 128) does
+        imu = (int) (sdrm_bits(fmaf(L.st.mu, (float) SDRM_MMSE_STEPS, SDRM_RINT_MAGIC)) & 0xffu);
     } else {
         F.row_ok = (scaled >= 0.0f) & (scaled <= (float) SDRM_MMSE_STEPS);  // false for NaN
         imu = F.row_ok ? (int) rintf(scaled) : 0;
@@ -399,8 +409,17 @@ SDRM_HD float sdrm_k3_step(sdrm_k3_lane &L, const sdrm_k3_operands &F) {
     const float o = (FINITE || F.row_ok) ? acc : NAN;
     // regular symbol (clock_recovery_mm.c:115-123)
     const float last = L.st.last;
-    const float a = (last < 0.0f) ? -o : o;        // slice(last) * o
-    const float bneg = (o < 0.0f) ? -last : last;  // slice(o) * last
+    float a, bneg;
+    if (FINITE) {
+        // Both products take the sign sign(o) ^ sign(last).  The sign bit is the `< 0` test here: a finite dot product
+        // accumulated from +0 is never -0 (x + y is -0 only if both are), so neither o nor last can be -0 or NaN.
+        const uint32_t bo = sdrm_bits(o), bl = sdrm_bits(last), x = bo ^ bl;
+        a = sdrm_from_bits(sdrm_bfi(0x7fffffffu, bo, x));
+        bneg = sdrm_from_bits(sdrm_bfi(0x7fffffffu, bl, x));
+    } else {
+        a = (last < 0.0f) ? -o : o;        // slice(last) * o
+        bneg = (o < 0.0f) ? -last : last;  // slice(o) * last
+    }
     const float mm = a - bneg;
     float om = L.st.omega + L.k.gain_omega * mm;
     const float dev = om - L.k.omega_mid;

@@ -391,6 +391,114 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // one of this workgroup's channels.  One barrier per step hands block k to the consumer while block k+1 is written.
 size_t k3_lds_bytes() { return (size_t) (SDRM_K3_LANES * SDRM_K3_CPITCH + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_LANES) * sizeof(float); }
 
+// The FINITE symbol loop of the clock stage, scheduled by hand (same operations, same order per lane as
+// sdrm_k3_fetch<true> + sdrm_k3_step<true> + sdrm_soft_to_i8_finite; the C++ form stays in use for the SOFT build and
+// is what the CPU emulation runs).  Why by hand: one wave issues one instruction per 4 cycles whatever its dependences,
+// so the symbol time is the instruction count plus whatever LDS latency is left exposed.  Here: 43 VALU instructions
+// (the compiler's form: 51), one SALU pair for the loop, FOUR operand loads (an LDS instruction costs a lone wave ~12
+// cycles of issue whatever its width: two 16-byte reads for the MMSE row, two ds_read2_b64 for the window's pair
+// elements), two waits, and the previous symbol quantised and stored behind the loads.
+//   v64..v87 are scratch (named, so that halves of the 64-bit pairs can be addressed); everything else is allocated
+//   by the compiler.  exec is narrowed as lanes run out of samples and restored on exit.
+__device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, uint32_t col_addr, uint32_t bank_addr,
+                                                uint32_t &off, uint32_t off_end, const int8_t *out_base) {
+    // row address = bank + rowbytes * rint(mu * 128): the low 24 bits of (mu * 128 + 1.5 * 2^23) are 0x400000 + row, so a
+    // 24-bit multiply-add with this bias lands on the row (the sum wraps modulo 2^32)
+    const uint32_t bias = bank_addr - 0x400000u * (SDRM_K3_BANKPITCH * 4u);
+    float mu = L.st.mu, omega = L.st.omega, last = L.st.last;
+    int ii = L.st.ii, inc = L.st.inc;
+    unsigned long long saved_exec;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        // operands of the first symbol: MMSE row (2 x 16 bytes) and the window's four pair elements
+        "v_sub_u32 v64, %[ii], %[kept]\n\t"
+        "v_and_b32 v64, %[m255], v64\n\t"
+        "v_lshl_add_u32 v64, v64, 3, %[col]\n\t"
+        "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t"
+        "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t"
+        "ds_read_b128 v[66:69], v65\n\t"
+        "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t"
+        "ds_read_b128 v[70:73], v65 offset:16\n\t"
+        "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n"
+        "1:\n\t"
+        // o = ((((((((0 + w0 t0) + w1 t1) + ...) + w7 t7)   (mmse_fir_interpolator.c:188-191, fir_filter.c:116-121)
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_pk_mul_f32 v[66:67], v[66:67], v[74:75]\n\t"
+        "v_pk_mul_f32 v[68:69], v[68:69], v[76:77]\n\t"
+        "v_add_f32 v82, 0, v66\n\t"
+        "v_add_f32 v82, v67, v82\n\t"
+        "v_add_f32 v82, v68, v82\n\t"
+        "v_add_f32 v82, v69, v82\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_mul_f32 v[70:71], v[70:71], v[78:79]\n\t"
+        "v_pk_mul_f32 v[72:73], v[72:73], v[80:81]\n\t"
+        "v_add_f32 v82, v70, v82\n\t"
+        "v_add_f32 v82, v71, v82\n\t"
+        "v_add_f32 v82, v72, v82\n\t"
+        "v_add_f32 v82, v73, v82\n\t"
+        // mm = slice(last) * o - slice(o) * last   (clock_recovery_mm.c:115): both terms take sign(o) ^ sign(last)
+        "v_xor_b32 v83, v82, %[last]\n\t"
+        "v_bfi_b32 v84, %[mask], v82, v83\n\t"
+        "v_bfi_b32 v85, %[mask], %[last], v83\n\t"
+        "v_sub_f32 v84, v84, v85\n\t"
+        // omega += gain_omega * mm; omega = mid + clip(omega - mid, lim)   (:119-120, branchless_clip :74-76)
+        "v_mul_f32 v85, %[go], v84\n\t"
+        "v_add_f32 %[omega], %[omega], v85\n\t"
+        "v_sub_f32 %[omega], %[omega], %[mid]\n\t"
+        "v_add_f32 v85, %[olim], %[omega]\n\t"
+        "v_sub_f32 v86, %[omega], %[olim]\n\t"
+        "v_sub_f32_e64 v85, |v85|, |v86|\n\t"
+        "v_mul_f32 v85, 0.5, v85\n\t"
+        "v_add_f32 %[omega], %[mid], v85\n\t"
+        // mu = mu + omega + gain_mu * mm; ii += floor(mu); mu -= floor(mu)   (:121-123)
+        "v_mul_f32 v84, %[gm], v84\n\t"
+        "v_add_f32 %[mu], %[mu], %[omega]\n\t"
+        "v_add_f32 %[mu], %[mu], v84\n\t"
+        "v_floor_f32 v85, %[mu]\n\t"
+        "v_cvt_i32_f32 %[inc], v85\n\t"
+        "v_sub_f32 %[mu], %[mu], v85\n\t"
+        "v_add_u32 %[ii], %[ii], %[inc]\n\t"
+        // while (ii < limit && oo < cap)   (:103): compared here, combined after the loads (the scalar unit then
+        // does not wait for the vector compares)
+        "v_cmp_lt_u32 vcc, %[ii], %[lim]\n\t"
+        "v_cmp_ne_u32 s[74:75], %[off], %[offlast]\n\t"
+        // operands of the next symbol
+        "v_sub_u32 v64, %[ii], %[kept]\n\t"
+        "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t"
+        "v_and_b32 v64, %[m255], v64\n\t"
+        "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t"
+        "v_lshl_add_u32 v64, v64, 3, %[col]\n\t"
+        "ds_read_b128 v[66:69], v65\n\t"
+        "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t"
+        "ds_read_b128 v[70:73], v65 offset:16\n\t"
+        "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t"
+        // int8 soft bit of the symbol just computed (fsk_demod.c:106), in the shadow of the loads
+        "v_mov_b32 %[last], v82\n\t"
+        "v_mul_f32 v83, %[c127], v82\n\t"
+        "v_med3_f32 v83, v83, %[lo], %[hi]\n\t"
+        "v_add_f32 v83, %[magic], v83\n\t"
+        "global_store_byte %[off], v83, %[out]\n\t"
+        "v_add_u32 %[off], 1, %[off]\n\t"
+        "s_and_b64 vcc, vcc, s[74:75]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execnz 1b\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [mu] "+v"(mu), [omega] "+v"(omega), [last] "+v"(last), [ii] "+v"(ii), [inc] "+v"(inc), [off] "+v"(off),
+          [sv] "=&s"(saved_exec)
+        : [kept] "v"(L.kept), [lim] "v"(lim), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [go] "v"(L.k.gain_omega),
+          [gm] "v"(L.k.gain_mu), [mid] "v"(L.k.omega_mid), [olim] "v"(L.k.omega_lim), [lo] "v"(-128.0f), [hi] "v"(127.0f),
+          [offlast] "v"(off_end - 1u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base),
+          [m255] "s"(255u), [c127] "s"(127.0f), [rowb] "n"(SDRM_K3_BANKPITCH * 4)
+        : "memory", "vcc", "s74", "s75", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+          "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+    L.st.mu = mu;
+    L.st.omega = omega;
+    L.st.last = last;
+    L.st.ii = ii;
+    L.st.inc = inc;
+}
+
 template <bool SOFT>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     extern __shared__ __attribute__((aligned(16))) float k3_lds[];
@@ -489,19 +597,25 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     {                                                                                                        \
         const int n_ = (k) * SDRM_K3_BLOCK + lane;                                                            \
         if (uniform && ((k) + 1) * SDRM_K3_BLOCK <= min_nz) {                                                 \
-            float *row_ = ring + ((n_ & (SDRM_K3_RING - 1)) + SDRM_K3_PRE);                                   \
+            /* sample n_ = first half of element n_, second half of element n_ - 1 (of every channel r) */  \
+            float *lo_ = ring + 2 * ((n_ & (SDRM_K3_RING - 1)) + SDRM_K3_PRE);                                \
+            float *hi_ = ring + 2 * (((n_ - 1) & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) + 1;                      \
             _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                row_[r * SDRM_K3_CPITCH] = pre[r];                                                            \
+                lo_[r * SDRM_K3_CPITCH] = pre[r];                                                             \
+                hi_[r * SDRM_K3_CPITCH] = pre[r];                                                             \
             }                                                                                                \
             __builtin_amdgcn_wave_barrier();                                                                  \
+            /* mirrors, one channel per lane: elements 0..7 above the ring when this block wrote them (and the */ \
+            /* second half of element 255 below it), elements 253..255 below the ring when it wrote those */  \
             if ((((k) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                          \
-                _Pragma("unroll") for (int j = 0; j < SDRM_K3_POST; j++) {                                    \
-                    my_col[j + SDRM_K3_RING + SDRM_K3_PRE] = my_col[j + SDRM_K3_PRE];                         \
+                _Pragma("unroll") for (int j = 0; j < 2 * SDRM_K3_POST; j++) {                                \
+                    my_col[j + 2 * (SDRM_K3_RING + SDRM_K3_PRE)] = my_col[j + 2 * SDRM_K3_PRE];               \
                 }                                                                                            \
+                my_col[2 * (SDRM_K3_PRE - 1) + 1] = my_col[2 * (SDRM_K3_RING - 1 + SDRM_K3_PRE) + 1];         \
             }                                                                                                \
             if (((((k) + 1) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                    \
-                _Pragma("unroll") for (int j = 0; j < SDRM_K3_PRE; j++) {                                     \
-                    my_col[j] = my_col[j + SDRM_K3_RING];                                                     \
+                _Pragma("unroll") for (int j = 0; j < 2 * SDRM_K3_PRE; j++) {                                 \
+                    my_col[j] = my_col[j + 2 * SDRM_K3_RING];                                                 \
                 }                                                                                            \
             }                                                                                                \
         } else {                                                                                             \
@@ -561,6 +675,13 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         } while (((uint32_t) L.st.ii < lim) & ((uint32_t) (uintptr_t) p8 != end_lo));                        \
         L.oo = (uint32_t) (p8 - o8);                                                                          \
     }
+    // the hand-scheduled loop addresses the output as uniform base + 32-bit lane offset
+    const bool fits32 = (unsigned long long) b.n_channels * b.out_stride + b.out_stride < 0xffffffffull;
+    const uint32_t off_base = (uint32_t) ((active ? c : 0) * (unsigned long long) b.out_stride);
+    uint32_t off = off_base;
+    const uint32_t off_end = off_base + L.cap;
+    const uint32_t col_addr = (uint32_t) (uintptr_t) col_l;
+    const uint32_t bank_addr = (uint32_t) (uintptr_t) (lds_cf) bank_rev;
     unsigned long long t_wait = 0, t_drain = 0, n_iter = 0;
     for (int k = 0; k <= nblocks; k++) {
         // k == nblocks: nothing new, only drains what the carried history alone allows (nz == 0 case)
@@ -573,7 +694,13 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         avail = avail < L.nz ? avail : L.nz;
         const uint32_t lim = active ? sdrm_k3_limit(L, avail) : 0u;
         const uint32_t oo0 = L.oo;
-        if (wave_clean) {
+        if (wave_clean && !SOFT && fits32) {
+            if (sdrm_k3_can_step(L, lim)) {
+                k3_drain_finite(L, lim, col_addr, bank_addr, off, off_end, b.out_i8);
+                L.oo = off - off_base;
+                p8 = o8 + L.oo;
+            }
+        } else if (wave_clean) {
             K3_DRAIN(true)
         } else {
             K3_DRAIN(false)

@@ -35,6 +35,30 @@ __global__ __launch_bounds__(64) void k(float *out, unsigned long long *stamps, 
             asm volatile(".rept 512\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\t.endr" : "+v"(s), "+v"(t2) : "v"(t));
         } else if (MODE == 7) {  // dependent v_pk_mul_f32
             asm volatile(".rept 1024\n\tv_pk_mul_f32 %0, %0, %1\n\t.endr" : "+v"(pk) : "v"(pk1));
+        } else if (MODE == 9) {  // 8-byte encodings (VOP3 form of the same add): is a single wave fetch-limited?
+            asm volatile(".rept 512\n\tv_add_f32_e64 %0, %0, %2\n\tv_add_f32_e64 %1, %1, %2\n\t.endr" : "+v"(s), "+v"(t2) : "v"(t));
+        } else if (MODE == 10) {  // 16 trips of a 64-instruction loop of 4-byte adds: cost of the taken branch
+            asm volatile("s_mov_b32 s20, 16\n1:\n\t.rept 32\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\t.endr\n\t"
+                         "s_sub_u32 s20, s20, 1\n\ts_cmp_lg_u32 s20, 0\n\ts_cbranch_scc1 1b" : "+v"(s), "+v"(t2) : "v"(t) : "s20", "scc");
+        } else if (MODE == 11) {  // the same loop with 8-byte adds
+            asm volatile("s_mov_b32 s20, 16\n1:\n\t.rept 32\n\tv_add_f32_e64 %0, %0, %2\n\tv_add_f32_e64 %1, %1, %2\n\t.endr\n\t"
+                         "s_sub_u32 s20, s20, 1\n\ts_cmp_lg_u32 s20, 0\n\ts_cbranch_scc1 1b" : "+v"(s), "+v"(t2) : "v"(t) : "s20", "scc");
+        } else if (MODE == 12) {  // s_waitcnt that never waits, between adds
+            asm volatile(".rept 512\n\tv_add_f32 %0, %0, %2\n\ts_waitcnt lgkmcnt(0)\n\t.endr" : "+v"(s), "+v"(t2) : "v"(t));
+        } else if (MODE == 13) {  // ds_read_b64 issue cost: one independent LDS read per add
+            asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tds_read_b64 v[40:41], %3\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 8) : "v40", "v41");
+        } else if (MODE == 14) {
+            asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tds_read_b32 v40, %3\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 16) : "v40", "v41");
+        } else if (MODE == 15) {
+            asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tds_read_b128 v[40:43], %3\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 16) : "v40", "v41", "v42", "v43");
+        } else if (MODE == 16) {
+            asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tds_read2_b32 v[40:41], %3 offset0:1 offset1:2\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 16) : "v40", "v41");
+        } else if (MODE == 17) {
+            asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tds_read2_b64 v[40:43], %3 offset0:1 offset1:2\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 16) : "v40", "v41", "v42", "v43");
+        } else if (MODE == 18) {  // 4 adds per LDS read: does the read's cost hide behind VALU work?
+            asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tds_read_b64 v[40:41], %3\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 16) : "v40", "v41");
+        } else if (MODE == 19) {  // byte store per 8 adds
+            asm volatile(".rept 128\n\t.rept 8\n\tv_add_f32 %0, %0, %2\n\t.endr\n\tglobal_store_byte %3, %0, %4\n\t.endr" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 4096), "s"(out) : "memory");
         } else if (MODE == 8) {  // v_cmp -> v_cndmask dependent pair (+ the add closing the chain)
             asm volatile(".rept 512\n\tv_cmp_gt_f32 vcc, 0, %0\n\tv_cndmask_b32 %0, %0, %1, vcc\n\t.endr" : "+v"(s) : "v"(t) : "vcc");
         }
@@ -68,7 +92,7 @@ static void run(const char *name, int blocks, int reps, int steps_per_rep) {
 }
 
 int main() {
-    for (int blocks : {4, 256, 4096}) {
+    for (int blocks : {4}) {
         run<0>("dependent v_add_f32", blocks, 200, 1024);
         run<1>("dpp wave_shr chain", blocks, 200, 1024);
         run<2>("dpp row_shr chain", blocks, 200, 1024);
@@ -78,6 +102,17 @@ int main() {
         run<6>("2 indep v_add chains", blocks, 200, 1024);
         run<7>("dependent v_pk_mul_f32", blocks, 200, 1024);
         run<8>("v_cmp+v_cndmask chain", blocks, 200, 1024);
+        run<9>("2 chains, 8-byte adds", blocks, 200, 1024);
+        run<10>("64-instr loop, 4-byte", blocks, 200, 1024);
+        run<11>("64-instr loop, 8-byte", blocks, 200, 1024);
+        run<12>("add + idle s_waitcnt", blocks, 200, 512);
+        run<13>("add + ds_read_b64", blocks, 200, 256);
+        run<14>("add + ds_read_b32", blocks, 200, 256);
+        run<15>("add + ds_read_b128", blocks, 200, 256);
+        run<16>("add + ds_read2_b32", blocks, 200, 256);
+        run<17>("add + ds_read2_b64", blocks, 200, 256);
+        run<18>("4 adds + ds_read_b64", blocks, 200, 256);
+        run<19>("8 adds + store_byte", blocks, 20, 128);
     }
     return 0;
 }
