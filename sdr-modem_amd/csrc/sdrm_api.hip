@@ -361,6 +361,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.out_len = b->d_outlen;
     d.out_stride = out_stride;
     d.t1_max = pl.t1_max;
+    d.t2_max = pl.t2_max;
     d.rx_cap = pl.rx_cap;
     d.rs_cap = pl.rs_cap;
     d.any_dc = any_dc;

@@ -173,6 +173,88 @@ SDRM_HD void sdrm_fir_block_r(const float *xs, const float *taps, int ntaps, flo
     }
 }
 
+// Two-wide helper for the real FIR: on the device a 2-vector whose multiply and add become one v_pk_mul_f32 / v_pk_add_f32
+// (each component rounded separately, no contraction); on the host the same two operations written out.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float sdrm_v2 __attribute__((ext_vector_type(2)));
+SDRM_HD sdrm_v2 sdrm_v2_make(float a, float b) {
+    sdrm_v2 v = {a, b};
+    return v;
+}
+SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) { return acc + x * t; }
+#else
+struct sdrm_v2 {
+    float x, y;
+};
+SDRM_HD sdrm_v2 sdrm_v2_make(float a, float b) {
+    sdrm_v2 v = {a, b};
+    return v;
+}
+SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) {
+    sdrm_v2 r;
+    r.x = acc.x + x.x * t;
+    r.y = acc.y + x.y * t;
+    return r;
+}
+#endif
+
+// The same real FIR block with neighbouring outputs paired: (acc[2p], acc[2p+1]) += (x[2p+u], x[2p+u+1]) * tap, one
+// packed multiply and one packed add per pair and tap (half the VALU instructions of sdrm_fir_block_r; per output the
+// operations and their order are unchanged).  The window is kept twice, as even-aligned pairs (x[2k], x[2k+1]) and as
+// odd-aligned pairs (x[2k+1], x[2k+2]), so that every pair operand is a register pair whatever the tap's parity.
+template <int N, int K>
+SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, float (&acc)[N]) {
+    constexpr int P = N / 2;
+    constexpr int W = N + K - 1;  // window floats per step
+    sdrm_v2 pa[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        pa[p] = sdrm_v2_make(acc[2 * p], acc[2 * p + 1]);
+    }
+    float tail = (N & 1) ? acc[N - 1] : 0.0f;
+    int j0 = 0;
+    for (; j0 + K <= ntaps; j0 += K) {
+        sdrm_v2 we[(W + 1) / 2], wo[(W + 1) / 2];
+#pragma unroll
+        for (int k = 0; 2 * k + 1 < W; k++) {
+            we[k] = sdrm_v2_make(xs[j0 + 2 * k], xs[j0 + 2 * k + 1]);
+        }
+#pragma unroll
+        for (int k = 0; 2 * k + 2 < W; k++) {
+            wo[k] = sdrm_v2_make(xs[j0 + 2 * k + 1], xs[j0 + 2 * k + 2]);
+        }
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const float tp = taps[j0 + u];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const int i = 2 * p + u;
+                pa[p] = sdrm_v2_mac(pa[p], (i & 1) ? wo[i / 2] : we[i / 2], tp);
+            }
+            if (N & 1) {
+                const int i = N - 1 + u;
+                const float x = (i & 1) ? we[i / 2].y : we[i / 2].x;
+                tail = tail + x * tp;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        acc[2 * p] = pa[p].x;
+        acc[2 * p + 1] = pa[p].y;
+    }
+    if (N & 1) {
+        acc[N - 1] = tail;
+    }
+    for (; j0 < ntaps; j0++) {
+        const float tp = taps[j0];
+#pragma unroll
+        for (int r = 0; r < N; r++) {
+            acc[r] = acc[r] + xs[j0 + r] * tp;
+        }
+    }
+}
+
 // values a K1 thread keeps in registers between phases
 struct sdrm_k1_regs {
     sdrm_f2 y[SDRM_K1_R];
@@ -235,7 +317,7 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
         acc[r] = 0.0f;
     }
     if (p.decim == 1) {
-        sdrm_fir_block_r<SDRM_K1_RZ, SDRM_K1_U>(qs + base, taps2_rev, (int) p.T2, acc);
+        sdrm_fir_block_rp<SDRM_K1_RZ, SDRM_K1_U>(qs + base, taps2_rev, (int) p.T2, acc);
     } else {
         const int d = (int) p.decim;
         for (int j = 0; j < (int) p.T2; j++) {

@@ -79,12 +79,15 @@ void launch_nco(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uin
 
 // ================================================================================================ K1
 
-size_t k1_lds_bytes(uint32_t t1_max) {
+size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) {
     // the quadrature-demod tile (NY + pad floats) reuses the raw-IQ tile's space: LPF1 is done with it by then
     size_t xs = SDRM_K1_XS_BYTES(t1_max);
     size_t bnd = (size_t) SDRM_K1_THREADS * sizeof(sdrm_f2);
     size_t tab = 260 * sizeof(float);
-    return xs + bnd + tab;
+    // both filters' taps, staged per workgroup: read from LDS next to the samples instead of waited for from global
+    // memory inside the tap loop
+    size_t taps = (size_t) (((t1_max + 3) & ~3u) + ((t2_max + 3) & ~3u) + 8) * sizeof(float);
+    return xs + bnd + tab + taps;
 }
 
 // grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
@@ -111,17 +114,39 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, co
 
     const bool stamp = b.k3_stamps != nullptr;  // diagnostics: per-phase cycles, summed over workgroups
     unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    // The taps go to LDS as well.  Their loads are issued BEFORE the tile's (short filters: up to three values per
+    // thread held in registers), so that one wait covers both; long filters take the plain loop afterwards.
+    float *taps1 = tab + 260, *taps2 = taps1 + ((p.T1 + 3) & ~3u);  // 16-byte aligned (tab starts aligned, 260 % 4 == 0)
+    const bool short_taps = p.T1 <= 2 * SDRM_K1_THREADS && p.T2 <= SDRM_K1_THREADS;
+    float tv0 = 0.0f, tv1 = 0.0f, tv2 = 0.0f;
+    if (short_taps) {
+        if ((uint32_t) tid < p.T1) tv0 = b.tap_pool[p.taps1_off + tid];
+        if ((uint32_t) tid + SDRM_K1_THREADS < p.T1) tv1 = b.tap_pool[p.taps1_off + tid + SDRM_K1_THREADS];
+        if ((uint32_t) tid < p.T2) tv2 = b.tap_pool[p.taps2_off + tid];
+    }
     sdrm_k1_phase_load(tid, t, in, hist, (int) p.hist_len, b.atan_tab, xs, tab);
+    if (short_taps) {
+        if ((uint32_t) tid < p.T1) taps1[tid] = tv0;
+        if ((uint32_t) tid + SDRM_K1_THREADS < p.T1) taps1[tid + SDRM_K1_THREADS] = tv1;
+        if ((uint32_t) tid < p.T2) taps2[tid] = tv2;
+    } else {
+        for (uint32_t k = tid; k < p.T1; k += SDRM_K1_THREADS) {
+            taps1[k] = b.tap_pool[p.taps1_off + k];
+        }
+        for (uint32_t k = tid; k < p.T2; k += SDRM_K1_THREADS) {
+            taps2[k] = b.tap_pool[p.taps2_off + k];
+        }
+    }
     __syncthreads();
     unsigned long long t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_regs regs;
-    sdrm_k1_phase_lpf1(tid, t, p, b.tap_pool + p.taps1_off, xs, bnd, regs);
+    sdrm_k1_phase_lpf1(tid, t, p, taps1, xs, bnd, regs);
     __syncthreads();
     unsigned long long t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_quad(tid, t, p, tab, bnd, regs, qs);
     __syncthreads();
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    sdrm_k1_phase_lpf2(tid, t, p, b.tap_pool + p.taps2_off, qs, zs, b.nonfinite + c);
+    sdrm_k1_phase_lpf2(tid, t, p, taps2, qs, zs, b.nonfinite + c);
     __syncthreads();
     sdrm_k1_phase_store(tid, t, zs, b.z + (size_t) c * b.z_stride);
     if (stamp && tid == 0) {
@@ -159,7 +184,7 @@ void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, h
         return;
     }
     static size_t granted = 0;
-    const size_t lds = k1_lds_bytes(b.t1_max);
+    const size_t lds = k1_lds_bytes(b.t1_max, b.t2_max);
     allow_lds(k1_front, lds, &granted);
     dim3 grid(b.max_tiles, (unsigned) b.n_channels);
     hipLaunchKernelGGL(k1_front, grid, dim3(SDRM_K1_THREADS), lds, s, b, d_in, in_stride);

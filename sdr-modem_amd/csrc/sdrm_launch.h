@@ -39,12 +39,12 @@ struct DeviceBatch {
     uint32_t nco_stride;
     // launch geometry (host-computed maxima over the batch)
     uint32_t max_tiles;              // K1 grid.x for this call
-    uint32_t t1_max;                 // sizes K1's LDS
+    uint32_t t1_max, t2_max;         // size K1's LDS
     uint32_t rx_cap, rs_cap;         // DC ring capacities (floats) sizing K2's LDS
     int any_dc;
 };
 
-size_t k1_lds_bytes(uint32_t t1_max);
+size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap);
 
 void launch_nco(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);

@@ -93,6 +93,7 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
             plan.rs_cap = std::max(plan.rs_cap, rs);
         }
         plan.t1_max = std::max(plan.t1_max, p.T1);
+        plan.t2_max = std::max(plan.t2_max, p.T2);
         h_max = std::max(h_max, p.hist_len);
         maxlen_max = std::max(maxlen_max, p.max_len);
     }

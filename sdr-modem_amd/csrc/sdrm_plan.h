@@ -20,7 +20,7 @@ struct BatchPlan {
     std::vector<sdrm_chan_params> params;
     std::vector<float> tap_pool;  // reversed taps of every distinct filter, 8-float aligned
     // geometry shared by the whole batch
-    uint32_t t1_max = 0, hist_stride = 0, z_stride = 0, out_stride = 0, in_stride = 0;
+    uint32_t t1_max = 0, t2_max = 0, hist_stride = 0, z_stride = 0, out_stride = 0, in_stride = 0;
     uint32_t rx_cap = 64, rs_cap = 64;
     size_t dc_state_floats = 0;
     int any_dc = 0;
