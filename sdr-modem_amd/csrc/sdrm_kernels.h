@@ -110,7 +110,8 @@ SDRM_HD sdrm_k1_tile sdrm_k1_tile_setup(const sdrm_chan_params &p, const sdrm_ch
 
 // logical input stream of a call: history for negative indices, the caller's buffer otherwise
 SDRM_HD sdrm_f2 sdrm_ext_sample(const sdrm_f2 *in, const sdrm_f2 *hist, int hist_len, int i) {
-    return (i < 0) ? hist[hist_len + i] : in[i];
+    const sdrm_f2 *p = (i < 0) ? hist + (hist_len + i) : in + i;  // one 8-byte load from the selected address
+    return *p;
 }
 
 // K sequential taps on N adjacent outputs of a unit-stride FIR, register blocked: for every output the
@@ -263,7 +264,27 @@ struct sdrm_k1_regs {
 // phase 0: stage the raw tile (+halo) and the arctan table into LDS
 SDRM_HD void sdrm_k1_phase_load(int tid, const sdrm_k1_tile &t, const sdrm_f2 *in, const sdrm_f2 *hist, int hist_len,
                                 const float *atan_tab, sdrm_f2 *xs, float *tab) {
-    for (int k = tid; k < t.nx; k += SDRM_K1_THREADS) {
+    // the first 16 samples of every thread (a whole tile with a halo of up to 256) are loaded before any is stored, so
+    // that the loads are in flight together; longer halos take the plain loop
+    constexpr int DEPTH = 16;
+    sdrm_f2 v[DEPTH];
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++) {
+        const int k = tid + i * SDRM_K1_THREADS;
+        v[i].x = 0.0f;
+        v[i].y = 0.0f;
+        if (k < t.nx) {
+            v[i] = sdrm_ext_sample(in, hist, hist_len, t.x_first + k);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++) {
+        const int k = tid + i * SDRM_K1_THREADS;
+        if (k < t.nx) {
+            xs[k] = v[i];
+        }
+    }
+    for (int k = tid + DEPTH * SDRM_K1_THREADS; k < t.nx; k += SDRM_K1_THREADS) {
         xs[k] = sdrm_ext_sample(in, hist, hist_len, t.x_first + k);
     }
     for (int k = tid; k < 257; k += SDRM_K1_THREADS) {
