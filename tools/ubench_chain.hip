@@ -59,6 +59,11 @@ __global__ __launch_bounds__(64) void k(float *out, unsigned long long *stamps, 
             asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tds_read_b64 v[40:41], %3\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 16) : "v40", "v41");
         } else if (MODE == 19) {  // byte store per 8 adds
             asm volatile(".rept 128\n\t.rept 8\n\tv_add_f32 %0, %0, %2\n\t.endr\n\tglobal_store_byte %3, %0, %4\n\t.endr" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 4096), "s"(out) : "memory");
+        } else if (MODE == 20) {  // two interleaved in-order DPP chains (each gives the other its wait states)
+            asm volatile(".rept 512\n\tv_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t.endr" : "+v"(s), "+v"(t2) : "v"(t));
+        } else if (MODE == 21) {  // four interleaved chains, no nops
+            asm volatile(".rept 256\n\tv_add_f32_dpp %0, %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %2, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(s), "+v"(t2), "+v"(pk.x), "+v"(pk.y) : "v"(t));
         } else if (MODE == 8) {  // v_cmp -> v_cndmask dependent pair (+ the add closing the chain)
             asm volatile(".rept 512\n\tv_cmp_gt_f32 vcc, 0, %0\n\tv_cndmask_b32 %0, %0, %1, vcc\n\t.endr" : "+v"(s) : "v"(t) : "vcc");
         }
@@ -106,6 +111,8 @@ int main() {
         run<10>("64-instr loop, 4-byte", blocks, 200, 1024);
         run<11>("64-instr loop, 8-byte", blocks, 200, 1024);
         run<12>("add + idle s_waitcnt", blocks, 200, 512);
+        run<20>("2 DPP chains interleaved", blocks, 200, 512);
+        run<21>("4 DPP chains interleaved", blocks, 200, 256);
         run<13>("add + ds_read_b64", blocks, 200, 256);
         run<14>("add + ds_read_b32", blocks, 200, 256);
         run<15>("add + ds_read_b128", blocks, 200, 256);
