@@ -525,3 +525,32 @@ def test_dsp_workers_sharing_one_batcher_write_the_reference_files():
         dump = np.fromfile(os.path.join(tmp, "rx.sdr2demod.20.cf32"), dtype=np.complex64)
         assert np.array_equal(dump, iq)
     bt.close()
+
+
+# ---------------------------------------------------------------- next row f-2: file source -> workers -> file sinks
+
+import subprocess  # noqa: E402
+
+
+@pytest.mark.parametrize("workers", [1, 3])
+def test_file_source_harness_reproduces_the_reference_fixture_files(workers):
+    """tools/file_demod.c: a C program against the C-ABI alone reads lucky7.expected.cf32 in 4096-sample chunks like the
+    reference's file source (file_source.c:101), feeds dsp_workers (one private demodulator, or three on a shared
+    batcher) and leaves rx.demod2client.<id>.s8: identical to the oracle, within the reference's 2 LSB of its golden."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "file_demod")
+    if not os.path.exists(exe):
+        subprocess.check_call(["gcc", "-O2", "-pthread", os.path.join(root, "tools", "file_demod.c"), "-I" + os.path.join(root, "include"),
+                               "-L" + os.path.join(root, "sdr-modem_amd", "csrc"), "-lsdrmodem_hip",
+                               "-Wl,-rpath," + os.path.join(root, "sdr-modem_amd", "csrc"), "-o", exe])
+    src = os.path.join(GOLDEN, "lucky7.expected.cf32")
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.check_call([exe, "-d", "-n", str(workers), src, tmp, "48000", "4800", "5000", "2", "2000", "1"], timeout=120)
+        iq = np.fromfile(src, dtype=np.complex64)
+        want, _ = orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq, 4096)
+        golden = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.s8"), dtype=np.int8)
+        for i in range(workers):
+            got = np.fromfile(os.path.join(tmp, "rx.demod2client.%d.s8" % i), dtype=np.int8)
+            assert np.array_equal(got, want), i
+            assert len(got) == len(golden) and np.abs(got.astype(np.int32) - golden.astype(np.int32)).max() <= 2
+        assert np.array_equal(np.fromfile(os.path.join(tmp, "rx.sdr2demod.0.cf32"), dtype=np.complex64), iq)
