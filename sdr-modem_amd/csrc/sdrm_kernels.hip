@@ -416,6 +416,70 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // one of this workgroup's channels.  One barrier per step hands block k to the consumer while block k+1 is written.
 size_t k3_lds_bytes() { return (size_t) (SDRM_K3_LANES * SDRM_K3_CPITCH + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_LANES) * sizeof(float); }
 
+// Order of work inside a symbol:
+//   o = ((((((((0 + w0 t0) + w1 t1) + ...) + w7 t7)   (mmse_fir_interpolator.c:188-191, fir_filter.c:116-121)
+//   mm = slice(last) * o - slice(o) * last   (clock_recovery_mm.c:115): both terms take sign(o) ^ sign(last)
+//   omega += gain_omega * mm; omega = mid + clip(omega - mid, lim)   (:119-120, branchless_clip :74-76)
+//   mu = mu + omega + gain_mu * mm; ii += floor(mu); mu -= floor(mu)   (:121-123)
+//   while (ii < limit && oo < cap)   (:103): compared here, combined after the loads (the scalar unit then
+//   does not wait for the vector compares)
+//   operands of the next symbol
+//   int8 soft bit of the symbol just computed (fsk_demod.c:106), in the shadow of the loads
+// one symbol of the hand-scheduled loop (see k3_drain_finite); exec is narrowed at its end
+#define K3_SYMBOL_ASM \
+    "s_waitcnt lgkmcnt(2)\n\t" \
+    "v_pk_mul_f32 v[66:67], v[66:67], v[74:75]\n\t" \
+    "v_pk_mul_f32 v[68:69], v[68:69], v[76:77]\n\t" \
+    "v_add_f32 v82, 0, v66\n\t" \
+    "v_add_f32 v82, v67, v82\n\t" \
+    "v_add_f32 v82, v68, v82\n\t" \
+    "v_add_f32 v82, v69, v82\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_pk_mul_f32 v[70:71], v[70:71], v[78:79]\n\t" \
+    "v_pk_mul_f32 v[72:73], v[72:73], v[80:81]\n\t" \
+    "v_add_f32 v82, v70, v82\n\t" \
+    "v_add_f32 v82, v71, v82\n\t" \
+    "v_add_f32 v82, v72, v82\n\t" \
+    "v_add_f32 v82, v73, v82\n\t" \
+    "v_xor_b32 v83, v82, %[last]\n\t" \
+    "v_bfi_b32 v84, %[mask], v82, v83\n\t" \
+    "v_bfi_b32 v85, %[mask], %[last], v83\n\t" \
+    "v_sub_f32 v84, v84, v85\n\t" \
+    "v_mul_f32 v85, %[go], v84\n\t" \
+    "v_add_f32 %[omega], %[omega], v85\n\t" \
+    "v_sub_f32 %[omega], %[omega], %[mid]\n\t" \
+    "v_add_f32 v85, %[olim], %[omega]\n\t" \
+    "v_sub_f32 v86, %[omega], %[olim]\n\t" \
+    "v_sub_f32_e64 v85, |v85|, |v86|\n\t" \
+    "v_mul_f32 v85, 0.5, v85\n\t" \
+    "v_add_f32 %[omega], %[mid], v85\n\t" \
+    "v_mul_f32 v84, %[gm], v84\n\t" \
+    "v_add_f32 %[mu], %[mu], %[omega]\n\t" \
+    "v_add_f32 %[mu], %[mu], v84\n\t" \
+    "v_floor_f32 v85, %[mu]\n\t" \
+    "v_cvt_i32_f32 %[inc], v85\n\t" \
+    "v_sub_f32 %[mu], %[mu], v85\n\t" \
+    "v_add_u32 %[ii], %[ii], %[inc]\n\t" \
+    "v_cmp_lt_u32 vcc, %[ii], %[lim]\n\t" \
+    "v_cmp_ne_u32 s[74:75], %[off], %[offlast]\n\t" \
+    "v_sub_u32 v64, %[ii], %[kept]\n\t" \
+    "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t" \
+    "v_and_b32 v64, %[m255], v64\n\t" \
+    "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t" \
+    "v_lshl_add_u32 v64, v64, 3, %[col]\n\t" \
+    "ds_read_b128 v[66:69], v65\n\t" \
+    "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t" \
+    "ds_read_b128 v[70:73], v65 offset:16\n\t" \
+    "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
+    "v_mov_b32 %[last], v82\n\t" \
+    "v_mul_f32 v83, %[c127], v82\n\t" \
+    "v_med3_f32 v83, v83, %[lo], %[hi]\n\t" \
+    "v_add_f32 v83, %[magic], v83\n\t" \
+    "global_store_byte %[off], v83, %[out]\n\t" \
+    "v_add_u32 %[off], 1, %[off]\n\t" \
+    "s_and_b64 vcc, vcc, s[74:75]\n\t" \
+    "s_and_b64 exec, exec, vcc\n\t"
+
 // The FINITE symbol loop of the clock stage, scheduled by hand (same operations, same order per lane as
 // sdrm_k3_fetch<true> + sdrm_k3_step<true> + sdrm_soft_to_i8_finite; the C++ form stays in use for the SOFT build and
 // is what the CPU emulation runs).  Why by hand: one wave issues one instruction per 4 cycles whatever its dependences,
@@ -446,67 +510,16 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         "ds_read_b128 v[70:73], v65 offset:16\n\t"
         "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n"
         "1:\n\t"
-        // o = ((((((((0 + w0 t0) + w1 t1) + ...) + w7 t7)   (mmse_fir_interpolator.c:188-191, fir_filter.c:116-121)
-        "s_waitcnt lgkmcnt(2)\n\t"
-        "v_pk_mul_f32 v[66:67], v[66:67], v[74:75]\n\t"
-        "v_pk_mul_f32 v[68:69], v[68:69], v[76:77]\n\t"
-        "v_add_f32 v82, 0, v66\n\t"
-        "v_add_f32 v82, v67, v82\n\t"
-        "v_add_f32 v82, v68, v82\n\t"
-        "v_add_f32 v82, v69, v82\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_pk_mul_f32 v[70:71], v[70:71], v[78:79]\n\t"
-        "v_pk_mul_f32 v[72:73], v[72:73], v[80:81]\n\t"
-        "v_add_f32 v82, v70, v82\n\t"
-        "v_add_f32 v82, v71, v82\n\t"
-        "v_add_f32 v82, v72, v82\n\t"
-        "v_add_f32 v82, v73, v82\n\t"
-        // mm = slice(last) * o - slice(o) * last   (clock_recovery_mm.c:115): both terms take sign(o) ^ sign(last)
-        "v_xor_b32 v83, v82, %[last]\n\t"
-        "v_bfi_b32 v84, %[mask], v82, v83\n\t"
-        "v_bfi_b32 v85, %[mask], %[last], v83\n\t"
-        "v_sub_f32 v84, v84, v85\n\t"
-        // omega += gain_omega * mm; omega = mid + clip(omega - mid, lim)   (:119-120, branchless_clip :74-76)
-        "v_mul_f32 v85, %[go], v84\n\t"
-        "v_add_f32 %[omega], %[omega], v85\n\t"
-        "v_sub_f32 %[omega], %[omega], %[mid]\n\t"
-        "v_add_f32 v85, %[olim], %[omega]\n\t"
-        "v_sub_f32 v86, %[omega], %[olim]\n\t"
-        "v_sub_f32_e64 v85, |v85|, |v86|\n\t"
-        "v_mul_f32 v85, 0.5, v85\n\t"
-        "v_add_f32 %[omega], %[mid], v85\n\t"
-        // mu = mu + omega + gain_mu * mm; ii += floor(mu); mu -= floor(mu)   (:121-123)
-        "v_mul_f32 v84, %[gm], v84\n\t"
-        "v_add_f32 %[mu], %[mu], %[omega]\n\t"
-        "v_add_f32 %[mu], %[mu], v84\n\t"
-        "v_floor_f32 v85, %[mu]\n\t"
-        "v_cvt_i32_f32 %[inc], v85\n\t"
-        "v_sub_f32 %[mu], %[mu], v85\n\t"
-        "v_add_u32 %[ii], %[ii], %[inc]\n\t"
-        // while (ii < limit && oo < cap)   (:103): compared here, combined after the loads (the scalar unit then
-        // does not wait for the vector compares)
-        "v_cmp_lt_u32 vcc, %[ii], %[lim]\n\t"
-        "v_cmp_ne_u32 s[74:75], %[off], %[offlast]\n\t"
-        // operands of the next symbol
-        "v_sub_u32 v64, %[ii], %[kept]\n\t"
-        "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t"
-        "v_and_b32 v64, %[m255], v64\n\t"
-        "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t"
-        "v_lshl_add_u32 v64, v64, 3, %[col]\n\t"
-        "ds_read_b128 v[66:69], v65\n\t"
-        "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t"
-        "ds_read_b128 v[70:73], v65 offset:16\n\t"
-        "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t"
-        // int8 soft bit of the symbol just computed (fsk_demod.c:106), in the shadow of the loads
-        "v_mov_b32 %[last], v82\n\t"
-        "v_mul_f32 v83, %[c127], v82\n\t"
-        "v_med3_f32 v83, v83, %[lo], %[hi]\n\t"
-        "v_add_f32 v83, %[magic], v83\n\t"
-        "global_store_byte %[off], v83, %[out]\n\t"
-        "v_add_u32 %[off], 1, %[off]\n\t"
-        "s_and_b64 vcc, vcc, s[74:75]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
-        "s_cbranch_execnz 1b\n\t"
+        // four symbols per trip: the taken branch back costs a lone wave ~25 cycles
+        K3_SYMBOL_ASM
+        "s_cbranch_execz 2f\n\t"
+        K3_SYMBOL_ASM
+        "s_cbranch_execz 2f\n\t"
+        K3_SYMBOL_ASM
+        "s_cbranch_execz 2f\n\t"
+        K3_SYMBOL_ASM
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         : [mu] "+v"(mu), [omega] "+v"(omega), [last] "+v"(last), [ii] "+v"(ii), [inc] "+v"(inc), [off] "+v"(off),
