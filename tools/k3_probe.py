@@ -8,8 +8,9 @@ from sdr_modem_amd import binding, siggen
 Cn = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = 131072
 cfg = (48000, 9600, 5000, 1, 2000, True, N)
-base = np.stack([siggen.gmsk_channel(i, 2 * N) for i in range(8)])
-x = torch.from_numpy(np.tile(base, (Cn // 8, 1)).view(np.float32)).cuda()
+D = int(os.environ.get('DISTINCT', '8'))  # distinct waveforms (the rest are copies): 8 = little LDS bank conflict
+base = np.stack([siggen.gmsk_channel(i, 2 * N) for i in range(D)])
+x = torch.from_numpy(np.tile(base, (Cn // D, 1)).view(np.float32)).cuda()
 b = binding.Batch([cfg] * Cn)
 L = binding.load()
 L.sdrm_batch_k3_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
