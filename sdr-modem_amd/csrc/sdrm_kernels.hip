@@ -231,6 +231,130 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 
 size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap) { return ((size_t) rx_cap + 3 * (size_t) rs_cap) * sizeof(float); }
 
+// What one stage wave of the DC blocker does, specialised per stage so that the loop over full 64-sample blocks carries
+// no stage or validity tests (a lone wave pays ~4 cycles per scalar instruction and ~25 per taken branch; the
+// generic loop spent as long on control flow as on the 63-step chain).  All four stages execute the same number of
+// barriers: 3*STAGE - 1 idle ones, one iteration that only prefetches, one per block, then idle ones up to nb + 9.
+struct k2_ctx {
+    float *lds;               // the channel's LDS area: input ring, then the three stage rings
+    uint32_t rx_cap, rs_cap;  // ring capacities (floats)
+    uint32_t mx, ms;          // ring masks of this channel
+    uint32_t L, nz, zbase;
+    float Lf;
+    const float *z;           // LPF2 output of this call (stage 0 feeds the input ring from it)
+    float *out;               // DC-free output (stage 3)
+    int lane;
+};
+
+#define K2_SKEW 3
+#define K2_BARRIER() asm volatile("s_barrier" ::: "memory")
+// everything this wave issued to the LDS is at least one iteration old when this runs: the wait is free, and it is what
+// guarantees that the previous iteration's store is complete before the barrier after which its reader may look at it
+#define K2_SETTLE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int STAGE, int MODE>
+__device__ __forceinline__ void k2_stage(const k2_ctx &k, float &acc, bool &odd) {
+    typedef float k2_f4 __attribute__((ext_vector_type(4)));
+    const int lane = k.lane;
+    const int nb = (int) ((k.nz + 63) / 64), nfull = (int) (k.nz / 64);
+    const uint32_t rin = STAGE == 0 ? 0u : k.rx_cap + (uint32_t) (STAGE - 1) * k.rs_cap;
+    const uint32_t m_in = STAGE == 0 ? k.mx : k.ms;
+    const uint32_t rout = k.rx_cap + (uint32_t) (STAGE < 3 ? STAGE : 0) * k.rs_cap;
+    float *rx = k.lds;
+    const k2_f4 *z4 = reinterpret_cast<const k2_f4 *>(k.z);  // rows start 256-byte aligned (z_stride % 64 == 0)
+    k2_f4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
+    float u_n = 0.0f, ud_n = 0.0f, xd_n = 0.0f;
+    // Stage 0 also feeds the input ring: every fourth block it commits four blocks that it loaded four iterations
+    // earlier (one float4 per lane) and issues the load of the four after those: a load has four iterations to land.
+    auto commit = [&](int first_block, const k2_f4 &v) {
+        const uint32_t n4 = (uint32_t) first_block * 64u + 4u * (uint32_t) lane;
+        const uint32_t pos4 = k.zbase + n4;
+        if (n4 < k.nz) rx[pos4 & k.mx] = v.x;
+        if (n4 + 1u < k.nz) rx[(pos4 + 1u) & k.mx] = v.y;
+        if (n4 + 2u < k.nz) rx[(pos4 + 2u) & k.mx] = v.z;
+        if (n4 + 3u < k.nz) rx[(pos4 + 3u) & k.mx] = v.w;
+    };
+    auto feed = [&](int blk) {  // blk % 4 == 0
+        commit(blk + 4, xq);
+        const uint32_t nn = ((uint32_t) blk + 8u) * 64u + 4u * (uint32_t) lane;
+        if (nn < k.nz) {
+            xq = z4[(blk + 8) * 16 + lane];
+        }
+    };
+    // inputs of block `blk` into registers: written by the previous stage two iterations ago (stage 0: by the feed)
+    auto prefetch = [&](int blk) {
+        const uint32_t pos = k.zbase + (uint32_t) blk * 64u + lane;
+        u_n = k.lds[rin + (pos & m_in)];
+        ud_n = k.lds[rin + ((pos - k.L) & m_in)];
+        if (STAGE == 3) {
+            xd_n = rx[(pos - 2 * (k.L - 1)) & k.mx];
+        }
+    };
+    // one block: `count` valid samples (64 except in the last block)
+    auto block = [&](int blk, int count, bool more) {
+        const uint32_t n = (uint32_t) blk * 64u + lane;
+        const uint32_t pos = k.zbase + n;
+        const bool valid = count == 64 || lane < count;
+        const float t = valid ? sdrm_boxcar_term(u_n, ud_n) : 0.0f;
+        const float xd = xd_n;
+        if (more) {
+            prefetch(blk + 1);
+        }
+        const float s = wave_inorder_sum<MODE>(t, acc);
+        acc = lane_bcast(s, count - 1);
+        const float v = sdrm_boxcar_out(s, k.Lf);
+        if (STAGE < 3) {
+            if (valid) {
+                k.lds[rout + (pos & k.ms)] = v;
+            }
+        } else if (valid) {
+            const float o = xd - v;
+            k.out[n] = o;
+            odd |= !(fabsf(o) < INFINITY);
+        }
+    };
+    if (STAGE == 0) {
+        if (4u * (uint32_t) lane < k.nz) {
+            const k2_f4 first = z4[lane];
+            commit(0, first);
+        }
+        if (256u + 4u * (uint32_t) lane < k.nz) {
+            xq = z4[64 + lane];
+        }
+        if (nb > 0) {
+            prefetch(0);
+        }
+    } else {
+        for (int i = 0; i < K2_SKEW * STAGE - 1; i++) {
+            K2_BARRIER();
+        }
+        if (nb > 0) {
+            prefetch(0);
+        }
+        K2_BARRIER();
+    }
+    for (int blk = 0; blk < nfull; blk++) {
+        K2_SETTLE();
+        if (STAGE == 0 && (blk & 3) == 0) {
+            feed(blk);
+        }
+        block(blk, 64, blk + 1 < nb);
+        K2_BARRIER();
+    }
+    if (nfull < nb) {
+        K2_SETTLE();
+        if (STAGE == 0 && (nfull & 3) == 0) {
+            feed(nfull);
+        }
+        block(nfull, (int) (k.nz - (uint32_t) nfull * 64u), false);
+        K2_BARRIER();
+    }
+    K2_SETTLE();
+    for (int i = 0; i < K2_SKEW * (3 - STAGE); i++) {
+        K2_BARRIER();
+    }
+}
+
 // One workgroup of four waves per channel, one wave per boxcar stage (reference src/dsp/dc_blocker.c:56-64,105-119:
 // four cascaded length-L boxcars, y = (u - u[-L]) + y_prev, out y/L; result x[n - 2(L-1)] - y4).
 // The stages form a software pipeline over 64-sample blocks: in iteration `it`, wave s works on block it - s.  Within a
@@ -267,108 +391,37 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     __syncthreads();
     __builtin_amdgcn_s_setprio(2);  // latency-bound chains: issue ahead of the front-end's waves on a shared SIMD
 
-    const float *z = b.z + (size_t) c * b.z_stride;
-    float *out = b.dcout + (size_t) c * b.z_stride;
-    const uint32_t L = p.dc_len;
-    const float Lf = p.dc_len_f;
-    const uint32_t nz = ctl.nz;
-    const int nb = (int) ((nz + 63) / 64);
-    // this stage's input ring (the previous stage's output; the raw LPF2 stream for stage 0) and output ring, as
-    // offsets into the one LDS array (pointers picked at run time would degrade to flat addressing)
-    const uint32_t rin_off = stage == 0 ? 0u : b.rx_cap + (uint32_t) (stage - 1) * b.rs_cap;
-    const uint32_t min_ = stage == 0 ? mx : ms;
-    const uint32_t rout_off = b.rx_cap + (uint32_t) (stage < 3 ? stage : 0) * b.rs_cap;
+    k2_ctx k;
+    k.lds = k2_lds;
+    k.rx_cap = b.rx_cap;
+    k.rs_cap = b.rs_cap;
+    k.mx = mx;
+    k.ms = ms;
+    k.L = p.dc_len;
+    k.nz = ctl.nz;
+    k.zbase = ctl.zbase;
+    k.Lf = p.dc_len_f;
+    k.z = b.z + (size_t) c * b.z_stride;
+    k.out = b.dcout + (size_t) c * b.z_stride;
+    k.lane = lane;
     bool odd = false;
-    // Stage 0 also feeds the input ring: every fourth iteration it commits four blocks that it loaded four iterations
-    // earlier (one float4 per lane) and issues the load of the four blocks after those, so a load has four iterations
-    // to land and the wait in front of the commit costs nothing.  Blocks it+4 .. it+7 are committed in iteration it;
-    // every stage reads its block's samples from LDS.
-    const bool stamp = b.k3_stamps != nullptr && blockIdx.x == 0;  // diagnostics: cycles in the scan / at the barrier
-    unsigned long long t_scan = 0, t_bar = 0;
+    const bool stamp = b.k3_stamps != nullptr && blockIdx.x == 0;  // diagnostics: this channel's cycles per iteration
     const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    typedef float k2_f4 __attribute__((ext_vector_type(4)));
-    const k2_f4 *z4 = reinterpret_cast<const k2_f4 *>(z);  // rows start 256-byte aligned (z_stride % 64 == 0)
-    k2_f4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
-#define K2_COMMIT(first_block, V)                                                       \
-    {                                                                                   \
-        const uint32_t n4 = (uint32_t) (first_block) * 64u + 4u * (uint32_t) lane;      \
-        const uint32_t pos4 = ctl.zbase + n4;                                           \
-        if (n4 < nz) rx[pos4 & mx] = (V).x;                                             \
-        if (n4 + 1u < nz) rx[(pos4 + 1u) & mx] = (V).y;                                 \
-        if (n4 + 2u < nz) rx[(pos4 + 2u) & mx] = (V).z;                                 \
-        if (n4 + 3u < nz) rx[(pos4 + 3u) & mx] = (V).w;                                 \
-    }
     if (stage == 0) {
-        if (4u * (uint32_t) lane < nz) {
-            const k2_f4 first = z4[lane];
-            K2_COMMIT(0, first)
-        }
-        if (256u + 4u * (uint32_t) lane < nz) {
-            xq = z4[64 + lane];
-        }
+        k2_stage<0, MODE>(k, acc, odd);
+    } else if (stage == 1) {
+        k2_stage<1, MODE>(k, acc, odd);
+    } else if (stage == 2) {
+        k2_stage<2, MODE>(k, acc, odd);
+    } else {
+        k2_stage<3, MODE>(k, acc, odd);
     }
-#define K2_FEED(it_)                                                                    \
-    if (stage == 0 && (it_) < nb) {                                                     \
-        K2_COMMIT((it_) + 4, xq)                                                        \
-        const uint32_t nn = ((uint32_t) (it_) + 8u) * 64u + 4u * (uint32_t) lane;       \
-        if (nn < nz) {                                                                  \
-            xq = z4[((it_) + 8) * 16 + lane];                                           \
-        }                                                                               \
-    }
-#define K2_ITER(it_)                                                                                         \
-    if ((it_) < nb + 3) {                                                                                    \
-        const int blk = (it_) - stage;                                                                       \
-        if (blk >= 0 && blk < nb) {                                                                          \
-            const uint32_t n = (uint32_t) blk * 64u + lane;                                                   \
-            const bool valid = n < nz;                                                                        \
-            const int last = (int) ((nz - (uint32_t) blk * 64u < 64u ? nz - (uint32_t) blk * 64u : 64u) - 1u); \
-            const uint32_t pos = ctl.zbase + n; /* stream index (mod 2^32; ring sizes divide 2^32) */         \
-            const float u = k2_lds[rin_off + (pos & min_)];                                                   \
-            const float ud = k2_lds[rin_off + ((pos - L) & min_)];                                            \
-            const float t = valid ? sdrm_boxcar_term(u, ud) : 0.0f;                                           \
-            const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                          \
-            const float s = wave_inorder_sum<MODE>(t, acc);                                                   \
-            acc = lane_bcast(s, last);                                                                        \
-            if (stamp) {                                                                                      \
-                t_scan += __builtin_amdgcn_s_memtime() - ts0;                                                 \
-            }                                                                                                \
-            const float v = sdrm_boxcar_out(s, Lf);                                                           \
-            if (stage < 3) {                                                                                  \
-                if (valid) {                                                                                  \
-                    k2_lds[rout_off + (pos & ms)] = v;                                                        \
-                }                                                                                            \
-            } else if (valid) {                                                                               \
-                const float o = rx[(pos - 2 * (L - 1)) & mx] - v;                                             \
-                out[n] = o;                                                                                   \
-                odd |= !(fabsf(o) < INFINITY);                                                                \
-            }                                                                                                \
-        }                                                                                                    \
-        /* hand-off between stage waves goes through LDS only: wait for LDS, not for global prefetch/store */ \
-        const unsigned long long tb0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                              \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                       \
-        if (stamp) {                                                                                          \
-            t_bar += __builtin_amdgcn_s_memtime() - tb0;                                                      \
-        }                                                                                                    \
-    }
-    for (int it = 0; it < nb + 3; it += 4) {
-        K2_FEED(it)
-        K2_ITER(it)
-        K2_ITER(it + 1)
-        K2_ITER(it + 2)
-        K2_ITER(it + 3)
-    }
-#undef K2_FEED
-#undef K2_COMMIT
-    if (stamp && lane == 0) {
+    __syncthreads();  // all rings final before they go back to the channel's state
+    if (stamp && lane == 0 && stage == 0) {
         unsigned long long *k2s = b.k3_stamps + ((b.n_channels + 63) / 64) * 4 + 8;  // after the K3 and K1 records
-        k2s[stage * 2] = t_scan;
-        k2s[stage * 2 + 1] = t_bar;
-        if (stage == 0) {
-            k2s[8] = __builtin_amdgcn_s_memtime() - t_begin;
-            k2s[9] = (unsigned long long) (nb + 3);
-        }
+        k2s[8] = __builtin_amdgcn_s_memtime() - t_begin;
+        k2s[9] = (unsigned long long) ((ctl.nz + 63) / 64 + 3 * K2_SKEW);
     }
-#undef K2_ITER
     if (odd) {
         b.nonfinite[c] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
     }

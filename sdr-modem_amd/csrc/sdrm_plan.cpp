@@ -82,9 +82,10 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
         if (p.dc_len) {
             plan.any_dc = 1;
             p.dc_len_f = (float) p.dc_len;
-            // the four stage waves of K2 run one 64-sample block apart: rings cover the delay plus the blocks in flight;
-            // the input ring is also fed up to 8 blocks ahead of the first stage (3 behind + 8 ahead + the block itself)
-            const uint32_t rs = pow2_at_least(p.dc_len + 128), rx = pow2_at_least(2 * (p.dc_len - 1) + 13 * 64 + 64);
+            // The four stage waves of K2 run three 64-sample blocks apart and prefetch one block ahead: a stage ring
+            // covers its delay plus the blocks between its writer and its reader; the input ring is also fed up to 8
+            // blocks ahead of the first stage and read 2(L-1) behind the last one.
+            const uint32_t rs = pow2_at_least(p.dc_len + 4 * 64), rx = pow2_at_least(2 * (p.dc_len - 1) + 17 * 64);
             p.rs_mask = rs - 1;
             p.rx_mask = rx - 1;
             p.dc_state_off = (uint32_t) plan.dc_state_floats;

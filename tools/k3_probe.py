@@ -33,5 +33,4 @@ for w in range(min(waves, 2)):
     print("wave %d: wait-for-producer %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration" % (
         w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1)))
 if k2[9]:
-    print("K2 channel 0: %d iterations, %.0f cycles each; per stage wave (scan, barrier wait) cycles/iteration: %s" % (
-        k2[9], k2[8] / k2[9], ", ".join("(%.0f, %.0f)" % (k2[2 * s] / k2[9], k2[2 * s + 1] / k2[9]) for s in range(4))))
+    print("K2 channel 0: %d iterations, %.0f cycles each (the 63-step chain alone is 756)" % (k2[9], k2[8] / k2[9]))
