@@ -25,13 +25,14 @@ sys.path.insert(0, ROOT)
 FS, BAUD, DEV, DECIM, TW, DC = 48000, 9600, 5000, 1, 2000, True
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DISTINCT = 32          # distinct seeded waveforms per rank; further channels are circular shifts of them
+SWEEP_STEPS = 24       # timed steps per extra channel count of the sweep
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--channels-per-gpu", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=131072)
     ap.add_argument("--chunks-resident", type=int, default=8)
@@ -252,14 +253,14 @@ def main():
                     torch.cuda.synchronize()
                     b2.timing_enable(True)
                     t0 = time.perf_counter()
-                    for i in range(6):
+                    for i in range(SWEEP_STEPS):
                         b2.process_device(x2.data_ptr() + (i % 2) * N * 8, 2 * N, ln, stream)
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
                     km = [b2.timing_read(w) for w in range(3)]
                     fr = km[0][0] / max(km[0][1], 1)
-                    sweep[str(c2)] = {"value": round(c2 * N * 6 / dt / 1e6, 1), "unit": "Msamples/s",
-                                      "ms_per_step": round(dt / 6 * 1e3, 3),
+                    sweep[str(c2)] = {"value": round(c2 * N * SWEEP_STEPS / dt / 1e6, 1), "unit": "Msamples/s",
+                                      "ms_per_step": round(dt / SWEEP_STEPS * 1e3, 3), "steps": SWEEP_STEPS,
                                       "kernel_ms": [round(m / max(n, 1), 3) for m, n in km],
                                       "front_hbm_frac": round(c2 * N * 8.0 / (fr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                     b2.close()
