@@ -214,6 +214,26 @@ def test_mixed_batch_with_ragged_lengths():
     g.close()
 
 
+def test_default_build_of_the_clock_stage_on_ragged_mixed_streams():
+    """Without KEEP_SOFT_F32 the clock stage runs its hand-scheduled symbol loop (int8 only): the same ragged,
+    mixed-rate, multi-call streams as above, including sps >= 8 (tail quirk) and decimated channels, int8 bit-exact."""
+    cfgs = [(48000, 9600, 5000, 1, 2000, True, 8192), (48000, 4800, 5000, 2, 2000, False, 8192),
+            (240000, 19200, 5000, 5, 2000, True, 8192), (240000, 9600, 5000, 1, 2000, True, 8192),
+            (192000, 40000, 5000, 1, 2500, True, 8192)] * 14
+    sigs = [siggen.gmsk_channel(i, 20000, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    g = binding.Batch(cfgs)
+    assert g.code == 0
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    for lo, hi in [(0, 8192), (8192, 8200), (8200, 8201), (8201, 16000), (16000, 16000), (16000, 20000)]:
+        lens = [(hi - lo) if i % 5 else max(0, hi - lo - 33) for i in range(len(cfgs))]
+        parts = [s[lo:lo + n] for s, n in zip(sigs, lens)]
+        g8 = g.process(parts)
+        for i, o in enumerate(oracles):
+            o8, _ = o.process(parts[i])
+            assert np.array_equal(g8[i], o8), (i, lo, hi)
+    g.close()
+
+
 def test_full_size_chunk_properties_131072():
     """BASELINE chunk size (config.conf:11 buffer_size 131072): spot-check channels against the oracle and check the
     size-independent property that splitting the stream differently gives the same symbols (sps < 8)."""
