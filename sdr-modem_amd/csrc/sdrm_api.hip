@@ -104,6 +104,7 @@ struct sdrm_batch_t {
     bool back_pending = false;               // the newest submitted call's copy-back is not enqueued yet
     uint64_t submitted = 0, collected = 0;
     uint64_t first_pipelined_call = 0;
+    uint64_t stamp_only_call = 0;  // diagnostics: 0 = every call writes the cycle stamps, else only that call
 };
 
 static int8_t *out8_of(const sdrm_batch_t *b, uint64_t call) { return (b->d_out8_b && (call & 1)) ? b->d_out8_b : b->d_out8; }
@@ -498,6 +499,9 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     const uint32_t max_tiles = sdrm::plan_call(b->plan, lens, h);
     sdrm_chunk_ctl *d_ctl = b->d_ctl + (size_t) slot * C;
     sdrm::DeviceBatch d = b->dev;
+    if (b->stamp_only_call != 0 && b->stamp_only_call != i + 1) {
+        d.k3_stamps = nullptr;
+    }
     bool with_nco = false;
     uint32_t nco_max_len = 0;
     if (segs != nullptr && n_segs > 0) {
@@ -1100,6 +1104,13 @@ extern "C" int sdrm_batch_k3_stamps(sdrm_batch *b, int enable, unsigned long lon
     }
     HIP_TRY(hipSetDevice(b->device));
     const size_t waves = (b->plan.params.size() + 63) / 64;
+    // enable == 1: every call from now on; enable = k > 1: only the k-th call from now (a call in the middle of a
+    // pipelined run can then be looked at)
+    if (enable > 1) {
+        b->stamp_only_call = b->calls + (uint64_t) enable;
+    } else if (enable == 1) {
+        b->stamp_only_call = 0;
+    }
     if (b->dev.k3_stamps == nullptr && enable) {
         HIP_TRY(hipMalloc((void **) &b->dev.k3_stamps, (waves * 4 + 24) * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(b->dev.k3_stamps, 0, (waves * 4 + 24) * sizeof(unsigned long long)));

@@ -774,6 +774,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     const uint32_t col_addr = (uint32_t) (uintptr_t) col_l;
     const uint32_t bank_addr = (uint32_t) (uintptr_t) (lds_cf) bank_rev;
     unsigned long long t_wait = 0, t_drain = 0, n_iter = 0;
+    const unsigned long long real0 = b.k3_stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz reference clock
     for (int k = 0; k <= nblocks; k++) {
         // k == nblocks: nothing new, only drains what the carried history alone allows (nz == 0 case)
         unsigned long long t0 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -811,7 +812,8 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     if (b.k3_stamps && lane == 0) {  // diagnostic only: cycles waiting for the producer vs in the symbol loops
         b.k3_stamps[blockIdx.x * 4 + 0] = t_wait;
         b.k3_stamps[blockIdx.x * 4 + 1] = t_drain;
-        b.k3_stamps[blockIdx.x * 4 + 2] = (unsigned long long) nblocks;
+        // steps in the low half, 100 MHz ticks of the whole loop in the high half (shader clock = cycles / time)
+        b.k3_stamps[blockIdx.x * 4 + 2] = (unsigned long long) nblocks | ((__builtin_amdgcn_s_memrealtime() - real0) << 32);
         b.k3_stamps[blockIdx.x * 4 + 3] = n_iter;
     }
 #undef K3_DRAIN

@@ -14,10 +14,17 @@ x = torch.from_numpy(np.tile(base, (Cn // D, 1)).view(np.float32)).cuda()
 b = binding.Batch([cfg] * Cn)
 L = binding.load()
 L.sdrm_batch_k3_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
-L.sdrm_batch_k3_stamps(b.h, 1, None, 0)
+NCALLS = int(os.environ.get("CALLS", "4"))  # CALLS=12 MID=8: look at the 8th of 12 back-to-back (overlapped) calls
+L.sdrm_batch_k3_stamps(b.h, int(os.environ.get("MID", "1")), None, 0)
 st = torch.cuda.current_stream().cuda_stream
-for i in range(4):
+for i in range(NCALLS):
     b.process_device(x.data_ptr() + (i % 2) * N * 8, 2 * N, [N] * Cn, st)
+if os.environ.get("LOAD"):  # keep the rest of the chip busy (fp32 GEMMs on a side stream) while the last call runs
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(int(os.environ["LOAD"])):
+            a = (a @ a) * 1e-4
 torch.cuda.synchronize()
 waves = (Cn + 63) // 64
 out = np.zeros(waves * 4 + 24, dtype=np.uint64)
@@ -29,8 +36,9 @@ if k1[4]:
     print("K1 per workgroup (cycles): load %.0f, lpf1 %.0f, quad %.0f, lpf2+store %.0f  (%d workgroups)" % (
         k1[0] / k1[4], k1[1] / k1[4], k1[2] / k1[4], k1[3] / k1[4], k1[4]))
 for w in range(min(waves, 2)):
-    stg, drn, nb, it = [int(v) for v in out[w]]
-    print("wave %d: wait-for-producer %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration" % (
-        w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1)))
+    stg, drn, packed, it = [int(v) for v in out[w]]
+    nb, ticks = packed & 0xffffffff, packed >> 32
+    print("wave %d: wait-for-producer %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration, "
+          "%.3f ms at %.0f MHz" % (w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1), ticks / 1e5, (stg + drn) / max(ticks, 1) * 100))
 if k2[9]:
     print("K2 channel 0: %d iterations, %.0f cycles each (the 63-step chain alone is 756)" % (k2[9], k2[8] / k2[9]))
