@@ -20,7 +20,7 @@
 #define SDRM_K1_THREADS 256
 #define SDRM_K1_R 15   // LPF1 outputs per thread (odd: lane stride 15*8 B is LDS-bank-conflict free)
 #define SDRM_K1_RZ 15  // LPF2 outputs per thread
-#define SDRM_K1_U 4    // taps per unrolled step
+#define SDRM_K1_U 6    // taps per unrolled step
 #define SDRM_K1_NY (SDRM_K1_THREADS * SDRM_K1_R)
 #define SDRM_K1_QPAD 16
 // bytes of the K1 tile area in LDS: raw IQ tile + halo, later reused by the demodulated samples with the tile's LPF2
