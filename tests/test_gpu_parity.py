@@ -252,6 +252,27 @@ def test_full_size_chunk_properties_131072():
     b.close()
 
 
+def test_reference_perf_configuration_maximum_buffer():
+    """test/perf_fsk_modem.c: fsk_demod_create(48000, 4800, 5000, 2, 2000, true, 2016000): one call with the whole
+    2 016 000-sample buffer (the largest buffer the reference allocates), then the perf loop's own 4096-sample calls of
+    `re = (uint8_t) i, im = 0` (perf_fsk_modem.c:81-83), all on one handle."""
+    cfg = (48000, 4800, 5000, 2, 2000, True)
+    big = 2016000
+    d = binding.FskDemod(*cfg, big)
+    o = orc.Fsk(*cfg, big)
+    assert d.code == 0 and o.code == 0
+    sig = siggen.gmsk_channel(11, big, fs=48000, baud=4800)
+    g8 = d.process(sig)
+    o8, _ = o.process(sig)
+    assert len(g8) == len(o8) and abs(len(g8) - big // 10) < 50
+    assert np.array_equal(g8, o8)
+    ramp = np.zeros(4096, dtype=np.complex64)
+    ramp.real = (np.arange(4096) % 256).astype(np.float32)
+    for _ in range(20):
+        assert np.array_equal(d.process(ramp), o.process(ramp)[0])
+    d.close()
+
+
 # ---------------------------------------------------------------- device-resident path + worker surface
 
 def test_device_resident_call_matches_host_call():
