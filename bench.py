@@ -229,6 +229,31 @@ def main():
                 "sample": "oracle (plain-C restatement of the reference path, gcc -O2 -ffp-contract=off), one "
                           "independent channel per thread on %d threads, %d-sample chunks of channel 0 looped for "
                           "%.1f s wall (%.0f Msamples total)" % (cores, N, secs, smp / 1e6)}
+        if world == 1 and not args.no_cpu_baseline:
+            # the reference's own perf harness (test/perf_fsk_modem.c:70-98): one handle, 100 calls of 4096 samples
+            # `re = (uint8_t) i, im = 0`, fsk_demod_create(48000, 4800, 5000, 2, 2000, true, 2016000); its published
+            # figures are seconds per 100 calls on one CPU core.  One channel is one
+            # sequential chain: this is a latency figure, not what the GPU path is built for.
+            ramp = np.zeros(4096, dtype=np.complex64)
+            ramp.real = (np.arange(4096) % 256).astype(np.float32)
+            d1 = binding.FskDemod(48000, 4800, 5000, 2, 2000, True, 2016000)
+            o1 = orc.Fsk(48000, 4800, 5000, 2, 2000, True, 2016000)
+            for _ in range(10):
+                d1.process(ramp)
+                o1.process(ramp)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                d1.process(ramp)
+            t_gpu = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for _ in range(100):
+                o1.process(ramp)
+            t_cpu = time.perf_counter() - t0
+            d1.close()
+            out["perf_fsk_modem_style"] = {"seconds_per_100x4096_gpu_one_handle": round(t_gpu, 5),
+                                           "seconds_per_100x4096_cpu_port_one_thread": round(t_cpu, 5),
+                                           "note": "reference publishes 0.0368 s (MacBook Air M1) and 0.656 s (Raspberry "
+                                                   "Pi 3) for this loop; includes the Python call overhead here"}
         if world == 1 and args.sweep:
             # the named workload (256 channels) is bounded by the sequential clock-recovery chain of 4 waves; show how
             # the same pipeline fills the GPU with more channels (short runs, 2 resident chunks)
