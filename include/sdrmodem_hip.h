@@ -4,10 +4,14 @@
  * Drop-in boundary for dernasherbrezon/sdr-modem's fsk_demod operator and the dsp_worker push/pull
  * surface around it.  Plain pointers and sizes only; no C++/torch types.
  *
- * Three layers, bottom-up:
- *   1. sdrm_batch_*      many independent RX channels demodulated per launch on one GPU (the new part);
+ * Layers, bottom-up:
+ *   1. sdrm_batch_*      many independent RX channels demodulated per launch on one GPU (the new part): blocking
+ *                        host-buffer call, device-resident call, and the pipelined host path (arena/submit/collect);
  *   2. fsk_demod_*       the reference operator, same names/signature/semantics (a batch of one);
- *   3. create_queue/...  and sdrm_worker_*: the reference's queue + dsp_worker surface, feeding (2).
+ *   3. sdrm_batcher_*    the queue + worker surface of many clients in front of ONE batch (one device call per round);
+ *   4. create_queue/...  and dsp_worker_*: the reference's queue + dsp_worker surface, feeding (2) or (3);
+ *      sdrm_doppler_*    the reference's Doppler batching (per-second shifts from the caller's orbit model) for the
+ *                        device-side NCO in front of the demodulator.
  *
  * Every entry point fails loudly (non-zero return / abort message on stderr with the "<3>" systemd
  * prefix the reference uses) when no HIP device is usable: there is NO CPU fallback in this library.
