@@ -208,6 +208,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": C * N * 8,
+                         # SURVEY 8d also defines the fused-pipeline figure: 8 B in + baud/fs B out per sample at the
+                         # whole-path rate.  It is far below the front-end's because the step time is the clock
+                         # recovery chain (latency-bound, 4 waves), not a memory stream.
+                         "whole_path_hbm_frac": round(msps * 1e6 / world * (8.0 + BAUD / FS / DECIM) / 1e9 / HBM_PEAK_GBS, 5),
                          "valu_exact_ceiling_frac": round(35.9e12 / 291.0 * 8.0 / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "8 B of IQ read per input sample (SURVEY 8d LPF-stage HBM-read term). The kernel is "
                                  "fp32-VALU-bound: bit-exact parity needs a separately rounded multiply and add per tap "
