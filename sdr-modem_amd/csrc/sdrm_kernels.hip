@@ -170,12 +170,20 @@ __global__ __launch_bounds__(256) void k1_hist_roll(DeviceBatch b, const sdrm_f2
     sdrm_hist_roll((int) threadIdx.x, (int) blockDim.x, p, ctl, in, cur, next);
 }
 
-// dynamic LDS above the 64 KiB default has to be requested per kernel (up to the CU's 160 KiB)
+// dynamic LDS above the 64 KiB default has to be requested per kernel (up to the CU's 160 KiB); the attribute belongs
+// to the kernel's code object on ONE device, so what has been granted is remembered per device (a process that drives
+// several GPUs gets it right for each)
+struct lds_grant {
+    size_t bytes[16] = {};
+};
 template <typename K>
-static void allow_lds(K kernel, size_t bytes, size_t *granted) {
-    if (bytes > 64 * 1024 && bytes > *granted) {
+static void allow_lds(K kernel, size_t bytes, lds_grant *granted) {
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    size_t &have = granted->bytes[dev & 15];
+    if (bytes > 64 * 1024 && bytes > have) {
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
-        *granted = bytes;
+        have = bytes;
     }
 }
 
@@ -183,7 +191,7 @@ void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, h
     if (b.max_tiles == 0) {
         return;
     }
-    static size_t granted = 0;
+    static lds_grant granted;
     const size_t lds = k1_lds_bytes(b.t1_max, b.t2_max);
     allow_lds(k1_front, lds, &granted);
     dim3 grid(b.max_tiles, (unsigned) b.n_channels);
@@ -445,7 +453,7 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
         return;
     }
     size_t lds = k2_lds_bytes(b.rx_cap, b.rs_cap);
-    static size_t granted0 = 0, granted1 = 0;
+    static lds_grant granted0, granted1;
     allow_lds(k2_dc<0>, lds, &granted0);
     allow_lds(k2_dc<1>, lds, &granted1);
     if (g_scan_mode == 0) {
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 
 void launch_clock(const DeviceBatch &b, hipStream_t s) {
     unsigned blocks = (unsigned) ((b.n_channels + SDRM_K3_LANES - 1) / SDRM_K3_LANES);
-    static size_t granted_t = 0, granted_f = 0;
+    static lds_grant granted_t, granted_f;
     const size_t lds = k3_lds_bytes();
     if (b.out_f32) {
         allow_lds(k3_clock<true>, lds, &granted_t);
