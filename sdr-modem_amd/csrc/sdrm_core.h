@@ -170,6 +170,16 @@ SDRM_HD float sdrm_nco_advance(float phase, float step) {
     return phase;
 }
 
+// The same step without branches, for |phase| <= 2 pi and |step| <= 2 pi (what the accumulator's own wrap maintains):
+// the sum can only leave the interval on the side the step points to, so one magnitude test and one subtraction of
+// w = copysign(2 pi, step) do the work of the two tests above (x + 2 pi and x - (-2 pi) are the same operation).
+SDRM_HD float sdrm_nco_advance_signed(float phase, float step, float w) {
+    const float two_pi = 6.28318530717958647692f;
+    const float q = phase + step;
+    const float t = q - w;
+    return (fabsf(q) > two_pi) ? t : q;
+}
+
 // input sample times oscillator sample: C complex multiply as VOLK generic volk_32fc_x2_multiply_32fc (sig_source.c:71)
 SDRM_HD sdrm_f2 sdrm_nco_mix(sdrm_f2 in, sdrm_f2 osc) {
     sdrm_f2 o;

@@ -31,6 +31,24 @@ __global__ __launch_bounds__(64) void k0_nco_phase(DeviceBatch b) {
             phase = sdrm_nco_advance(phase, step);
             left--;
         }
+        const float two_pi = 6.28318530717958647692f;
+        if (fabsf(step) <= two_pi && fabsf(phase) <= two_pi) {
+            // the usual case: branch-free step, four dependent instructions per sample instead of two divergent tests
+            const float w = copysignf(two_pi, step);
+            for (; left >= 4; left -= 4) {
+                float4 v;
+                v.x = phase;
+                phase = sdrm_nco_advance_signed(phase, step, w);
+                v.y = phase;
+                phase = sdrm_nco_advance_signed(phase, step, w);
+                v.z = phase;
+                phase = sdrm_nco_advance_signed(phase, step, w);
+                v.w = phase;
+                phase = sdrm_nco_advance_signed(phase, step, w);
+                *reinterpret_cast<float4 *>(out + n) = v;
+                n += 4;
+            }
+        }
         for (; left >= 4; left -= 4) {
             float4 v;
             v.x = phase;
