@@ -36,3 +36,26 @@ def fanout_configs(cfgs_rank0, total, device="cpu"):
         dist.broadcast(table, src=0)
     lo, hi = shard_range(total, world, rank)
     return decode(table[lo:hi].cpu()), lo, hi
+
+
+def fanout_nco_segments(segments_rank0, total, device="cpu"):
+    """Doppler pre-correction at node scale: rank 0 runs the orbit model and the planner for every channel
+    of the node and holds the call's NCO batches as (global_channel, len, freq_hz), grouped by channel; one broadcast
+    (a count, then an int64 table -- RCCL on GPUs, KB-sized) gives every rank the batches of its own channels, with
+    the channel index rebased to the rank's shard.  Returns this rank's list of (local_channel, len, freq_hz)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    count = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == 0:
+        count[0] = len(segments_rank0)
+    if world > 1:
+        dist.broadcast(count, src=0)
+    n = int(count.item())
+    table = torch.zeros((max(n, 1), 3), dtype=torch.int64, device=device)
+    if rank == 0 and n:
+        table[:n].copy_(torch.tensor([[int(c), int(ln), int(f)] for c, ln, f in segments_rank0], dtype=torch.int64))
+    if world > 1:
+        dist.broadcast(table, src=0)
+    lo, hi = shard_range(total, world, rank)
+    rows = table[:n].cpu().tolist()
+    return [(int(c) - lo, int(ln), int(f)) for c, ln, f in rows if lo <= c < hi]

@@ -36,6 +36,26 @@ def _worker(rank, world, port, ret):
     for i, c in enumerate(cfgs):
         want8, _ = orc.demod_stream(c[:6], sigs[i], 4096)
         ok = ok and np.array_equal(want8, got8[i])
+    # Doppler batches for one call, planned on rank 0 for the whole node, fanned out and applied per shard
+    n = 4096
+    segs0 = None
+    if rank == 0:
+        segs0 = []
+        for c in range(total):
+            if c % 2 == 0:  # every other channel is corrected, in two batches
+                segs0 += [(c, 1000, 1500 - 100 * c), (c, n - 1000, 1490 - 100 * c)]
+    mine = shard.fanout_nco_segments(segs0, total)
+    ok = ok and all(0 <= ch < hi - lo for ch, _, _ in mine)
+    ok = ok and sorted(set(ch + lo for ch, _, _ in mine)) == [c for c in range(lo, hi) if c % 2 == 0]
+    e2 = emu_api.EmuBatch(cfgs)
+    got8, _ = e2.process(sigs, segments=mine)
+    for i, c in enumerate(cfgs):
+        x = sigs[i].view(np.float32)
+        if (lo + i) % 2 == 0:
+            osc = orc.Nco(1.0, c[0], n)
+            x = np.concatenate([osc.multiply(1500 - 100 * (lo + i), x[:2000]), osc.multiply(1490 - 100 * (lo + i), x[2000:])])
+        want8, _ = orc.demod_stream(c[:6], x.view(np.complex64), n)
+        ok = ok and np.array_equal(want8, got8[i])
     # every rank reports its range; rank 0 checks the shards tile [0, total)
     ranges = [None] * world
     dist.all_gather_object(ranges, (lo, hi, bool(ok)))
