@@ -245,14 +245,16 @@ def main():
             for _ in range(10):
                 d1.process(ramp)
                 o1.process(ramp)
-            t0 = time.perf_counter()
-            for _ in range(100):
-                d1.process(ramp)
-            t_gpu = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            for _ in range(100):
-                o1.process(ramp)
-            t_cpu = time.perf_counter() - t0
+            t_gpu = t_cpu = 1e9
+            for _ in range(3):  # best of three: the host cores have just run the multi-thread baseline
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    d1.process(ramp)
+                t_gpu = min(t_gpu, time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    o1.process(ramp)
+                t_cpu = min(t_cpu, time.perf_counter() - t0)
             d1.close()
             out["perf_fsk_modem_style"] = {"seconds_per_100x4096_gpu_one_handle": round(t_gpu, 5),
                                            "seconds_per_100x4096_cpu_port_one_thread": round(t_cpu, 5),
