@@ -105,6 +105,8 @@ struct sdrm_batch_t {
     uint64_t submitted = 0, collected = 0;
     uint64_t first_pipelined_call = 0;
     uint64_t stamp_only_call = 0;  // diagnostics: 0 = every call writes the cycle stamps, else only that call
+    unsigned long long *d_timeline = nullptr;  // diagnostics: see sdrm_batch_timeline
+    uint64_t timeline_first_call = 0;
 };
 
 static int8_t *out8_of(const sdrm_batch_t *b, uint64_t call) { return (b->d_out8_b && (call & 1)) ? b->d_out8_b : b->d_out8; }
@@ -188,6 +190,9 @@ static void batch_free(sdrm_batch_t *b) {
     }
     if (b->d_outlen_b) {
         (void) hipFree(b->d_outlen_b);
+    }
+    if (b->d_timeline) {
+        (void) hipFree(b->d_timeline);
     }
     void *dev_ptrs[] = {b->d_params, b->d_ctl, b->d_taps, b->d_atan, b->d_bank, b->d_hist, b->d_z, b->d_dcout,
                         b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in, b->d_flags, b->d_z2, b->d_dcout2,
@@ -502,6 +507,8 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     if (b->stamp_only_call != 0 && b->stamp_only_call != i + 1) {
         d.k3_stamps = nullptr;
     }
+    d.timeline = (b->d_timeline != nullptr && i - b->timeline_first_call < 64) ? b->d_timeline : nullptr;
+    d.tl_row = (uint32_t) (i - b->timeline_first_call);
     bool with_nco = false;
     uint32_t nco_max_len = 0;
     if (segs != nullptr && n_segs > 0) {
@@ -1121,6 +1128,35 @@ extern "C" int sdrm_batch_k3_stamps(sdrm_batch *b, int enable, unsigned long lon
                           hipMemcpyDeviceToHost));
     }
     return (int) waves;
+}
+
+// diagnostics: when and for how long each kernel of the next (up to 64) calls really runs on the device, whatever
+// the streams and the dispatcher make of the dependencies.  enable != 0 attaches a fresh table; `out` (may be NULL)
+// receives rows of {front start, front end, dc start, dc end, clock start, clock end} in 10 ns ticks of the device's
+// reference clock for the calls made since the table was attached.  Returns the number of rows written.
+extern "C" int sdrm_batch_timeline(sdrm_batch *b, int enable, unsigned long long *out, size_t max_rows) {
+    if (b == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    int rows = 0;
+    if (out != nullptr && b->d_timeline != nullptr) {
+        rows = (int) std::min<uint64_t>(std::min<uint64_t>(b->calls - b->timeline_first_call, 64), max_rows);
+        HIP_TRY(hipMemcpy(out, b->d_timeline, (size_t) rows * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (enable) {
+        if (b->d_timeline == nullptr) {
+            HIP_TRY(hipMalloc((void **) &b->d_timeline, 64 * 6 * sizeof(unsigned long long)));
+        }
+        std::vector<unsigned long long> init(64 * 6);
+        for (size_t k = 0; k < init.size(); k++) {
+            init[k] = (k & 1) ? 0ull : ~0ull;  // starts take the minimum, ends the maximum
+        }
+        HIP_TRY(hipMemcpy(b->d_timeline, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        b->timeline_first_call = b->calls;
+    }
+    return rows;
 }
 
 // selects the in-order scan flavour (0 = wave_shr DPP, 1 = row_shr DPP + readlane) for the probe and the DC kernel

@@ -5,6 +5,20 @@
 
 namespace sdrm {
 
+// diagnostics: when a timeline buffer is attached every workgroup records when it started and ended (first start / last
+// end per kernel and call survive), in ticks of the 100 MHz reference clock
+__device__ __forceinline__ void tl_mark(const DeviceBatch &b, int kernel, int end) {
+    if (b.timeline != nullptr && threadIdx.x == 0) {
+        unsigned long long *slot = b.timeline + ((size_t) b.tl_row * 3 + kernel) * 2 + end;
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (end) {
+            atomicMax(slot, t);
+        } else {
+            atomicMin(slot, t);
+        }
+    }
+}
+
 // ================================================================================================ K0 (NCO, row f-1)
 
 // Phase accumulator, one lane per channel: the fp32 recursion phase += step with its wrap is sequential
@@ -118,6 +132,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, co
     if (blockIdx.x >= ctl.tiles) {
         return;
     }
+    tl_mark(b, 0, 0);
     const sdrm_chan_params p = b.params[c];
     sdrm_f2 *xs = reinterpret_cast<sdrm_f2 *>(k1_lds);
     float *qs = reinterpret_cast<float *>(xs);  // aliases the raw tile: written only after every LPF1 read (barrier)
@@ -167,6 +182,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, co
     sdrm_k1_phase_lpf2(tid, t, p, taps2, qs, zs, b.nonfinite + c);
     __syncthreads();
     sdrm_k1_phase_store(tid, t, zs, b.z + (size_t) c * b.z_stride);
+    tl_mark(b, 0, 1);
     if (stamp && tid == 0) {
         unsigned long long t4 = __builtin_amdgcn_s_memtime();
         unsigned long long *k1s = b.k3_stamps + ((b.n_channels + 63) / 64) * 4;  // after the K3 per-wave records
@@ -396,6 +412,7 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     if (p.dc_len == 0) {
         return;
     }
+    tl_mark(b, 1, 0);
     const sdrm_chunk_ctl ctl = b.ctl[c];
     const int lane = threadIdx.x & 63;
     const int stage = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -462,6 +479,7 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     if (lane == 0) {
         st_acc[stage] = acc;
     }
+    tl_mark(b, 1, 1);
 }
 
 static int g_scan_mode = 0;
@@ -623,6 +641,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     float *ring = bank_rev + ((129 * SDRM_K3_BANKPITCH + 3) & ~3);  // [LANES][CPITCH]
     int *nz_sh = reinterpret_cast<int *>(ring + SDRM_K3_LANES * SDRM_K3_CPITCH);  // [64] samples per channel
     int *dc_sh = nz_sh + SDRM_K3_LANES;                                          // [64] reads dcout (1) or z (0)
+    tl_mark(b, 2, 0);
     const int lane = threadIdx.x & 63;
     const bool producer = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) != 0;
     const int c0 = blockIdx.x * SDRM_K3_LANES;
@@ -857,6 +876,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
         b.out_len[c] = L.oo;
     }
+    tl_mark(b, 2, 1);
 }
 
 void launch_clock(const DeviceBatch &b, hipStream_t s) {

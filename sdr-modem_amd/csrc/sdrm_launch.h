@@ -30,6 +30,8 @@ struct DeviceBatch {
     uint32_t *out_len;               // [C]
     uint32_t *nonfinite;             // [C] of the call's control slot: set by K1/K2 when NaN/Inf reaches the clock stage
     uint32_t out_stride;
+    unsigned long long *timeline;    // diagnostics (normally null): [64 calls][front, dc, clock][first start, last end], 100 MHz ticks
+    uint32_t tl_row;
     unsigned long long *k3_stamps;   // diagnostics (normally null): per K3 wave {staging cycles, loop cycles, steps, iterations}
     // NCO pre-mix (optional): per-call segment table, per-channel fp32 phase, phase scratch and mixed-IQ buffer
     const sdrm_nco_seg *nco_segs;
