@@ -580,6 +580,9 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         if (have_prev2) {
             HIP_TRY(hipStreamWaitEvent(b->s_dc, b->slot_done[prev2], 0));
         }
+        if (!b->serial && have_prev2) {
+            sdrm::launch_dc_hold(d, b->s_dc);  // many channels: the clock stage released by the same event takes its CUs first
+        }
         if (b->timing) {
             timing_begin(b, 1, b->s_dc, &ev);
         }

@@ -271,7 +271,33 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap) { return ((size_t) rx_cap + 3 * (size_t) rs_cap) * sizeof(float); }
+// With several hundred channels a CU carries several DC workgroups, i.e. several chain waves per SIMD whose
+// 4-in-12-cycle adds add up to a busy vector unit, and a symbol loop of the clock stage sharing such a SIMD runs ~1.4x
+// slower (5.4 instead of 4.4 ms per chunk at 1024 channels).  From 384 channels on the DC kernel therefore asks for at
+// least 20 KB of LDS per workgroup: a clock-recovery workgroup holds 141 KB of a CU's 160 KB, so the two can then never
+// share a CU.  (With one DC workgroup per CU the sharing costs ~1 % and the exclusion is not worth its risk, below.)
+bool k2_keeps_off_clock_cus(int n_channels) { return n_channels >= 384; }
+
+size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap, int n_channels) {
+    const size_t need = ((size_t) rx_cap + 3 * (size_t) rs_cap) * sizeof(float);
+    const size_t floor_bytes = k2_keeps_off_clock_cus(n_channels) ? 20 * 1024 : 0;
+    return need < floor_bytes ? floor_bytes : need;
+}
+
+// The exclusion only helps if the clock stage of call k gets its CUs BEFORE the DC workgroups of call k+1 spread over
+// the chip -- both are released by the same event (the clock stage of call k-1 finishing) and the DC kernel is
+// dispatched ~25 us earlier; when it wins, the clock stage waits for DC workgroups to finish (+1 ms).  This one-wave
+// kernel sits in the DC stream in front of the DC kernel and sleeps ~100 us (of the 2 ms of slack that stage has).
+__global__ void k2_hold(int loops) {
+    for (int i = 0; i < loops; i++) {
+        __builtin_amdgcn_s_sleep(127);
+    }
+}
+void launch_dc_hold(const DeviceBatch &b, hipStream_t s) {
+    if (b.any_dc && k2_keeps_off_clock_cus(b.n_channels)) {
+        hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 30);
+    }
+}
 
 // What one stage wave of the DC blocker does, specialised per stage so that the loop over full 64-sample blocks carries
 // no stage or validity tests (a lone wave pays ~4 cycles per scalar instruction and ~25 per taken branch; the
@@ -488,7 +514,7 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
     if (!b.any_dc) {
         return;
     }
-    size_t lds = k2_lds_bytes(b.rx_cap, b.rs_cap);
+    size_t lds = k2_lds_bytes(b.rx_cap, b.rs_cap, b.n_channels);
     static lds_grant granted0, granted1;
     allow_lds(k2_dc<0>, lds, &granted0);
     allow_lds(k2_dc<1>, lds, &granted1);

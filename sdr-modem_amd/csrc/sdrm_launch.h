@@ -47,7 +47,8 @@ struct DeviceBatch {
 };
 
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
-size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap);
+void launch_dc_hold(const DeviceBatch &b, hipStream_t s);
+size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap, int n_channels);
 
 void launch_nco(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);
 void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
