@@ -530,13 +530,15 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // One lane per channel, 64 channels per CONSUMER wave (reference src/dsp/clock_recovery_mm.c:78-139 per lane); a second
 // PRODUCER wave of the same workgroup stages the samples, so the two overlap.
 // Producer: per step, SDRM_K3_BLOCK (= 64, one per lane) samples of each of the 64 channels go from global memory
-// (coalesced row reads, lane = time, prefetched one step ahead into registers) into per-channel LDS rings
-// (ring[channel][slot], channel pitch 267 floats: the producer's lane = time writes are contiguous, the consumer's
-// lane = channel reads spread over the banks).  A ring holds 4 steps; mirror slots at both ends keep every window
-// contiguous.  Consumer: each lane runs its own loop while staged samples last (lanes drop out of the exec mask as
-// they run out); a symbol's 8 window samples are one base address plus constant offsets, and the next symbol's
-// operands are fetched before the current symbol is quantised and stored.  The short FINITE form of the loop body is used unless a producer kernel flagged NaN/Inf in
-// one of this workgroup's channels.  One barrier per step hands block k to the consumer while block k+1 is written.
+// (coalesced row reads, lane = time, prefetched one step ahead into registers) into per-channel LDS rings of pair
+// elements {x[e], x[e+1]} (sdrm_kernels.h; channel pitch 534 floats: the producer's lane = time writes walk through a
+// ring, the consumer's lane = channel reads spread over the banks).  A ring holds 4 steps; mirror elements at both ends
+// keep every window contiguous.  Consumer: each lane runs its own loop while staged samples last (lanes drop out of the
+// exec mask as they run out); a symbol's 8 window samples are one base address plus constant offsets, and the next
+// symbol's operands are fetched before the current symbol is quantised and stored.  Without NaN/Inf in the wave's
+// channels the int8-only build runs the hand-scheduled loop below (k3_drain_finite), otherwise and for the
+// float-soft-bit build the C++ form of the same arithmetic.  One barrier per step hands block k to the consumer while
+// block k+1 is written.
 size_t k3_lds_bytes() { return (size_t) (SDRM_K3_LANES * SDRM_K3_CPITCH + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_LANES) * sizeof(float); }
 
 // Order of work inside a symbol:
