@@ -119,6 +119,13 @@ int sdrm_batch_process_nco(sdrm_batch *batch, const sdrm_cf32 *const *inputs, co
                            const sdrm_nco_segment *segments, size_t n_segments, int8_t **outputs, size_t *output_lens);
 int sdrm_batch_process_device_nco(sdrm_batch *batch, const void *d_input, size_t in_stride, const size_t *input_lens,
                                   const sdrm_nco_segment *segments, size_t n_segments, void *stream);
+/* A channel of a batch can be handed to a new stream (a client disconnects, another connects): its streaming state is
+ * cleared and, with config != NULL, its configuration replaced -- what fsk_demod_destroy + fsk_demod_create do for a
+ * single handle.  The batch keeps the geometry it was created with: the new configuration's filters, DC length and
+ * buffer size must not exceed the largest the batch was created for (-ENOTSUP), and a DC blocker needs a batch created
+ * with at least one DC-blocked channel.  Waits for all enqueued calls first. */
+int sdrm_batch_reset_channel(sdrm_batch *batch, size_t channel, const sdrm_fsk_config *config);
+
 /* Pipelined host-buffer path.  The reference's boundary hands over HOST buffers (src/dsp/fsk_demod.h:13, filled by
  * queue_put's memcpy, src/queue.c:99-154), so at batch scale the host link decides the rate.  sdrm_batch_arena pins
  * `slots` (>= 2) input slots of [channels][*chan_stride] complex samples each (slot s starts at base + s * *slot_stride)
@@ -186,6 +193,10 @@ void sdrm_batcher_put(sdrm_batcher *batcher, size_t channel, const sdrm_cf32 *bu
 void sdrm_batcher_take(sdrm_batcher *batcher, size_t channel, int8_t **output, size_t *output_len);
 void sdrm_batcher_complete(sdrm_batcher *batcher, size_t channel);
 void sdrm_batcher_interrupt(sdrm_batcher *batcher, size_t channel);
+/* A channel changes hands (one client leaves, another arrives): waits until everything put on the channel has been
+ * consumed, lets the rounds in flight finish, then resets the channel as sdrm_batch_reset_channel does (config NULL =
+ * same configuration) and reopens it if it had been interrupted.  Other channels keep their streams. */
+int sdrm_batcher_reset_channel(sdrm_batcher *batcher, size_t channel, const sdrm_fsk_config *config);
 /* Doppler pre-correction for one channel: `planner` (borrowed, see sdrm_doppler_create) is asked for the segments of
  * every buffer of that channel when its round is launched; NULL switches it off */
 int sdrm_batcher_set_doppler(sdrm_batcher *batcher, size_t channel, sdrm_doppler *planner);

@@ -53,9 +53,9 @@ EXPORTS = [
     "sdrm_batch_process", "sdrm_batch_process_device", "sdrm_batch_device_outputs", "sdrm_batch_last_soft",
     "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
     "sdrm_batch_process_nco", "sdrm_batch_process_device_nco", "sdrm_batch_last_mixed",
-    "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect",
+    "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect", "sdrm_batch_reset_channel",
     "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt",
-    "sdrm_batcher_set_doppler", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
+    "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_wave_scan", "sdrm_set_scan_mode", "sdrm_version", "sdrm_device_count",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
@@ -79,6 +79,7 @@ def bind_batcher(L):
     L.sdrm_batcher_complete.restype = None
     L.sdrm_batcher_interrupt.argtypes = [vp, C.c_size_t]
     L.sdrm_batcher_interrupt.restype = None
+    L.sdrm_batcher_reset_channel.argtypes = [vp, C.c_size_t, C.POINTER(FskConfig)]
     L.sdrm_batcher_channels.argtypes = [vp]
     L.sdrm_batcher_channels.restype = C.c_size_t
     L.sdrm_batcher_rounds.argtypes = [vp]
@@ -127,6 +128,7 @@ def load():
     bind_batcher(L)
     L.sdrm_batcher_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.c_int, C.POINTER(BatcherConfig), C.POINTER(vp)]
     L.sdrm_batcher_set_doppler.argtypes = [vp, C.c_size_t, vp]
+    L.sdrm_batch_reset_channel.argtypes = [vp, C.c_size_t, C.POINTER(FskConfig)]
     L.sdrm_batch_arena.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.sdrm_batch_submit.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t]
     L.sdrm_batch_collect.argtypes = [vp, C.POINTER(i8p), C.POINTER(C.c_size_t)]
@@ -248,6 +250,11 @@ class Batch:
             raise RuntimeError("sdrm_batch_process_nco failed: %d" % code)
         return [np.ctypeslib.as_array(outs[c], shape=(olens[c],)).copy() if olens[c] else np.zeros(0, np.int8)
                 for c in range(self.n)]
+
+    def reset_channel(self, c, cfg=None):
+        """hand channel c to a new stream; cfg = 7-tuple for a new configuration, None to keep the current one"""
+        arr = make_configs([cfg]) if cfg is not None else None
+        return self.L.sdrm_batch_reset_channel(self.h, c, arr)
 
     def arena(self, slots=3):
         """Pinned input arena of the pipelined host path: float32 view [slots][C][2*chan_stride] (interleaved I,Q)."""
@@ -378,6 +385,10 @@ class Batcher:
 
     def rounds(self):
         return int(self.L.sdrm_batcher_rounds(self.h))
+
+    def reset_channel(self, channel, cfg=None):
+        arr = make_configs([cfg]) if cfg is not None else None
+        return self.L.sdrm_batcher_reset_channel(self.h, channel, arr)
 
     def set_doppler(self, channel, planner):
         return self.L.sdrm_batcher_set_doppler(self.h, channel, planner.h if planner is not None else None)

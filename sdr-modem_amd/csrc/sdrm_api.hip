@@ -275,7 +275,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     const uint32_t hist_stride = pl.hist_stride, z_stride = pl.z_stride, out_stride = pl.out_stride;
     code = code ? code : dev_alloc_zero(&b->d_params, C);
     code = code ? code : dev_alloc_zero(&b->d_ctl, C * SDRM_CTL_SLOTS);
-    code = code ? code : dev_alloc_zero(&b->d_taps, pool.size() + 16);
+    code = code ? code : dev_alloc_zero(&b->d_taps, pl.private_taps_base + C * pl.private_taps_slot + 16);
     code = code ? code : dev_alloc_zero(&b->d_atan, 260);
     code = code ? code : dev_alloc_zero(&b->d_bank, 129 * 8);
     code = code ? code : dev_alloc_zero(&b->d_hist, C * 2 * (size_t) hist_stride);
@@ -393,6 +393,48 @@ extern "C" int sdrm_batch_info(const sdrm_batch *b, size_t c, sdrm_fsk_info *inf
     info->gain_omega = d.gain_omega;
     info->gain_mu = d.gain_mu;
     info->omega_lim = d.omega_lim;
+    return 0;
+}
+
+// Hand channel `c` to a new stream: zero its streaming state (filter histories, DC blocker, timing loop, NCO phase)
+// and, with `cfg` != NULL, give it a new configuration.  The batch's geometry stays what it was created with, so the
+// new filters, DC length and buffer size must not exceed the batch's largest (-ENOTSUP).  Waits for enqueued calls.
+extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_config *cfg) {
+    if (b == nullptr || c >= b->plan.design.size()) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    sdrm::BatchPlan &pl = b->plan;
+    const sdrm_fsk_config use = cfg ? *cfg : pl.design[c].cfg;
+    std::vector<float> slot;
+    int code = sdrm::replan_channel(pl, c, use, slot);
+    if (code != 0) {
+        return code;
+    }
+    const sdrm_chan_params &p = pl.params[c];
+    HIP_TRY(hipMemcpy(b->d_taps + p.taps1_off, slot.data(), sizeof(float) * slot.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_params + c, &p, sizeof(p), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(b->d_hist + c * 2 * (size_t) pl.hist_stride, 0, sizeof(sdrm_f2) * 2 * (size_t) pl.hist_stride));
+    if (b->d_dcstate != nullptr && pl.dc_region_floats) {
+        HIP_TRY(hipMemset(b->d_dcstate + c * pl.dc_region_floats, 0, sizeof(float) * pl.dc_region_floats));
+    }
+    sdrm_clock_state cs;
+    memset(&cs, 0, sizeof(cs));
+    cs.mu = 0.5f;
+    cs.omega = pl.design[c].sps;
+    HIP_TRY(hipMemcpy(b->d_clock + c, &cs, sizeof(cs), hipMemcpyHostToDevice));
+    for (int s = 0; s < SDRM_CTL_SLOTS; s++) {
+        HIP_TRY(hipMemset(b->d_flags + (size_t) s * pl.design.size() + c, 0, sizeof(uint32_t)));
+    }
+    if (b->d_nco_state != nullptr) {
+        HIP_TRY(hipMemset(b->d_nco_state + c, 0, sizeof(float)));
+    }
+    b->any_nodc = false;
+    for (const sdrm_chan_params &q : pl.params) {
+        b->any_nodc = b->any_nodc || q.dc_len == 0;
+    }
+    b->last_lens[c] = 0;
     return 0;
 }
 

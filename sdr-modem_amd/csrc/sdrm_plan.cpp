@@ -19,6 +19,48 @@ static uint32_t pow2_at_least(uint32_t v) {
     return p;
 }
 
+// everything of a channel's device parameters that follows from its design alone (no offsets into shared storage)
+static int params_from_design(const ChannelDesign &d, sdrm_chan_params &p, uint32_t *rx, uint32_t *rs) {
+    memset(&p, 0, sizeof(p));
+    p.T1 = (uint32_t) d.taps1.size();
+    p.T2 = (uint32_t) d.taps2.size();
+    p.decim = d.cfg.decimation;
+    p.dc_len = d.dc_length;
+    p.hist_len = p.T1 + p.T2 - 1;
+    if (p.T2 + 2 > (uint32_t) SDRM_K1_NY) {
+        fprintf(stderr, "<3>low-pass filter of %u taps does not fit a tile\n", p.T2);
+        return -ENOTSUP;
+    }
+    // a tile computes SDRM_K1_NY LPF1 positions: (m-1)*d + T2 + 1 of them are needed for m outputs
+    uint32_t by_halo = (uint32_t) ((SDRM_K1_NY - 1 - (int) p.T2) / (int) p.decim + 1);
+    p.tile_m = std::min<uint32_t>((uint32_t) (SDRM_K1_THREADS * SDRM_K1_RZ), by_halo);
+    p.max_len = d.cfg.max_input_buffer_length;
+    p.quad_gain = d.quad_gain;
+    p.omega_mid = d.sps;
+    p.omega_lim = d.omega_lim;
+    p.gain_omega = d.gain_omega;
+    p.gain_mu = d.gain_mu;
+    *rx = *rs = 0;
+    if (p.dc_len) {
+        p.dc_len_f = (float) p.dc_len;
+        // The four stage waves of K2 run three 64-sample blocks apart and prefetch one block ahead: a stage ring
+        // covers its delay plus the blocks between its writer and its reader; the input ring is also fed up to 8
+        // blocks ahead of the first stage and read 2(L-1) behind the last one.
+        *rs = pow2_at_least(p.dc_len + 4 * 64);
+        *rx = pow2_at_least(2 * (p.dc_len - 1) + 17 * 64);
+        p.rs_mask = *rs - 1;
+        p.rx_mask = *rx - 1;
+    }
+    return 0;
+}
+
+static void append_taps(std::vector<float> &pool, const std::vector<float> &taps) {
+    pool.insert(pool.end(), taps.rbegin(), taps.rend());  // reversed: fir_filter.c:25-28
+    while (pool.size() % 8) {
+        pool.push_back(0.0f);
+    }
+}
+
 int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
     plan.design.resize(n);
     for (size_t c = 0; c < n; c++) {
@@ -36,11 +78,11 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
     for (size_t c = 0; c < n; c++) {
         const ChannelDesign &d = plan.design[c];
         sdrm_chan_params &p = plan.params[c];
-        memset(&p, 0, sizeof(p));
-        p.T1 = (uint32_t) d.taps1.size();
-        p.T2 = (uint32_t) d.taps2.size();
-        p.decim = d.cfg.decimation;
-        p.dc_len = d.dc_length;
+        uint32_t rx = 0, rs = 0;
+        int code = params_from_design(d, p, &rx, &rs);
+        if (code != 0) {
+            return code;
+        }
         // channels with the same filters share one copy of the taps (batches are mostly a few distinct configs)
         bool shared = false;
         const size_t probes[2] = {last_distinct, c ? c - 1 : 0};
@@ -55,41 +97,12 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
         if (!shared) {
             last_distinct = c;
             p.taps1_off = (uint32_t) plan.tap_pool.size();
-            plan.tap_pool.insert(plan.tap_pool.end(), d.taps1.rbegin(), d.taps1.rend());  // reversed: fir_filter.c:25-28
-            while (plan.tap_pool.size() % 8) {
-                plan.tap_pool.push_back(0.0f);
-            }
+            append_taps(plan.tap_pool, d.taps1);
             p.taps2_off = (uint32_t) plan.tap_pool.size();
-            plan.tap_pool.insert(plan.tap_pool.end(), d.taps2.rbegin(), d.taps2.rend());
-            while (plan.tap_pool.size() % 8) {
-                plan.tap_pool.push_back(0.0f);
-            }
+            append_taps(plan.tap_pool, d.taps2);
         }
-        p.hist_len = p.T1 + p.T2 - 1;
-        if (p.T2 + 2 > (uint32_t) SDRM_K1_NY) {
-            fprintf(stderr, "<3>low-pass filter of %u taps does not fit a tile\n", p.T2);
-            return -ENOTSUP;
-        }
-        // a tile computes SDRM_K1_NY LPF1 positions: (m-1)*d + T2 + 1 of them are needed for m outputs
-        uint32_t by_halo = (uint32_t) ((SDRM_K1_NY - 1 - (int) p.T2) / (int) p.decim + 1);
-        p.tile_m = std::min<uint32_t>((uint32_t) (SDRM_K1_THREADS * SDRM_K1_RZ), by_halo);
-        p.max_len = d.cfg.max_input_buffer_length;
-        p.quad_gain = d.quad_gain;
-        p.omega_mid = d.sps;
-        p.omega_lim = d.omega_lim;
-        p.gain_omega = d.gain_omega;
-        p.gain_mu = d.gain_mu;
         if (p.dc_len) {
             plan.any_dc = 1;
-            p.dc_len_f = (float) p.dc_len;
-            // The four stage waves of K2 run three 64-sample blocks apart and prefetch one block ahead: a stage ring
-            // covers its delay plus the blocks between its writer and its reader; the input ring is also fed up to 8
-            // blocks ahead of the first stage and read 2(L-1) behind the last one.
-            const uint32_t rs = pow2_at_least(p.dc_len + 4 * 64), rx = pow2_at_least(2 * (p.dc_len - 1) + 17 * 64);
-            p.rs_mask = rs - 1;
-            p.rx_mask = rx - 1;
-            p.dc_state_off = (uint32_t) plan.dc_state_floats;
-            plan.dc_state_floats += (size_t) rx + 3 * (size_t) rs + 8;
             plan.rx_cap = std::max(plan.rx_cap, rx);
             plan.rs_cap = std::max(plan.rs_cap, rs);
         }
@@ -98,10 +111,56 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
         h_max = std::max(h_max, p.hist_len);
         maxlen_max = std::max(maxlen_max, p.max_len);
     }
+    // every channel gets a DC state region of the batch's largest size, so that a channel can later be given any
+    // configuration the batch's geometry holds (replan_channel)
+    plan.dc_region_floats = plan.any_dc ? (size_t) plan.rx_cap + 3 * (size_t) plan.rs_cap + 8 : 0;
+    for (size_t c = 0; c < n; c++) {
+        plan.params[c].dc_state_off = (uint32_t) (c * plan.dc_region_floats);
+    }
+    plan.dc_state_floats = n * plan.dc_region_floats;
+    // behind the shared taps, one private slot per channel for configurations assigned later
+    plan.private_taps_base = plan.tap_pool.size();
+    plan.private_taps_slot = (size_t) round_up_u32(plan.t1_max, 8) + round_up_u32(plan.t2_max, 8);
     plan.hist_stride = round_up_u32(h_max, 8);
     plan.z_stride = round_up_u32(maxlen_max + 64, 64);
     plan.out_stride = round_up_u32(maxlen_max + 64, 64);
     plan.in_stride = round_up_u32(std::max<uint32_t>(maxlen_max, 1), 64);
+    return 0;
+}
+
+int replan_channel(BatchPlan &plan, size_t c, const sdrm_fsk_config &cfg, std::vector<float> &taps_slot) {
+    if (c >= plan.params.size()) {
+        return -1;
+    }
+    ChannelDesign d;
+    int code = design_channel(cfg, d);
+    if (code != 0) {
+        return code;
+    }
+    sdrm_chan_params p;
+    uint32_t rx = 0, rs = 0;
+    code = params_from_design(d, p, &rx, &rs);
+    if (code != 0) {
+        return code;
+    }
+    // the batch's geometry (LDS sizes, strides, buffers) was fixed when it was created
+    if (p.T1 > plan.t1_max || p.T2 > plan.t2_max || p.hist_len > plan.hist_stride || p.max_len > plan.in_stride ||
+        p.max_len + 64 > plan.z_stride || (p.dc_len && (!plan.any_dc || rx > plan.rx_cap || rs > plan.rs_cap))) {
+        fprintf(stderr, "<3>configuration does not fit the batch it is assigned to (filters of %u / %u taps, DC length %u, "
+                        "buffer %u)\n", p.T1, p.T2, p.dc_len, p.max_len);
+        return -ENOTSUP;
+    }
+    p.dc_state_off = (uint32_t) (c * plan.dc_region_floats);
+    p.taps1_off = (uint32_t) (plan.private_taps_base + c * plan.private_taps_slot);
+    p.taps2_off = p.taps1_off + round_up_u32(plan.t1_max, 8);
+    taps_slot.assign(plan.private_taps_slot, 0.0f);
+    std::copy(d.taps1.rbegin(), d.taps1.rend(), taps_slot.begin());
+    std::copy(d.taps2.rbegin(), d.taps2.rend(), taps_slot.begin() + round_up_u32(plan.t1_max, 8));
+    plan.design[c] = d;
+    plan.params[c] = p;
+    plan.phase[c] = 0;
+    plan.parity[c] = 0;
+    plan.zbase[c] = 0;
     return 0;
 }
 

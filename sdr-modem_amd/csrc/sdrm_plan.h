@@ -22,7 +22,8 @@ struct BatchPlan {
     // geometry shared by the whole batch
     uint32_t t1_max = 0, t2_max = 0, hist_stride = 0, z_stride = 0, out_stride = 0, in_stride = 0;
     uint32_t rx_cap = 64, rs_cap = 64;
-    size_t dc_state_floats = 0;
+    size_t dc_state_floats = 0, dc_region_floats = 0;  // every channel owns a region of the largest size
+    size_t private_taps_base = 0, private_taps_slot = 0;  // per-channel tap slots behind the shared pool (replan_channel)
     int any_dc = 0;
     // streaming bookkeeping that depends on input lengths only (kept on the host)
     std::vector<uint32_t> phase, parity, zbase;
@@ -30,6 +31,11 @@ struct BatchPlan {
 
 // 0, or the error of design_channel() / -ENOTSUP for geometry the tiles cannot hold
 int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan);
+
+// Give channel c a new configuration (same batch geometry: filters, DC length and buffer size no larger than what the
+// batch was created for).  Fills `taps_slot` with the channel's private copy of both filters' reversed taps (to be put at
+// tap_pool offset params[c].taps1_off) and resets the channel's streaming bookkeeping.  0, a design error, or -ENOTSUP.
+int replan_channel(BatchPlan &plan, size_t c, const sdrm_fsk_config &cfg, std::vector<float> &taps_slot);
 
 // Fill ctl[C] for one call and advance the bookkeeping.  lens[c] > max_len prints the reference's message
 // (src/dsp/fir_filter.c:147-152) and is treated as an empty input.  Returns the largest tile count.

@@ -24,9 +24,13 @@ int Batcher::init() {
     if (code != 0) {
         return code;
     }
+    // every channel gets room for the largest buffer of the batch: a channel may be given another configuration later
+    for (size_t c = 0; c < n_; c++) {
+        out_cap_ = std::max<size_t>(out_cap_, be_->max_len(c));
+    }
     out_off_.assign(n_ + 1, 0);
     for (size_t c = 0; c < n_; c++) {
-        out_off_[c + 1] = out_off_[c] + be_->max_len(c);
+        out_off_[c + 1] = out_off_[c] + out_cap_;
     }
     for (Round &rd : rounds_) {
         rd.len.assign(n_, 0);
@@ -181,6 +185,9 @@ void Batcher::complete(size_t c) {
     mine_[c].pop_front();
     rd.unconsumed--;
     retire_locked();
+    if (mine_[c].empty()) {
+        cv_result_.notify_all();  // a reset of this channel may be waiting for it to run dry
+    }
 }
 
 void Batcher::interrupt(size_t c) {
@@ -197,6 +204,34 @@ void Batcher::interrupt(size_t c) {
     cv_work_.notify_all();  // rounds no longer wait for this channel
     cv_space_.notify_all();
     cv_result_.notify_all();
+}
+
+int Batcher::reset_channel(size_t c, const sdrm_fsk_config *cfg) {
+    if (c >= n_) {
+        return -1;
+    }
+    Reset req;
+    req.channel = c;
+    req.has_cfg = cfg != nullptr;
+    if (cfg != nullptr) {
+        req.cfg = *cfg;
+    }
+    req.done = false;
+    req.code = 0;
+    std::unique_lock<std::mutex> lk(m_);
+    // what was put for the previous client is still delivered to (and has to be consumed by) its consumer
+    while (!mine_[c].empty() && !stopping_) {
+        cv_result_.wait(lk);
+    }
+    if (stopping_) {
+        return -1;
+    }
+    resets_.push_back(&req);
+    cv_work_.notify_all();
+    while (!req.done && !stopping_) {
+        cv_result_.wait(lk);
+    }
+    return req.done ? req.code : -1;
 }
 
 bool Batcher::launchable_locked(const Round &rd, std::chrono::steady_clock::time_point now) const {
@@ -224,7 +259,22 @@ void Batcher::run() {
         const auto now = std::chrono::steady_clock::now();
         Round &rd = round(fill_base_);
         const bool fresh = rd.state == FILLING && rd.id == fill_base_;
-        if (fresh && inflight_.size() < MAX_FLIGHT && launchable_locked(rd, now)) {
+        if (!resets_.empty() && inflight_.empty()) {
+            Reset *req = resets_.front();
+            resets_.pop_front();
+            lk.unlock();
+            const int code = be_->reset_channel(req->channel, req->has_cfg ? &req->cfg : nullptr);
+            lk.lock();
+            if (code == 0 && closed_[req->channel]) {
+                closed_[req->channel] = 0;  // the slot serves a new client
+                open_++;
+            }
+            req->code = code;
+            req->done = true;
+            cv_result_.notify_all();
+            continue;
+        }
+        if (resets_.empty() && fresh && inflight_.size() < MAX_FLIGHT && launchable_locked(rd, now)) {
             segs.clear();
             for (size_t c = 0; c < n_; c++) {
                 lens[c] = rd.has[c] ? rd.len[c] : 0;
@@ -259,7 +309,7 @@ void Batcher::run() {
             int code = be_->collect(outs.data(), olens.data());
             Round &done = round(r);
             for (size_t c = 0; c < n_; c++) {
-                const size_t n = (code == 0 && done.has[c]) ? std::min<size_t>(olens[c], be_->max_len(c)) : 0;
+                const size_t n = (code == 0 && done.has[c]) ? std::min<size_t>(olens[c], out_cap_) : 0;
                 if (n) {
                     memcpy(done.out.data() + out_off_[c], outs[c], n);
                 }
@@ -303,6 +353,10 @@ extern "C" void sdrm_batcher_complete(sdrm_batcher *b, size_t channel) {
     if (b != nullptr) {
         reinterpret_cast<sdrm::Batcher *>(b)->complete(channel);
     }
+}
+
+extern "C" int sdrm_batcher_reset_channel(sdrm_batcher *b, size_t channel, const sdrm_fsk_config *config) {
+    return b != nullptr ? reinterpret_cast<sdrm::Batcher *>(b)->reset_channel(channel, config) : -1;
 }
 
 extern "C" void sdrm_batcher_interrupt(sdrm_batcher *b, size_t channel) {

@@ -36,6 +36,8 @@ struct BatchBackend {
     virtual int arena(size_t slots, sdrm_cf32 **base, size_t *chan_stride, size_t *slot_stride) = 0;
     virtual int submit(size_t slot, const size_t *lens, const sdrm_nco_segment *segs, size_t n_segs) = 0;
     virtual int collect(int8_t **outputs, size_t *lens) = 0;
+    // same contract as sdrm_batch_reset_channel (nothing is in flight when the batcher calls it)
+    virtual int reset_channel(size_t channel, const sdrm_fsk_config *cfg) = 0;
 };
 
 typedef size_t (*doppler_plan_fn)(void *planner, uint32_t channel, size_t input_len, sdrm_nco_segment *segments, size_t cap);
@@ -51,6 +53,9 @@ public:
     void complete(size_t channel);
     void interrupt(size_t channel);
     void set_doppler(size_t channel, doppler_plan_fn fn, void *planner);
+    // hand the channel to a new client: waits until everything put on it has been consumed, drains the device, resets
+    // the channel (cfg may be NULL = same configuration) and reopens it after a poison pill
+    int reset_channel(size_t channel, const sdrm_fsk_config *cfg);
     size_t channels() const { return n_; }
     uint64_t rounds_launched() const { return launched_; }
 
@@ -92,6 +97,15 @@ private:
         void *planner = nullptr;
     };
     std::vector<Doppler> doppler_;
+    struct Reset {
+        size_t channel;
+        bool has_cfg;
+        sdrm_fsk_config cfg;
+        bool done;
+        int code;
+    };
+    std::deque<Reset *> resets_;  // pending channel resets, executed by the batcher thread with the device idle
+    size_t out_cap_ = 0;          // result bytes reserved per channel and round (the batch's largest buffer)
     bool stopping_ = false;
     uint64_t launched_ = 0;
     std::mutex m_;

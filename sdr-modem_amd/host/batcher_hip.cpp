@@ -22,6 +22,13 @@ struct HipBackend : sdrm::BatchBackend {
         return sdrm_batch_submit(batch, slot, lens, segs, n);
     }
     int collect(int8_t **outs, size_t *lens) override { return sdrm_batch_collect(batch, outs, lens); }
+    int reset_channel(size_t c, const sdrm_fsk_config *cfg) override {
+        int code = sdrm_batch_reset_channel(batch, c, cfg);
+        if (code == 0 && cfg != nullptr) {
+            maxlen[c] = cfg->max_input_buffer_length;
+        }
+        return code;
+    }
 };
 
 size_t plan_with_doppler(void *planner, uint32_t channel, size_t len, sdrm_nco_segment *segs, size_t cap) {

@@ -180,6 +180,16 @@ int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *
         }
         w->batcher = cfg->batcher;
         w->channel = cfg->batcher_channel;
+        /* the slot starts a new stream with this client's parameters (fsk_demod_create's part, src/dsp_worker.c:138-144) */
+        sdrm_fsk_config fc = {cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
+                              (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
+                              cfg->demod_fsk_use_dc_block, cfg->buffer_size};
+        code = sdrm_batcher_reset_channel(w->batcher, w->channel, &fc);
+        if (code != 0) {
+            fprintf(stderr, "<3>[%d] unable to create demodulator\n", w->id);
+            free(w);
+            return code;
+        }
         if (cfg->doppler_shift != NULL) {
             code = sdrm_doppler_create(cfg->rx_sampling_freq, cfg->doppler_shift, cfg->doppler_user, &w->doppler);
             if (code == 0) {

@@ -13,6 +13,7 @@
 struct EmuBatch;
 extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out);
 extern "C" void emu_destroy(EmuBatch *b);
+extern "C" int emu_reset_channel(EmuBatch *b, size_t c, const sdrm_fsk_config *cfg);
 extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t *lens, const int8_t **out8,
                            const float **outf, size_t *outlens);
 extern "C" int emu_process_nco(EmuBatch *b, const float *const *inputs, const size_t *lens, const sdrm_nco_segment *segs,
@@ -58,6 +59,11 @@ struct EmuBackend : sdrm::BatchBackend {
         for (size_t c = 0; c < C; c++) r.out[c].assign(o8[c], o8[c] + ol[c]);
         done.push_back(std::move(r));
         return 0;
+    }
+    int reset_channel(size_t c, const sdrm_fsk_config *cfg) override {
+        int code = emu_reset_channel(emu, c, cfg);
+        if (code == 0 && cfg != nullptr) maxlen[c] = cfg->max_input_buffer_length;
+        return code;
     }
     std::vector<std::vector<int8_t>> last;
     int collect(int8_t **outs, size_t *lens) override {

@@ -44,6 +44,7 @@ extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out)
     b->z.assign(n * (size_t) pl.z_stride, 0.0f);
     b->dcout.assign(n * (size_t) pl.z_stride, 0.0f);
     b->dcstate.assign(pl.dc_state_floats + 8, 0.0f);
+    b->plan.tap_pool.resize(pl.private_taps_base + n * pl.private_taps_slot + 16, 0.0f);  // room for reassigned channels
     b->clock.resize(n);
     for (size_t c = 0; c < n; c++) {
         memset(&b->clock[c], 0, sizeof(sdrm_clock_state));
@@ -62,6 +63,26 @@ extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out)
 }
 
 extern "C" void emu_destroy(EmuBatch *b) { delete b; }
+
+// the emulation's counterpart of sdrm_batch_reset_channel (same planning code, state vectors instead of device memory)
+extern "C" int emu_reset_channel(EmuBatch *b, size_t c, const sdrm_fsk_config *cfg) {
+    BatchPlan &pl = b->plan;
+    if (c >= pl.params.size()) return -1;
+    const sdrm_fsk_config use = cfg ? *cfg : pl.design[c].cfg;
+    std::vector<float> slot;
+    int code = replan_channel(pl, c, use, slot);
+    if (code != 0) return code;
+    std::copy(slot.begin(), slot.end(), pl.tap_pool.begin() + pl.params[c].taps1_off);
+    std::fill(b->hist.begin() + c * 2 * pl.hist_stride, b->hist.begin() + (c + 1) * 2 * pl.hist_stride, sdrm_f2{0.0f, 0.0f});
+    if (pl.dc_region_floats)
+        std::fill(b->dcstate.begin() + c * pl.dc_region_floats, b->dcstate.begin() + (c + 1) * pl.dc_region_floats, 0.0f);
+    memset(&b->clock[c], 0, sizeof(sdrm_clock_state));
+    b->clock[c].mu = 0.5f;
+    b->clock[c].omega = pl.design[c].sps;
+    b->nonfinite[c] = 0;
+    b->nco_state[c] = 0.0f;
+    return 0;
+}
 
 static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
     const BatchPlan &pl = b->plan;

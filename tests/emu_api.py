@@ -22,6 +22,7 @@ def lib():
         subprocess.check_call(["make", "-s", "-C", EMU_DIR], stdout=subprocess.DEVNULL)
         L = C.CDLL(os.path.join(EMU_DIR, "libsdrm_emu.so"))
         L.emu_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.POINTER(C.c_void_p)]
+        L.emu_reset_channel.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FskConfig)]
         L.emu_destroy.argtypes = [C.c_void_p]
         L.emu_destroy.restype = None
         L.emu_process.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
@@ -83,6 +84,10 @@ class EmuBatch:
             r8.append(np.ctypeslib.as_array(C.cast(o8[c], C.POINTER(C.c_int8)), shape=(n,)).copy() if n else np.zeros(0, np.int8))
             rf.append(np.ctypeslib.as_array(C.cast(of[c], C.POINTER(C.c_float)), shape=(n,)).copy() if n else np.zeros(0, np.float32))
         return r8, rf
+
+    def reset_channel(self, c, cfg=None):
+        arr = make_configs([cfg]) if cfg is not None else None
+        return lib().emu_reset_channel(self.h, c, arr)
 
     def mixed(self, c):
         n = lib().emu_mixed(self.h, c, None, 0)

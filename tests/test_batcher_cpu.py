@@ -150,3 +150,37 @@ def test_oversize_buffer_is_refused_with_the_reference_message(capfd):
     bt.put(0, sig[:4096])
     assert np.array_equal(bt.take(0), oracle_stream(CFG_A, [sig[:4096]])[0])
     bt.close()
+
+
+def test_channel_changes_hands_while_the_others_keep_streaming():
+    """sdrm_batcher_reset_channel: client A leaves channel 1 (poison pill), client B takes the slot with another
+    configuration; channel 0 streams across the hand-over without a glitch; B's soft bits are those of a fresh
+    demodulator."""
+    big = (48000, 4800, 5000, 2, 2000, True, 4096)
+    bt = emu_api.emu_batcher([big, big], slots=4, max_wait_us=2000, blocking=True)
+    s0 = siggen.gmsk_channel(60, 4 * 4096, fs=48000, baud=4800)
+    sa = siggen.gmsk_channel(61, 4096, fs=48000, baud=4800)
+    sb = siggen.gmsk_channel(62, 2 * 4096, fs=48000, baud=9600)
+    o0, oa = orc.Fsk(*big), orc.Fsk(*big)
+    bt.put(0, s0[:4096])
+    bt.put(1, sa)
+    assert np.array_equal(bt.take(0), o0.process(s0[:4096])[0])
+    assert np.array_equal(bt.take(1), oa.process(sa)[0])
+    bt.interrupt(1)
+    assert bt.take(1) is None
+    cfg_b = (48000, 9600, 5000, 1, 2000, False, 4096)
+    # a put that races with the hand-over: channel 0 keeps going meanwhile
+    t = threading.Thread(target=lambda: bt.put(0, s0[4096:8192]))
+    t.start()
+    assert bt.reset_channel(1, cfg_b) == 0
+    t.join(10)
+    ob = orc.Fsk(*cfg_b)
+    bt.put(1, sb[:4096])
+    assert np.array_equal(bt.take(0), o0.process(s0[4096:8192])[0])
+    assert np.array_equal(bt.take(1), ob.process(sb[:4096])[0])
+    bt.put(0, s0[8192:12288])
+    bt.put(1, sb[4096:])
+    assert np.array_equal(bt.take(0), o0.process(s0[8192:12288])[0])
+    assert np.array_equal(bt.take(1), ob.process(sb[4096:])[0])
+    assert bt.reset_channel(1, (48000, 1200, 5000, 1, 2000, True, 4096)) != 0  # 207-tap filter: larger than the batch's
+    bt.close()

@@ -595,3 +595,81 @@ def test_file_source_harness_reproduces_the_reference_fixture_files(workers):
             assert np.array_equal(got, want), i
             assert len(got) == len(golden) and np.abs(got.astype(np.int32) - golden.astype(np.int32)).max() <= 2
         assert np.array_equal(np.fromfile(os.path.join(tmp, "rx.sdr2demod.0.cf32"), dtype=np.complex64), iq)
+
+
+# ---------------------------------------------------------------- channels changing hands
+
+def test_batch_channel_reassignment_on_the_device():
+    """sdrm_batch_reset_channel: after streaming, channels are given other configurations (other rates, decimation, DC
+    blocker off) or just a new stream; they then match freshly created oracles, their neighbours are undisturbed, a
+    configuration beyond the batch's geometry is refused and leaves the channel alone."""
+    big = (48000, 4800, 5000, 2, 2000, True, 8192)
+    cfgs = [big, (48000, 9600, 5000, 1, 2000, True, 8192), big, (240000, 19200, 5000, 5, 2000, True, 8192)]
+    g = binding.Batch(cfgs, keep_soft=True)
+    assert g.code == 0
+    sigs = [siggen.gmsk_channel(300 + i, 3 * 8192, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    orcs = [orc.Fsk(*c) for c in cfgs]
+    g8 = g.process([s[:8192] for s in sigs])
+    for i in range(4):
+        assert np.array_equal(g8[i], orcs[i].process(sigs[i][:8192])[0])
+    new1 = (48000, 9600, 5000, 1, 2000, False, 8192)
+    new3 = (48000, 2400, 2400, 4, 1000, True, 4096)
+    assert g.reset_channel(1, new1) == 0 and g.reset_channel(2) == 0 and g.reset_channel(3, new3) == 0
+    assert g.reset_channel(0, (48000, 1200, 5000, 1, 2000, True, 8192)) != 0
+    orcs[1], orcs[2], orcs[3] = orc.Fsk(*new1), orc.Fsk(*big), orc.Fsk(*new3)
+    sigs[1] = siggen.gmsk_channel(311, 3 * 8192, fs=48000, baud=9600)
+    sigs[3] = siggen.gmsk_channel(313, 3 * 8192, fs=48000, baud=2400)
+    for k in (1, 2):
+        parts = [s[k * 8192:(k + 1) * 8192] for s in sigs]
+        parts[3] = parts[3][:4096]
+        g8 = g.process(parts)
+        for i in range(4):
+            o8, of = orcs[i].process(parts[i])
+            assert_same(of, g.last_soft(i), o8, g8[i], where="channel %d call %d" % (i, k))
+    g.close()
+
+
+def test_worker_slots_are_reused_by_clients_with_other_parameters():
+    """The server flow on a shared batcher: two workers run, one leaves, a third client with different demodulator
+    parameters takes over its slot; every file sink equals the oracle's output for that client's stream."""
+    L = binding.load()
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    slot_cfg = (48000, 4800, 5000, 2, 2000, True, 4096)
+    bt = binding.Batcher([slot_cfg] * 2, slots=4, max_wait_us=5000, blocking=True)
+    assert bt.code == 0
+
+    def make(wid, slot, baud, decim, dc):
+        wc = binding.WorkerConfig(48000, baud, 5000, decim, 2000, dc, False, 0, 4096, 4, True, tmp.encode())
+        wc.batcher = bt.h
+        wc.batcher_channel = slot
+        w = C.c_void_p()
+        assert L.dsp_worker_create(wid, -1, C.byref(wc), C.byref(w)) == 0
+        return w
+
+    def feed(w, x):
+        for off in range(0, len(x), 4096):
+            part = np.ascontiguousarray(x[off:off + 4096]).view(np.float32)
+            L.dsp_worker_put(part.ctypes.data, len(part) // 2, w)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        w0, w1 = make(40, 0, 4800, 2, True), make(41, 1, 4800, 2, True)
+        half = (len(iq) // 2) // 4096 * 4096
+        t = [threading.Thread(target=feed, args=(w, iq[:half])) for w in (w0, w1)]
+        for x in t:
+            x.start()
+        for x in t:
+            x.join(120)
+        L.dsp_worker_destroy(w1)                       # client 41 leaves
+        w2 = make(42, 1, 9600, 1, False)               # client 42 takes slot 1 with other parameters
+        t = [threading.Thread(target=feed, args=(w0, iq[half:])), threading.Thread(target=feed, args=(w2, iq[:half]))]
+        for x in t:
+            x.start()
+        for x in t:
+            x.join(120)
+        L.dsp_worker_destroy(w0)
+        L.dsp_worker_destroy(w2)
+        got = {i: np.fromfile(os.path.join(tmp, "rx.demod2client.%d.s8" % i), dtype=np.int8) for i in (40, 41, 42)}
+    assert np.array_equal(got[40], orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq, 4096)[0])
+    assert np.array_equal(got[41], orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq[:half], 4096)[0])
+    assert np.array_equal(got[42], orc.demod_stream((48000, 9600, 5000, 1, 2000, False), iq[:half], 4096)[0])
+    bt.close()

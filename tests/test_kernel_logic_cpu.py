@@ -177,3 +177,31 @@ def test_nco_then_demod_matches_oracle_doppler_then_demod():
         assert np.array_equal(e.mixed(0).view(np.uint32), mixed.view(np.uint32))
         assert np.array_equal(of.view(np.uint32), ef[0].view(np.uint32))
         assert np.array_equal(o8, e8[0])
+
+
+def test_channel_reassignment_matches_a_fresh_demodulator():
+    """sdrm_batch_reset_channel's planning and state reset (shared host code, kernel emulation): a channel that has
+    streamed with one configuration is given another (shorter filters, other rates, DC blocker off / on) and then
+    behaves like a freshly created demodulator; its neighbours keep streaming undisturbed; what does not fit the
+    batch's geometry is refused."""
+    big = (48000, 4800, 5000, 2, 2000, True, 4096)       # 157-tap LPF1: the batch's largest filters
+    cfgs = [big, (48000, 9600, 5000, 1, 2000, True, 4096), big]
+    e = emu_api.EmuBatch(cfgs)
+    assert e.code == 0
+    sigs = [siggen.gmsk_channel(40 + i, 3 * 4096, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    keep = [orc.Fsk(*c) for c in cfgs]
+    got, _ = e.process([s[:4096] for s in sigs])
+    for i in range(3):
+        assert np.array_equal(got[i], keep[i].process(sigs[i][:4096])[0])
+    new_cfg = (48000, 9600, 5000, 1, 2000, False, 4096)
+    assert e.reset_channel(1, new_cfg) == 0
+    assert e.reset_channel(2) == 0                        # same configuration, new stream
+    assert e.reset_channel(0, (48000, 1200, 5000, 1, 2000, True, 4096)) != 0  # 207 taps: does not fit, channel 0 untouched
+    fresh = {1: orc.Fsk(*new_cfg), 2: orc.Fsk(*big)}
+    new_sig = {1: siggen.gmsk_channel(77, 2 * 4096, fs=48000, baud=9600), 2: siggen.gmsk_channel(78, 2 * 4096, fs=48000, baud=4800)}
+    for k in range(2):
+        parts = [sigs[0][(k + 1) * 4096:(k + 2) * 4096], new_sig[1][k * 4096:(k + 1) * 4096], new_sig[2][k * 4096:(k + 1) * 4096]]
+        got, _ = e.process(parts)
+        assert np.array_equal(got[0], keep[0].process(parts[0])[0])
+        assert np.array_equal(got[1], fresh[1].process(parts[1])[0])
+        assert np.array_equal(got[2], fresh[2].process(parts[2])[0])
