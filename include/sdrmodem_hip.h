@@ -166,6 +166,17 @@ int sdrm_probe_wave_scan(const float *terms, float carry_in, float *out, size_t 
  * 1 = the same wave_shr data flow through the compiler's update_dpp builtin */
 void sdrm_set_scan_mode(int mode);
 
+/* Diagnostics (tools/k3_probe.py, tools/sweep_point.py; never needed for results).
+ * sdrm_batch_k3_stamps: enable = 1 makes every call (enable = k > 1: only the k-th call from now) record cycle counts
+ * inside the kernels; `out` receives 4 x uint64 per clock-stage wave {cycles waiting for staged samples, cycles in the
+ * symbol loops, steps | 100 MHz ticks << 32, loop iterations} followed by the front-end's per-phase cycle sums and one
+ * DC-blocker channel's cycles.  Returns the number of clock-stage waves.
+ * sdrm_batch_timeline: enable != 0 attaches a table for the next 64 calls; `out` receives one row per call made since,
+ * {front start, front end, dc start, dc end, clock start, clock end} in 10 ns ticks of the device's reference clock (first
+ * workgroup start / last workgroup end).  Returns the number of rows. */
+int sdrm_batch_k3_stamps(sdrm_batch *batch, int enable, unsigned long long *out, size_t max_waves);
+int sdrm_batch_timeline(sdrm_batch *batch, int enable, unsigned long long *out, size_t max_rows);
+
 const char *sdrm_version(void);
 int sdrm_device_count(void);
 

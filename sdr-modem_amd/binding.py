@@ -58,6 +58,7 @@ EXPORTS = [
     "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_wave_scan", "sdrm_set_scan_mode", "sdrm_version", "sdrm_device_count",
+    "sdrm_batch_k3_stamps", "sdrm_batch_timeline",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
     "interrupt_waiting_the_data", "destroy_queue",
     "dsp_worker_create", "dsp_worker_put", "dsp_worker_shutdown", "dsp_worker_find_by_id", "dsp_worker_destroy",
