@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sdrmodem_hip.h"
@@ -1051,14 +1052,71 @@ extern "C" int sdrm_batch_last_soft(sdrm_batch *b, size_t c, float *dst, size_t 
 // ================================================================================================
 // Reference operator API (src/dsp/fsk_demod.h:11-15): a batch of one channel.
 
+// ---- the reference operator.  By default a handle is a private batch of one channel.  With SDRM_SHARED_SLOTS=n in the
+// environment the handles of the process share ONE batcher of n slots instead (created by the first handle, whose
+// configuration fixes the batch's geometry): fsk_demod_process then puts its buffer on the handle's slot and blocks
+// until the round it went into has come back, so the per-client DSP threads of an unmodified sdr-modem
+// (src/dsp_worker.c:44-106, one fsk_demod_process per buffer each) are served by one device call per round.
+// SDRM_SHARED_WAIT_US (default 1000) is how long a round waits for more handles to join.
 struct fsk_demod_t {
     sdrm_batch_t *batch;
+    sdrm_batcher *shared;
+    size_t slot;
+    uint32_t max_len;
+    int8_t *out;  // the handle's own copy of its last result (valid until its next call, as in the reference)
 };
+
+namespace {
+struct SharedPool {
+    std::mutex m;
+    sdrm_batcher *bt = nullptr;
+    std::vector<uint8_t> used;
+    bool failed = false;
+};
+SharedPool g_pool;
+
+bool shared_attach(fsk_demod_t *d, const sdrm_fsk_config &cfg) {
+    const char *env = getenv("SDRM_SHARED_SLOTS");
+    const long n = env ? atol(env) : 0;
+    if (n <= 0) {
+        return false;
+    }
+    std::lock_guard<std::mutex> g(g_pool.m);
+    if (g_pool.bt == nullptr && !g_pool.failed) {
+        std::vector<sdrm_fsk_config> cfgs((size_t) n, cfg);
+        const char *w = getenv("SDRM_SHARED_WAIT_US");
+        sdrm_batcher_config bc = {4, (uint32_t) (w ? atol(w) : 1000), true};
+        if (sdrm_batcher_create(cfgs.data(), cfgs.size(), -1, &bc, &g_pool.bt) != 0) {
+            g_pool.bt = nullptr;
+            g_pool.failed = true;
+        } else {
+            g_pool.used.assign((size_t) n, 0);
+        }
+    }
+    if (g_pool.bt == nullptr) {
+        return false;
+    }
+    for (size_t s = 0; s < g_pool.used.size(); s++) {
+        if (!g_pool.used[s]) {
+            // the slot gets this handle's parameters and a clean state; what does not fit the shared batch's geometry
+            // (longer filters, larger buffers than the first handle's) gets a private batch instead
+            if (sdrm_batcher_reset_channel(g_pool.bt, s, &cfg) != 0) {
+                return false;
+            }
+            g_pool.used[s] = 1;
+            d->shared = g_pool.bt;
+            d->slot = s;
+            return true;
+        }
+    }
+    return false;
+}
+}  // namespace
 
 extern "C" int fsk_demod_create(uint64_t sampling_freq, uint32_t baud_rate, int64_t deviation, uint8_t decimation,
                                 uint32_t transition_width, bool use_dc_block, uint32_t max_input_buffer_length,
                                 fsk_demod **demod) {
-    fsk_demod_t *d = (fsk_demod_t *) malloc(sizeof(fsk_demod_t));
+    fsk_demod_t *d = (fsk_demod_t *) calloc(1, sizeof(fsk_demod_t));
     if (d == nullptr) {
         return -ENOMEM;
     }
@@ -1071,6 +1129,16 @@ extern "C" int fsk_demod_create(uint64_t sampling_freq, uint32_t baud_rate, int6
     cfg.transition_width = transition_width;
     cfg.use_dc_block = use_dc_block;
     cfg.max_input_buffer_length = max_input_buffer_length;
+    d->max_len = max_input_buffer_length;
+    if (shared_attach(d, cfg)) {
+        d->out = (int8_t *) malloc(max_input_buffer_length ? max_input_buffer_length : 1);
+        if (d->out == nullptr) {
+            fsk_demod_destroy(d);
+            return -ENOMEM;
+        }
+        *demod = d;
+        return 0;
+    }
     int code = sdrm_batch_create(&cfg, 1, -1, 0, &d->batch);
     if (code != 0) {
         free(d);
@@ -1082,6 +1150,26 @@ extern "C" int fsk_demod_create(uint64_t sampling_freq, uint32_t baud_rate, int6
 
 extern "C" void fsk_demod_process(const sdrm_cf32 *input, size_t input_len, int8_t **output, size_t *output_len,
                                   fsk_demod *demod) {
+    if (demod->shared != nullptr) {
+        *output = demod->out;
+        *output_len = 0;
+        if (input_len > demod->max_len) {
+            fprintf(stderr, "<3>requested buffer %zu is more than max: %zu\n", input_len, (size_t) demod->max_len);
+            return;
+        }
+        int8_t *soft = nullptr;
+        size_t n = 0;
+        sdrm_batcher_put(demod->shared, demod->slot, input, input_len);
+        sdrm_batcher_take(demod->shared, demod->slot, &soft, &n);
+        if (soft == nullptr) {
+            fprintf(stderr, "<3>sdrmodem_hip: the shared batcher went away under fsk_demod_process\n");
+            abort();
+        }
+        memcpy(demod->out, soft, n);
+        sdrm_batcher_complete(demod->shared, demod->slot);
+        *output_len = n;
+        return;
+    }
     const sdrm_cf32 *ins[1] = {input};
     size_t lens[1] = {input_len};
     int8_t *outs[1] = {nullptr};
@@ -1100,7 +1188,14 @@ extern "C" void fsk_demod_destroy(fsk_demod *demod) {
     if (demod == nullptr) {
         return;
     }
-    batch_free(demod->batch);
+    if (demod->shared != nullptr) {
+        std::lock_guard<std::mutex> g(g_pool.m);
+        g_pool.used[demod->slot] = 0;  // the next handle that takes the slot resets it
+    }
+    if (demod->batch != nullptr) {
+        batch_free(demod->batch);
+    }
+    free(demod->out);
     free(demod);
 }
 

@@ -673,3 +673,42 @@ def test_worker_slots_are_reused_by_clients_with_other_parameters():
     assert np.array_equal(got[41], orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq[:half], 4096)[0])
     assert np.array_equal(got[42], orc.demod_stream((48000, 9600, 5000, 1, 2000, False), iq[:half], 4096)[0])
     bt.close()
+
+
+def test_plain_fsk_demod_handles_share_one_batcher_when_asked_to(monkeypatch):
+    """SDRM_SHARED_SLOTS: the reference's own usage -- one fsk_demod handle and one DSP thread per client, one blocking
+    fsk_demod_process per buffer -- with the handles of the process served by one batched device call per round.
+    Twelve threads with different parameters (all within the first handle's geometry) and one handle whose filters
+    are longer (falls back to a private batch): every stream bit-exact, far fewer device calls than buffers."""
+    monkeypatch.setenv("SDRM_SHARED_SLOTS", "16")
+    monkeypatch.setenv("SDRM_SHARED_WAIT_US", "20000")
+    first = (48000, 4800, 5000, 2, 2000, True, 4096)           # 157 / 57 taps, DC on: the shared geometry
+    others = [(48000, 9600, 5000, 1, 2000, True, 4096), (48000, 9600, 5000, 1, 2000, False, 4096),
+              (48000, 4800, 5000, 2, 2000, False, 2048)]
+    cfgs = [first] + [others[i % 3] for i in range(11)] + [(48000, 1200, 5000, 8, 2000, True, 4096)]  # last: 207 taps
+    K = 6
+    sigs = [siggen.gmsk_channel(500 + i, K * c[6], fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    handles = [binding.FskDemod(*c) for c in cfgs]  # created in order: the first fixes the geometry
+    assert all(h.code == 0 for h in handles)
+    got = [[] for _ in cfgs]
+    start = threading.Barrier(len(cfgs))
+
+    def client(i):
+        n = cfgs[i][6]
+        start.wait()
+        for k in range(K):
+            got[i].append(handles[i].process(sigs[i][k * n:(k + 1) * n]))
+
+    th = [threading.Thread(target=client, args=(i,)) for i in range(len(cfgs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+        assert not t.is_alive()
+    for i, c in enumerate(cfgs):
+        o = orc.Fsk(*c)
+        n = c[6]
+        for k in range(K):
+            assert np.array_equal(got[i][k], o.process(sigs[i][k * n:(k + 1) * n])[0]), (i, k)
+    for h in handles:
+        h.close()
