@@ -326,7 +326,10 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     e = e ? e : hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     const int prio_mid = (prio_low + prio_high) / 2;
     e = e ? e : hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, prio_low);
-    if (getenv("SDRM_SERIAL_STAGES") != nullptr) {
+    if (getenv("SDRM_SERIAL_STAGES") != nullptr || n_channels == 1) {
+        // A batch of one channel (a plain fsk_demod handle) gains nothing from overlapping its stages across calls --
+        // the caller waits for every call -- and a server with one handle per client would otherwise hold four streams
+        // per client on a handful of hardware queues.
         // escape hatch: all stages on one stream (no overlap between consecutive calls); same kernels, same results
         b->s_dc = b->s_front;
         b->s_clock = b->s_front;

@@ -15,4 +15,4 @@ t0 = time.perf_counter()
 for _ in range(200):
     d.process(ramp)
 dt = (time.perf_counter() - t0) / 200
-print("fsk_demod_process(%d samples): %.1f us per call (%s)" % (n, dt * 1e6, "serial stages" if os.environ.get("SDRM_SERIAL_STAGES") else "three streams"))
+print("fsk_demod_process(%d samples): %.1f us per call (%s)" % (n, dt * 1e6, "one handle = one stream"))
