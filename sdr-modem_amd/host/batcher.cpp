@@ -185,7 +185,7 @@ void Batcher::complete(size_t c) {
     mine_[c].pop_front();
     rd.unconsumed--;
     retire_locked();
-    if (mine_[c].empty()) {
+    if (mine_[c].empty() && reset_waiters_ > 0) {
         cv_result_.notify_all();  // a reset of this channel may be waiting for it to run dry
     }
 }
@@ -220,9 +220,11 @@ int Batcher::reset_channel(size_t c, const sdrm_fsk_config *cfg) {
     req.code = 0;
     std::unique_lock<std::mutex> lk(m_);
     // what was put for the previous client is still delivered to (and has to be consumed by) its consumer
+    reset_waiters_++;
     while (!mine_[c].empty() && !stopping_) {
         cv_result_.wait(lk);
     }
+    reset_waiters_--;
     if (stopping_) {
         return -1;
     }

@@ -105,6 +105,7 @@ private:
         int code;
     };
     std::deque<Reset *> resets_;  // pending channel resets, executed by the batcher thread with the device idle
+    int reset_waiters_ = 0;       // resets waiting for their channel to run dry (complete() wakes them)
     size_t out_cap_ = 0;          // result bytes reserved per channel and round (the batch's largest buffer)
     bool stopping_ = false;
     uint64_t launched_ = 0;
