@@ -22,6 +22,9 @@ void set_scan_mode(int mode);
 
 #define SDRM_CTL_SLOTS 8
 #define SDRM_RES_SETS 4    // pinned result sets of the pipelined host path
+// row pitch of the NCO phase buffers: every channel's generator writes the same column at the same time, and a pitch that
+// is a power of two would put all of those writes on one memory channel; 4 KiB + 256 B more per row spreads them
+#define SDRM_PHASE_STRIDE(in_stride) ((in_stride) + 1088u)
 #define SDRM_MAX_FLIGHT 3  // uncollected calls it allows (copy-in, kernels and copy-back of different calls overlap)
 
 #define HIP_TRY(expr)                                                                                   \
@@ -59,7 +62,9 @@ struct sdrm_batch_t {
     // NCO pre-mix (allocated on first use)
     sdrm_nco_seg *d_nco_segs = nullptr, *h_nco_segs = nullptr;  // [SLOTS][nco_seg_cap]
     size_t nco_seg_cap = 0;
-    float *d_nco_state = nullptr, *d_nco_phase = nullptr;
+    float *d_nco_state = nullptr, *d_nco_phase = nullptr, *d_nco_phase2 = nullptr;  // phases: one buffer per call parity
+    hipStream_t s_nco = nullptr;                 // phase accumulator of the next call runs beside this call's stages
+    hipEvent_t ev_phase[SDRM_CTL_SLOTS] = {};    // phases (and control block) of the call are on the device
     sdrm_f2 *d_nco_out = nullptr;
     std::vector<sdrm_nco_seg> nco_table;
     sdrm_f2 *d_in = nullptr;  // staging for the host-buffer API (lazy)
@@ -145,14 +150,15 @@ static void batch_free(sdrm_batch_t *b) {
         }
     }
     for (int i = 0; i < SDRM_CTL_SLOTS; i++) {
-        hipEvent_t evs[4] = {b->slot_done[i], b->ev_in[i], b->ev_front[i], b->ev_dc[i]};
+        hipEvent_t evs[5] = {b->slot_done[i], b->ev_in[i], b->ev_front[i], b->ev_dc[i], b->ev_phase[i]};
         for (hipEvent_t e : evs) {
             if (e) {
                 (void) hipEventDestroy(e);
             }
         }
     }
-    hipStream_t streams[3] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock};
+    hipStream_t streams[4] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock,
+                              b->s_nco != b->s_front ? b->s_nco : nullptr};
     for (hipStream_t st : streams) {
         if (st) {
             (void) hipStreamDestroy(st);
@@ -197,7 +203,7 @@ static void batch_free(sdrm_batch_t *b) {
     }
     void *dev_ptrs[] = {b->d_params, b->d_ctl, b->d_taps, b->d_atan, b->d_bank, b->d_hist, b->d_z, b->d_dcout,
                         b->d_dcstate, b->d_clock, b->d_out8, b->d_outf, b->d_outlen, b->d_in, b->d_flags, b->d_z2, b->d_dcout2,
-                        b->d_nco_segs, b->d_nco_state, b->d_nco_phase, b->d_nco_out};
+                        b->d_nco_segs, b->d_nco_state, b->d_nco_phase, b->d_nco_phase2, b->d_nco_out};
     for (void *p : dev_ptrs) {
         if (p) {
             (void) hipFree(p);
@@ -530,7 +536,25 @@ static int ensure_nco(sdrm_batch_t *b) {
     int code = 0;
     code = code ? code : dev_alloc_zero(&b->d_nco_segs, b->nco_seg_cap * SDRM_CTL_SLOTS);
     code = code ? code : dev_alloc_zero(&b->d_nco_state, C);
-    code = code ? code : dev_alloc_zero(&b->d_nco_phase, C * (size_t) b->in_stride);
+    code = code ? code : dev_alloc_zero(&b->d_nco_phase, C * (size_t) SDRM_PHASE_STRIDE(b->in_stride));
+    if (b->serial) {
+        b->d_nco_phase2 = nullptr;
+        b->s_nco = b->s_front;
+    } else {
+        // The phase recursion depends on nothing but the batch table and its own state: it gets a stream of its own and
+        // a second phase buffer, and runs while the previous call is still in its later stages.
+        code = code ? code : dev_alloc_zero(&b->d_nco_phase2, C * (size_t) SDRM_PHASE_STRIDE(b->in_stride));
+        int prio_low = 0, prio_high = 0;
+        if (code == 0 && (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess ||
+                          hipStreamCreateWithPriority(&b->s_nco, hipStreamNonBlocking, prio_high) != hipSuccess)) {
+            code = -ENOMEM;
+        }
+    }
+    for (int i = 0; i < SDRM_CTL_SLOTS && code == 0; i++) {
+        if (hipEventCreateWithFlags(&b->ev_phase[i], hipEventDisableTiming) != hipSuccess) {
+            code = -ENOMEM;
+        }
+    }
     code = code ? code : dev_alloc_zero(&b->d_nco_out, C * (size_t) b->in_stride);
     if (code == 0 && hipHostMalloc((void **) &b->h_nco_segs, sizeof(sdrm_nco_seg) * b->nco_seg_cap * SDRM_CTL_SLOTS) != hipSuccess) {
         code = -ENOMEM;
@@ -581,9 +605,10 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     }
     d.nco_segs = with_nco ? b->d_nco_segs + (size_t) slot * b->nco_seg_cap : nullptr;
     d.nco_phase_state = b->d_nco_state;
-    d.nco_phase = b->d_nco_phase;
+    d.nco_phase = (b->d_nco_phase2 != nullptr && (i & 1)) ? b->d_nco_phase2 : b->d_nco_phase;
     d.nco_out = b->d_nco_out;
     d.nco_stride = b->in_stride;
+    d.nco_phase_stride = SDRM_PHASE_STRIDE(b->in_stride);
     d.ctl = d_ctl;
     d.nonfinite = b->d_flags + (size_t) slot * C;
     d.max_tiles = max_tiles;
@@ -594,6 +619,19 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     const int prev2 = (int) ((i + SDRM_CTL_SLOTS - 2) % SDRM_CTL_SLOTS);  // the call that last used these buffers
     const bool have_prev2 = i >= 2;
 
+    // ---- NCO phases: need neither the input nor an earlier stage, only the phase buffer released by the mix of call i-2
+    const bool nco_aside = with_nco && b->s_nco != b->s_front;
+    if (nco_aside) {
+        if (have_prev2) {
+            HIP_TRY(hipStreamWaitEvent(b->s_nco, b->ev_front[prev2], 0));
+        }
+        HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, b->s_nco));
+        HIP_TRY(hipMemcpyAsync(b->d_nco_segs + (size_t) slot * b->nco_seg_cap, b->h_nco_segs + (size_t) slot * b->nco_seg_cap,
+                               sizeof(sdrm_nco_seg) * b->nco_table.size(), hipMemcpyHostToDevice, b->s_nco));
+        sdrm::launch_nco_phase(d, b->s_nco);
+        HIP_TRY(hipEventRecord(b->ev_phase[slot], b->s_nco));
+    }
+
     // ---- front-end: needs the input, and z[i&1] released by its readers of call i-2
     HIP_TRY(hipEventRecord(b->ev_in[slot], caller));
     HIP_TRY(hipStreamWaitEvent(b->s_front, b->ev_in[slot], 0));
@@ -603,11 +641,18 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
             HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[prev2], 0));  // channels without DC: K3 reads z
         }
     }
-    HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, b->s_front));
+    if (nco_aside) {
+        HIP_TRY(hipStreamWaitEvent(b->s_front, b->ev_phase[slot], 0));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, b->s_front));
+    }
     if (with_nco) {
-        HIP_TRY(hipMemcpyAsync(b->d_nco_segs + (size_t) slot * b->nco_seg_cap, b->h_nco_segs + (size_t) slot * b->nco_seg_cap,
-                               sizeof(sdrm_nco_seg) * b->nco_table.size(), hipMemcpyHostToDevice, b->s_front));
-        sdrm::launch_nco(d, d_in, in_stride, nco_max_len, b->s_front);
+        if (!nco_aside) {
+            HIP_TRY(hipMemcpyAsync(b->d_nco_segs + (size_t) slot * b->nco_seg_cap, b->h_nco_segs + (size_t) slot * b->nco_seg_cap,
+                                   sizeof(sdrm_nco_seg) * b->nco_table.size(), hipMemcpyHostToDevice, b->s_front));
+            sdrm::launch_nco_phase(d, b->s_front);
+        }
+        sdrm::launch_nco_mix(d, d_in, in_stride, nco_max_len, b->s_front);
     }
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (b->timing) {

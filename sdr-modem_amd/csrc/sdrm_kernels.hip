@@ -21,68 +21,197 @@ __device__ __forceinline__ void tl_mark(const DeviceBatch &b, int kernel, int en
 
 // ================================================================================================ K0 (NCO, row f-1)
 
-// Phase accumulator, one lane per channel: the fp32 recursion phase += step with its wrap is sequential
-// (reference src/dsp/sig_source.c:43-58).  Writes the phase of every sample (4 samples per 16-byte store).
-__global__ __launch_bounds__(64) void k0_nco_phase(DeviceBatch b) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= b.n_channels) {
-        return;
+// Phase accumulator (reference src/dsp/sig_source.c:43-58): the fp32 recursion phase += step with its wrap is sequential
+// per channel, four dependent instructions per sample at best, so a chunk costs its length times ~18 cycles whatever the
+// channel count.  One workgroup serves 64 channels with two waves: the generator wave runs the recursion, lane per
+// channel, and drops 64-sample blocks into an LDS ring (rows of 64 + 4 floats: conflict-free b128 writes); the store
+// wave reads them back time-major and writes whole 256-byte runs per channel, so the memory system sees 8 lines per
+// store instruction instead of the 64 a lane-per-channel store touches.  One barrier per block hands a ring half over.
+#define K0_BLK 64
+#define K0_ROW (K0_BLK + 4)
+// hand a ring half over: the wave's own LDS traffic has landed (the store wave's global stores stay in flight)
+#define K0_HANDOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// true when every lane can run a whole block branch-free: no batch boundary inside it and |step|, |phase| <= 2 pi
+__device__ __forceinline__ bool k0_block_is_plain(uint32_t left, float step, float phase) {
+    const float two_pi = 6.28318530717958647692f;
+    return __all(left >= K0_BLK && fabsf(step) <= two_pi && fabsf(phase) <= two_pi);
+}
+
+// Four steps of sdrm_nco_advance_signed in the order that costs a lone wave five issue slots per sample: the compare's
+// result may be read two slots after it is written and the subtraction fills one of them (the compiler puts the
+// subtraction first and pads with s_nop 1: 24 cycles per sample instead of 20, tools/ubench_nco.hip).
+// v = the phases of the four samples, phase = the phase after them.
+#define K0_STEP(in, out) \
+    "v_add_f32 " out ", " in ", %5\n\t"          \
+    "v_cmp_gt_f32_e64 vcc, |" out "|, %6\n\t"    \
+    "v_sub_f32 %4, " out ", %7\n\t"              \
+    "s_nop 0\n\t"                                \
+    "v_cndmask_b32 " out ", " out ", %4, vcc\n\t"
+__device__ __forceinline__ void k0_advance4(float4 &v, float &phase, float step, float w) {
+    float y, z, u, next, t;
+    asm volatile(K0_STEP("%8", "%0") K0_STEP("%0", "%1") K0_STEP("%1", "%2") K0_STEP("%2", "%3")
+                 : "=&v"(y), "=&v"(z), "=&v"(u), "=&v"(next), "=&v"(t)
+                 : "v"(step), "s"(6.28318530717958647692f), "v"(w), "v"(phase)
+                 : "vcc");
+    v.x = phase;
+    v.y = y;
+    v.z = z;
+    v.w = u;
+    phase = next;
+}
+
+__global__ __launch_bounds__(128) void k0_nco_phase(DeviceBatch b) {
+    __shared__ __attribute__((aligned(16))) float ring[2][64 * K0_ROW];
+    __shared__ uint32_t blocks_of[64];
+    __shared__ uint32_t blocks_max;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 64;
+    if (threadIdx.x == 0) {
+        blocks_max = 0;
     }
-    const sdrm_chunk_ctl ctl = b.ctl[c];
-    if (ctl.nco_cnt == 0) {
-        return;
-    }
-    float phase = b.nco_phase_state[c];
-    float *out = b.nco_phase + (size_t) c * b.nco_stride;
-    const sdrm_nco_seg *seg = b.nco_segs + ctl.nco_off;
-    uint32_t n = 0;
-    for (uint32_t k = 0; k < ctl.nco_cnt; k++) {
-        const float step = seg[k].step;
-        uint32_t left = seg[k].len;
-        // peel to a 4-sample boundary, then whole float4 stores
-        while (left > 0 && (n & 3u)) {
-            out[n++] = phase;
-            phase = sdrm_nco_advance(phase, step);
-            left--;
+    __syncthreads();
+    if (wave == 0) {
+        const int c = c0 + lane;
+        uint32_t nb = 0;
+        if (c < b.n_channels && b.ctl[c].nco_cnt != 0) {
+            nb = (b.ctl[c].n_in + K0_BLK - 1) / K0_BLK;
         }
-        const float two_pi = 6.28318530717958647692f;
-        if (fabsf(step) <= two_pi && fabsf(phase) <= two_pi) {
-            // the usual case: branch-free step, four dependent instructions per sample instead of two divergent tests
-            const float w = copysignf(two_pi, step);
-            for (; left >= 4; left -= 4) {
-                float4 v;
-                v.x = phase;
-                phase = sdrm_nco_advance_signed(phase, step, w);
-                v.y = phase;
-                phase = sdrm_nco_advance_signed(phase, step, w);
-                v.z = phase;
-                phase = sdrm_nco_advance_signed(phase, step, w);
-                v.w = phase;
-                phase = sdrm_nco_advance_signed(phase, step, w);
-                *reinterpret_cast<float4 *>(out + n) = v;
-                n += 4;
+        blocks_of[lane] = nb;
+        atomicMax(&blocks_max, nb);
+    }
+    __syncthreads();
+    const uint32_t n_blocks = blocks_max;
+    if (n_blocks == 0) {
+        return;
+    }
+    if (wave == 0) {
+        // ---- generator: a single dependent chain; issue ahead of whatever else shares the SIMD
+        __builtin_amdgcn_s_setprio(3);
+        const int c = c0 + lane;
+        const bool mine = blocks_of[lane] != 0;
+        sdrm_chunk_ctl ctl;
+        ctl.nco_cnt = 0;
+        ctl.nco_off = 0;
+        if (mine) {
+            ctl = b.ctl[c];
+        }
+        const sdrm_nco_seg *seg = b.nco_segs + ctl.nco_off;
+        float phase = mine ? b.nco_phase_state[c] : 0.0f;
+        float last = phase;      // the state to keep: the phase after the channel's last sample
+        bool open = mine;        // still inside its batches
+        uint32_t k = 0, left = 0;
+        float step = 0.0f;
+        float *row = &ring[0][0] + lane * K0_ROW;
+        for (uint32_t blk = 0; blk < n_blocks; blk++) {
+            float *dst = row + (blk & 1) * (64 * K0_ROW);
+            if (left == 0 && open) {
+                // next batch (empty ones are skipped); past the last one the lane idles on step 0 until the block loop ends
+                while (k < ctl.nco_cnt && seg[k].len == 0) {
+                    k++;
+                }
+                if (k < ctl.nco_cnt) {
+                    step = seg[k].step;
+                    left = seg[k].len;
+                    k++;
+                } else {
+                    open = false;
+                    last = phase;
+                    step = 0.0f;
+                }
+            }
+            if (!open) {
+                left = 0xffffffffu;
+            }
+            if (k0_block_is_plain(left, step, phase)) {
+                const float w = copysignf(6.28318530717958647692f, step);
+#pragma unroll
+                for (int g = 0; g < K0_BLK / 4; g++) {
+                    float4 v;
+                    k0_advance4(v, phase, step, w);
+                    *reinterpret_cast<float4 *>(dst + 4 * g) = v;
+                }
+                left -= K0_BLK;
+            } else {
+                // a batch ends inside this block for some lane (about once a second per channel), or a step beyond one
+                // turn: the reference's two-test wrap, batch bookkeeping per sample
+                for (int s = 0; s < K0_BLK; s++) {
+                    while (left == 0 && open) {
+                        if (k < ctl.nco_cnt) {
+                            step = seg[k].step;
+                            left = seg[k].len;
+                            k++;
+                        } else {
+                            open = false;
+                            last = phase;
+                            step = 0.0f;
+                            left = 0xffffffffu;
+                        }
+                    }
+                    dst[s] = phase;
+                    phase = sdrm_nco_advance(phase, step);
+                    left--;
+                }
+            }
+            K0_HANDOVER();
+        }
+        if (mine) {
+            b.nco_phase_state[c] = open ? phase : last;
+        }
+    } else {
+        // ---- store wave: 16 lanes per channel row, 4 rows per instruction
+        __builtin_amdgcn_s_setprio(2);
+        const int piece = lane & 15, sub = lane >> 4;
+        uint32_t nb[16], nb_all = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            nb[q] = blocks_of[q * 4 + sub];
+            nb_all = nb[q] < nb_all ? nb[q] : nb_all;
+        }
+        // blocks every channel of the workgroup still has: stores without a test
+        uint32_t n_common = n_blocks;
+        for (int l = 0; l < 64; l++) {
+            const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) nb_all, l);
+            n_common = v < n_common ? v : n_common;
+        }
+        // uniform base + 32-bit lane offset: one address register per row, the block advance is scalar
+        float *base = b.nco_phase + (size_t) c0 * b.nco_phase_stride;
+        uint32_t off[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            off[q] = ((uint32_t) (q * 4 + sub) * b.nco_phase_stride + (uint32_t) piece * 4) * (uint32_t) sizeof(float);
+        }
+        const float *src = &ring[0][0] + sub * K0_ROW + piece * 4;
+        for (uint32_t blk = 0; blk < n_blocks; blk++) {
+            K0_HANDOVER();
+            const float *from = src + (blk & 1) * (64 * K0_ROW);
+            float4 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                v[q] = *reinterpret_cast<const float4 *>(from + q * 4 * K0_ROW);
+            }
+            // all sixteen reads in flight before the first store: the compiler would otherwise sink each read into its
+            // store's branch and pay one LDS round trip per row
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+            }
+            char *col = reinterpret_cast<char *>(base + (size_t) blk * K0_BLK);
+            if (blk < n_common) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    *reinterpret_cast<float4 *>(col + off[q]) = v[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    if (blk < nb[q]) {
+                        *reinterpret_cast<float4 *>(col + off[q]) = v[q];
+                    }
+                }
             }
         }
-        for (; left >= 4; left -= 4) {
-            float4 v;
-            v.x = phase;
-            phase = sdrm_nco_advance(phase, step);
-            v.y = phase;
-            phase = sdrm_nco_advance(phase, step);
-            v.z = phase;
-            phase = sdrm_nco_advance(phase, step);
-            v.w = phase;
-            phase = sdrm_nco_advance(phase, step);
-            *reinterpret_cast<float4 *>(out + n) = v;
-            n += 4;
-        }
-        while (left > 0) {
-            out[n++] = phase;
-            phase = sdrm_nco_advance(phase, step);
-            left--;
-        }
     }
-    b.nco_phase_state[c] = phase;
 }
 
 // mix: out[n] = in[n] * (cos, sin)(phase[n]), cos/sin in double on the fp32 phase (sig_source.c:46, :71)
@@ -93,18 +222,24 @@ __global__ __launch_bounds__(256) void k0_nco_mix(DeviceBatch b, const sdrm_f2 *
         return;
     }
     const sdrm_f2 *in = d_in + (size_t) c * in_stride;
-    const float *ph = b.nco_phase + (size_t) c * b.nco_stride;
+    const float *ph = b.nco_phase + (size_t) c * b.nco_phase_stride;
     sdrm_f2 *out = b.nco_out + (size_t) c * b.nco_stride;
     for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < ctl.n_in; n += gridDim.x * blockDim.x) {
         out[n] = sdrm_nco_mix(in[n], sdrm_nco_sample(ph[n]));
     }
 }
 
-void launch_nco(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s) {
+void launch_nco_phase(const DeviceBatch &b, hipStream_t s) {
+    if (b.nco_segs == nullptr) {
+        return;
+    }
+    hipLaunchKernelGGL(k0_nco_phase, dim3((unsigned) ((b.n_channels + 63) / 64)), dim3(128), 0, s, b);
+}
+
+void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s) {
     if (b.nco_segs == nullptr || max_len == 0) {
         return;
     }
-    hipLaunchKernelGGL(k0_nco_phase, dim3((unsigned) ((b.n_channels + 63) / 64)), dim3(64), 0, s, b);
     unsigned gx = (max_len + 1023) / 1024;
     hipLaunchKernelGGL(k0_nco_mix, dim3(gx ? gx : 1, (unsigned) b.n_channels), dim3(256), 0, s, b, d_in, in_stride);
 }

@@ -36,9 +36,10 @@ struct DeviceBatch {
     // NCO pre-mix (optional): per-call segment table, per-channel fp32 phase, phase scratch and mixed-IQ buffer
     const sdrm_nco_seg *nco_segs;
     float *nco_phase_state;          // [C]
-    float *nco_phase;                // [C][nco_stride] phase of every sample of the call
+    float *nco_phase;                // [C][nco_phase_stride] phase of every sample of the call
     sdrm_f2 *nco_out;                // [C][nco_stride] input after the mix (what K1 reads for NCO channels)
     uint32_t nco_stride;
+    uint32_t nco_phase_stride;       // padded off the power of two: all channels write the same column at the same time
     // launch geometry (host-computed maxima over the batch)
     uint32_t max_tiles;              // K1 grid.x for this call
     uint32_t t1_max, t2_max;         // size K1's LDS
@@ -50,7 +51,8 @@ size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s);
 size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap, int n_channels);
 
-void launch_nco(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);
+void launch_nco_phase(const DeviceBatch &b, hipStream_t s);
+void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);
 void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
 void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
 void launch_dc(const DeviceBatch &b, hipStream_t s);

@@ -450,6 +450,51 @@ def test_mixed_rate_batch_with_per_channel_doppler_ramp():
     g.close()
 
 
+def test_nco_ragged_batches_and_large_steps_match_oracle():
+    """The phase generator works in 64-sample blocks, 64 channels per workgroup: batches that end anywhere inside a
+    block, empty batches, empty and odd-length inputs, channels that skip the correction for a call, a partly filled
+    second workgroup, and shifts beyond the sampling rate (|step| > 2 pi: the reference's two-test wrap,
+    sig_source.c:47-53) must all give the oscillator the oracle gives, sample for sample."""
+    rng = np.random.default_rng(77)
+    n_ch, maxlen, fs = 70, 5000, 48000
+    g = binding.Batch([(fs, 9600, 5000, 1, 2000, True, maxlen)] * n_ch)
+    assert g.code == 0
+    ncos = [orc.Nco(1.0, fs, maxlen) for _ in range(n_ch)]
+    total = same = 0
+    for call in range(4):
+        parts, segs, want = [], [], []
+        for c in range(n_ch):
+            n = int(rng.choice([0, 1, 3, 63, 64, 65, 1000, 4097, maxlen])) if rng.random() < 0.5 else int(rng.integers(0, maxlen + 1))
+            x = (rng.standard_normal(2 * n) * 0.5).astype(np.float32)
+            parts.append(x.view(np.complex64))
+            if n == 0 or rng.random() < 0.1:
+                want.append(None)
+                continue
+            k = int(rng.integers(1, 7))
+            cuts = np.sort(rng.integers(0, n + 1, size=k - 1))
+            lens = np.diff(np.concatenate([[0], cuts, [n]])).astype(int)
+            ref, off = [], 0
+            for ln in lens:
+                f = int(rng.choice([60000, -70000, 123457])) if rng.random() < 0.08 else int(rng.integers(-20000, 20001))
+                segs.append((c, int(ln), f))
+                if ln:
+                    ref.append(ncos[c].multiply(f, x[2 * off:2 * (off + ln)]))
+                off += ln
+            want.append(np.concatenate(ref))
+        g.process_nco(parts, segs)
+        for c in range(n_ch):
+            got = g.last_mixed(c)
+            if want[c] is None:
+                assert len(got) == 0, (call, c)
+                continue
+            assert len(got) == len(want[c]), (call, c)
+            assert np.abs(got - want[c]).max() < 1e-6, (call, c)
+            total += len(got)
+            same += int(np.sum(got.view(np.uint32) == want[c].view(np.uint32)))
+    assert same / total > 0.9999, same / total
+    g.close()
+
+
 def test_dsp_worker_with_doppler_callback():
     """the worker's Doppler leg (reference src/dsp_worker.c:65-71): shifts come from a per-second callback"""
     L = binding.load()
