@@ -641,6 +641,11 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
             HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[prev2], 0));  // channels without DC: K3 reads z
         }
     }
+    if (!b->serial && i >= 3 && sdrm::front_waits_for_clock_start((int) C)) {
+        // let the clock stage of call i-2 (released by the end of call i-3's) take its CUs before this grid floods the chip
+        HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[(i + SDRM_CTL_SLOTS - 3) % SDRM_CTL_SLOTS], 0));
+        sdrm::launch_front_hold(b->s_front);
+    }
     if (nco_aside) {
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->ev_phase[slot], 0));
     } else {

@@ -30,19 +30,40 @@
          ? (size_t) (SDRM_K1_NY + (t1_max)) * 8                                      \
          : (size_t) (2 * SDRM_K1_NY + SDRM_K1_QPAD) * 4)
 
-#define SDRM_K3_LANES 64
-#define SDRM_K3_RING 256    // per-channel sample ring in LDS (power of two): 4 staging blocks
+// Channels per clock-recovery workgroup (one per consumer lane).  The rings of a workgroup fill most of a CU's LDS
+// (which also keeps the other stages' workgroups off that CU), so channels x ring length is fixed: fewer channels =
+// longer rings = longer staging steps, i.e. fewer hand-overs (barrier, limits, loop entry with its exposed first loads)
+// per symbol, and LDS instructions that move a quarter of the data.  A lone wave pays per instruction, not per lane:
+// with 16 of the consumer's 64 lanes in use a symbol costs ~257 cycles instead of ~312 (64 lanes), at the price of four
+// times as many CUs held.  sdrm_k3_lanes_for() picks per batch size.
+#define SDRM_K3_WAVE 64     // lanes of the staging wave (lane = time)
 #define SDRM_K3_PRE 3       // mirror slots below slot 0 (a symbol reads up to 3 samples before its window)
 #define SDRM_K3_POST 8      // mirror slots above slot RING-1 (a window is 8 samples)
-#define SDRM_K3_ROWS (SDRM_K3_PRE + SDRM_K3_RING + SDRM_K3_POST)
 // A channel's ring holds PAIRS: element e = {x[e], x[e+1]} (8 bytes, 8-byte aligned), so that the 8 samples of a window
 // starting anywhere are elements s, s+2, s+4, s+6: two ds_read2_b64 instead of four ds_read2_b32 (an LDS instruction
-// costs a lone wave ~12 cycles of issue whatever its width, tools/ubench_chain.hip).
-#define SDRM_K3_CPITCH (2 * SDRM_K3_ROWS)  // floats between two channels' rings (534: 22 mod 64, conflict-free b64 reads)
+// costs a lone wave ~12 cycles of issue whatever its width, tools/ubench_chain.hip; a 16-byte read that is only 4-byte
+// aligned is served, but in 64 cycles: tools/ubench_lds_unaligned.hip).
+template <int LANES>
+struct sdrm_k3_geom {
+    static constexpr int lanes = LANES;
+    static constexpr int ring = 16384 / LANES;           // per-channel sample ring in LDS (power of two): 4 staging blocks
+    static constexpr int block = ring / 4;               // samples staged per channel per step
+    static constexpr int segs = block / SDRM_K3_WAVE;    // 64-sample row segments per channel and step
+    static constexpr int rows = SDRM_K3_PRE + ring + SDRM_K3_POST;
+    static constexpr int cpitch = 2 * rows;              // floats between two channels' rings (22 mod 64 for every LANES: conflict-free b64 reads)
+};
 #ifndef SDRM_K3_BANKPITCH
 #define SDRM_K3_BANKPITCH 12  // floats between two rows of the MMSE bank copy in LDS (48 B: rows start on 16 different bank offsets instead of 8)
 #endif
-#define SDRM_K3_BLOCK 64    // samples staged per channel per step (one per producer lane)
+// channels per workgroup for a batch of n channels: 16 while that holds at most a quarter of the CUs (the other stages
+// need the rest from ~1000 channels on), else 64.  Measured (ms per step, 131072-sample chunks; lanes 64 / 32 / 16 / 8):
+// 256 channels 3.96 / 3.18 / 3.09 / 3.07, 1024: 4.67 / 4.37 / 3.88 / 4.46, 2048: 6.98 / 7.08 / 7.46 / 8.94.
+static inline int sdrm_k3_lanes_for(int n_channels, int forced) {
+    if (forced == 16 || forced == 64) {
+        return forced;
+    }
+    return n_channels <= 1024 ? 16 : 64;
+}
 
 // immutable per-channel parameters (device array, one per channel)
 struct sdrm_chan_params {
@@ -384,7 +405,7 @@ SDRM_HD void sdrm_hist_roll(int tid, int nthreads, const sdrm_chan_params &p, co
 // ------------------------------------------------------------------------------------------------ K3
 
 // per-lane context of the clock-recovery kernel; col = this channel's sample ring in LDS (ring[channel][slot]).
-// Ring slot of chunk-relative sample n (n < 0: carried history) is n & (SDRM_K3_RING-1).
+// Ring slot of chunk-relative sample n (n < 0: carried history) is n & (RING-1).
 struct sdrm_k3_lane {
     sdrm_mm_state st;
     sdrm_mm_consts k;
@@ -397,23 +418,26 @@ struct sdrm_k3_lane {
 // `col` = this channel's ring (ring + channel * CPITCH).  Element e = {x[e], x[e+1]} lives at col[2 * (slot + PRE)],
 // slot = e & (RING-1).  Slots < POST are mirrored above the ring and slots >= RING-PRE below it, so the elements
 // [slot-3, slot+7] around any slot are contiguous: a symbol's samples are one base address plus constant offsets.
+template <int RING>
 SDRM_HD void sdrm_k3_elem_put(float *col, int slot, int half, float v) {
     col[2 * (slot + SDRM_K3_PRE) + half] = v;
     if (slot < SDRM_K3_POST) {
-        col[2 * (slot + SDRM_K3_RING + SDRM_K3_PRE) + half] = v;
+        col[2 * (slot + RING + SDRM_K3_PRE) + half] = v;
     }
-    if (slot >= SDRM_K3_RING - SDRM_K3_PRE) {
-        col[2 * (slot - SDRM_K3_RING + SDRM_K3_PRE) + half] = v;
+    if (slot >= RING - SDRM_K3_PRE) {
+        col[2 * (slot - RING + SDRM_K3_PRE) + half] = v;
     }
 }
 
 // sample n is the first half of its own element and the second half of its predecessor's
+template <int RING>
 SDRM_HD void sdrm_k3_ring_put(float *col, int n, float v) {
-    sdrm_k3_elem_put(col, n & (SDRM_K3_RING - 1), 0, v);
-    sdrm_k3_elem_put(col, (n - 1) & (SDRM_K3_RING - 1), 1, v);
+    sdrm_k3_elem_put<RING>(col, n & (RING - 1), 0, v);
+    sdrm_k3_elem_put<RING>(col, (n - 1) & (RING - 1), 1, v);
 }
 
-SDRM_HD float sdrm_k3_ring_get(const float *col, int n) { return col[2 * ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE)]; }
+template <int RING>
+SDRM_HD float sdrm_k3_ring_get(const float *col, int n) { return col[2 * ((n & (RING - 1)) + SDRM_K3_PRE)]; }
 
 // The loop condition `ii < working_len - 7` (clock_recovery_mm.c:103, ii compared as size_t: negative => stop) with
 // `avail` chunk samples staged, as ONE unsigned compare against a per-block limit: the window starts at chunk-relative
@@ -439,10 +463,10 @@ struct sdrm_k3_operands {
 
 // reference src/dsp/mmse_fir_interpolator.c:189: row = rint(mu * 128) (mu*128 in fp32, half-to-even)
 // (RingPtr / BankPtr: plain `const float *` on the host, LDS-address-space pointers in the kernel)
-template <bool FINITE, typename RingPtr, typename BankPtr>
+template <bool FINITE, int RING, typename RingPtr, typename BankPtr>
 SDRM_HD void sdrm_k3_fetch(const sdrm_k3_lane &L, RingPtr col, BankPtr bank_rev, sdrm_k3_operands &F) {
     const int n = L.st.ii - L.kept;
-    const RingPtr base = col + 2 * ((n & (SDRM_K3_RING - 1)) + SDRM_K3_PRE);
+    const RingPtr base = col + 2 * ((n & (RING - 1)) + SDRM_K3_PRE);
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {  // elements s, s+2, s+4, s+6
         F.w[j] = base[2 * j];

@@ -428,6 +428,17 @@ __global__ void k2_hold(int loops) {
         __builtin_amdgcn_s_sleep(127);
     }
 }
+// The front-end of call k+2 and the clock stage of call k are both free to go when the clock stage of call k-1 ends.
+// A clock-recovery workgroup needs a CU's LDS nearly to itself; once the front-end's thousands of small workgroups are
+// streaming through the chip no CU ever has that much free, and the clock stage starts only when the front-end's grid
+// has drained (seen: every other call 0.5-1.2 ms late at 512 channels).  Half a hold in the front-end's stream lets
+// the clock stage place its workgroups first.
+// Measured with and without (ms per step, 131072-sample chunks): 384 channels 3.30 / 3.86, 512: 3.39 / 3.96, 768: 3.43 /
+// 4.34, 1024: 3.93 / 3.90; below (256: 3.22 / 3.10) the stages' phases happen to miss each other anyway and above
+// (1536: 5.46 / 5.24) the front-end is what the step waits for: neither is held.
+bool front_waits_for_clock_start(int n_channels) { return n_channels >= 384 && n_channels <= 1024; }
+void launch_front_hold(hipStream_t s) { hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 12); }
+
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s) {
     if (b.any_dc && k2_keeps_off_clock_cus(b.n_channels)) {
         hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 30);
@@ -662,19 +673,23 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 
 // ================================================================================================ K3
 
-// One lane per channel, 64 channels per CONSUMER wave (reference src/dsp/clock_recovery_mm.c:78-139 per lane); a second
-// PRODUCER wave of the same workgroup stages the samples, so the two overlap.
-// Producer: per step, SDRM_K3_BLOCK (= 64, one per lane) samples of each of the 64 channels go from global memory
-// (coalesced row reads, lane = time, prefetched one step ahead into registers) into per-channel LDS rings of pair
-// elements {x[e], x[e+1]} (sdrm_kernels.h; channel pitch 534 floats: the producer's lane = time writes walk through a
-// ring, the consumer's lane = channel reads spread over the banks).  A ring holds 4 steps; mirror elements at both ends
-// keep every window contiguous.  Consumer: each lane runs its own loop while staged samples last (lanes drop out of the
-// exec mask as they run out); a symbol's 8 window samples are one base address plus constant offsets, and the next
-// symbol's operands are fetched before the current symbol is quantised and stored.  Without NaN/Inf in the wave's
-// channels the int8-only build runs the hand-scheduled loop below (k3_drain_finite), otherwise and for the
-// float-soft-bit build the C++ form of the same arithmetic.  One barrier per step hands block k to the consumer while
-// block k+1 is written.
-size_t k3_lds_bytes() { return (size_t) (SDRM_K3_LANES * SDRM_K3_CPITCH + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_LANES) * sizeof(float); }
+// One lane per channel, LANES (16 or 64, sdrm_k3_lanes_for) channels per CONSUMER wave (reference
+// src/dsp/clock_recovery_mm.c:78-139 per lane); a second PRODUCER wave of the same workgroup stages the samples, so the
+// two overlap.
+// Producer: per step, a block (a quarter ring: 256 or 64 samples) of each of the workgroup's channels goes from global
+// memory (coalesced 64-sample row segments, lane = time, prefetched one step ahead into registers) into per-channel LDS
+// rings of pair elements {x[e], x[e+1]} (sdrm_kernels.h; channel pitch 22 mod 64 floats: the producer's lane = time
+// writes walk through a ring, the consumer's lane = channel reads spread over the banks).  A ring holds 4 steps; mirror
+// elements at both ends keep every window contiguous.  Consumer: each lane runs its own loop while staged samples last
+// (lanes drop out of the exec mask as they run out); a symbol's 8 window samples are one base address plus constant
+// offsets, and the next symbol's operands are fetched before the current symbol is quantised and stored.  Without
+// NaN/Inf in the wave's channels the int8-only build runs the hand-scheduled loop below (k3_drain_finite), otherwise
+// and for the float-soft-bit build the C++ form of the same arithmetic.  One barrier per step hands block k to the
+// consumer while block k+1 is written.
+size_t k3_lds_bytes(int lanes) {
+    const size_t rings = lanes == 16 ? (size_t) 16 * sdrm_k3_geom<16>::cpitch : (size_t) 64 * sdrm_k3_geom<64>::cpitch;
+    return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_WAVE) * sizeof(float);
+}
 
 // Order of work inside a symbol:
 //   o = ((((((((0 + w0 t0) + w1 t1) + ...) + w7 t7)   (mmse_fir_interpolator.c:188-191, fir_filter.c:116-121)
@@ -750,7 +765,7 @@ size_t k3_lds_bytes() { return (size_t) (SDRM_K3_LANES * SDRM_K3_CPITCH + 129 * 
 //   v64..v87 are scratch (named, so that halves of the 64-bit pairs can be addressed); everything else is allocated
 //   by the compiler.  exec is narrowed as lanes run out of samples and restored on exit.
 __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, uint32_t col_addr, uint32_t bank_addr,
-                                                uint32_t &off, uint32_t off_end, const int8_t *out_base) {
+                                                uint32_t &off, uint32_t off_end, const int8_t *out_base, uint32_t ring_mask) {
     // row address = bank + rowbytes * rint(mu * 128): the low 24 bits of (mu * 128 + 1.5 * 2^23) are 0x400000 + row, so a
     // 24-bit multiply-add with this bias lands on the row (the sum wraps modulo 2^32)
     const uint32_t bias = bank_addr - 0x400000u * (SDRM_K3_BANKPITCH * 4u);
@@ -787,7 +802,7 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         : [kept] "v"(L.kept), [lim] "v"(lim), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [go] "v"(L.k.gain_omega),
           [gm] "v"(L.k.gain_mu), [mid] "v"(L.k.omega_mid), [olim] "v"(L.k.omega_lim), [lo] "v"(-128.0f), [hi] "v"(127.0f),
           [offlast] "v"(off_end - 1u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base),
-          [m255] "s"(255u), [c127] "s"(127.0f), [rowb] "n"(SDRM_K3_BANKPITCH * 4)
+          [m255] "s"(ring_mask), [c127] "s"(127.0f), [rowb] "n"(SDRM_K3_BANKPITCH * 4)
         : "memory", "vcc", "s74", "s75", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
           "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
     L.st.mu = mu;
@@ -797,20 +812,21 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     L.st.inc = inc;
 }
 
-template <bool SOFT>
+template <bool SOFT, int LANES>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
+    typedef sdrm_k3_geom<LANES> G;
     extern __shared__ __attribute__((aligned(16))) float k3_lds[];
     float *bank_rev = k3_lds;                       // [129*8] at LDS offset 0: a row is two aligned ds_read_b128
     float *ring = bank_rev + ((129 * SDRM_K3_BANKPITCH + 3) & ~3);  // [LANES][CPITCH]
-    int *nz_sh = reinterpret_cast<int *>(ring + SDRM_K3_LANES * SDRM_K3_CPITCH);  // [64] samples per channel
-    int *dc_sh = nz_sh + SDRM_K3_LANES;                                          // [64] reads dcout (1) or z (0)
+    int *nz_sh = reinterpret_cast<int *>(ring + G::lanes * G::cpitch);  // [64] samples per channel
+    int *dc_sh = nz_sh + SDRM_K3_WAVE;                                           // [64] reads dcout (1) or z (0)
     tl_mark(b, 2, 0);
     const int lane = threadIdx.x & 63;
     const bool producer = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) != 0;
-    const int c0 = blockIdx.x * SDRM_K3_LANES;
+    const int c0 = blockIdx.x * G::lanes;
     const int c = c0 + lane;
-    const bool active = c < b.n_channels;
-    const int nrows = b.n_channels - c0 < SDRM_K3_LANES ? b.n_channels - c0 : SDRM_K3_LANES;
+    const bool active = lane < G::lanes && c < b.n_channels;
+    const int nrows = b.n_channels - c0 < G::lanes ? b.n_channels - c0 : G::lanes;
     for (int k = threadIdx.x; k < 129 * 8; k += 128) {
         bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];  // rows reversed once: tap j meets window sample j
     }
@@ -825,7 +841,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     L.st.ii = 0;
     L.st.inc = 0;
     L.k.omega_mid = L.k.omega_lim = L.k.gain_omega = L.k.gain_mu = 0.0f;
-    float *my_col = ring + lane * SDRM_K3_CPITCH;  // this channel's ring
+    float *my_col = ring + (lane & (G::lanes - 1)) * G::cpitch;  // this channel's ring
     sdrm_clock_state *cs = b.clock_state + (active ? c : 0);
     bool clean = true;
     uint32_t flagged = 0;
@@ -847,7 +863,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             flagged = b.nonfinite[c];
             clean = (flagged == 0) & (cs->poison == 0);
             for (int j = 0; j < L.kept; j++) {
-                sdrm_k3_ring_put(my_col, j - L.kept, cs->hist[j]);
+                sdrm_k3_ring_put<G::ring>(my_col, j - L.kept, cs->hist[j]);
             }
         }
         nz_sh[lane] = L.nz;
@@ -865,27 +881,31 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         max_nz = v > max_nz ? v : max_nz;
         min_nz = v < min_nz ? v : min_nz;
     }
-    const bool uniform = same_src && nrows == SDRM_K3_LANES;
-    const int nblocks = (max_nz + SDRM_K3_BLOCK - 1) / SDRM_K3_BLOCK;
+    const bool uniform = same_src && nrows == G::lanes;
+    const int nblocks = (max_nz + G::block - 1) / G::block;
 
     if (producer) {
         const float *row0 = (__builtin_amdgcn_readfirstlane(my_dc) ? b.dcout : b.z) + (size_t) c0 * b.z_stride;
-        float pre[SDRM_K3_LANES];  // prefetched row segments: pre[r] = sample `lane` of channel c0+r's next block
+        float pre[G::lanes * G::segs];  // prefetched row segments: pre[r * SEGS + h] = sample h*64 + lane of channel c0+r's next block
 #define K3_ROW_SRC(r) ((__builtin_amdgcn_readlane(my_dc, (r)) ? b.dcout : b.z) + (size_t) (c0 + (r)) * b.z_stride)
 #define K3_ISSUE(k)                                                                                          \
     {                                                                                                        \
-        const int n_ = (k) * SDRM_K3_BLOCK + lane;                                                            \
-        if (uniform && ((k) + 1) * SDRM_K3_BLOCK <= min_nz) {                                                 \
+        const int n_ = (k) * G::block + lane;                                                            \
+        if (uniform && ((k) + 1) * G::block <= min_nz) {                                                 \
             const float *p_ = row0 + n_;                                                                      \
-            _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                pre[r] = *p_;                                                                                 \
+            _Pragma("unroll") for (int r = 0; r < G::lanes; r++) {                                       \
+                _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                    \
+                    pre[r * G::segs + h] = p_[h * SDRM_K3_WAVE];                                         \
+                }                                                                                            \
                 p_ += b.z_stride;                                                                             \
             }                                                                                                \
         } else {                                                                                             \
-            _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                pre[r] = 0.0f;                                                                                \
-                if (r < nrows && n_ < __builtin_amdgcn_readlane(my_nz, r)) {                                  \
-                    pre[r] = K3_ROW_SRC(r)[n_];                                                               \
+            _Pragma("unroll") for (int r = 0; r < G::lanes; r++) {                                       \
+                _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                    \
+                    pre[r * G::segs + h] = 0.0f;                                                         \
+                    if (r < nrows && n_ + h * SDRM_K3_WAVE < __builtin_amdgcn_readlane(my_nz, r)) {           \
+                        pre[r * G::segs + h] = K3_ROW_SRC(r)[n_ + h * SDRM_K3_WAVE];                     \
+                    }                                                                                        \
                 }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
@@ -894,34 +914,39 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         // mirror rows with a small copy pass, the ragged path goes element by element through sdrm_k3_ring_put
 #define K3_COMMIT(k)                                                                                         \
     {                                                                                                        \
-        const int n_ = (k) * SDRM_K3_BLOCK + lane;                                                            \
-        if (uniform && ((k) + 1) * SDRM_K3_BLOCK <= min_nz) {                                                 \
-            /* sample n_ = first half of element n_, second half of element n_ - 1 (of every channel r) */  \
-            float *lo_ = ring + 2 * ((n_ & (SDRM_K3_RING - 1)) + SDRM_K3_PRE);                                \
-            float *hi_ = ring + 2 * (((n_ - 1) & (SDRM_K3_RING - 1)) + SDRM_K3_PRE) + 1;                      \
-            _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
-                lo_[r * SDRM_K3_CPITCH] = pre[r];                                                             \
-                hi_[r * SDRM_K3_CPITCH] = pre[r];                                                             \
+        const int n_ = (k) * G::block + lane;                                                            \
+        if (uniform && ((k) + 1) * G::block <= min_nz) {                                                 \
+            /* sample n = first half of element n, second half of element n - 1 (of every channel r) */      \
+            _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                        \
+                const int nh_ = n_ + h * SDRM_K3_WAVE;                                                        \
+                float *lo_ = ring + 2 * ((nh_ & (G::ring - 1)) + SDRM_K3_PRE);                           \
+                float *hi_ = ring + 2 * (((nh_ - 1) & (G::ring - 1)) + SDRM_K3_PRE) + 1;                 \
+                _Pragma("unroll") for (int r = 0; r < G::lanes; r++) {                                   \
+                    lo_[r * G::cpitch] = pre[r * G::segs + h];                                      \
+                    hi_[r * G::cpitch] = pre[r * G::segs + h];                                      \
+                }                                                                                            \
             }                                                                                                \
             __builtin_amdgcn_wave_barrier();                                                                  \
             /* mirrors, one channel per lane: elements 0..7 above the ring when this block wrote them (and the */ \
-            /* second half of element 255 below it), elements 253..255 below the ring when it wrote those */  \
-            if ((((k) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                          \
+            /* second half of the last element below it), the last three elements below the ring when it wrote those */ \
+            if ((((k) * G::block) & (G::ring - 1)) == 0 && lane < G::lanes) {                  \
                 _Pragma("unroll") for (int j = 0; j < 2 * SDRM_K3_POST; j++) {                                \
-                    my_col[j + 2 * (SDRM_K3_RING + SDRM_K3_PRE)] = my_col[j + 2 * SDRM_K3_PRE];               \
+                    my_col[j + 2 * (G::ring + SDRM_K3_PRE)] = my_col[j + 2 * SDRM_K3_PRE];               \
                 }                                                                                            \
-                my_col[2 * (SDRM_K3_PRE - 1) + 1] = my_col[2 * (SDRM_K3_RING - 1 + SDRM_K3_PRE) + 1];         \
+                my_col[2 * (SDRM_K3_PRE - 1) + 1] = my_col[2 * (G::ring - 1 + SDRM_K3_PRE) + 1];         \
             }                                                                                                \
-            if (((((k) + 1) * SDRM_K3_BLOCK) & (SDRM_K3_RING - 1)) == 0) {                                    \
+            if (((((k) + 1) * G::block) & (G::ring - 1)) == 0 && lane < G::lanes) {            \
                 _Pragma("unroll") for (int j = 0; j < 2 * SDRM_K3_PRE; j++) {                                 \
-                    my_col[j] = my_col[j + 2 * SDRM_K3_RING];                                                 \
+                    my_col[j] = my_col[j + 2 * G::ring];                                                 \
                 }                                                                                            \
             }                                                                                                \
         } else {                                                                                             \
-            _Pragma("unroll") for (int r = 0; r < SDRM_K3_LANES; r++) {                                       \
+            _Pragma("unroll") for (int r = 0; r < G::lanes; r++) {                                       \
                 const int nz_r = r < nrows ? __builtin_amdgcn_readlane(my_nz, r) : 0;                         \
-                if (n_ < nz_r) {                                                                              \
-                    sdrm_k3_ring_put(ring + r * SDRM_K3_CPITCH, n_, pre[r]);                                  \
+                _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                    \
+                    if (n_ + h * SDRM_K3_WAVE < nz_r) {                                                       \
+                        sdrm_k3_ring_put<G::ring>(ring + r * G::cpitch, n_ + h * SDRM_K3_WAVE, pre[r * G::segs + h]); \
+                    }                                                                                        \
                 }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
@@ -962,10 +987,10 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 #define K3_DRAIN(FIN)                                                                                        \
     if (sdrm_k3_can_step(L, lim)) {                                                                          \
         sdrm_k3_operands F;                                                                                   \
-        sdrm_k3_fetch<FIN>(L, col_l, bank_rev, F);                                                            \
+        sdrm_k3_fetch<FIN, G::ring>(L, col_l, bank_rev, F);                                                            \
         do {                                                                                                 \
             const float soft = sdrm_k3_step<FIN>(L, F);                                                       \
-            sdrm_k3_fetch<FIN>(L, col_l, bank_rev, F);                                                        \
+            sdrm_k3_fetch<FIN, G::ring>(L, col_l, bank_rev, F);                                                        \
             *p8++ = FIN ? sdrm_soft_to_i8_finite(soft) : sdrm_soft_to_i8(soft);                               \
             if (SOFT) {                                                                                       \
                 *pf++ = soft;                                                                                 \
@@ -990,13 +1015,13 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             __syncthreads();  // block k staged
         }
         unsigned long long t1 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
-        int avail = (k + 1) * SDRM_K3_BLOCK;
+        int avail = (k + 1) * G::block;
         avail = avail < L.nz ? avail : L.nz;
         const uint32_t lim = active ? sdrm_k3_limit(L, avail) : 0u;
         const uint32_t oo0 = L.oo;
         if (wave_clean && !SOFT && fits32) {
             if (sdrm_k3_can_step(L, lim)) {
-                k3_drain_finite(L, lim, col_addr, bank_addr, off, off_end, b.out_i8);
+                k3_drain_finite(L, lim, col_addr, bank_addr, off, off_end, b.out_i8, (uint32_t) (G::ring - 1));
                 L.oo = off - off_base;
                 p8 = o8 + L.oo;
             }
@@ -1010,7 +1035,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             t_wait += t1 - t0;
             t_drain += t2 - t1;
             uint32_t most = 0;  // loop iterations of this block = the most symbols any lane produced in it
-            for (int r = 0; r < SDRM_K3_LANES; r++) {
+            for (int r = 0; r < G::lanes; r++) {
                 const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) (L.oo - oo0), r);
                 most = v > most ? v : most;
             }
@@ -1029,7 +1054,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         int from_n, new_kept;
         sdrm_k3_finish(L, &from_n, &new_kept);
         for (int j = 0; j < new_kept; j++) {
-            cs->hist[j] = sdrm_k3_ring_get(my_col, from_n + j);
+            cs->hist[j] = sdrm_k3_ring_get<G::ring>(my_col, from_n + j);
         }
         cs->kept = (uint32_t) new_kept;
         cs->mu = L.st.mu;
@@ -1042,16 +1067,34 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     tl_mark(b, 2, 1);
 }
 
+template <bool SOFT, int LANES>
+static void launch_clock_as(const DeviceBatch &b, hipStream_t s) {
+    const unsigned blocks = (unsigned) ((b.n_channels + LANES - 1) / LANES);
+    static lds_grant granted;
+    const size_t lds = k3_lds_bytes(LANES);
+    allow_lds(k3_clock<SOFT, LANES>, lds, &granted);
+    hipLaunchKernelGGL((k3_clock<SOFT, LANES>), dim3(blocks), dim3(128), lds, s, b);
+}
+
+int k3_forced_lanes() {
+    const char *e = getenv("SDRM_K3_LANES");  // tests and measurements: force one workgroup shape (read per launch)
+    return e ? atoi(e) : 0;
+}
+
 void launch_clock(const DeviceBatch &b, hipStream_t s) {
-    unsigned blocks = (unsigned) ((b.n_channels + SDRM_K3_LANES - 1) / SDRM_K3_LANES);
-    static lds_grant granted_t, granted_f;
-    const size_t lds = k3_lds_bytes();
+    const int lanes = sdrm_k3_lanes_for(b.n_channels, k3_forced_lanes());
     if (b.out_f32) {
-        allow_lds(k3_clock<true>, lds, &granted_t);
-        hipLaunchKernelGGL(k3_clock<true>, dim3(blocks), dim3(128), lds, s, b);
+        if (lanes == 16) {
+            launch_clock_as<true, 16>(b, s);
+        } else {
+            launch_clock_as<true, 64>(b, s);
+        }
     } else {
-        allow_lds(k3_clock<false>, lds, &granted_f);
-        hipLaunchKernelGGL(k3_clock<false>, dim3(blocks), dim3(128), lds, s, b);
+        if (lanes == 16) {
+            launch_clock_as<false, 16>(b, s);
+        } else {
+            launch_clock_as<false, 64>(b, s);
+        }
     }
 }
 

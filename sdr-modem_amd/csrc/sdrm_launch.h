@@ -49,6 +49,8 @@ struct DeviceBatch {
 
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s);
+bool front_waits_for_clock_start(int n_channels);
+void launch_front_hold(hipStream_t s);
 size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap, int n_channels);
 
 void launch_nco_phase(const DeviceBatch &b, hipStream_t s);

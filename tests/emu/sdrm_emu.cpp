@@ -161,19 +161,21 @@ static void emu_dc(EmuBatch *b) {
     }
 }
 
-static void emu_clock(EmuBatch *b) {
+template <int LANES>
+static void emu_clock_as(EmuBatch *b) {
+    typedef sdrm_k3_geom<LANES> G;
     const BatchPlan &pl = b->plan;
     const int C = (int) pl.params.size();
-    std::vector<float> ring(SDRM_K3_LANES * SDRM_K3_CPITCH);
+    std::vector<float> ring(G::lanes * G::cpitch);
     float bank_rev[129 * SDRM_K3_BANKPITCH];
     for (int k = 0; k < 129 * 8; k++) bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = (&sdrm_mmse_bank[0][0])[(k & ~7) + 7 - (k & 7)];
-    for (int c0 = 0; c0 < C; c0 += SDRM_K3_LANES) {
+    for (int c0 = 0; c0 < C; c0 += G::lanes) {
         for (auto &v : ring) v = NAN;
-        sdrm_k3_lane lanes[SDRM_K3_LANES];
-        bool clean[SDRM_K3_LANES];
-        uint32_t flagged[SDRM_K3_LANES];
+        sdrm_k3_lane lanes[G::lanes];
+        bool clean[G::lanes];
+        uint32_t flagged[G::lanes];
         int max_nz = 0;
-        const int nl = C - c0 < SDRM_K3_LANES ? C - c0 : SDRM_K3_LANES;
+        const int nl = C - c0 < G::lanes ? C - c0 : G::lanes;
         for (int l = 0; l < nl; l++) {
             const int c = c0 + l;
             const sdrm_chan_params &p = pl.params[c];
@@ -191,27 +193,27 @@ static void emu_clock(EmuBatch *b) {
             L.st.inc = 0;
             flagged[l] = b->nonfinite[c];
             clean[l] = flagged[l] == 0 && cs.poison == 0;
-            float *col = ring.data() + l * SDRM_K3_CPITCH;
-            for (int j = 0; j < L.kept; j++) sdrm_k3_ring_put(col, j - L.kept, cs.hist[j]);
+            float *col = ring.data() + l * G::cpitch;
+            for (int j = 0; j < L.kept; j++) sdrm_k3_ring_put<G::ring>(col, j - L.kept, cs.hist[j]);
             max_nz = L.nz > max_nz ? L.nz : max_nz;
         }
-        const int nblocks = (max_nz + SDRM_K3_BLOCK - 1) / SDRM_K3_BLOCK;
+        const int nblocks = (max_nz + G::block - 1) / G::block;
         for (int k = 0; k <= nblocks; k++) {
             if (k < nblocks) {
                 for (int r = 0; r < nl; r++) {
                     const int cr = c0 + r;
                     const float *src = (pl.params[cr].dc_len ? b->dcout.data() : b->z.data()) + (size_t) cr * pl.z_stride;
-                    float *col = ring.data() + r * SDRM_K3_CPITCH;
-                    for (int n = k * SDRM_K3_BLOCK; n < (k + 1) * SDRM_K3_BLOCK && n < lanes[r].nz; n++)
-                        sdrm_k3_ring_put(col, n, src[n]);
+                    float *col = ring.data() + r * G::cpitch;
+                    for (int n = k * G::block; n < (k + 1) * G::block && n < lanes[r].nz; n++)
+                        sdrm_k3_ring_put<G::ring>(col, n, src[n]);
                 }
             }
             for (int l = 0; l < nl; l++) {
                 sdrm_k3_lane &L = lanes[l];
-                int avail = (k + 1) * SDRM_K3_BLOCK;
+                int avail = (k + 1) * G::block;
                 avail = avail < L.nz ? avail : L.nz;
                 const int c = c0 + l;
-                const float *col = ring.data() + l * SDRM_K3_CPITCH;
+                const float *col = ring.data() + l * G::cpitch;
                 const uint32_t lim = sdrm_k3_limit(L, avail);
                 while (sdrm_k3_can_step(L, lim)) {
                     // the GPU picks the window/step flavour per wave; every flavour must give the same values, so the
@@ -219,10 +221,10 @@ static void emu_clock(EmuBatch *b) {
                     sdrm_k3_operands F;
                     float soft;
                     if (clean[l]) {
-                        sdrm_k3_fetch<true>(L, col, bank_rev, F);
+                        sdrm_k3_fetch<true, G::ring>(L, col, bank_rev, F);
                         soft = sdrm_k3_step<true>(L, F);
                     } else {
-                        sdrm_k3_fetch<false>(L, col, bank_rev, F);
+                        sdrm_k3_fetch<false, G::ring>(L, col, bank_rev, F);
                         soft = sdrm_k3_step<false>(L, F);
                     }
                     b->out8[(size_t) c * pl.out_stride + L.oo] = clean[l] ? sdrm_soft_to_i8_finite(soft) : sdrm_soft_to_i8(soft);
@@ -237,9 +239,9 @@ static void emu_clock(EmuBatch *b) {
             sdrm_clock_state &cs = b->clock[c];
             int from_n, new_kept;
             sdrm_k3_finish(L, &from_n, &new_kept);
-            const float *col = ring.data() + l * SDRM_K3_CPITCH;
+            const float *col = ring.data() + l * G::cpitch;
             float tmp[SDRM_CLOCK_HCAP];
-            for (int j = 0; j < new_kept; j++) tmp[j] = sdrm_k3_ring_get(col, from_n + j);
+            for (int j = 0; j < new_kept; j++) tmp[j] = sdrm_k3_ring_get<G::ring>(col, from_n + j);
             for (int j = 0; j < new_kept; j++) cs.hist[j] = tmp[j];
             cs.kept = (uint32_t) new_kept;
             cs.mu = L.st.mu;
@@ -249,6 +251,16 @@ static void emu_clock(EmuBatch *b) {
             b->nonfinite[c] = 0;
             b->outlen[c] = L.oo;
         }
+    }
+}
+
+// the workgroup shape the library would launch for this batch (same policy, same SDRM_K3_LANES override)
+static void emu_clock(EmuBatch *b) {
+    const char *e = getenv("SDRM_K3_LANES");
+    if (sdrm_k3_lanes_for((int) b->plan.params.size(), e ? atoi(e) : 0) == 16) {
+        emu_clock_as<16>(b);
+    } else {
+        emu_clock_as<64>(b);
     }
 }
 

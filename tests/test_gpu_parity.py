@@ -104,6 +104,40 @@ def test_design_parameters_match_oracle():
     g.close()
 
 
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_clock_stage_workgroup_shapes(lanes, monkeypatch):
+    """The clock stage runs with 16 channels per workgroup (256-sample steps) up to 1024 channels and with 64 (64-sample
+    steps) beyond; SDRM_K3_LANES forces a shape.  Both shapes, both builds (float soft bits kept / int8 only, i.e. the C++
+    loop and the hand-scheduled one), ragged chunks of one stream and a ragged 69-channel mixed batch with NaN input."""
+    monkeypatch.setenv("SDRM_K3_LANES", str(lanes))
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    chunks = [0, 1, 7, 100, 255, 256, 257, 3839, 5000, 9000, 1, 8191, 12000, 64, 63, 65, 1]
+    assert run_stream((48000, 9600, 5000, 1, 2000, True), iq, chunks, 12000) > 0
+    cfgs = [(48000, 9600, 5000, 1, 2000, True, 8192), (48000, 4800, 5000, 2, 2000, False, 8192),
+            (240000, 19200, 5000, 5, 2000, True, 8192)] * 23
+    sigs = [siggen.gmsk_channel(i, 9000, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    sigs[4][6000] = np.nan
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    want = []
+    spans = [(0, 5000), (5000, 5003), (5003, 9000)]
+    for lo, hi in spans:
+        lens = [(hi - lo) if i % 7 else max(0, hi - lo - 17) for i in range(len(cfgs))]
+        want.append([o.process(s[lo:lo + n]) for o, s, n in zip(oracles, sigs, lens)])
+    for keep_soft in (True, False):
+        g = binding.Batch(cfgs, keep_soft=keep_soft)
+        assert g.code == 0
+        for (lo, hi), ref in zip(spans, want):
+            lens = [(hi - lo) if i % 7 else max(0, hi - lo - 17) for i in range(len(cfgs))]
+            g8 = g.process([s[lo:lo + n] for s, n in zip(sigs, lens)])
+            for i, (o8, of) in enumerate(ref):
+                assert np.array_equal(o8, g8[i]), (lanes, keep_soft, lo, i)
+                if keep_soft:
+                    gf = g.last_soft(i)
+                    both_nan = np.isnan(of) & np.isnan(gf)
+                    assert np.array_equal(of.view(np.uint32)[~both_nan], gf.view(np.uint32)[~both_nan]), (lanes, lo, i)
+        g.close()
+
+
 # ---------------------------------------------------------------- the reference's own fixtures (test/test_fsk_demod.c)
 
 E2E = [
