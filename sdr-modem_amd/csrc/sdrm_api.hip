@@ -1303,7 +1303,7 @@ extern "C" int sdrm_batch_k3_stamps(sdrm_batch *b, int enable, unsigned long lon
         return -1;
     }
     HIP_TRY(hipSetDevice(b->device));
-    const size_t waves = (b->plan.params.size() + 63) / 64;
+    const size_t waves = SDRM_STAMP_K3_WAVES(b->plan.params.size());
     // enable == 1: every call from now on; enable = k > 1: only the k-th call from now (a call in the middle of a
     // pipelined run can then be looked at)
     if (enable > 1) {

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, co
     tl_mark(b, 0, 1);
     if (stamp && tid == 0) {
         unsigned long long t4 = __builtin_amdgcn_s_memtime();
-        unsigned long long *k1s = b.k3_stamps + ((b.n_channels + 63) / 64) * 4;  // after the K3 per-wave records
+        unsigned long long *k1s = b.k3_stamps + SDRM_STAMP_K3_WAVES(b.n_channels) * 4;  // after the K3 per-wave records
         atomicAdd(k1s + 0, t1 - t0);
         atomicAdd(k1s + 1, t2 - t1);
         atomicAdd(k1s + 2, t3 - t2);
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
     }
     __syncthreads();  // all rings final before they go back to the channel's state
     if (stamp && lane == 0 && stage == 0) {
-        unsigned long long *k2s = b.k3_stamps + ((b.n_channels + 63) / 64) * 4 + 8;  // after the K3 and K1 records
+        unsigned long long *k2s = b.k3_stamps + SDRM_STAMP_K3_WAVES(b.n_channels) * 4 + 8;  // after the K3 and K1 records
         k2s[8] = __builtin_amdgcn_s_memtime() - t_begin;
         k2s[9] = (unsigned long long) ((ctl.nz + 63) / 64 + 3 * K2_SKEW);
     }
@@ -694,31 +694,36 @@ size_t k3_lds_bytes(int lanes) {
 // Order of work inside a symbol:
 //   o = ((((((((0 + w0 t0) + w1 t1) + ...) + w7 t7)   (mmse_fir_interpolator.c:188-191, fir_filter.c:116-121)
 //   mm = slice(last) * o - slice(o) * last   (clock_recovery_mm.c:115): both terms take sign(o) ^ sign(last)
-//   omega += gain_omega * mm; omega = mid + clip(omega - mid, lim)   (:119-120, branchless_clip :74-76)
+//   omega += gain_omega * mm; omega = mid + clip(omega - mid, lim)   (:119-120, branchless_clip :74-76); the clip's
+//   final 0.5 * y and the addition of mid are one v_fma: halving is exact (were y the smallest denormals it would not
+//   be, but then both forms return mid), so the fused form rounds once, where the addition does
 //   mu = mu + omega + gain_mu * mm; ii += floor(mu); mu -= floor(mu)   (:121-123)
 //   operands of the next symbol
 //   while (ii < limit && oo < cap)   (:103): compared right behind the loads, combined at the symbol's end (nothing
 //   waits for the compares, and they cost the dependent chain in front of the loads nothing: 316 -> 312 cycles)
 //   int8 soft bit of the symbol just computed (fsk_demod.c:106), in the shadow of the loads
 // one symbol of the hand-scheduled loop (see k3_drain_finite); exec is narrowed at its end
-#define K3_SYMBOL_ASM \
+// ACC / LAST: the register the symbol is accumulated in and the one that holds the previous symbol; consecutive symbols
+// swap them, which saves the copy.  CAPCMP / CAPAND: the `oo < output_len` half of the loop condition, empty in the
+// variant used while the output buffer cannot fill up within the call.
+#define K3_SYMBOL_ASM(ACC, LAST, CAPCMP, CAPAND) \
     "s_waitcnt lgkmcnt(2)\n\t" \
     "v_pk_mul_f32 v[66:67], v[66:67], v[74:75]\n\t" \
     "v_pk_mul_f32 v[68:69], v[68:69], v[76:77]\n\t" \
-    "v_add_f32 v82, 0, v66\n\t" \
-    "v_add_f32 v82, v67, v82\n\t" \
-    "v_add_f32 v82, v68, v82\n\t" \
-    "v_add_f32 v82, v69, v82\n\t" \
+    "v_add_f32 " ACC ", 0, v66\n\t" \
+    "v_add_f32 " ACC ", v67, " ACC "\n\t" \
+    "v_add_f32 " ACC ", v68, " ACC "\n\t" \
+    "v_add_f32 " ACC ", v69, " ACC "\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
     "v_pk_mul_f32 v[70:71], v[70:71], v[78:79]\n\t" \
     "v_pk_mul_f32 v[72:73], v[72:73], v[80:81]\n\t" \
-    "v_add_f32 v82, v70, v82\n\t" \
-    "v_add_f32 v82, v71, v82\n\t" \
-    "v_add_f32 v82, v72, v82\n\t" \
-    "v_add_f32 v82, v73, v82\n\t" \
-    "v_xor_b32 v83, v82, %[last]\n\t" \
-    "v_bfi_b32 v84, %[mask], v82, v83\n\t" \
-    "v_bfi_b32 v85, %[mask], %[last], v83\n\t" \
+    "v_add_f32 " ACC ", v70, " ACC "\n\t" \
+    "v_add_f32 " ACC ", v71, " ACC "\n\t" \
+    "v_add_f32 " ACC ", v72, " ACC "\n\t" \
+    "v_add_f32 " ACC ", v73, " ACC "\n\t" \
+    "v_xor_b32 v83, " ACC ", " LAST "\n\t" \
+    "v_bfi_b32 v84, %[mask], " ACC ", v83\n\t" \
+    "v_bfi_b32 v85, %[mask], " LAST ", v83\n\t" \
     "v_sub_f32 v84, v84, v85\n\t" \
     "v_mul_f32 v85, %[go], v84\n\t" \
     "v_add_f32 %[omega], %[omega], v85\n\t" \
@@ -726,8 +731,7 @@ size_t k3_lds_bytes(int lanes) {
     "v_add_f32 v85, %[olim], %[omega]\n\t" \
     "v_sub_f32 v86, %[omega], %[olim]\n\t" \
     "v_sub_f32_e64 v85, |v85|, |v86|\n\t" \
-    "v_mul_f32 v85, 0.5, v85\n\t" \
-    "v_add_f32 %[omega], %[mid], v85\n\t" \
+    "v_fma_f32 %[omega], v85, 0.5, %[mid]\n\t" \
     "v_mul_f32 v84, %[gm], v84\n\t" \
     "v_add_f32 %[mu], %[mu], %[omega]\n\t" \
     "v_add_f32 %[mu], %[mu], v84\n\t" \
@@ -745,15 +749,16 @@ size_t k3_lds_bytes(int lanes) {
     "ds_read_b128 v[70:73], v65 offset:16\n\t" \
     "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
     "v_cmp_lt_u32 vcc, %[ii], %[lim]\n\t" \
-    "v_cmp_ne_u32 s[74:75], %[off], %[offlast]\n\t" \
-    "v_mov_b32 %[last], v82\n\t" \
-    "v_mul_f32 v83, %[c127], v82\n\t" \
+    CAPCMP \
+    "v_mul_f32 v83, %[c127], " ACC "\n\t" \
     "v_med3_f32 v83, v83, %[lo], %[hi]\n\t" \
     "v_add_f32 v83, %[magic], v83\n\t" \
     "global_store_byte %[off], v83, %[out]\n\t" \
     "v_add_u32 %[off], 1, %[off]\n\t" \
-    "s_and_b64 vcc, vcc, s[74:75]\n\t" \
+    CAPAND \
     "s_and_b64 exec, exec, vcc\n\t"
+#define K3_CAPCMP "v_cmp_ne_u32 s[74:75], %[off], %[offlast]\n\t"
+#define K3_CAPAND "s_and_b64 vcc, vcc, s[74:75]\n\t"
 
 // The FINITE symbol loop of the clock stage, scheduled by hand (same operations, same order per lane as
 // sdrm_k3_fetch<true> + sdrm_k3_step<true> + sdrm_soft_to_i8_finite; the C++ form stays in use for the SOFT build and
@@ -764,6 +769,7 @@ size_t k3_lds_bytes(int lanes) {
 // elements), two waits, and the previous symbol quantised and stored behind the loads.
 //   v64..v87 are scratch (named, so that halves of the 64-bit pairs can be addressed); everything else is allocated
 //   by the compiler.  exec is narrowed as lanes run out of samples and restored on exit.
+template <bool CAP>
 __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, uint32_t col_addr, uint32_t bank_addr,
                                                 uint32_t &off, uint32_t off_end, const int8_t *out_base, uint32_t ring_mask) {
     // row address = bank + rowbytes * rint(mu * 128): the low 24 bits of (mu * 128 + 1.5 * 2^23) are 0x400000 + row, so a
@@ -772,39 +778,62 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     float mu = L.st.mu, omega = L.st.omega, last = L.st.last;
     int ii = L.st.ii, inc = L.st.inc;
     unsigned long long saved_exec;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        // operands of the first symbol: MMSE row (2 x 16 bytes) and the window's four pair elements
-        "v_sub_u32 v64, %[ii], %[kept]\n\t"
-        "v_and_b32 v64, %[m255], v64\n\t"
-        "v_lshl_add_u32 v64, v64, 3, %[col]\n\t"
-        "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t"
-        "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t"
-        "ds_read_b128 v[66:69], v65\n\t"
-        "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t"
-        "ds_read_b128 v[70:73], v65 offset:16\n\t"
-        "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n"
-        "1:\n\t"
-        // four symbols per trip: the taken branch back costs a lone wave ~25 cycles
-        K3_SYMBOL_ASM
-        "s_cbranch_execz 2f\n\t"
-        K3_SYMBOL_ASM
-        "s_cbranch_execz 2f\n\t"
-        K3_SYMBOL_ASM
-        "s_cbranch_execz 2f\n\t"
-        K3_SYMBOL_ASM
-        "s_cbranch_execnz 1b\n"
-        "2:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        : [mu] "+v"(mu), [omega] "+v"(omega), [last] "+v"(last), [ii] "+v"(ii), [inc] "+v"(inc), [off] "+v"(off),
-          [sv] "=&s"(saved_exec)
-        : [kept] "v"(L.kept), [lim] "v"(lim), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [go] "v"(L.k.gain_omega),
-          [gm] "v"(L.k.gain_mu), [mid] "v"(L.k.omega_mid), [olim] "v"(L.k.omega_lim), [lo] "v"(-128.0f), [hi] "v"(127.0f),
-          [offlast] "v"(off_end - 1u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base),
-          [m255] "s"(ring_mask), [c127] "s"(127.0f), [rowb] "n"(SDRM_K3_BANKPITCH * 4)
-        : "memory", "vcc", "s74", "s75", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
-          "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+#define K3_DRAIN_ASM(CMP, AND) \
+    asm volatile( \
+        "s_mov_b64 %[sv], exec\n\t" \
+        /* operands of the first symbol: MMSE row (2 x 16 bytes) and the window's four pair elements */ \
+        "v_sub_u32 v64, %[ii], %[kept]\n\t" \
+        "v_and_b32 v64, %[m255], v64\n\t" \
+        "v_lshl_add_u32 v64, v64, 3, %[col]\n\t" \
+        "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t" \
+        "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t" \
+        "ds_read_b128 v[66:69], v65\n\t" \
+        "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t" \
+        "ds_read_b128 v[70:73], v65 offset:16\n\t" \
+        "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
+        "v_mov_b32 v87, %[last]\n\t" \
+        "v_mov_b32 v88, %[off]\n" \
+        "1:\n\t" \
+        /* eight symbols per trip: the taken branch back costs a lone wave ~25 cycles */ \
+        K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
+        "s_cbranch_execz 2f\n\t" \
+        K3_SYMBOL_ASM("v87", "v82", CMP, AND) \
+        "s_cbranch_execz 2f\n\t" \
+        K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
+        "s_cbranch_execz 2f\n\t" \
+        K3_SYMBOL_ASM("v87", "v82", CMP, AND) \
+        "s_cbranch_execz 2f\n\t" \
+        K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
+        "s_cbranch_execz 2f\n\t" \
+        K3_SYMBOL_ASM("v87", "v82", CMP, AND) \
+        "s_cbranch_execz 2f\n\t" \
+        K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
+        "s_cbranch_execz 2f\n\t" \
+        K3_SYMBOL_ASM("v87", "v82", CMP, AND) \
+        "s_cbranch_execnz 1b\n" \
+        "2:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "s_mov_b64 exec, %[sv]\n\t" \
+        /* a lane's last symbol sits in v82 after an odd number of symbols, else in v87 */ \
+        "v_xor_b32 v88, v88, %[off]\n\t" \
+        "v_and_b32 v88, 1, v88\n\t" \
+        "v_cmp_eq_u32 vcc, 1, v88\n\t" \
+        "s_nop 1\n\t" \
+        "v_cndmask_b32 %[last], v87, v82, vcc\n\t" \
+        : [mu] "+v"(mu), [omega] "+v"(omega), [last] "+v"(last), [ii] "+v"(ii), [inc] "+v"(inc), [off] "+v"(off), \
+          [sv] "=&s"(saved_exec) \
+        : [kept] "v"(L.kept), [lim] "v"(lim), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [go] "v"(L.k.gain_omega), \
+          [gm] "v"(L.k.gain_mu), [mid] "v"(L.k.omega_mid), [olim] "v"(L.k.omega_lim), [lo] "v"(-128.0f), [hi] "v"(127.0f), \
+          [offlast] "v"(off_end - 1u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base), \
+          [m255] "s"(ring_mask), [c127] "s"(127.0f), [rowb] "n"(SDRM_K3_BANKPITCH * 4) \
+        : "memory", "vcc", "s74", "s75", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", \
+          "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88")
+    if (CAP) {
+        K3_DRAIN_ASM(K3_CAPCMP, K3_CAPAND);
+    } else {
+        K3_DRAIN_ASM("", "");
+    }
+#undef K3_DRAIN_ASM
     L.st.mu = mu;
     L.st.omega = omega;
     L.st.last = last;
@@ -1021,7 +1050,14 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         const uint32_t oo0 = L.oo;
         if (wave_clean && !SOFT && fits32) {
             if (sdrm_k3_can_step(L, lim)) {
-                k3_drain_finite(L, lim, col_addr, bank_addr, off, off_end, b.out_i8, (uint32_t) (G::ring - 1));
+                // every symbol consumes at least one sample when omega cannot fall below 1, and a call never has more
+                // than a ring of them staged: with that much room left in every lane's output the loop needs no output
+                // test (reference clock_recovery_mm.c:103 `oo < output_len`, true throughout)
+                if (__all(L.k.omega_mid - L.k.omega_lim >= 1.0f && off_end - off > (uint32_t) G::ring + 8u)) {
+                    k3_drain_finite<false>(L, lim, col_addr, bank_addr, off, off_end, b.out_i8, (uint32_t) (G::ring - 1));
+                } else {
+                    k3_drain_finite<true>(L, lim, col_addr, bank_addr, off, off_end, b.out_i8, (uint32_t) (G::ring - 1));
+                }
                 L.oo = off - off_base;
                 p8 = o8 + L.oo;
             }

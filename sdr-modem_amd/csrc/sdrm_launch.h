@@ -58,6 +58,9 @@ void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride,
 void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
 void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
 void launch_dc(const DeviceBatch &b, hipStream_t s);
+// diagnostics buffer layout: 4 words per clock-stage workgroup (room for the smallest shape, 16 channels each), then 8
+// words of the front-end, then 10 of the DC blocker
+#define SDRM_STAMP_K3_WAVES(n_channels) (((n_channels) + 15) / 16)
 void launch_clock(const DeviceBatch &b, hipStream_t s);
 
 // test probes

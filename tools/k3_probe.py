@@ -26,12 +26,14 @@ if os.environ.get("LOAD"):  # keep the rest of the chip busy (fp32 GEMMs on a si
         for _ in range(int(os.environ["LOAD"])):
             a = (a @ a) * 1e-4
 torch.cuda.synchronize()
-waves = (Cn + 63) // 64
-out = np.zeros(waves * 4 + 24, dtype=np.uint64)
-L.sdrm_batch_k3_stamps(b.h, 1, out.ctypes.data, waves)
-k1 = [int(v) for v in out[waves * 4:waves * 4 + 5]]
-k2 = [int(v) for v in out[waves * 4 + 8:waves * 4 + 18]]
-out = out[:waves * 4].reshape(waves, 4)
+lanes = int(os.environ.get('SDRM_K3_LANES', '16' if Cn <= 1024 else '64'))
+slots = (Cn + 15) // 16  # record slots (sized for the smallest workgroup shape)
+waves = (Cn + lanes - 1) // lanes
+out = np.zeros(slots * 4 + 24, dtype=np.uint64)
+L.sdrm_batch_k3_stamps(b.h, 1, out.ctypes.data, slots)
+k1 = [int(v) for v in out[slots * 4:slots * 4 + 5]]
+k2 = [int(v) for v in out[slots * 4 + 8:slots * 4 + 18]]
+out = out[:slots * 4].reshape(slots, 4)
 if k1[4]:
     print("K1 per workgroup (cycles): load %.0f, lpf1 %.0f, quad %.0f, lpf2+store %.0f  (%d workgroups)" % (
         k1[0] / k1[4], k1[1] / k1[4], k1[2] / k1[4], k1[3] / k1[4], k1[4]))
@@ -40,5 +42,6 @@ for w in range(min(waves, 2)):
     nb, ticks = packed & 0xffffffff, packed >> 32
     print("wave %d: wait-for-producer %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration, "
           "%.3f ms at %.0f MHz" % (w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1), ticks / 1e5, (stg + drn) / max(ticks, 1) * 100))
+print("cycles per iteration, all %d consumer waves: %s" % (waves, " ".join("%.0f" % (int(out[w][1]) / max(int(out[w][3]), 1)) for w in range(waves))))
 if k2[9]:
     print("K2 channel 0: %d iterations, %.0f cycles each (the 63-step chain alone is 756)" % (k2[9], k2[8] / k2[9]))
