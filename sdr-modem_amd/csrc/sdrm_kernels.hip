@@ -22,13 +22,18 @@ __device__ __forceinline__ void tl_mark(const DeviceBatch &b, int kernel, int en
 // ================================================================================================ K0 (NCO, row f-1)
 
 // Phase accumulator (reference src/dsp/sig_source.c:43-58): the fp32 recursion phase += step with its wrap is sequential
-// per channel, four dependent instructions per sample at best, so a chunk costs its length times ~18 cycles whatever the
-// channel count.  One workgroup serves 64 channels with two waves: the generator wave runs the recursion, lane per
-// channel, and drops 64-sample blocks into an LDS ring (rows of 64 + 4 floats: conflict-free b128 writes); the store
-// wave reads them back time-major and writes whole 256-byte runs per channel, so the memory system sees 8 lines per
-// store instruction instead of the 64 a lane-per-channel store touches.  One barrier per block hands a ring half over.
-#define K0_BLK 64
+// per channel, five issue slots per sample at best, so a chunk costs its length times ~30 cycles whatever the channel
+// count.  One workgroup serves K0_CH = 64 channels with two waves: the generator wave runs the recursion, lane per
+// channel, and drops 128-sample blocks into an LDS ring (rows of 128 + 4 floats: conflict-free b128 writes); the store
+// wave reads them back time-major and writes 512-byte runs per channel (a lane-per-channel store touches one cache line
+// per lane).  One barrier per block hands a ring half over.  (Unlike the clock stage, this chain gains nothing from a
+// narrower wave: with 16 lanes a step costs 22.5 cycles instead of 20.2 and the hand-over 7.8 instead of 7.2 per
+// sample, tools/ubench_nco.hip; 16 channels x 256-sample blocks measured 1.91 ms per chunk, 64 x 64 1.80.)
+#define K0_CH 64
+#define K0_BLK 128
 #define K0_ROW (K0_BLK + 4)
+#define K0_ROWS_PER_STORE (256 / K0_BLK)            // channel rows one 64-lane x 16-byte access covers
+#define K0_STORES (K0_CH / K0_ROWS_PER_STORE)       // accesses per block
 // hand a ring half over: the wave's own LDS traffic has landed (the store wave's global stores stay in flight)
 #define K0_HANDOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -62,16 +67,16 @@ __device__ __forceinline__ void k0_advance4(float4 &v, float &phase, float step,
 }
 
 __global__ __launch_bounds__(128) void k0_nco_phase(DeviceBatch b) {
-    __shared__ __attribute__((aligned(16))) float ring[2][64 * K0_ROW];
-    __shared__ uint32_t blocks_of[64];
+    __shared__ __attribute__((aligned(16))) float ring[2][K0_CH * K0_ROW];
+    __shared__ uint32_t blocks_of[K0_CH];
     __shared__ uint32_t blocks_max;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = blockIdx.x * 64;
+    const int c0 = blockIdx.x * K0_CH;
     if (threadIdx.x == 0) {
         blocks_max = 0;
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && lane < K0_CH) {
         const int c = c0 + lane;
         uint32_t nb = 0;
         if (c < b.n_channels && b.ctl[c].nco_cnt != 0) {
@@ -88,125 +93,125 @@ __global__ __launch_bounds__(128) void k0_nco_phase(DeviceBatch b) {
     if (wave == 0) {
         // ---- generator: a single dependent chain; issue ahead of whatever else shares the SIMD
         __builtin_amdgcn_s_setprio(3);
-        const int c = c0 + lane;
-        const bool mine = blocks_of[lane] != 0;
-        sdrm_chunk_ctl ctl;
-        ctl.nco_cnt = 0;
-        ctl.nco_off = 0;
-        if (mine) {
-            ctl = b.ctl[c];
-        }
-        const sdrm_nco_seg *seg = b.nco_segs + ctl.nco_off;
-        float phase = mine ? b.nco_phase_state[c] : 0.0f;
-        float last = phase;      // the state to keep: the phase after the channel's last sample
-        bool open = mine;        // still inside its batches
-        uint32_t k = 0, left = 0;
-        float step = 0.0f;
-        float *row = &ring[0][0] + lane * K0_ROW;
-        for (uint32_t blk = 0; blk < n_blocks; blk++) {
-            float *dst = row + (blk & 1) * (64 * K0_ROW);
-            if (left == 0 && open) {
-                // next batch (empty ones are skipped); past the last one the lane idles on step 0 until the block loop ends
-                while (k < ctl.nco_cnt && seg[k].len == 0) {
-                    k++;
-                }
-                if (k < ctl.nco_cnt) {
-                    step = seg[k].step;
-                    left = seg[k].len;
-                    k++;
-                } else {
-                    open = false;
-                    last = phase;
-                    step = 0.0f;
-                }
+        if (lane < K0_CH) {  // the other lanes stay out of the exec mask for good (the barriers below are per wave)
+            const int c = c0 + lane;
+            const bool mine = blocks_of[lane] != 0;
+            sdrm_chunk_ctl ctl;
+            ctl.nco_cnt = 0;
+            ctl.nco_off = 0;
+            if (mine) {
+                ctl = b.ctl[c];
             }
-            if (!open) {
-                left = 0xffffffffu;
-            }
-            if (k0_block_is_plain(left, step, phase)) {
-                const float w = copysignf(6.28318530717958647692f, step);
+            const sdrm_nco_seg *seg = b.nco_segs + ctl.nco_off;
+            float phase = mine ? b.nco_phase_state[c] : 0.0f;
+            float last = phase;      // the state to keep: the phase after the channel's last sample
+            bool open = mine;        // still inside its batches
+            uint32_t k = 0, left = 0;
+            float step = 0.0f;
+            float *row = &ring[0][0] + lane * K0_ROW;
+            for (uint32_t blk = 0; blk < n_blocks; blk++) {
+                float *dst = row + (blk & 1) * (K0_CH * K0_ROW);
+                if (left == 0 && open) {
+                    // next batch (empty ones are skipped); past the last one the lane idles on step 0 until the block loop ends
+                    while (k < ctl.nco_cnt && seg[k].len == 0) {
+                        k++;
+                    }
+                    if (k < ctl.nco_cnt) {
+                        step = seg[k].step;
+                        left = seg[k].len;
+                        k++;
+                    } else {
+                        open = false;
+                        last = phase;
+                        step = 0.0f;
+                    }
+                }
+                if (!open) {
+                    left = 0xffffffffu;
+                }
+                if (k0_block_is_plain(left, step, phase)) {
+                    const float w = copysignf(6.28318530717958647692f, step);
+                    for (int g0 = 0; g0 < K0_BLK / 4; g0 += 16) {
 #pragma unroll
-                for (int g = 0; g < K0_BLK / 4; g++) {
-                    float4 v;
-                    k0_advance4(v, phase, step, w);
-                    *reinterpret_cast<float4 *>(dst + 4 * g) = v;
-                }
-                left -= K0_BLK;
-            } else {
-                // a batch ends inside this block for some lane (about once a second per channel), or a step beyond one
-                // turn: the reference's two-test wrap, batch bookkeeping per sample
-                for (int s = 0; s < K0_BLK; s++) {
-                    while (left == 0 && open) {
-                        if (k < ctl.nco_cnt) {
-                            step = seg[k].step;
-                            left = seg[k].len;
-                            k++;
-                        } else {
-                            open = false;
-                            last = phase;
-                            step = 0.0f;
-                            left = 0xffffffffu;
+                        for (int g = 0; g < 16; g++) {
+                            float4 v;
+                            k0_advance4(v, phase, step, w);
+                            *reinterpret_cast<float4 *>(dst + 4 * (g0 + g)) = v;
                         }
                     }
-                    dst[s] = phase;
-                    phase = sdrm_nco_advance(phase, step);
-                    left--;
+                    left -= K0_BLK;
+                } else {
+                    // a batch ends inside this block for some lane (about once a second per channel), or a step beyond
+                    // one turn: the reference's two-test wrap, batch bookkeeping per sample
+                    for (int s = 0; s < K0_BLK; s++) {
+                        while (left == 0 && open) {
+                            if (k < ctl.nco_cnt) {
+                                step = seg[k].step;
+                                left = seg[k].len;
+                                k++;
+                            } else {
+                                open = false;
+                                last = phase;
+                                step = 0.0f;
+                                left = 0xffffffffu;
+                            }
+                        }
+                        dst[s] = phase;
+                        phase = sdrm_nco_advance(phase, step);
+                        left--;
+                    }
                 }
+                K0_HANDOVER();
             }
-            K0_HANDOVER();
-        }
-        if (mine) {
-            b.nco_phase_state[c] = open ? phase : last;
+            if (mine) {
+                b.nco_phase_state[c] = open ? phase : last;
+            }
         }
     } else {
-        // ---- store wave: 16 lanes per channel row, 4 rows per instruction
+        // ---- store wave: K0_BLK / 4 lanes per channel row, K0_ROWS_PER_STORE rows per instruction, 16 instructions per pass
         __builtin_amdgcn_s_setprio(2);
-        const int piece = lane & 15, sub = lane >> 4;
-        uint32_t nb[16], nb_all = 0xffffffffu;
+        const int piece = lane % (K0_BLK / 4), sub = lane / (K0_BLK / 4);
+        uint32_t nb[K0_STORES], n_common = 0xffffffffu;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            nb[q] = blocks_of[q * 4 + sub];
-            nb_all = nb[q] < nb_all ? nb[q] : nb_all;
+        for (int q = 0; q < K0_STORES; q++) {
+            nb[q] = blocks_of[q * K0_ROWS_PER_STORE + sub];
+            n_common = nb[q] < n_common ? nb[q] : n_common;
         }
         // blocks every channel of the workgroup still has: stores without a test
-        uint32_t n_common = n_blocks;
-        for (int l = 0; l < 64; l++) {
-            const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) nb_all, l);
-            n_common = v < n_common ? v : n_common;
+        uint32_t all_common = n_blocks;
+        for (int l = 0; l < 64; l += K0_BLK / 4) {
+            const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) n_common, l);
+            all_common = v < all_common ? v : all_common;
         }
-        // uniform base + 32-bit lane offset: one address register per row, the block advance is scalar
-        float *base = b.nco_phase + (size_t) c0 * b.nco_phase_stride;
-        uint32_t off[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            off[q] = ((uint32_t) (q * 4 + sub) * b.nco_phase_stride + (uint32_t) piece * 4) * (uint32_t) sizeof(float);
-        }
+        float *base = b.nco_phase + (size_t) (c0 + sub) * b.nco_phase_stride + piece * 4;
         const float *src = &ring[0][0] + sub * K0_ROW + piece * 4;
         for (uint32_t blk = 0; blk < n_blocks; blk++) {
             K0_HANDOVER();
-            const float *from = src + (blk & 1) * (64 * K0_ROW);
-            float4 v[16];
+            const float *from = src + (blk & 1) * (K0_CH * K0_ROW);
+            float *col = base + (size_t) blk * K0_BLK;
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                v[q] = *reinterpret_cast<const float4 *>(from + q * 4 * K0_ROW);
-            }
-            // all sixteen reads in flight before the first store: the compiler would otherwise sink each read into its
-            // store's branch and pay one LDS round trip per row
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
-            }
-            char *col = reinterpret_cast<char *>(base + (size_t) blk * K0_BLK);
-            if (blk < n_common) {
+            for (int q0 = 0; q0 < K0_STORES; q0 += 16) {
+                float4 v[16];
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
-                    *reinterpret_cast<float4 *>(col + off[q]) = v[q];
+                    v[q] = *reinterpret_cast<const float4 *>(from + (q0 + q) * K0_ROWS_PER_STORE * K0_ROW);
                 }
-            } else {
+                // all sixteen reads in flight before the first store
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
-                    if (blk < nb[q]) {
-                        *reinterpret_cast<float4 *>(col + off[q]) = v[q];
+                    asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+                }
+                if (blk < all_common) {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        *reinterpret_cast<float4 *>(col + (size_t) ((q0 + q) * K0_ROWS_PER_STORE) * b.nco_phase_stride) = v[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        if (blk < nb[q0 + q]) {
+                            *reinterpret_cast<float4 *>(col + (size_t) ((q0 + q) * K0_ROWS_PER_STORE) * b.nco_phase_stride) = v[q];
+                        }
                     }
                 }
             }
@@ -233,7 +238,7 @@ void launch_nco_phase(const DeviceBatch &b, hipStream_t s) {
     if (b.nco_segs == nullptr) {
         return;
     }
-    hipLaunchKernelGGL(k0_nco_phase, dim3((unsigned) ((b.n_channels + 63) / 64)), dim3(128), 0, s, b);
+    hipLaunchKernelGGL(k0_nco_phase, dim3((unsigned) ((b.n_channels + K0_CH - 1) / K0_CH)), dim3(128), 0, s, b);
 }
 
 void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s) {

@@ -31,6 +31,9 @@ __global__ __launch_bounds__(64) void k(float *out, unsigned long long *stamps, 
         if (MODE == 7) asm volatile(".rept 64\n\t" STEP_A STEP_A STEP_A STEP_A "ds_write_b128 %4, v[42:45]\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(p) : "v"(step), "v"(w), "s"(two_pi), "v"(addr) : "v40", "v41", "v42", "v43", "v44", "v45", "vcc");
         if (MODE == 8) asm volatile(".rept 64\n\t" STEP_C STEP_C STEP_C STEP_C "ds_write_b128 %4, v[42:45]\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(p) : "v"(step), "v"(w), "s"(two_pi), "v"(addr) : "v40", "v41", "v42", "v43", "v44", "v45", "vcc");
         if (MODE == 9) asm volatile(".rept 64\n\t" STEP_C STEP_C STEP_C STEP_C "ds_write_b32 %4, v42\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(p) : "v"(step), "v"(w), "s"(two_pi), "v"(addr) : "v40", "v41", "v42", "v43", "v44", "v45", "vcc");
+        if (MODE == 10) asm volatile(".rept 64\n\t" STEP_B STEP_B STEP_B STEP_B "ds_write_b128 %4, v[42:45]\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(p) : "v"(step), "v"(w), "s"(two_pi), "v"(addr) : "v40", "v41", "v42", "v43", "v44", "v45", "vcc");
+        if (MODE == 11) asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b64 exec, 0xffff\n\t.rept 64\n\t" STEP_B STEP_B STEP_B STEP_B "ds_write_b128 %4, v[42:45]\n\t.endr\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[20:21]" : "+v"(p) : "v"(step), "v"(w), "s"(two_pi), "v"(addr) : "v40", "v41", "v42", "v43", "v44", "v45", "vcc", "s20", "s21");
+        if (MODE == 12) asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b64 exec, 0xffff\n\t.rept 256\n\t" STEP_B ".endr\n\ts_mov_b64 exec, s[20:21]" : "+v"(p) : "v"(step), "v"(w), "s"(two_pi) : "v40", "v41", "vcc", "s20", "s21");
     }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[threadIdx.x] = p + lds[threadIdx.x];
@@ -50,10 +53,11 @@ int main() {
                            "add, cmpx |q| -> exec, masked sub, s_mov exec", "add, sub, sub, ashr, bfi (no SGPR)",
                            "positive-step domain, 4-byte: add, cmp, subrev, s_nop 0, cndmask", "positive-step domain, 4-byte: add, cmpx, masked subrev, s_mov exec",
                            "compiler's order + 4 v_mov + ds_write_b128 per 4 samples", "compiler's order + ds_write_b128 per 4 samples",
-                           "cmpx form + ds_write_b128 per 4 samples", "cmpx form + ds_write_b32 per 4 samples"};
+                           "cmpx form + ds_write_b128 per 4 samples", "cmpx form + ds_write_b32 per 4 samples",
+                           "hand order + ds_write_b128 per 4 samples, 64 lanes", "hand order + ds_write_b128 per 4 samples, 16 lanes", "hand order, 16 lanes, no write"};
 #define RUN(M) hipLaunchKernelGGL(k<M>, dim3(1), dim3(64), 0, 0, out, st, reps); hipDeviceSynchronize(); \
     hipLaunchKernelGGL(k<M>, dim3(1), dim3(64), 0, 0, out, st, reps); hipDeviceSynchronize(); \
     hipMemcpy(h, st, 16, hipMemcpyDeviceToHost); printf("mode %d: %6.2f cycles per sample at %4.0f MHz  (%s)\n", M, (double) h[0] / (reps * 256.0), (double) h[0] / (double) h[1] * 100.0, names[M]);
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12)
     return 0;
 }
