@@ -295,9 +295,9 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     }
     code = code ? code : dev_alloc_zero(&b->d_clock, C);
     code = code ? code : dev_alloc_zero(&b->d_out8, C * (size_t) out_stride);
-    if (flags & SDRM_FLAG_KEEP_SOFT_F32) {
-        code = code ? code : dev_alloc_zero(&b->d_outf, C * (size_t) out_stride);
-    }
+    // the clock stage writes float soft bits, a pointwise kernel behind it the int8 ones: the float buffer always exists
+    // (SDRM_FLAG_KEEP_SOFT_F32 only promises the caller that it may read it)
+    code = code ? code : dev_alloc_zero(&b->d_outf, C * (size_t) out_stride);
     code = code ? code : dev_alloc_zero(&b->d_outlen, C);
     code = code ? code : dev_alloc_zero(&b->d_flags, C * SDRM_CTL_SLOTS);
     if (code != 0) {
@@ -612,6 +612,21 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     d.ctl = d_ctl;
     d.nonfinite = b->d_flags + (size_t) slot * C;
     d.max_tiles = max_tiles;
+    {
+        // no channel can produce more symbols than this in the call (grid of the int8 conversion): every symbol advances
+        // by at least floor(omega_mid - omega_lim) samples of what the call brings plus the <= 63 carried ones
+        uint32_t most = 0;
+        for (size_t c = 0; c < C; c++) {
+            const sdrm_chan_params &p = b->plan.params[c];
+            const float adv = floorf(p.omega_mid - p.omega_lim);
+            uint32_t bound = p.max_len;
+            if (adv >= 1.0f) {
+                bound = std::min<uint32_t>(bound, (uint32_t) ((h[c].nz + 64u) / (uint32_t) adv) + 8u);
+            }
+            most = std::max(most, bound);
+        }
+        d.max_symbols = most;
+    }
     d.z = (i & 1) ? b->d_z2 : b->d_z;
     d.dcout = (i & 1) ? b->d_dcout2 : b->d_dcout;
     d.out_i8 = out8_of(b, i);

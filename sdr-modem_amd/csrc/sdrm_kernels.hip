@@ -755,11 +755,8 @@ size_t k3_lds_bytes(int lanes) {
     "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
     "v_cmp_lt_u32 vcc, %[ii], %[lim]\n\t" \
     CAPCMP \
-    "v_mul_f32 v83, %[c127], " ACC "\n\t" \
-    "v_med3_f32 v83, v83, %[lo], %[hi]\n\t" \
-    "v_add_f32 v83, %[magic], v83\n\t" \
-    "global_store_byte %[off], v83, %[out]\n\t" \
-    "v_add_u32 %[off], 1, %[off]\n\t" \
+    "global_store_dword %[off], " ACC ", %[out]\n\t" \
+    "v_add_u32 %[off], 4, %[off]\n\t" \
     CAPAND \
     "s_and_b64 exec, exec, vcc\n\t"
 #define K3_CAPCMP "v_cmp_ne_u32 s[74:75], %[off], %[offlast]\n\t"
@@ -776,7 +773,7 @@ size_t k3_lds_bytes(int lanes) {
 //   by the compiler.  exec is narrowed as lanes run out of samples and restored on exit.
 template <bool CAP>
 __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, uint32_t col_addr, uint32_t bank_addr,
-                                                uint32_t &off, uint32_t off_end, const int8_t *out_base, uint32_t ring_mask) {
+                                                uint32_t &off, uint32_t off_end, const float *out_base, uint32_t ring_mask) {
     // row address = bank + rowbytes * rint(mu * 128): the low 24 bits of (mu * 128 + 1.5 * 2^23) are 0x400000 + row, so a
     // 24-bit multiply-add with this bias lands on the row (the sum wraps modulo 2^32)
     const uint32_t bias = bank_addr - 0x400000u * (SDRM_K3_BANKPITCH * 4u);
@@ -821,16 +818,16 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         "s_mov_b64 exec, %[sv]\n\t" \
         /* a lane's last symbol sits in v82 after an odd number of symbols, else in v87 */ \
         "v_xor_b32 v88, v88, %[off]\n\t" \
-        "v_and_b32 v88, 1, v88\n\t" \
-        "v_cmp_eq_u32 vcc, 1, v88\n\t" \
+        "v_and_b32 v88, 4, v88\n\t" \
+        "v_cmp_eq_u32 vcc, 4, v88\n\t" \
         "s_nop 1\n\t" \
         "v_cndmask_b32 %[last], v87, v82, vcc\n\t" \
         : [mu] "+v"(mu), [omega] "+v"(omega), [last] "+v"(last), [ii] "+v"(ii), [inc] "+v"(inc), [off] "+v"(off), \
           [sv] "=&s"(saved_exec) \
         : [kept] "v"(L.kept), [lim] "v"(lim), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [go] "v"(L.k.gain_omega), \
-          [gm] "v"(L.k.gain_mu), [mid] "v"(L.k.omega_mid), [olim] "v"(L.k.omega_lim), [lo] "v"(-128.0f), [hi] "v"(127.0f), \
-          [offlast] "v"(off_end - 1u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base), \
-          [m255] "s"(ring_mask), [c127] "s"(127.0f), [rowb] "n"(SDRM_K3_BANKPITCH * 4) \
+          [gm] "v"(L.k.gain_mu), [mid] "v"(L.k.omega_mid), [olim] "v"(L.k.omega_lim), \
+          [offlast] "v"(off_end - 4u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base), \
+          [m255] "s"(ring_mask), [rowb] "n"(SDRM_K3_BANKPITCH * 4) \
         : "memory", "vcc", "s74", "s75", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", \
           "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88")
     if (CAP) {
@@ -846,7 +843,7 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     L.st.inc = inc;
 }
 
-template <bool SOFT, int LANES>
+template <int LANES>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     typedef sdrm_k3_geom<LANES> G;
     extern __shared__ __attribute__((aligned(16))) float k3_lds[];
@@ -1004,15 +1001,14 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     // ------------------------------------------------------------------ consumer wave
     // a long dependent chain on one wave: let it win issue arbitration against the throughput kernels sharing the SIMD
     __builtin_amdgcn_s_setprio(3);
-    int8_t *o8 = b.out_i8 + (size_t) (active ? c : 0) * b.out_stride;
-    float *of = SOFT ? b.out_f32 + (size_t) (active ? c : 0) * b.out_stride : nullptr;
+    // the stage writes the float soft bits; k3_quantize turns them into the int8 output behind it
+    float *of = b.out_f32 + (size_t) (active ? c : 0) * b.out_stride;
     const bool wave_clean = __all(clean);
     // Run every lane's loop as far as the staged samples allow.  A lane that cannot step now cannot step later in
     // the same block either, so the loop only ever shrinks the exec mask.  The operands of the NEXT symbol are issued
     // before the current one is quantised and stored, so part of the LDS latency hides behind that work.
-    int8_t *p8 = o8;
     float *pf = of;
-    const uint32_t end_lo = (uint32_t) (uintptr_t) (o8 + L.cap);
+    const uint32_t end_lo = (uint32_t) (uintptr_t) (of + L.cap);
     // LDS-typed, opaque copy of this lane's ring address: the compiler then keeps it in one register and reaches the
     // window through the ds_read2 immediate offsets instead of re-adding the ring's LDS offset per symbol
     typedef const __attribute__((address_space(3))) float *lds_cf;
@@ -1025,19 +1021,16 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         do {                                                                                                 \
             const float soft = sdrm_k3_step<FIN>(L, F);                                                       \
             sdrm_k3_fetch<FIN, G::ring>(L, col_l, bank_rev, F);                                                        \
-            *p8++ = FIN ? sdrm_soft_to_i8_finite(soft) : sdrm_soft_to_i8(soft);                               \
-            if (SOFT) {                                                                                       \
-                *pf++ = soft;                                                                                 \
-            }                                                                                                \
+            *pf++ = soft;                                                                                     \
             /* `oo < output_len`: the output pointer stands in for the symbol count (low words suffice) */    \
-        } while (((uint32_t) L.st.ii < lim) & ((uint32_t) (uintptr_t) p8 != end_lo));                        \
-        L.oo = (uint32_t) (p8 - o8);                                                                          \
+        } while (((uint32_t) L.st.ii < lim) & ((uint32_t) (uintptr_t) pf != end_lo));                        \
+        L.oo = (uint32_t) (pf - of);                                                                          \
     }
-    // the hand-scheduled loop addresses the output as uniform base + 32-bit lane offset
-    const bool fits32 = (unsigned long long) b.n_channels * b.out_stride + b.out_stride < 0xffffffffull;
-    const uint32_t off_base = (uint32_t) ((active ? c : 0) * (unsigned long long) b.out_stride);
+    // the hand-scheduled loop addresses the output as uniform base (the workgroup's first channel) + 32-bit byte offset
+    const float *wg_out = b.out_f32 + (size_t) c0 * b.out_stride;
+    const uint32_t off_base = (uint32_t) ((active ? lane : 0) * (size_t) b.out_stride * sizeof(float));
     uint32_t off = off_base;
-    const uint32_t off_end = off_base + L.cap;
+    const uint32_t off_end = off_base + L.cap * (uint32_t) sizeof(float);
     const uint32_t col_addr = (uint32_t) (uintptr_t) col_l;
     const uint32_t bank_addr = (uint32_t) (uintptr_t) (lds_cf) bank_rev;
     unsigned long long t_wait = 0, t_drain = 0, n_iter = 0;
@@ -1053,21 +1046,18 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         avail = avail < L.nz ? avail : L.nz;
         const uint32_t lim = active ? sdrm_k3_limit(L, avail) : 0u;
         const uint32_t oo0 = L.oo;
-        if (wave_clean && !SOFT && fits32) {
+        if (wave_clean) {
             if (sdrm_k3_can_step(L, lim)) {
                 // every symbol consumes at least one sample when omega cannot fall below 1, and a call never has more
                 // than a ring of them staged: with that much room left in every lane's output the loop needs no output
                 // test (reference clock_recovery_mm.c:103 `oo < output_len`, true throughout)
-                if (__all(L.k.omega_mid - L.k.omega_lim >= 1.0f && off_end - off > (uint32_t) G::ring + 8u)) {
-                    k3_drain_finite<false>(L, lim, col_addr, bank_addr, off, off_end, b.out_i8, (uint32_t) (G::ring - 1));
+                if (__all(L.k.omega_mid - L.k.omega_lim >= 1.0f && off_end - off > 4u * ((uint32_t) G::ring + 8u))) {
+                    k3_drain_finite<false>(L, lim, col_addr, bank_addr, off, off_end, wg_out, (uint32_t) (G::ring - 1));
                 } else {
-                    k3_drain_finite<true>(L, lim, col_addr, bank_addr, off, off_end, b.out_i8, (uint32_t) (G::ring - 1));
+                    k3_drain_finite<true>(L, lim, col_addr, bank_addr, off, off_end, wg_out, (uint32_t) (G::ring - 1));
                 }
-                L.oo = off - off_base;
-                p8 = o8 + L.oo;
+                L.oo = (off - off_base) / (uint32_t) sizeof(float);
             }
-        } else if (wave_clean) {
-            K3_DRAIN(true)
         } else {
             K3_DRAIN(false)
         }
@@ -1108,13 +1098,40 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     tl_mark(b, 2, 1);
 }
 
-template <bool SOFT, int LANES>
+// int8 soft bits from the float ones (reference src/dsp/fsk_demod.c:106), pointwise behind the clock stage: the
+// recursion's wave pays ~4.4 cycles for every instruction it issues, three of which were this conversion.
+// grid (ceil(max_symbols / 1024), channels), 256 threads, four symbols per thread
+__global__ __launch_bounds__(256) void k3_quantize(DeviceBatch b) {
+    const int c = blockIdx.y;
+    const uint32_t n = b.out_len[c];
+    const uint32_t j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j >= n) {
+        return;
+    }
+    const float4 v = *reinterpret_cast<const float4 *>(b.out_f32 + (size_t) c * b.out_stride + j);
+    int8_t *dst = b.out_i8 + (size_t) c * b.out_stride + j;
+    if (j + 4 <= n) {
+        char4 q;
+        q.x = sdrm_soft_to_i8(v.x);
+        q.y = sdrm_soft_to_i8(v.y);
+        q.z = sdrm_soft_to_i8(v.z);
+        q.w = sdrm_soft_to_i8(v.w);
+        *reinterpret_cast<char4 *>(dst) = q;
+    } else {
+        const float t[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t i = 0; j + i < n; i++) {
+            dst[i] = sdrm_soft_to_i8(t[i]);
+        }
+    }
+}
+
+template <int LANES>
 static void launch_clock_as(const DeviceBatch &b, hipStream_t s) {
     const unsigned blocks = (unsigned) ((b.n_channels + LANES - 1) / LANES);
     static lds_grant granted;
     const size_t lds = k3_lds_bytes(LANES);
-    allow_lds(k3_clock<SOFT, LANES>, lds, &granted);
-    hipLaunchKernelGGL((k3_clock<SOFT, LANES>), dim3(blocks), dim3(128), lds, s, b);
+    allow_lds(k3_clock<LANES>, lds, &granted);
+    hipLaunchKernelGGL((k3_clock<LANES>), dim3(blocks), dim3(128), lds, s, b);
 }
 
 int k3_forced_lanes() {
@@ -1123,19 +1140,13 @@ int k3_forced_lanes() {
 }
 
 void launch_clock(const DeviceBatch &b, hipStream_t s) {
-    const int lanes = sdrm_k3_lanes_for(b.n_channels, k3_forced_lanes());
-    if (b.out_f32) {
-        if (lanes == 16) {
-            launch_clock_as<true, 16>(b, s);
-        } else {
-            launch_clock_as<true, 64>(b, s);
-        }
+    if (sdrm_k3_lanes_for(b.n_channels, k3_forced_lanes()) == 16) {
+        launch_clock_as<16>(b, s);
     } else {
-        if (lanes == 16) {
-            launch_clock_as<false, 16>(b, s);
-        } else {
-            launch_clock_as<false, 64>(b, s);
-        }
+        launch_clock_as<64>(b, s);
+    }
+    if (b.max_symbols > 0) {
+        hipLaunchKernelGGL(k3_quantize, dim3((b.max_symbols + 1023) / 1024, (unsigned) b.n_channels), dim3(256), 0, s, b);
     }
 }
 

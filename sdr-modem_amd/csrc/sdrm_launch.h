@@ -42,6 +42,7 @@ struct DeviceBatch {
     uint32_t nco_phase_stride;       // padded off the power of two: all channels write the same column at the same time
     // launch geometry (host-computed maxima over the batch)
     uint32_t max_tiles;              // K1 grid.x for this call
+    uint32_t max_symbols;            // upper bound of any channel's symbol count this call (k3_quantize grid)
     uint32_t t1_max, t2_max;         // size K1's LDS
     uint32_t rx_cap, rs_cap;         // DC ring capacities (floats) sizing K2's LDS
     int any_dc;
