@@ -70,7 +70,8 @@ typedef struct {
     float quad_gain, sps, gain_omega, gain_mu, omega_lim;
 } sdrm_fsk_info;
 
-#define SDRM_FLAG_KEEP_SOFT_F32 1u /* also keep the float soft bits (clock-recovery output) per call */
+#define SDRM_FLAG_KEEP_SOFT_F32 1u /* the caller reads the float soft bits (clock-recovery output) of a call; the stage
+                                    * produces them in any case, the int8 output is converted from them */
 
 /* device < 0: current HIP device.  Returns 0, -ENOMEM, -1 (bad parameters), -ENODEV (no usable GPU),
  * -ENOTSUP (samples-per-symbol outside the supported range). */
@@ -100,7 +101,7 @@ int sdrm_batch_sync(sdrm_batch *batch);
 /* device pointers: int8 soft bits [C][out_stride], per-channel counts uint32[C], float soft bits or NULL */
 int sdrm_batch_device_outputs(sdrm_batch *batch, void **d_out_i8, size_t *out_stride, void **d_out_len,
                               void **d_out_f32);
-/* after a synchronised call: copy channel c's float soft bits of the last call to host (needs KEEP_SOFT_F32) */
+/* after a synchronised call: copy channel c's float soft bits of the last call to host */
 int sdrm_batch_last_soft(sdrm_batch *batch, size_t channel, float *dst, size_t dst_cap, size_t *len);
 /* copy the last call's int8 outputs of every channel to host: lens[C], data[C][stride] */
 int sdrm_batch_fetch(sdrm_batch *batch, int8_t *data, size_t stride, size_t *lens);
@@ -170,7 +171,8 @@ void sdrm_set_scan_mode(int mode);
  * sdrm_batch_k3_stamps: enable = 1 makes every call (enable = k > 1: only the k-th call from now) record cycle counts
  * inside the kernels; `out` receives 4 x uint64 per clock-stage wave {cycles waiting for staged samples, cycles in the
  * symbol loops, steps | 100 MHz ticks << 32, loop iterations} followed by the front-end's per-phase cycle sums and one
- * DC-blocker channel's cycles.  Returns the number of clock-stage waves.
+ * DC-blocker channel's cycles.  Returns the number of wave records (one per 16 channels; a batch run with 64
+ * channels per clock-stage workgroup fills the first quarter).
  * sdrm_batch_timeline: enable != 0 attaches a table for the next 64 calls; `out` receives one row per call made since,
  * {front start, front end, dc start, dc end, clock start, clock end} in 10 ns ticks of the device's reference clock (first
  * workgroup start / last workgroup end).  Returns the number of rows. */
