@@ -687,10 +687,10 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // writes walk through a ring, the consumer's lane = channel reads spread over the banks).  A ring holds 4 steps; mirror
 // elements at both ends keep every window contiguous.  Consumer: each lane runs its own loop while staged samples last
 // (lanes drop out of the exec mask as they run out); a symbol's 8 window samples are one base address plus constant
-// offsets, and the next symbol's operands are fetched before the current symbol is quantised and stored.  Without
-// NaN/Inf in the wave's channels the int8-only build runs the hand-scheduled loop below (k3_drain_finite), otherwise
-// and for the float-soft-bit build the C++ form of the same arithmetic.  One barrier per step hands block k to the
-// consumer while block k+1 is written.
+// offsets, and the next symbol's operands are fetched before the current symbol's float soft bit is stored (the int8
+// conversion is k3_quantize's, behind this kernel).  Without NaN/Inf in the wave's channels the consumer runs the
+// hand-scheduled loop below (k3_drain_finite), otherwise the C++ form of the same arithmetic.  One barrier per step
+// hands block k to the consumer while block k+1 is written.
 size_t k3_lds_bytes(int lanes) {
     const size_t rings = lanes == 16 ? (size_t) 16 * sdrm_k3_geom<16>::cpitch : (size_t) 64 * sdrm_k3_geom<64>::cpitch;
     return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_WAVE) * sizeof(float);
@@ -763,13 +763,13 @@ size_t k3_lds_bytes(int lanes) {
 #define K3_CAPAND "s_and_b64 vcc, vcc, s[74:75]\n\t"
 
 // The FINITE symbol loop of the clock stage, scheduled by hand (same operations, same order per lane as
-// sdrm_k3_fetch<true> + sdrm_k3_step<true> + sdrm_soft_to_i8_finite; the C++ form stays in use for the SOFT build and
-// is what the CPU emulation runs).  Why by hand: one wave issues one instruction per 4 cycles whatever its dependences,
-// so the symbol time is the instruction count plus whatever LDS latency is left exposed.  Here: 43 VALU instructions
-// (the compiler's form: 51), one SALU pair for the loop, FOUR operand loads (an LDS instruction costs a lone wave ~12
-// cycles of issue whatever its width: two 16-byte reads for the MMSE row, two ds_read2_b64 for the window's pair
-// elements), two waits, and the previous symbol quantised and stored behind the loads.
-//   v64..v87 are scratch (named, so that halves of the 64-bit pairs can be addressed); everything else is allocated
+// sdrm_k3_fetch<true> + sdrm_k3_step<true>, which is what the CPU emulation runs).  Why by hand: one wave issues one
+// instruction per ~4.4 cycles whatever its dependences, so the symbol time is the instruction count plus whatever LDS
+// latency is left exposed.  Here: 38 VALU instructions (the compiler's form: 51; one more and a second SALU instruction
+// while the output buffer could fill up), one SALU instruction for the loop, FOUR operand loads (two 16-byte reads for
+// the MMSE row, two ds_read2_b64 for the window's pair elements), two waits, and the previous symbol's float soft bit
+// stored behind the loads.
+//   v64..v88 are scratch (named, so that halves of the 64-bit pairs can be addressed); everything else is allocated
 //   by the compiler.  exec is narrowed as lanes run out of samples and restored on exit.
 template <bool CAP>
 __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, uint32_t col_addr, uint32_t bank_addr,
