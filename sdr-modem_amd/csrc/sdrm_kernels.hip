@@ -698,7 +698,9 @@ size_t k3_lds_bytes(int lanes) {
 
 // Order of work inside a symbol:
 //   o = ((((((((0 + w0 t0) + w1 t1) + ...) + w7 t7)   (mmse_fir_interpolator.c:188-191, fir_filter.c:116-121)
-//   mm = slice(last) * o - slice(o) * last   (clock_recovery_mm.c:115): both terms take sign(o) ^ sign(last)
+//   mm = slice(last) * o - slice(o) * last   (clock_recovery_mm.c:115): both terms take sign(o) ^ sign(last);
+//   gain_omega * mm and gain_mu * mm are one v_pk_mul_f32, (omega - mid) + lim and (omega - mid) - lim one
+//   v_pk_add_f32 (per component the same IEEE operation as the scalar forms; op_sel broadcasts the common operand)
 //   omega += gain_omega * mm; omega = mid + clip(omega - mid, lim)   (:119-120, branchless_clip :74-76); the clip's
 //   final 0.5 * y and the addition of mid are one v_fma: halving is exact (were y the smallest denormals it would not
 //   be, but then both forms return mid), so the fused form rounds once, where the addition does
@@ -730,16 +732,14 @@ size_t k3_lds_bytes(int lanes) {
     "v_bfi_b32 v84, %[mask], " ACC ", v83\n\t" \
     "v_bfi_b32 v85, %[mask], " LAST ", v83\n\t" \
     "v_sub_f32 v84, v84, v85\n\t" \
-    "v_mul_f32 v85, %[go], v84\n\t" \
-    "v_add_f32 %[omega], %[omega], v85\n\t" \
-    "v_sub_f32 %[omega], %[omega], %[mid]\n\t" \
-    "v_add_f32 v85, %[olim], %[omega]\n\t" \
-    "v_sub_f32 v86, %[omega], %[olim]\n\t" \
-    "v_sub_f32_e64 v85, |v85|, |v86|\n\t" \
+    "v_pk_mul_f32 v[64:65], v[84:85], %[gg] op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
+    "v_add_f32 %[omega], %[omega], v64\n\t" \
+    "v_sub_f32 v84, %[omega], %[mid]\n\t" \
+    "v_pk_add_f32 v[84:85], v[84:85], %[ll] op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
+    "v_sub_f32_e64 v85, |v84|, |v85|\n\t" \
     "v_fma_f32 %[omega], v85, 0.5, %[mid]\n\t" \
-    "v_mul_f32 v84, %[gm], v84\n\t" \
     "v_add_f32 %[mu], %[mu], %[omega]\n\t" \
-    "v_add_f32 %[mu], %[mu], v84\n\t" \
+    "v_add_f32 %[mu], %[mu], v65\n\t" \
     "v_floor_f32 v85, %[mu]\n\t" \
     "v_cvt_i32_f32 %[inc], v85\n\t" \
     "v_sub_f32 %[mu], %[mu], v85\n\t" \
@@ -780,6 +780,10 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     float mu = L.st.mu, omega = L.st.omega, last = L.st.last;
     int ii = L.st.ii, inc = L.st.inc;
     unsigned long long saved_exec;
+    // operand pairs of the two packed instructions: {gain_omega, gain_mu} * mm, (omega - mid) + {lim, -lim}
+    typedef float k3_f2 __attribute__((ext_vector_type(2)));
+    const k3_f2 gains = {L.k.gain_omega, L.k.gain_mu};
+    const k3_f2 limits = {L.k.omega_lim, -L.k.omega_lim};
 #define K3_DRAIN_ASM(CMP, AND) \
     asm volatile( \
         "s_mov_b64 %[sv], exec\n\t" \
@@ -824,8 +828,8 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         "v_cndmask_b32 %[last], v87, v82, vcc\n\t" \
         : [mu] "+v"(mu), [omega] "+v"(omega), [last] "+v"(last), [ii] "+v"(ii), [inc] "+v"(inc), [off] "+v"(off), \
           [sv] "=&s"(saved_exec) \
-        : [kept] "v"(L.kept), [lim] "v"(lim), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [go] "v"(L.k.gain_omega), \
-          [gm] "v"(L.k.gain_mu), [mid] "v"(L.k.omega_mid), [olim] "v"(L.k.omega_lim), \
+        : [kept] "v"(L.kept), [lim] "v"(lim), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [gg] "v"(gains), \
+          [ll] "v"(limits), [mid] "v"(L.k.omega_mid), \
           [offlast] "v"(off_end - 4u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base), \
           [m255] "s"(ring_mask), [rowb] "n"(SDRM_K3_BANKPITCH * 4) \
         : "memory", "vcc", "s74", "s75", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", \
