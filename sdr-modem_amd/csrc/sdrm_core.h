@@ -111,6 +111,54 @@ SDRM_HD float sdrm_quad_sample(sdrm_f2 cur, sdrm_f2 prev, float gain, const floa
     return gain * sdrm_fast_atan2f(im, re, tab);
 }
 
+// (double) z < TAN_MAP_RES (0.003921569, fast_atan2f.c:18,107) for a float z: the constant is not a float, so the test is
+// z <= the float below it, i.e. z < the float above it
+#define SDRM_TAN_MAP_RES_UP_BITS 0x3B808082u
+
+// The same value as sdrm_fast_atan2f without a branch: a wave's lanes land in all eight octants, so every branch of the
+// form above is taken by somebody and the wave pays for all of them (two divisions, ~140 instructions per sample; this
+// form: one division, ~45).  Identities used, all exact:
+//  * the two quotients are one division with selected operands (ya < xa and xa > ya are the same test);
+//  * the table path is evaluated for every z (z < RES gives index 0) and selected afterwards; z is in [0, 1] or NaN, so
+//    the plain conversion equals sdrm_cvt_i32 (& 0xff of INT_MIN is 0, and the device converts NaN to 0);
+//  * every octant's result is offset + (+-base) with offset in {-0, +-pi, +-pi/2}: "pi - base" and "pi + (-base)" are
+//    the same fp32 operation; the offset of the first octant is MINUS zero, which leaves both base = +0 and -base = -0
+//    as they are (+0 would turn -0 into +0);
+//  * the sign is flipped when (x >= 0) != (y >= 0) in the |x| > |y| half and when they are equal in the other.
+SDRM_HD float sdrm_fast_atan2f_flat(float y, float x, const float *tab) {
+    const float ya = fabsf(y), xa = fabsf(x);
+    const bool wide = xa > ya;
+    const float z = (wide ? ya : xa) / (wide ? xa : ya);
+    const float a = z * 255.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int ia;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(ia) : "v"(a));  // NaN -> 0, no undefined behaviour for the compiler to use
+    const int idx = ia & 0xff;
+#else
+    const int idx = sdrm_cvt_i32(a) & 0xff;
+#endif
+    const float t0 = tab[idx];
+    const float t1 = tab[idx + 1];
+    const float interp = t0 + (t1 - t0) * (a - (float) idx);
+    const float base = (z < sdrm_from_bits(SDRM_TAN_MAP_RES_UP_BITS)) ? z : interp;
+    const bool xp = x >= 0.0f, yp = y >= 0.0f;
+    const float pi_f = 3.14159265358979323846f;
+    const float half_pi_f = 1.57079632679489661923f;
+    const float off_wide = xp ? -0.0f : (yp ? pi_f : -pi_f);
+    const float off_tall = yp ? half_pi_f : -half_pi_f;
+    const bool flip = (xp != yp) != !wide;
+    const float signed_base = sdrm_from_bits(sdrm_bits(base) ^ (flip ? 0x80000000u : 0u));
+    const float angle = (wide ? off_wide : off_tall) + signed_base;
+    return (ya > 0.0f || xa > 0.0f) ? angle : 0.0f;
+}
+
+// reference src/dsp/quadrature_demod.c:65-67 through the branch-free arctangent (what the front-end kernel runs)
+SDRM_HD float sdrm_quad_sample_flat(sdrm_f2 cur, sdrm_f2 prev, float gain, const float *tab) {
+    const float re = cur.x * prev.x + cur.y * prev.y;
+    const float im = cur.y * prev.x - cur.x * prev.y;
+    return gain * sdrm_fast_atan2f_flat(im, re, tab);
+}
+
 // one boxcar stage of the DC blocker, pointwise parts (reference src/dsp/dc_blocker.c:61-63).
 // The running sum itself (y = t + y_prev) is the in-order chain done by the caller.
 SDRM_HD float sdrm_boxcar_term(float u, float u_delayed) { return u - u_delayed; }

@@ -18,9 +18,16 @@
 #include "sdrm_core.h"
 
 #define SDRM_K1_THREADS 256
+#ifndef SDRM_K1_R
 #define SDRM_K1_R 15   // LPF1 outputs per thread (odd: lane stride 15*8 B is LDS-bank-conflict free)
-#define SDRM_K1_RZ 15  // LPF2 outputs per thread
+#endif
+#define SDRM_K1_RZ SDRM_K1_R  // LPF2 outputs per thread
+#ifndef SDRM_K1_U
 #define SDRM_K1_U 6    // taps per unrolled step
+#endif
+#ifndef SDRM_K1_WGS
+#define SDRM_K1_WGS 4  // workgroups per CU the register budget is set for
+#endif
 #define SDRM_K1_NY (SDRM_K1_THREADS * SDRM_K1_R)
 #define SDRM_K1_QPAD 16
 // bytes of the K1 tile area in LDS: raw IQ tile + halo, later reused by the demodulated samples with the tile's LPF2
@@ -285,9 +292,9 @@ struct sdrm_k1_regs {
 // phase 0: stage the raw tile (+halo) and the arctan table into LDS
 SDRM_HD void sdrm_k1_phase_load(int tid, const sdrm_k1_tile &t, const sdrm_f2 *in, const sdrm_f2 *hist, int hist_len,
                                 const float *atan_tab, sdrm_f2 *xs, float *tab) {
-    // the first 16 samples of every thread (a whole tile with a halo of up to 256) are loaded before any is stored, so
+    // the first R + 1 samples of every thread (a whole tile with a halo of up to 256) are loaded before any is stored, so
     // that the loads are in flight together; longer halos take the plain loop
-    constexpr int DEPTH = 16;
+    constexpr int DEPTH = SDRM_K1_R + 1;
     sdrm_f2 v[DEPTH];
 #pragma unroll
     for (int i = 0; i < DEPTH; i++) {
@@ -336,13 +343,20 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
     if (tid > 0) {
         prev = bnd[tid - 1];
     }
+    // all of the thread's samples first, unconditionally (threads past the tile's end hold zeros): fifteen independent
+    // chains the compiler can interleave, so that the table reads and the reciprocals wait for each other's work
+    float q[SDRM_K1_R];
+#pragma unroll
+    for (int r = 0; r < SDRM_K1_R; r++) {
+        q[r] = sdrm_quad_sample_flat(regs.y[r], prev, p.quad_gain, tab);
+        prev = regs.y[r];
+    }
 #pragma unroll
     for (int r = 0; r < SDRM_K1_R; r++) {
         int k = tid * SDRM_K1_R + r - 1;
         if (k >= 0 && k < t.nq) {
-            qs[k] = sdrm_quad_sample(regs.y[r], prev, p.quad_gain, tab);
+            qs[k] = q[r];
         }
-        prev = regs.y[r];
     }
 }
 

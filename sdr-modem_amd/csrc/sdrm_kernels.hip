@@ -264,7 +264,7 @@ size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) {
 
 // grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
 // per-thread boundary samples | arctan table.
-__global__ __launch_bounds__(SDRM_K1_THREADS, 4) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
+__global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
                                                             size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
     const int c = blockIdx.y;
@@ -1164,7 +1164,7 @@ __global__ void probe_atan2(const float *y, const float *x, const float *tab, fl
     __syncthreads();
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        out[i] = sdrm_fast_atan2f(y[i], x[i], t);
+        out[i] = sdrm_fast_atan2f_flat(y[i], x[i], t);  // the form the front-end kernel runs
     }
 }
 

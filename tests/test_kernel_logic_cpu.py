@@ -45,6 +45,38 @@ CONFIGS = [
 ]
 
 
+def atan_cases():
+    """(y, x) pairs: every octant, the axes and diagonals, signed zeros, denormals, the table's knots and the double-typed
+    threshold TAN_MAP_RES from both sides, quotients that underflow, Inf and NaN"""
+    rng = np.random.default_rng(3)
+    y = np.concatenate([rng.standard_normal(200000), [0, 0, 1, -1, 1e-3, -1e-9, 0.0, -0.0, np.inf, np.nan, 1e-42, 3e38, 1e-39,
+                                                      -1e-45, 1e-45, -0.0, 0.0, 1, -1, 1, -1, np.nan, np.inf, -np.inf, 2.0]])
+    x = np.concatenate([rng.standard_normal(200000), [0, -1, 1, -1, 1, -1, -0.0, 0.0, 1.0, 1.0, 1e-40, 3e38, 3e-39,
+                                                      3e38, -3e38, 1.0, -1.0, 1, 1, -1, -1, np.nan, np.inf, np.inf, -0.0]])
+    k = np.arange(1, 256, dtype=np.float64) / 255.0
+    res = np.float32(0.003921569)
+    edge = [res, np.nextafter(res, np.float32(1)), np.nextafter(res, np.float32(0)), 0.0039215689, 0.00392157]
+    ys = [y, k, k * (1 + 1e-7), k * (1 - 1e-7), edge]
+    xs = [x, np.ones(3 * 255 + len(edge))]
+    y = np.concatenate(ys).astype(np.float32)
+    x = np.concatenate(xs).astype(np.float32)
+    # and every sign / swap of the lot
+    return (np.concatenate([y, -y, y, -y, x, -x, x, -x]), np.concatenate([x, x, -x, -x, y, y, -y, -y]))
+
+
+def test_branch_free_arctangent_equals_the_reference_form():
+    """the front-end kernel evaluates fast_atan2f without branches (sdrm_fast_atan2f_flat: one division with selected
+    operands, offset + signed base); bit-identical to the oracle's transcription of src/math/fast_atan2f.c:87-157"""
+    y, x = atan_cases()
+    out = np.zeros(len(y), np.float32)
+    emu_api.lib().emu_fast_atan2f_flat(y.ctypes.data, x.ctypes.data, out.ctypes.data, len(y))
+    f = orc.lib().orc_fast_atan2f
+    want = np.array([f(a, b) for a, b in zip(y, x)], dtype=np.float32)
+    both_nan = np.isnan(out) & np.isnan(want)
+    assert np.array_equal(out.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan])
+    assert np.array_equal(np.isnan(out), np.isnan(want))
+
+
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c) for c in CONFIGS])
 def test_design_matches_oracle(cfg):
     o = orc.Fsk(*cfg, 4096)
