@@ -233,6 +233,15 @@ def main():
                 "sample": "oracle (plain-C restatement of the reference path, gcc -O2 -ffp-contract=off), one "
                           "independent channel per thread on %d threads, %d-sample chunks of channel 0 looped for "
                           "%.1f s wall (%.0f Msamples total)" % (cores, N, secs, smp / 1e6)}
+            if orc.tuned_lib() is not None:
+                # second figure: the same code with SIMD dot products (per-lane partial sums, -O3 -mavx2 -mfma), standing in
+                # for libvolk's tuned kernels, which the reference uses outside its tests; not bit-exact, timing only
+                t_one, _, _ = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), 1, min(2.0, args.cpu_seconds), tuned=True)
+                t_all, _, _ = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), cores, args.cpu_seconds, tuned=True)
+                out["cpu_baseline"]["simd_stand_in"] = {
+                    "value": round(t_all, 3), "single_thread_value": round(t_one, 3), "unit": "Msamples/s", "cores": cores,
+                    "note": "oracle source built -O3 -mavx2 -mfma with vectorised FIR dot products (different summation "
+                            "order: not the pinned arithmetic, never used as a checker)"}
         if world == 1 and not args.no_cpu_baseline:
             # the reference's own perf harness (test/perf_fsk_modem.c:70-98): one handle, 100 calls of 4096 samples
             # `re = (uint8_t) i, im = 0`, fsk_demod_create(48000, 4800, 5000, 2, 2000, true, 2016000); its published

@@ -106,6 +106,7 @@ struct orc_fir {
     int decim;
     size_t ntaps;
     float *rev;      /* taps reversed: rev[j] = h[T-1-j]  (fir_filter.c:25-28) */
+    float *rev2;     /* ORC_TUNED build only: every reversed tap twice (re, im lanes) */
     int width;       /* floats per sample */
     size_t cap;      /* max input samples per call */
     float *work;     /* kept tail of earlier input followed by this call's input */
@@ -137,6 +138,16 @@ int orc_fir_create(uint8_t decimation, const float *taps, size_t taps_len, size_
     for (size_t j = 0; j < taps_len; j++) {
         f->rev[j] = taps[taps_len - 1 - j];
     }
+#ifdef ORC_TUNED
+    f->rev2 = malloc(sizeof(float) * 2 * taps_len);
+    if (f->rev2 == NULL) {
+        orc_fir_destroy(f);
+        return -ENOMEM;
+    }
+    for (size_t j = 0; j < taps_len; j++) {
+        f->rev2[2 * j] = f->rev2[2 * j + 1] = f->rev[j];
+    }
+#endif
     *out = f;
     return 0;
 }
@@ -159,6 +170,47 @@ void orc_fir_process(orc_fir *f, const float *input, size_t n, float **output, s
     size_t pos = 0, made = 0;
     while (pos + T <= total) {
         const float *x = f->work + pos * w;
+#ifdef ORC_TUNED
+        /* TIMING STAND-IN ONLY (libsdrm_oracle_tuned.so, bench.py's second CPU figure): what libvolk's SIMD dot
+         * products do instead of the generic kernels -- partial sums per vector lane, i.e. a different summation
+         * order and therefore NOT the pinned arithmetic.  Never used as a checker. */
+        if (w == 1) {
+            float a[16] = {0};
+            size_t j = 0;
+            for (; j + 16 <= T; j += 16) {
+                for (int k = 0; k < 16; k++) {
+                    a[k] += x[j + k] * f->rev[j + k];
+                }
+            }
+            float acc = 0.0f;
+            for (int k = 0; k < 16; k++) {
+                acc += a[k];
+            }
+            for (; j < T; j++) {
+                acc += x[j] * f->rev[j];
+            }
+            f->out[made] = acc;
+        } else {
+            float a[16] = {0}; /* even entries: re, odd entries: im; rev2 holds every tap twice */
+            size_t j = 0;
+            for (; j + 16 <= 2 * T; j += 16) {
+                for (int k = 0; k < 16; k++) {
+                    a[k] += x[j + k] * f->rev2[j + k];
+                }
+            }
+            float re = 0.0f, im = 0.0f;
+            for (int k = 0; k < 16; k += 2) {
+                re += a[k];
+                im += a[k + 1];
+            }
+            for (; j < 2 * T; j += 2) {
+                re += x[j] * f->rev2[j];
+                im += x[j + 1] * f->rev2[j + 1];
+            }
+            f->out[2 * made] = re;
+            f->out[2 * made + 1] = im;
+        }
+#else
         if (w == 1) {
             float acc = 0.0f;
             for (size_t j = 0; j < T; j++) {
@@ -174,6 +226,7 @@ void orc_fir_process(orc_fir *f, const float *input, size_t n, float **output, s
             f->out[2 * made] = re;
             f->out[2 * made + 1] = im;
         }
+#endif
         made++;
         pos += (size_t) f->decim;
     }
@@ -195,6 +248,7 @@ void orc_fir_destroy(orc_fir *f) {
         return;
     }
     free(f->rev);
+    free(f->rev2);
     free(f->work);
     free(f->out);
     free(f);

@@ -323,10 +323,35 @@ def demod_stream(cfg, iq, chunk):
     return np.concatenate(i8s) if i8s else np.zeros(0, np.int8), np.concatenate(f32s) if f32s else np.zeros(0, np.float32)
 
 
-def bench_fsk(iq, chunk, cfg, threads, min_seconds):
+_BENCH_ARGS = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int64, C.c_uint8,
+               C.c_uint32, C.c_bool, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+_TUNED = None
+
+
+def tuned_lib():
+    """libsdrm_oracle_tuned.so (the oracle's source with SIMD dot products, -O3 -mavx2 -mfma): a TIMING stand-in for
+    libvolk's tuned kernels, different summation order, never a checker.  None when missing or the CPU lacks AVX2/FMA."""
+    global _TUNED
+    if _TUNED is None:
+        _TUNED = False
+        path = os.path.join(ORC_DIR, "libsdrm_oracle_tuned.so")
+        try:
+            flags = open("/proc/cpuinfo").read()
+            if os.path.exists(path) and " avx2" in flags and " fma" in flags:
+                L = C.CDLL(path)
+                L.orc_bench_fsk.argtypes = _BENCH_ARGS
+                L.orc_bench_fsk.restype = C.c_double
+                _TUNED = L
+        except OSError:
+            _TUNED = False
+    return _TUNED or None
+
+
+def bench_fsk(iq, chunk, cfg, threads, min_seconds, tuned=False):
     fs, baud, dev, decim, tw, dc = cfg
     iq = np.ascontiguousarray(iq).view(np.float32)
     secs, samples = C.c_double(), C.c_uint64()
-    msps = lib().orc_bench_fsk(iq.ctypes.data, len(iq) // 2, chunk, fs, baud, dev, decim, tw, dc, threads, min_seconds,
-                               C.byref(secs), C.byref(samples))
+    L = tuned_lib() if tuned else lib()
+    msps = L.orc_bench_fsk(iq.ctypes.data, len(iq) // 2, chunk, fs, baud, dev, decim, tw, dc, threads, min_seconds,
+                           C.byref(secs), C.byref(samples))
     return msps, secs.value, samples.value
