@@ -25,14 +25,14 @@ sys.path.insert(0, ROOT)
 FS, BAUD, DEV, DECIM, TW, DC = 48000, 9600, 5000, 1, 2000, True
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DISTINCT = 32          # distinct seeded waveforms per rank; further channels are circular shifts of them
-SWEEP_STEPS = 24       # timed steps per extra channel count of the sweep
+SWEEP_STEPS = 48       # timed steps per extra channel count of the sweep
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--channels-per-gpu", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=131072)
     ap.add_argument("--chunks-resident", type=int, default=8)
