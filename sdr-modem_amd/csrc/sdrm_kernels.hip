@@ -741,19 +741,17 @@ size_t k3_lds_bytes(int lanes) {
     "v_add_f32 %[mu], %[mu], %[omega]\n\t" \
     "v_add_f32 %[mu], %[mu], v65\n\t" \
     "v_floor_f32 v85, %[mu]\n\t" \
-    "v_cvt_i32_f32 %[inc], v85\n\t" \
     "v_sub_f32 %[mu], %[mu], v85\n\t" \
-    "v_add_u32 %[ii], %[ii], %[inc]\n\t" \
-    "v_sub_u32 v64, %[ii], %[kept]\n\t" \
+    "v_add_f32 %[pm], %[pm], v85\n\t" \
     "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t" \
-    "v_and_b32 v64, %[m255], v64\n\t" \
+    "v_and_b32 v64, %[m255], %[pm]\n\t" \
     "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t" \
     "v_lshl_add_u32 v64, v64, 3, %[col]\n\t" \
     "ds_read_b128 v[66:69], v65\n\t" \
     "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t" \
     "ds_read_b128 v[70:73], v65 offset:16\n\t" \
     "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
-    "v_cmp_lt_u32 vcc, %[ii], %[lim]\n\t" \
+    "v_cmp_lt_f32 vcc, %[pm], %[limm]\n\t" \
     CAPCMP \
     "global_store_dword %[off], " ACC ", %[out]\n\t" \
     "v_add_u32 %[off], 4, %[off]\n\t" \
@@ -765,7 +763,7 @@ size_t k3_lds_bytes(int lanes) {
 // The FINITE symbol loop of the clock stage, scheduled by hand (same operations, same order per lane as
 // sdrm_k3_fetch<true> + sdrm_k3_step<true>, which is what the CPU emulation runs).  Why by hand: one wave issues one
 // instruction per ~4.4 cycles whatever its dependences, so the symbol time is the instruction count plus whatever LDS
-// latency is left exposed.  Here: 38 VALU instructions (the compiler's form: 51; one more and a second SALU instruction
+// latency is left exposed.  Here: 36 VALU instructions (the compiler's form: 51; one more and a second SALU instruction
 // while the output buffer could fill up), one SALU instruction for the loop, FOUR operand loads (two 16-byte reads for
 // the MMSE row, two ds_read2_b64 for the window's pair elements), two waits, and the previous symbol's float soft bit
 // stored behind the loads.
@@ -784,6 +782,13 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     typedef float k3_f2 __attribute__((ext_vector_type(2)));
     const k3_f2 gains = {L.k.gain_omega, L.k.gain_mu};
     const k3_f2 limits = {L.k.omega_lim, -L.k.omega_lim};
+    // Inside the loop the position is a FLOAT: pm = 1.5 * 2^23 + (ii - kept).  Positions stay below 2^22 (checked by the
+    // caller), so every pm is exact, `pm += floor(mu)` is the integer addition, the low mantissa bits of pm ARE the ring
+    // slot (ii - kept) & mask (negative positions included: 0x400000 + p keeps p's low bits), and `pm < limm` is
+    // `ii < lim`: the conversion of floor(mu) to an integer, the integer addition and the subtraction of `kept` leave
+    // the symbol's dependent chain (two instructions less per symbol).
+    float pm = SDRM_RINT_MAGIC + (float) (ii - L.kept);
+    const float limm = SDRM_RINT_MAGIC + (float) ((int) lim - L.kept);
 #define K3_DRAIN_ASM(CMP, AND) \
     asm volatile( \
         "s_mov_b64 %[sv], exec\n\t" \
@@ -820,6 +825,11 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         "2:\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t" \
         "s_mov_b64 exec, %[sv]\n\t" \
+        /* back to integers: the advance of the lane's last symbol (its floor is still in v85) and the position */ \
+        "v_cvt_i32_f32 %[inc], v85\n\t" \
+        "v_sub_f32 v64, %[pm], %[magic]\n\t" \
+        "v_cvt_i32_f32 v64, v64\n\t" \
+        "v_add_u32 %[ii], v64, %[kept]\n\t" \
         /* a lane's last symbol sits in v82 after an odd number of symbols, else in v87 */ \
         "v_xor_b32 v88, v88, %[off]\n\t" \
         "v_and_b32 v88, 4, v88\n\t" \
@@ -827,8 +837,8 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         "s_nop 1\n\t" \
         "v_cndmask_b32 %[last], v87, v82, vcc\n\t" \
         : [mu] "+v"(mu), [omega] "+v"(omega), [last] "+v"(last), [ii] "+v"(ii), [inc] "+v"(inc), [off] "+v"(off), \
-          [sv] "=&s"(saved_exec) \
-        : [kept] "v"(L.kept), [lim] "v"(lim), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [gg] "v"(gains), \
+          [pm] "+v"(pm), [sv] "=&s"(saved_exec) \
+        : [kept] "v"(L.kept), [limm] "v"(limm), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [gg] "v"(gains), \
           [ll] "v"(limits), [mid] "v"(L.k.omega_mid), \
           [offlast] "v"(off_end - 4u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base), \
           [m255] "s"(ring_mask), [rowb] "n"(SDRM_K3_BANKPITCH * 4) \
@@ -1008,6 +1018,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     // the stage writes the float soft bits; k3_quantize turns them into the int8 output behind it
     float *of = b.out_f32 + (size_t) (active ? c : 0) * b.out_stride;
     const bool wave_clean = __all(clean);
+    const bool positions_fit = __all(L.nz < (1 << 22) - 2 * SDRM_CLOCK_HCAP);  // the hand-scheduled loop counts positions in a float's mantissa
     // Run every lane's loop as far as the staged samples allow.  A lane that cannot step now cannot step later in
     // the same block either, so the loop only ever shrinks the exec mask.  The operands of the NEXT symbol are issued
     // before the current one is quantised and stored, so part of the LDS latency hides behind that work.
@@ -1050,7 +1061,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         avail = avail < L.nz ? avail : L.nz;
         const uint32_t lim = active ? sdrm_k3_limit(L, avail) : 0u;
         const uint32_t oo0 = L.oo;
-        if (wave_clean) {
+        if (wave_clean && positions_fit) {
             if (sdrm_k3_can_step(L, lim)) {
                 // every symbol consumes at least one sample when omega cannot fall below 1, and a call never has more
                 // than a ring of them staged: with that much room left in every lane's output the loop needs no output
