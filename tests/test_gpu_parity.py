@@ -307,6 +307,26 @@ def test_reference_perf_configuration_maximum_buffer():
     d.close()
 
 
+def test_call_longer_than_the_float_position_range():
+    """The hand-scheduled symbol loop counts positions in a float's mantissa (1.5 * 2^23 + p, p < 2^22); a call with more
+    samples than that takes the C++ form of the loop.  One 4.3 M-sample call (decimation 1, so the clock stage sees all of
+    them), then ordinary calls on the same handle; a short-buffer handle on the same input must agree as well."""
+    cfg = (48000, 9600, 5000, 1, 2000, True)
+    big = (1 << 22) + 100000
+    sig = siggen.gmsk_channel(5, big + 3 * 8192)
+    d = binding.FskDemod(*cfg, big)
+    o = orc.Fsk(*cfg, big)
+    assert d.code == 0 and o.code == 0
+    g8 = d.process(sig[:big])
+    o8, _ = o.process(sig[:big])
+    assert len(g8) == len(o8) and len(g8) > big // 5 - 50
+    assert np.array_equal(g8, o8)
+    for k in range(3):
+        part = sig[big + k * 8192: big + (k + 1) * 8192]
+        assert np.array_equal(d.process(part), o.process(part)[0])
+    d.close()
+
+
 # ---------------------------------------------------------------- device-resident path + worker surface
 
 def test_device_resident_call_matches_host_call():
