@@ -84,6 +84,15 @@ struct sdrm_batch_t {
     bool any_nodc = false;
     bool serial = false;
     uint64_t calls = 0;
+    uint32_t last_max_symbols = 0;  // upper bound of any channel's symbol count in the call enqueued last
+    // Blocking calls of a one-channel batch (a plain fsk_demod handle) replay a captured graph: staged input -> control
+    // record -> kernels -> counts and soft bits back, one launch and one wait per call.  One graph per input length.
+    hipGraphExec_t sg_exec = nullptr;
+    size_t sg_len = 0;            // input length the graph was captured for
+    uint32_t sg_width = 0;        // soft-bit bytes it copies back
+    sdrm_f2 *h_in_stage = nullptr;  // pinned staging for the caller's (pageable) buffer
+    bool sg_broken = false;       // capture or instantiation failed once: stay on the plain path
+    size_t sg_prev_len = 0;       // length of the previous blocking call: a graph is captured when a length repeats
     int last_slot = -1;
     hipStream_t stream = nullptr;  // private stream of the host-buffer API
     sdrm::DeviceBatch dev = {};
@@ -220,6 +229,12 @@ static void batch_free(sdrm_batch_t *b) {
     }
     if (b->h_nco_segs) {
         (void) hipHostFree(b->h_nco_segs);
+    }
+    if (b->sg_exec) {
+        (void) hipGraphExecDestroy(b->sg_exec);
+    }
+    if (b->h_in_stage) {
+        (void) hipHostFree(b->h_in_stage);
     }
     if (b->stream) {
         (void) hipStreamDestroy(b->stream);
@@ -626,6 +641,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
             most = std::max(most, bound);
         }
         d.max_symbols = most;
+        b->last_max_symbols = most;
     }
     d.z = (i & 1) ? b->d_z2 : b->d_z;
     d.dcout = (i & 1) ? b->d_dcout2 : b->d_dcout;
@@ -865,6 +881,122 @@ extern "C" int sdrm_batch_process_nco(sdrm_batch *b, const sdrm_cf32 *const *inp
     return process_host(b, inputs, input_lens, outputs, output_lens, segments, n_segments);
 }
 
+// ---- one-channel blocking call through a captured graph ----------------------------------------------------------------
+// The reference's own usage (one handle per DSP thread, perf_fsk_modem.c: 100 calls of 4096 samples) is bound by launch
+// and synchronisation overhead here, not by the kernels: eight enqueue calls and the gaps between five small kernels.
+// Everything that changes from call to call lives in memory the graph reads through fixed addresses -- the staged
+// input, the control record written by plan_call, the results -- so a graph captured once per input length is replayed.
+// Grids and copy widths are captured for the most outputs a call of that length can have (the decimation phase moves
+// nz by one between calls); workgroups beyond the call's own tile count leave at once.
+#define SDRM_GRAPH_MAX_SAMPLES 65536u
+static const int SG_SLOT = SDRM_CTL_SLOTS - 1;
+
+static bool serial_graph_usable(const sdrm_batch_t *b, size_t n, const sdrm_nco_segment *segs) {
+    return getenv("SDRM_NO_GRAPH") == nullptr &&  // escape hatch for measurements
+           !b->sg_broken && b->serial && b->plan.design.size() == 1 && segs == nullptr && !b->timing &&
+           b->d_timeline == nullptr && b->dev.k3_stamps == nullptr && b->d_out8_b == nullptr && b->calls > 0 && n > 0 &&
+           n <= SDRM_GRAPH_MAX_SAMPLES && n <= b->plan.params[0].max_len;
+}
+
+static int serial_graph_capture(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h) {
+    if (b->sg_exec != nullptr) {
+        (void) hipGraphExecDestroy(b->sg_exec);
+        b->sg_exec = nullptr;
+    }
+    const sdrm_chan_params &p = b->plan.params[0];
+    sdrm::DeviceBatch d = b->dev;
+    d.k3_stamps = nullptr;
+    d.timeline = nullptr;
+    d.nco_segs = nullptr;
+    d.ctl = b->d_ctl + (size_t) SG_SLOT;
+    d.nonfinite = b->d_flags + (size_t) SG_SLOT;
+    const uint32_t nz_cap = (uint32_t) ((n + p.decim - 1) / p.decim) + 1u;
+    d.max_tiles = (nz_cap + p.tile_m - 1) / p.tile_m;
+    uint32_t most = p.max_len;
+    const float adv = floorf(p.omega_mid - p.omega_lim);
+    if (adv >= 1.0f) {
+        most = std::min<uint32_t>(most, (uint32_t) ((nz_cap + 64u) / (uint32_t) adv) + 8u);
+    }
+    d.max_symbols = most;
+    d.z = b->d_z;
+    d.dcout = b->d_dcout;
+    d.out_i8 = b->d_out8;
+    d.out_len = b->d_outlen;
+    b->sg_width = (uint32_t) std::min<size_t>(most, b->dev.out_stride);
+    hipStream_t s = b->stream;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        return -1;
+    }
+    hipError_t e = hipMemcpyAsync(b->d_in, b->h_in_stage, n * sizeof(sdrm_f2), hipMemcpyHostToDevice, s);
+    e = e ? e : hipMemcpyAsync(b->d_ctl + (size_t) SG_SLOT, h, sizeof(sdrm_chunk_ctl), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        sdrm::launch_front(d, b->d_in, b->in_stride, s);
+        sdrm::launch_hist_roll(d, b->d_in, b->in_stride, s);
+        if (d.any_dc) {
+            sdrm::launch_dc(d, s);
+        }
+        sdrm::launch_clock(d, s);
+        e = hipMemcpyAsync(b->h_outlen, d.out_len, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (b->sg_width > 0) {
+            e = e ? e : hipMemcpyAsync(b->h_out8, d.out_i8, b->sg_width, hipMemcpyDeviceToHost, s);
+        }
+    }
+    const hipError_t end = hipStreamEndCapture(s, &graph);
+    if (e != hipSuccess || end != hipSuccess || graph == nullptr) {
+        if (graph != nullptr) {
+            (void) hipGraphDestroy(graph);
+        }
+        (void) hipGetLastError();
+        return -1;
+    }
+    const hipError_t inst = hipGraphInstantiate(&b->sg_exec, graph, nullptr, nullptr, 0);
+    (void) hipGraphDestroy(graph);
+    if (inst != hipSuccess) {
+        b->sg_exec = nullptr;
+        (void) hipGetLastError();
+        return -1;
+    }
+    b->sg_len = n;
+    return 0;
+}
+
+// returns 1 when the call was served, 0 when the caller should take the plain path, < 0 on a device error
+static int serial_graph_call(sdrm_batch_t *b, const sdrm_cf32 *input, size_t n, int8_t **output, size_t *output_len) {
+    if (b->h_in_stage == nullptr &&
+        hipHostMalloc((void **) &b->h_in_stage, (size_t) SDRM_GRAPH_MAX_SAMPLES * sizeof(sdrm_f2)) != hipSuccess) {
+        (void) hipGetLastError();
+        b->sg_broken = true;
+        return 0;
+    }
+    if (b->last_slot >= 0) {
+        HIP_TRY(hipEventSynchronize(b->slot_done[b->last_slot]));  // an asynchronous device-resident call may still run
+    }
+    sdrm_chunk_ctl *h = b->h_ctl + (size_t) SG_SLOT;
+    if (b->sg_exec == nullptr || b->sg_len != n) {
+        // capture BEFORE the call's bookkeeping advances: a failure leaves the plain path an untouched stream
+        sdrm_chunk_ctl probe = {};
+        *h = probe;
+        if (serial_graph_capture(b, n, h) != 0) {
+            b->sg_broken = true;
+            return 0;
+        }
+    }
+    memcpy(b->h_in_stage, input, n * sizeof(sdrm_f2));
+    const size_t lens[1] = {n};
+    (void) sdrm::plan_call(b->plan, lens, h);
+    HIP_TRY(hipGraphLaunch(b->sg_exec, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const uint32_t got = b->h_outlen[0];
+    b->last_lens[0] = got;
+    b->last_max_symbols = b->sg_width;
+    b->last_slot = -1;  // nothing of this call is left in flight
+    b->calls++;
+    *output = b->h_out8;
+    *output_len = got;
+    return 1;
+}
+
 static int process_host(sdrm_batch *b, const sdrm_cf32 *const *inputs, const size_t *input_lens, int8_t **outputs,
                         size_t *output_lens, const sdrm_nco_segment *segs, size_t n_segs) {
     if (b == nullptr || input_lens == nullptr || outputs == nullptr || output_lens == nullptr) {
@@ -876,6 +1008,16 @@ static int process_host(sdrm_batch *b, const sdrm_cf32 *const *inputs, const siz
         return code;
     }
     const size_t C = b->plan.design.size();
+    const bool repeats = C == 1 && input_lens[0] == b->sg_prev_len;  // ragged streams are not worth a capture per call
+    if (C == 1) {
+        b->sg_prev_len = input_lens[0];
+    }
+    if (repeats && inputs != nullptr && inputs[0] != nullptr && serial_graph_usable(b, input_lens[0], segs)) {
+        const int served = serial_graph_call(b, inputs[0], input_lens[0], &outputs[0], &output_lens[0]);
+        if (served != 0) {
+            return served < 0 ? served : 0;
+        }
+    }
     for (size_t c = 0; c < C; c++) {
         size_t n = input_lens[c];
         if (n == 0 || n > b->plan.params[c].max_len || inputs == nullptr || inputs[c] == nullptr) {
@@ -890,19 +1032,25 @@ static int process_host(sdrm_batch *b, const sdrm_cf32 *const *inputs, const siz
     }
     HIP_TRY(hipStreamWaitEvent(b->stream, b->slot_done[b->last_slot], 0));
     const uint64_t me = b->calls - 1;
+    // counts and soft bits come back behind ONE synchronisation: every channel's copy is as long as the most symbols any
+    // channel can have produced in this call (known before the call runs), the counts say how much of it is valid
     HIP_TRY(hipMemcpyAsync(b->h_outlen, outlen_of(b, me), sizeof(uint32_t) * C, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    for (size_t c = 0; c < C; c++) {
-        uint32_t n = b->h_outlen[c];
-        b->last_lens[c] = n;
-        int8_t *dst = b->h_out8 + c * (size_t) b->dev.out_stride;
-        if (n > 0) {
-            HIP_TRY(hipMemcpyAsync(dst, out8_of(b, me) + c * (size_t) b->dev.out_stride, n, hipMemcpyDeviceToHost, b->stream));
+    const size_t width = std::min<size_t>(b->last_max_symbols, b->dev.out_stride);
+    if (width > 0) {
+        if (C == 1) {
+            HIP_TRY(hipMemcpyAsync(b->h_out8, out8_of(b, me), width, hipMemcpyDeviceToHost, b->stream));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(b->h_out8, b->dev.out_stride, out8_of(b, me), b->dev.out_stride, width, C,
+                                     hipMemcpyDeviceToHost, b->stream));
         }
-        outputs[c] = dst;
-        output_lens[c] = n;
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
+    for (size_t c = 0; c < C; c++) {
+        const uint32_t n = b->h_outlen[c];
+        b->last_lens[c] = n;
+        outputs[c] = b->h_out8 + c * (size_t) b->dev.out_stride;
+        output_lens[c] = n;
+    }
     return 0;
 }
 

@@ -327,6 +327,32 @@ def test_call_longer_than_the_float_position_range():
     d.close()
 
 
+def test_repeated_calls_of_one_handle_replay_a_graph():
+    """A plain fsk_demod handle called again with the same buffer length replays a captured graph (staged input, control
+    record, kernels, results: one launch, one wait).  Same-length runs, a length change (new capture), a ragged stretch
+    (plain path), NaN input (the clock stage's general loop inside the graph), an empty and an oversize call in between:
+    everything bit-identical to the oracle."""
+    cfg = (48000, 4800, 5000, 2, 2000, True)
+    sig = siggen.gmsk_channel(21, 200000, fs=48000, baud=4800)
+    plan = [4096] * 6 + [1000] * 4 + [4096, 333, 4096, 4097, 4095] + [4096] * 3 + [0, 4096, 70000, 4096] + [8192] * 3
+    o = orc.Fsk(*cfg, 65536)
+    d = binding.FskDemod(*cfg, 65536)
+    assert d.code == 0
+    pos = 0
+    for k, n in enumerate(plan):
+        part = sig[pos:pos + n].copy()
+        if n == 70000:  # more than the handle's maximum: "<3>requested buffer ..." and no output, stream untouched
+            assert len(d.process(part)) == 0
+            continue
+        pos += n
+        if k == 23:  # second call of its length: inside the graph
+            part[100:110] = np.nan
+        want, _ = o.process(part)
+        got = d.process(part)
+        assert np.array_equal(got, want), (k, n)
+    d.close()
+
+
 # ---------------------------------------------------------------- device-resident path + worker surface
 
 def test_device_resident_call_matches_host_call():
