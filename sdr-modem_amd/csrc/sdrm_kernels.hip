@@ -698,7 +698,9 @@ size_t k3_lds_bytes(int lanes) {
 
 // Order of work inside a symbol:
 //   o = ((((((((0 + w0 t0) + w1 t1) + ...) + w7 t7)   (mmse_fir_interpolator.c:188-191, fir_filter.c:116-121)
-//   mm = slice(last) * o - slice(o) * last   (clock_recovery_mm.c:115): both terms take sign(o) ^ sign(last);
+//   mm = slice(last) * o - slice(o) * last   (clock_recovery_mm.c:115): the first term is o with last's sign bit xor-ed in
+//   (taken from the previous symbol in the shadow of the loads), the second an exact product with copysign(1, o), so one
+//   v_fma (-slice(o) * last + first term) rounds once, exactly where the subtraction does;
 //   gain_omega * mm and gain_mu * mm are one v_pk_mul_f32, (omega - mid) + lim and (omega - mid) - lim one
 //   v_pk_add_f32 (per component the same IEEE operation as the scalar forms; op_sel broadcasts the common operand)
 //   omega += gain_omega * mm; omega = mid + clip(omega - mid, lim)   (:119-120, branchless_clip :74-76); the clip's
@@ -728,10 +730,9 @@ size_t k3_lds_bytes(int lanes) {
     "v_add_f32 " ACC ", v71, " ACC "\n\t" \
     "v_add_f32 " ACC ", v72, " ACC "\n\t" \
     "v_add_f32 " ACC ", v73, " ACC "\n\t" \
-    "v_xor_b32 v83, " ACC ", " LAST "\n\t" \
-    "v_bfi_b32 v84, %[mask], " ACC ", v83\n\t" \
-    "v_bfi_b32 v85, %[mask], " LAST ", v83\n\t" \
-    "v_sub_f32 v84, v84, v85\n\t" \
+    "v_xor_b32 v84, " ACC ", v86\n\t" \
+    "v_bfi_b32 v83, %[mask], 1.0, " ACC "\n\t" \
+    "v_fma_f32 v84, -v83, " LAST ", v84\n\t" \
     "v_pk_mul_f32 v[64:65], v[84:85], %[gg] op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
     "v_add_f32 %[omega], %[omega], v64\n\t" \
     "v_sub_f32 v84, %[omega], %[mid]\n\t" \
@@ -753,6 +754,7 @@ size_t k3_lds_bytes(int lanes) {
     "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
     "v_cmp_lt_f32 vcc, %[pm], %[limm]\n\t" \
     CAPCMP \
+    "v_and_b32 v86, %[sgn], " ACC "\n\t" \
     "global_store_dword %[off], " ACC ", %[out]\n\t" \
     "v_add_u32 %[off], 4, %[off]\n\t" \
     CAPAND \
@@ -763,7 +765,7 @@ size_t k3_lds_bytes(int lanes) {
 // The FINITE symbol loop of the clock stage, scheduled by hand (same operations, same order per lane as
 // sdrm_k3_fetch<true> + sdrm_k3_step<true>, which is what the CPU emulation runs).  Why by hand: one wave issues one
 // instruction per ~4.4 cycles whatever its dependences, so the symbol time is the instruction count plus whatever LDS
-// latency is left exposed.  Here: 36 VALU instructions (the compiler's form: 51; one more and a second SALU instruction
+// latency is left exposed.  Here: 36 VALU instructions (35 of them in front of the loads) (the compiler's form: 51; one more and a second SALU instruction
 // while the output buffer could fill up), one SALU instruction for the loop, FOUR operand loads (two 16-byte reads for
 // the MMSE row, two ds_read2_b64 for the window's pair elements), two waits, and the previous symbol's float soft bit
 // stored behind the loads.
@@ -803,6 +805,7 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         "ds_read_b128 v[70:73], v65 offset:16\n\t" \
         "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
         "v_mov_b32 v87, %[last]\n\t" \
+        "v_and_b32 v86, %[sgn], %[last]\n\t" \
         "v_mov_b32 v88, %[off]\n" \
         "1:\n\t" \
         /* eight symbols per trip: the taken branch back costs a lone wave ~25 cycles */ \
@@ -841,7 +844,7 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         : [kept] "v"(L.kept), [limm] "v"(limm), [col] "v"(col_addr), [magic] "v"(SDRM_RINT_MAGIC), [gg] "v"(gains), \
           [ll] "v"(limits), [mid] "v"(L.k.omega_mid), \
           [offlast] "v"(off_end - 4u), [c128] "v"(128.0f), [mask] "s"(0x7fffffffu), [bias] "s"(bias), [out] "s"(out_base), \
-          [m255] "s"(ring_mask), [rowb] "n"(SDRM_K3_BANKPITCH * 4) \
+          [m255] "s"(ring_mask), [rowb] "n"(SDRM_K3_BANKPITCH * 4), [sgn] "s"(0x80000000u) \
         : "memory", "vcc", "s74", "s75", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", \
           "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88")
     if (CAP) {
