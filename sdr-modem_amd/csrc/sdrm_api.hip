@@ -250,7 +250,11 @@ static int dev_alloc_zero(T **ptr, size_t count) {
         fprintf(stderr, "<3>sdrmodem_hip: hipMalloc(%zu) failed: %s\n", bytes, hipGetErrorString(e));
         return -ENOMEM;
     }
+    // hipMemset returns before the device has written the zeros, and the pipeline's streams are non-blocking streams:
+    // they do not wait for the null stream.  A buffer allocated lazily (the staged input of the first host call, the NCO
+    // buffers) would otherwise be zeroed while the first copy or kernel is already using it.
     e = hipMemset(*ptr, 0, bytes);
+    e = e ? e : hipStreamSynchronize(nullptr);
     return e == hipSuccess ? 0 : -EIO;
 }
 
@@ -455,6 +459,7 @@ extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_
     if (b->d_nco_state != nullptr) {
         HIP_TRY(hipMemset(b->d_nco_state + c, 0, sizeof(float)));
     }
+    HIP_TRY(hipStreamSynchronize(nullptr));  // the memsets above have landed before a (non-blocking) pipeline stream runs
     b->any_nodc = false;
     for (const sdrm_chan_params &q : pl.params) {
         b->any_nodc = b->any_nodc || q.dc_len == 0;

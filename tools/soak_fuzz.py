@@ -1,0 +1,79 @@
+"""Soak: seeded differential fuzz of the HIP path against the oracle for a given number of seconds (GPU box).
+Every round draws a batch of random configurations (as tests/test_gpu_fuzz.py), random signals -- GMSK, white noise over
+many decades, silence, denormal-scale and constant stretches spliced in -- and random call lengths up to 20000 samples;
+every third round also drives one plain fsk_demod handle with repeated lengths (the graph replay).  Bit-exact or it stops.
+python tools/soak_fuzz.py [seconds] [first seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sdrm_pkg; sdrm_pkg.load()
+from sdr_modem_amd import binding, siggen
+import orc
+from test_gpu_fuzz import _cases
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_end = time.time() + budget
+rounds = calls = 0
+
+
+def signal(rng, cfg, n, i):
+    kind = rng.integers(0, 6)
+    if kind <= 2:
+        s = siggen.gmsk_channel(int(rng.integers(0, 1 << 30)), n, fs=cfg[0], baud=cfg[1])
+    elif kind == 3:
+        s = (10.0 ** rng.uniform(-6, 6, n) * np.exp(1j * rng.uniform(-np.pi, np.pi, n))).astype(np.complex64)
+    elif kind == 4:
+        s = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(10.0 ** rng.uniform(-30, 3))
+    else:
+        s = np.full(n, np.complex64(1 + 0j))
+    s = s.copy()
+    for _ in range(int(rng.integers(0, 4))):  # splice in silence / denormal-scale / constant stretches
+        a = int(rng.integers(0, n)); b = min(n, a + int(rng.integers(1, 3000)))
+        what = rng.integers(0, 3)
+        s[a:b] = 0 if what == 0 else (s[a:b] * np.float32(1e-38) if what == 1 else s[a])
+    return s
+
+
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    maxlen = int(rng.choice([6000, 20000]))
+    cfgs = [c + (maxlen,) for c in _cases(seed, int(rng.integers(3, 40)))]
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    keep = [o.code == 0 for o in oracles]
+    cfgs = [c for c, k in zip(cfgs, keep) if k]; oracles = [o for o, k in zip(oracles, keep) if k]
+    keep_soft = bool(rng.integers(0, 2))
+    g = binding.Batch(cfgs, keep_soft=keep_soft)
+    if g.code != 0:
+        print("seed %d: batch create %d, skipped" % (seed, g.code)); seed += 1; continue
+    total = 6 * maxlen
+    sigs = [signal(rng, c, total, i) for i, c in enumerate(cfgs)]
+    pos = [0] * len(cfgs)
+    for call in range(6):
+        lens = [int(rng.choice([0, 1, 7, 100, 257, 1999, 4096, maxlen])) for _ in cfgs]
+        parts = [s[p:p + n] for s, p, n in zip(sigs, pos, lens)]
+        pos = [p + n for p, n in zip(pos, lens)]
+        g8 = g.process(parts)
+        for i, o in enumerate(oracles):
+            o8, of = o.process(parts[i])
+            if not np.array_equal(g8[i], o8):
+                print("MISMATCH int8: seed %d call %d channel %d cfg %s len %d" % (seed, call, i, cfgs[i], lens[i])); sys.exit(1)
+            if keep_soft:
+                gf = g.last_soft(i)
+                nn = np.isnan(of) & np.isnan(gf)
+                if not np.array_equal(gf.view(np.uint32)[~nn], of.view(np.uint32)[~nn]):
+                    print("MISMATCH float: seed %d call %d channel %d cfg %s" % (seed, call, i, cfgs[i])); sys.exit(1)
+        calls += 1
+    g.close()
+    if seed % 3 == 0:  # one plain handle, repeated lengths: graph replay
+        c = cfgs[0]
+        d = binding.FskDemod(*c); o = orc.Fsk(*c)
+        s = signal(rng, c, 40000, 0); p = 0
+        for n in [4096] * 4 + [1000] * 3 + [4096] * 2 + [c[6] // 3] * 3:
+            part = s[p:p + n]; p += n
+            if not np.array_equal(d.process(part), o.process(part)[0]):
+                print("MISMATCH handle: seed %d cfg %s len %d" % (seed, c, n)); sys.exit(1)
+        d.close()
+    rounds += 1; seed += 1
+print("soak ok: %d rounds, %d batch calls, seeds up to %d, %.0f s" % (rounds, calls, seed - 1, budget))
