@@ -1,7 +1,8 @@
 """Soak: seeded differential fuzz of the HIP path against the oracle for a given number of seconds (GPU box).
 Every round draws a batch of random configurations (as tests/test_gpu_fuzz.py), random signals -- GMSK, white noise over
 many decades, silence, denormal-scale and constant stretches spliced in -- and random call lengths up to 20000 samples;
-every third round also drives one plain fsk_demod handle with repeated lengths (the graph replay).  Bit-exact or it stops.
+every third round also drives one plain fsk_demod handle with repeated lengths (the graph replay), every fourth the
+pinned-arena pipeline with three calls in flight.  Bit-exact or it stops.
 python tools/soak_fuzz.py [seconds] [first seed]"""
 import os, sys, time
 import numpy as np
@@ -47,7 +48,7 @@ while time.time() < t_end:
     g = binding.Batch(cfgs, keep_soft=keep_soft)
     if g.code != 0:
         print("seed %d: batch create %d, skipped" % (seed, g.code)); seed += 1; continue
-    total = 6 * maxlen
+    total = 7 * maxlen  # the pinned-arena round below makes seven calls of up to maxlen samples from position 0
     sigs = [signal(rng, c, total, i) for i, c in enumerate(cfgs)]
     pos = [0] * len(cfgs)
     for call in range(6):
@@ -75,5 +76,34 @@ while time.time() < t_end:
             if not np.array_equal(d.process(part), o.process(part)[0]):
                 print("MISMATCH handle: seed %d cfg %s len %d" % (seed, c, n)); sys.exit(1)
         d.close()
+    if seed % 4 == 3:  # pinned arena, three calls in flight (copies and stages of consecutive calls overlap)
+        n_ch = len(cfgs)
+        g = binding.Batch(cfgs)
+        arena = g.arena(4)
+        lens_plan = [[int(rng.choice([0, 100, 1999, 4096, maxlen])) for _ in cfgs] for _ in range(7)]
+        pos = [0] * n_ch; got = [[] for _ in cfgs]; pending = 0
+        for k, lens in enumerate(lens_plan):
+            slot = k % 4
+            for c in range(n_ch):
+                part = sigs[c][pos[c]:pos[c] + lens[c]].view(np.float32)
+                arena[slot, c, :len(part)] = part
+                pos[c] += lens[c]
+            if g.submit(slot, lens) != 0:
+                for c, o8 in enumerate(g.collect()):
+                    got[c].append(o8)
+                pending -= 1
+                assert g.submit(slot, lens) == 0
+            pending += 1
+        while pending:
+            for c, o8 in enumerate(g.collect()):
+                got[c].append(o8)
+            pending -= 1
+        for c in range(n_ch):
+            o = orc.Fsk(*cfgs[c]); exp = []; p0 = 0
+            for lens in lens_plan:
+                exp.append(o.process(sigs[c][p0:p0 + lens[c]])[0]); p0 += lens[c]
+            if not np.array_equal(np.concatenate(got[c]), np.concatenate(exp)):
+                print("MISMATCH pipelined: seed %d channel %d cfg %s" % (seed, c, cfgs[c])); sys.exit(1)
+        g.close()
     rounds += 1; seed += 1
 print("soak ok: %d rounds, %d batch calls, seeds up to %d, %.0f s" % (rounds, calls, seed - 1, budget))
