@@ -82,6 +82,13 @@ int sdrm_batch_info(const sdrm_batch *batch, size_t channel, sdrm_fsk_info *info
 /* copy out the designed low-pass taps (design order) of stage 1 or 2; returns the tap count */
 size_t sdrm_batch_taps(const sdrm_batch *batch, size_t channel, int stage, float *dst, size_t dst_cap);
 
+/* input_lens[c] == SDRM_LEN_ABSENT: channel c takes no part in this call -- no output, and its stream state (filter
+ * histories, DC blocker, timing loop) stays exactly as it is.  That is NOT what a length of 0 means: an empty call is
+ * answered the way the reference answers it (its clock stage may emit a symbol from the samples it carries when
+ * samples/symbol >= 8, src/dsp/clock_recovery_mm.c:94-135).  The batcher marks the clients that have no buffer in a round
+ * this way.  Accepted by every call that takes input_lens. */
+#define SDRM_LEN_ABSENT ((size_t) -1)
+
 /* Host-buffer call: inputs[c] points at input_lens[c] complex samples (may be NULL when the length is 0).
  * Blocks until done.  outputs[c] / output_lens[c] receive borrowed pointers into handle-owned host memory,
  * valid until the next process/destroy.  Channels whose input exceeds their max get output_len 0. */

@@ -223,10 +223,11 @@ class Batch:
         return out
 
     def process(self, inputs):
-        """inputs: list (len C) of complex64 / interleaved-float32 arrays (or None). Returns list of int8 arrays."""
-        keep = [None if x is None else _as_f32(x) for x in inputs]
+        """inputs: list (len C) of complex64 / interleaved-float32 arrays (None = an empty call, ABSENT = the channel takes
+        no part in the call, SDRM_LEN_ABSENT). Returns list of int8 arrays."""
+        keep = [None if (x is None or x is ABSENT) else _as_f32(x) for x in inputs]
         ptrs = (C.c_void_p * self.n)(*[None if k is None or len(k) == 0 else k.ctypes.data for k in keep])
-        lens = (C.c_size_t * self.n)(*[0 if k is None else len(k) // 2 for k in keep])
+        lens = (C.c_size_t * self.n)(*[LEN_ABSENT if x is ABSENT else (0 if k is None else len(k) // 2) for x, k in zip(inputs, keep)])
         outs = (i8p * self.n)()
         olens = (C.c_size_t * self.n)()
         code = self.L.sdrm_batch_process(self.h, ptrs, lens, outs, olens)
@@ -404,6 +405,10 @@ class Batcher:
             self.close()
         except Exception:
             pass
+
+
+ABSENT = object()            # in a list of inputs: the channel takes no part in the call (its state stays as it is)
+LEN_ABSENT = C.c_size_t(-1).value  # SDRM_LEN_ABSENT
 
 
 class FskDemod:

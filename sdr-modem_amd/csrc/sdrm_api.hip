@@ -1176,7 +1176,8 @@ extern "C" int sdrm_batch_submit(sdrm_batch *b, size_t slot, const size_t *input
     for (size_t c = 0; c < C; c++) {
         const sdrm_chan_params &p = b->plan.params[c];
         const double step = std::max(1.0, (double) p.omega_mid - (double) p.omega_lim - 1.0);
-        const double bound = ((double) input_lens[c] / (double) p.decim + SDRM_CLOCK_HCAP) / step + 16.0;
+        const double n_in = input_lens[c] == SDRM_LEN_ABSENT ? 0.0 : (double) input_lens[c];
+        const double bound = (n_in / (double) p.decim + SDRM_CLOCK_HCAP) / step + 16.0;
         width = std::max<uint32_t>(width, (uint32_t) std::min<double>(bound, (double) p.max_len));
     }
     width = std::min<uint32_t>((width + 63u) & ~63u, b->dev.out_stride);

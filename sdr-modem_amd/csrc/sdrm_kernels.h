@@ -95,6 +95,8 @@ struct sdrm_chunk_ctl {
     uint32_t parity;  // which of the two raw-history buffers is current
     uint32_t zbase;   // LPF2 outputs produced by earlier calls (mod 2^32): DC ring phase
     uint32_t nco_off, nco_cnt;  // this call's NCO segments of the channel in the segment table (cnt 0: no NCO)
+    uint32_t absent;  // the channel takes no part in this call (SDRM_LEN_ABSENT): no output, stream state untouched --
+                      // unlike an EMPTY call, which the reference's clock stage answers from its carried samples
 };
 
 // one batch of the Doppler pre-correction: `len` samples mixed with an oscillator advancing `step` radians per sample

@@ -893,9 +893,11 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     sdrm_clock_state *cs = b.clock_state + (active ? c : 0);
     bool clean = true;
     uint32_t flagged = 0;
+    // a channel that takes no part in this call keeps its state as it is: the lane stays out of everything below
+    const bool absent = active && b.ctl[c].absent != 0;
     if (!producer) {
         int uses_dc = 0;
-        if (active) {
+        if (active && !absent) {
             const sdrm_chan_params p = b.params[c];
             L.k.omega_mid = p.omega_mid;
             L.k.omega_lim = p.omega_lim;
@@ -1099,7 +1101,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         b.k3_stamps[blockIdx.x * 4 + 3] = n_iter;
     }
 #undef K3_DRAIN
-    if (active) {
+    if (absent) {
+        b.out_len[c] = 0;
+    } else if (active) {
         int from_n, new_kept;
         sdrm_k3_finish(L, &from_n, &new_kept);
         for (int j = 0; j < new_kept; j++) {

@@ -170,6 +170,10 @@ uint32_t plan_call(BatchPlan &plan, const size_t *lens, sdrm_chunk_ctl *ctl) {
     for (size_t c = 0; c < n_ch; c++) {
         const sdrm_chan_params &p = plan.params[c];
         size_t n = lens ? lens[c] : 0;
+        const bool absent = n == SDRM_LEN_ABSENT;
+        if (absent) {
+            n = 0;
+        }
         if (n > p.max_len) {
             fprintf(stderr, "<3>requested buffer %zu is more than max: %zu\n", n, (size_t) p.max_len);
             n = 0;
@@ -185,6 +189,7 @@ uint32_t plan_call(BatchPlan &plan, const size_t *lens, sdrm_chunk_ctl *ctl) {
         k.zbase = plan.zbase[c];
         k.nco_off = 0;
         k.nco_cnt = 0;
+        k.absent = absent ? 1u : 0u;
         plan.phase[c] = k.i0 + k.nz * p.decim - k.n_in;
         plan.parity[c] ^= 1u;
         plan.zbase[c] += k.nz;

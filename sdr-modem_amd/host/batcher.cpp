@@ -279,7 +279,10 @@ void Batcher::run() {
         if (resets_.empty() && fresh && inflight_.size() < MAX_FLIGHT && launchable_locked(rd, now)) {
             segs.clear();
             for (size_t c = 0; c < n_; c++) {
-                lens[c] = rd.has[c] ? rd.len[c] : 0;
+                // a client without a buffer in this round is ABSENT from the call: an empty call would make the clock
+                // stage answer from its carried samples (it re-emits a symbol when samples/symbol >= 8) and the client's
+                // stream would no longer be the one it put
+                lens[c] = rd.has[c] ? rd.len[c] : SDRM_LEN_ABSENT;
                 if (rd.has[c] && doppler_[c].fn != nullptr && lens[c] > 0) {
                     size_t k = doppler_[c].fn(doppler_[c].planner, (uint32_t) c, lens[c], tmp, 64);
                     segs.insert(segs.end(), tmp, tmp + k);

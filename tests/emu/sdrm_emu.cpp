@@ -174,6 +174,7 @@ static void emu_clock_as(EmuBatch *b) {
         sdrm_k3_lane lanes[G::lanes];
         bool clean[G::lanes];
         uint32_t flagged[G::lanes];
+        bool absent[G::lanes];
         int max_nz = 0;
         const int nl = C - c0 < G::lanes ? C - c0 : G::lanes;
         for (int l = 0; l < nl; l++) {
@@ -182,9 +183,10 @@ static void emu_clock_as(EmuBatch *b) {
             sdrm_clock_state &cs = b->clock[c];
             sdrm_k3_lane &L = lanes[l];
             L.k = sdrm_mm_consts{p.omega_mid, p.omega_lim, p.gain_omega, p.gain_mu};
-            L.cap = p.max_len;
+            absent[l] = b->ctl[c].absent != 0;
+            L.cap = absent[l] ? 0u : p.max_len;  // an absent channel never steps and keeps its state
             L.nz = (int) b->ctl[c].nz;
-            L.kept = (int) cs.kept;
+            L.kept = absent[l] ? 0 : (int) cs.kept;
             L.oo = 0;
             L.st.mu = cs.mu;
             L.st.omega = cs.omega;
@@ -237,6 +239,10 @@ static void emu_clock_as(EmuBatch *b) {
             const int c = c0 + l;
             sdrm_k3_lane &L = lanes[l];
             sdrm_clock_state &cs = b->clock[c];
+            if (absent[l]) {
+                b->outlen[c] = 0;
+                continue;
+            }
             int from_n, new_kept;
             sdrm_k3_finish(L, &from_n, &new_kept);
             const float *col = ring.data() + l * G::cpitch;

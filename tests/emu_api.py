@@ -57,6 +57,9 @@ def emu_batcher(cfgs, slots=4, max_wait_us=2000, blocking=True, device_delay_us=
     return Batcher(cfgs, lib=lib(), handle=h)
 
 
+ABSENT = object()  # in a list of inputs: the channel takes no part in the call (SDRM_LEN_ABSENT)
+
+
 class EmuBatch:
     def __init__(self, cfgs):
         self.n = len(cfgs)
@@ -67,10 +70,11 @@ class EmuBatch:
     def process(self, inputs, segments=None):
         """inputs: list of complex64 arrays. Returns (list of int8 arrays, list of float32 arrays).
         segments: optional list of (channel, len, freq_hz) NCO batches."""
-        keep = [np.ascontiguousarray(x).view(np.float32) if x is not None else np.zeros(0, np.float32) for x in inputs]
+        keep = [np.ascontiguousarray(x).view(np.float32) if (x is not None and x is not ABSENT) else np.zeros(0, np.float32)
+                for x in inputs]
         dummy = np.zeros(2, np.float32)
         ptrs = (C.c_void_p * self.n)(*[(k.ctypes.data if len(k) else dummy.ctypes.data) for k in keep])
-        lens = (C.c_size_t * self.n)(*[len(k) // 2 for k in keep])
+        lens = (C.c_size_t * self.n)(*[C.c_size_t(-1).value if x is ABSENT else len(k) // 2 for x, k in zip(inputs, keep)])
         o8 = (C.c_void_p * self.n)()
         of = (C.c_void_p * self.n)()
         ol = (C.c_size_t * self.n)()

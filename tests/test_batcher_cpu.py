@@ -57,6 +57,42 @@ def test_many_clients_one_batch_ordered_and_bit_exact():
     bt.close()
 
 
+def test_round_without_a_clients_buffer_leaves_that_clients_stream_alone():
+    """A round that is launched because its wait ran out goes without the buffers of the clients that were late.  Those
+    channels must be ABSENT from the device call, not given an empty one: at 16 samples per symbol the clock stage answers
+    an empty call with a re-emitted symbol (clock_recovery_mm.c:127-135) and the late client's stream would change.
+    Two brisk clients keep rounds going while a slow one (16 samples per symbol) delivers a buffer now and then."""
+    slow = (96000, 1200, 5000, 5, 4000, False, 4096)
+    cfgs = [slow, CFG_A, CFG_A]
+    sizes = [[3000, 3000, 4096, 500, 1, 3000], [600] * 30, [600] * 30]
+    sigs = [siggen.gmsk_channel(20 + i, sum(sz), fs=c[0], baud=c[1]) for i, (c, sz) in enumerate(zip(cfgs, sizes))]
+    chunks = [[s[sum(sz[:k]):sum(sz[:k + 1])] for k in range(len(sz))] for s, sz in zip(sigs, sizes)]
+    bt = emu_api.emu_batcher(cfgs, slots=4, max_wait_us=300, blocking=True)
+    got = [[] for _ in cfgs]
+
+    def producer(c):
+        for k in range(len(sizes[c])):
+            time.sleep(0.02 if c == 0 else 0.004)  # both far beyond the round's wait
+            bt.put(c, chunks[c][k])
+
+    def consumer(c):
+        for k in range(len(sizes[c])):
+            got[c].append(bt.take(c))
+
+    th = [threading.Thread(target=f, args=(c,)) for c in range(len(cfgs)) for f in (producer, consumer)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+        assert not t.is_alive()
+    assert bt.rounds() > 12  # most rounds went without the slow client
+    for c, cfg in enumerate(cfgs):
+        exp = oracle_stream(cfg, chunks[c])
+        for k in range(len(sizes[c])):
+            assert np.array_equal(got[c][k], exp[k]), (c, k)
+    bt.close()
+
+
 def test_blocking_producer_waits_for_consumers():
     bt = emu_api.emu_batcher([CFG_A], slots=4, max_wait_us=100, blocking=True)
     sig = siggen.gmsk_channel(1, 6 * 2048)

@@ -353,6 +353,39 @@ def test_repeated_calls_of_one_handle_replay_a_graph():
     d.close()
 
 
+def test_absent_channel_keeps_its_state_on_the_device():
+    """SDRM_LEN_ABSENT: a channel that takes no part in a call (a batcher round launched without that client's buffer)
+    produces nothing and keeps its stream state, whereas an EMPTY call is answered like the reference answers it (at 16
+    samples per symbol the clock stage re-emits a symbol from its carried samples).  Same checks as the CPU emulation's."""
+    cfg = (96000, 1200, 5000, 5, 4000, False)
+    other = (48000, 9600, 5000, 1, 2000, True)
+    sig = siggen.gmsk_channel(9, 14000, fs=96000, baud=1200)
+    sig2 = siggen.gmsk_channel(10, 14000)
+    sizes = [3000, 3000, 4096, 500, 1, 3000]
+    o = orc.Fsk(*cfg, 4096)
+    g = binding.Batch([cfg + (4096,), other + (4096,)])
+    p = q = 0
+    for n in sizes:
+        assert len(g.process([binding.ABSENT, sig2[q:q + 700]])[0]) == 0
+        q += 700
+        got = g.process([sig[p:p + n], binding.ABSENT])
+        assert np.array_equal(got[0], o.process(sig[p:p + n])[0]) and len(got[1]) == 0
+        p += n
+        assert [len(r) for r in g.process([binding.ABSENT, binding.ABSENT])] == [0, 0]
+    g.close()
+    g = binding.Batch([cfg + (4096,)] * 2)
+    o = orc.Fsk(*cfg, 4096)
+    p = extra = 0
+    for n in sizes:
+        assert np.array_equal(g.process([sig[p:p + n]] * 2)[1], o.process(sig[p:p + n])[0])
+        p += n
+        a, b = g.process([None, None])[0], o.process(sig[0:0])[0]
+        assert np.array_equal(a, b)
+        extra += len(a)
+    assert extra > 0
+    g.close()
+
+
 # ---------------------------------------------------------------- device-resident path + worker surface
 
 def test_device_resident_call_matches_host_call():

@@ -248,3 +248,48 @@ def test_channel_reassignment_matches_a_fresh_demodulator():
         assert np.array_equal(got[0], keep[0].process(parts[0])[0])
         assert np.array_equal(got[1], fresh[1].process(parts[1])[0])
         assert np.array_equal(got[2], fresh[2].process(parts[2])[0])
+
+
+def test_absent_channel_keeps_its_state_while_an_empty_call_does_not():
+    """A round of the batcher may run without some client's buffer.  That channel is ABSENT from the call
+    (SDRM_LEN_ABSENT): no output, state untouched -- its stream stays the one the client put.  An EMPTY call is something
+    else: the reference's clock stage answers it from the samples it carries and, with 8 or more samples per symbol,
+    re-emits a symbol (clock_recovery_mm.c:127-135), so interleaving empty calls changes the stream (and the oracle fed
+    the same empty calls agrees with that)."""
+    cfg = (96000, 1200, 5000, 5, 4000, False)   # 16 samples per symbol
+    other = (48000, 9600, 5000, 1, 2000, True)
+    sig = siggen.gmsk_channel(9, 14000, fs=96000, baud=1200)
+    sig2 = siggen.gmsk_channel(10, 14000)
+    sizes = [3000, 3000, 4096, 500, 1, 3000]
+    o = orc.Fsk(*cfg, 4096)
+    want = []
+    p = 0
+    for n in sizes:
+        want.append(o.process(sig[p:p + n])[0])
+        p += n
+    # the same buffers with calls in between in which the channel is absent (the other channel goes on)
+    e = emu_api.EmuBatch([cfg + (4096,), other + (4096,)])
+    got, p, q = [], 0, 0
+    for n in sizes:
+        e.process([emu_api.ABSENT, sig2[q:q + 700]])
+        q += 700
+        got.append(e.process([sig[p:p + n], emu_api.ABSENT])[0][0])
+        p += n
+        r8, _ = e.process([emu_api.ABSENT, emu_api.ABSENT])
+        assert len(r8[0]) == 0 and len(r8[1]) == 0
+    for k in range(len(sizes)):
+        assert np.array_equal(got[k], want[k]), k
+    # empty calls in between are NOT neutral at 16 samples per symbol -- and the oracle says the same
+    e2 = emu_api.EmuBatch([cfg + (4096,)])
+    o2 = orc.Fsk(*cfg, 4096)
+    p, extra = 0, 0
+    for n in sizes:
+        a = e2.process([sig[p:p + n]])[0][0]
+        b = o2.process(sig[p:p + n])[0]
+        assert np.array_equal(a, b)
+        p += n
+        a = e2.process([None])[0][0]
+        b = o2.process(sig[0:0])[0]
+        assert np.array_equal(a, b)
+        extra += len(a)
+    assert extra > 0
