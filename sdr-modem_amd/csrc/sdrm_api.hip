@@ -85,13 +85,13 @@ struct sdrm_batch_t {
     bool serial = false;
     uint64_t calls = 0;
     uint32_t last_max_symbols = 0;  // upper bound of any channel's symbol count in the call enqueued last
-    // Blocking calls of a one-channel batch (a plain fsk_demod handle) replay a captured graph: staged input -> control
+    // Blocking calls of a one-channel batch (a plain fsk_demod handle) replay a graph: staged input -> control
     // record -> kernels -> counts and soft bits back, one launch and one wait per call.  One graph per input length.
     hipGraphExec_t sg_exec = nullptr;
-    size_t sg_len = 0;            // input length the graph was captured for
+    size_t sg_len = 0;            // input length the graph was built for
     uint32_t sg_width = 0;        // soft-bit bytes it copies back
     sdrm_f2 *h_in_stage = nullptr;  // pinned staging for the caller's (pageable) buffer
-    bool sg_broken = false;       // capture or instantiation failed once: stay on the plain path
+    bool sg_broken = false;       // building or instantiating the graph failed once: stay on the plain path
     size_t sg_prev_len = 0;       // length of the previous blocking call: a graph is captured when a length repeats
     int last_slot = -1;
     hipStream_t stream = nullptr;  // private stream of the host-buffer API
@@ -890,7 +890,7 @@ extern "C" int sdrm_batch_process_nco(sdrm_batch *b, const sdrm_cf32 *const *inp
 // The reference's own usage (one handle per DSP thread, perf_fsk_modem.c: 100 calls of 4096 samples) is bound by launch
 // and synchronisation overhead here, not by the kernels: eight enqueue calls and the gaps between five small kernels.
 // Everything that changes from call to call lives in memory the graph reads through fixed addresses -- the staged
-// input, the control record written by plan_call, the results -- so a graph captured once per input length is replayed.
+// input, the control record written by plan_call, the results -- so a graph built once per input length is replayed.
 // Grids and copy widths are captured for the most outputs a call of that length can have (the decimation phase moves
 // nz by one between calls); workgroups beyond the call's own tile count leave at once.
 #define SDRM_GRAPH_MAX_SAMPLES 65536u
@@ -903,7 +903,7 @@ static bool serial_graph_usable(const sdrm_batch_t *b, size_t n, const sdrm_nco_
            n <= SDRM_GRAPH_MAX_SAMPLES && n <= b->plan.params[0].max_len;
 }
 
-static int serial_graph_capture(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h) {
+static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h) {
     if (b->sg_exec != nullptr) {
         (void) hipGraphExecDestroy(b->sg_exec);
         b->sg_exec = nullptr;
@@ -928,30 +928,58 @@ static int serial_graph_capture(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl 
     d.out_i8 = b->d_out8;
     d.out_len = b->d_outlen;
     b->sg_width = (uint32_t) std::min<size_t>(most, b->dev.out_stride);
-    hipStream_t s = b->stream;
+    // The graph is BUILT, node by node, not captured from a stream: while any stream of the process is being captured
+    // ROCm fails legacy-stream calls of every other thread (another client's handle being created or reset), whatever
+    // the capture mode -- and fails the capture with them.
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    if (hipGraphCreate(&graph, 0) != hipSuccess) {
+        (void) hipGetLastError();
         return -1;
     }
-    hipError_t e = hipMemcpyAsync(b->d_in, b->h_in_stage, n * sizeof(sdrm_f2), hipMemcpyHostToDevice, s);
-    e = e ? e : hipMemcpyAsync(b->d_ctl + (size_t) SG_SLOT, h, sizeof(sdrm_chunk_ctl), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) {
-        sdrm::launch_front(d, b->d_in, b->in_stride, s);
-        sdrm::launch_hist_roll(d, b->d_in, b->in_stride, s);
-        if (d.any_dc) {
-            sdrm::launch_dc(d, s);
+    hipGraphNode_t prev = nullptr;
+    bool ok = true;
+    auto after = [&](hipGraphNode_t node) { prev = node; };
+    auto add_copy = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+        hipGraphNode_t node = nullptr;
+        ok = ok && bytes > 0 &&
+             hipGraphAddMemcpyNode1D(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, dst, src, bytes, kind) == hipSuccess;
+        if (ok) {
+            after(node);
         }
-        sdrm::launch_clock(d, s);
-        e = hipMemcpyAsync(b->h_outlen, d.out_len, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-        if (b->sg_width > 0) {
-            e = e ? e : hipMemcpyAsync(b->h_out8, d.out_i8, b->sg_width, hipMemcpyDeviceToHost, s);
+    };
+    const sdrm_f2 *d_in = b->d_in;
+    size_t in_stride = b->in_stride;
+    auto add_kernel = [&](const sdrm::KernelLaunch &k) {  // a kernel takes as many of the three arguments as it declares
+        if (k.func == nullptr || !ok) {
+            return;
         }
+        void *args[3] = {(void *) &d, (void *) &d_in, (void *) &in_stride};
+        hipKernelNodeParams kp = {};
+        kp.func = const_cast<void *>(k.func);
+        kp.gridDim = k.grid;
+        kp.blockDim = k.block;
+        kp.sharedMemBytes = (unsigned) k.lds;
+        kp.kernelParams = args;
+        kp.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        ok = hipGraphAddKernelNode(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp) == hipSuccess;
+        if (ok) {
+            after(node);
+        }
+    };
+    add_copy(b->d_in, b->h_in_stage, n * sizeof(sdrm_f2), hipMemcpyHostToDevice);
+    add_copy(b->d_ctl + (size_t) SG_SLOT, h, sizeof(sdrm_chunk_ctl), hipMemcpyHostToDevice);
+    add_kernel(sdrm::describe_front(d));
+    add_kernel(sdrm::describe_hist_roll(d));
+    add_kernel(sdrm::describe_dc(d));
+    add_kernel(sdrm::describe_clock(d));
+    add_kernel(sdrm::describe_quantize(d));
+    add_copy(b->h_outlen, d.out_len, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (b->sg_width > 0) {
+        add_copy(b->h_out8, d.out_i8, b->sg_width, hipMemcpyDeviceToHost);
     }
-    const hipError_t end = hipStreamEndCapture(s, &graph);
-    if (e != hipSuccess || end != hipSuccess || graph == nullptr) {
-        if (graph != nullptr) {
-            (void) hipGraphDestroy(graph);
-        }
+    if (!ok) {
+        (void) hipGraphDestroy(graph);
         (void) hipGetLastError();
         return -1;
     }
@@ -979,10 +1007,10 @@ static int serial_graph_call(sdrm_batch_t *b, const sdrm_cf32 *input, size_t n, 
     }
     sdrm_chunk_ctl *h = b->h_ctl + (size_t) SG_SLOT;
     if (b->sg_exec == nullptr || b->sg_len != n) {
-        // capture BEFORE the call's bookkeeping advances: a failure leaves the plain path an untouched stream
+        // build BEFORE the call's bookkeeping advances: a failure leaves the plain path an untouched stream
         sdrm_chunk_ctl probe = {};
         *h = probe;
-        if (serial_graph_capture(b, n, h) != 0) {
+        if (serial_graph_build(b, n, h) != 0) {
             b->sg_broken = true;
             return 0;
         }

@@ -361,19 +361,44 @@ static void allow_lds(K kernel, size_t bytes, lds_grant *granted) {
     }
 }
 
-void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s) {
+// Every stage's launch is described once (kernel, grid, block, dynamic LDS) and then either launched on a stream or put
+// into an explicitly built graph (sdrm_api.hip: the one-channel blocking call).  func == nullptr: nothing to launch.
+static void launch_described(const KernelLaunch &k, void **args, hipStream_t s) {
+    if (k.func != nullptr) {
+        (void) hipLaunchKernel(k.func, k.grid, k.block, args, k.lds, s);
+    }
+}
+
+KernelLaunch describe_front(const DeviceBatch &b) {
+    KernelLaunch k;
     if (b.max_tiles == 0) {
-        return;
+        return k;
     }
     static lds_grant granted;
-    const size_t lds = k1_lds_bytes(b.t1_max, b.t2_max);
-    allow_lds(k1_front, lds, &granted);
-    dim3 grid(b.max_tiles, (unsigned) b.n_channels);
-    hipLaunchKernelGGL(k1_front, grid, dim3(SDRM_K1_THREADS), lds, s, b, d_in, in_stride);
+    k.lds = k1_lds_bytes(b.t1_max, b.t2_max);
+    allow_lds(k1_front, k.lds, &granted);
+    k.func = reinterpret_cast<const void *>(k1_front);
+    k.grid = dim3(b.max_tiles, (unsigned) b.n_channels);
+    k.block = dim3(SDRM_K1_THREADS);
+    return k;
+}
+
+void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s) {
+    void *args[] = {(void *) &b, (void *) &d_in, (void *) &in_stride};
+    launch_described(describe_front(b), args, s);
+}
+
+KernelLaunch describe_hist_roll(const DeviceBatch &b) {
+    KernelLaunch k;
+    k.func = reinterpret_cast<const void *>(k1_hist_roll);
+    k.grid = dim3((unsigned) b.n_channels);
+    k.block = dim3(256);
+    return k;
 }
 
 void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s) {
-    hipLaunchKernelGGL(k1_hist_roll, dim3((unsigned) b.n_channels), dim3(256), 0, s, b, d_in, in_stride);
+    void *args[] = {(void *) &b, (void *) &d_in, (void *) &in_stride};
+    launch_described(describe_hist_roll(b), args, s);
 }
 
 // ================================================================================================ K2
@@ -661,19 +686,24 @@ __global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
 
 static int g_scan_mode = 0;
 
-void launch_dc(const DeviceBatch &b, hipStream_t s) {
+KernelLaunch describe_dc(const DeviceBatch &b) {
+    KernelLaunch k;
     if (!b.any_dc) {
-        return;
+        return k;
     }
-    size_t lds = k2_lds_bytes(b.rx_cap, b.rs_cap, b.n_channels);
+    k.lds = k2_lds_bytes(b.rx_cap, b.rs_cap, b.n_channels);
     static lds_grant granted0, granted1;
-    allow_lds(k2_dc<0>, lds, &granted0);
-    allow_lds(k2_dc<1>, lds, &granted1);
-    if (g_scan_mode == 0) {
-        hipLaunchKernelGGL(k2_dc<0>, dim3((unsigned) b.n_channels), dim3(256), lds, s, b);
-    } else {
-        hipLaunchKernelGGL(k2_dc<1>, dim3((unsigned) b.n_channels), dim3(256), lds, s, b);
-    }
+    allow_lds(k2_dc<0>, k.lds, &granted0);
+    allow_lds(k2_dc<1>, k.lds, &granted1);
+    k.func = g_scan_mode == 0 ? reinterpret_cast<const void *>(k2_dc<0>) : reinterpret_cast<const void *>(k2_dc<1>);
+    k.grid = dim3((unsigned) b.n_channels);
+    k.block = dim3(256);
+    return k;
+}
+
+void launch_dc(const DeviceBatch &b, hipStream_t s) {
+    void *args[] = {(void *) &b};
+    launch_described(describe_dc(b), args, s);
 }
 
 // ================================================================================================ K3
@@ -1148,12 +1178,15 @@ __global__ __launch_bounds__(256) void k3_quantize(DeviceBatch b) {
 }
 
 template <int LANES>
-static void launch_clock_as(const DeviceBatch &b, hipStream_t s) {
-    const unsigned blocks = (unsigned) ((b.n_channels + LANES - 1) / LANES);
+static KernelLaunch describe_clock_as(const DeviceBatch &b) {
+    KernelLaunch k;
     static lds_grant granted;
-    const size_t lds = k3_lds_bytes(LANES);
-    allow_lds(k3_clock<LANES>, lds, &granted);
-    hipLaunchKernelGGL((k3_clock<LANES>), dim3(blocks), dim3(128), lds, s, b);
+    k.lds = k3_lds_bytes(LANES);
+    allow_lds(k3_clock<LANES>, k.lds, &granted);
+    k.func = reinterpret_cast<const void *>(k3_clock<LANES>);
+    k.grid = dim3((unsigned) ((b.n_channels + LANES - 1) / LANES));
+    k.block = dim3(128);
+    return k;
 }
 
 int k3_forced_lanes() {
@@ -1161,15 +1194,25 @@ int k3_forced_lanes() {
     return e ? atoi(e) : 0;
 }
 
+KernelLaunch describe_clock(const DeviceBatch &b) {
+    return sdrm_k3_lanes_for(b.n_channels, k3_forced_lanes()) == 16 ? describe_clock_as<16>(b) : describe_clock_as<64>(b);
+}
+
+KernelLaunch describe_quantize(const DeviceBatch &b) {
+    KernelLaunch k;
+    if (b.max_symbols == 0) {
+        return k;
+    }
+    k.func = reinterpret_cast<const void *>(k3_quantize);
+    k.grid = dim3((b.max_symbols + 1023) / 1024, (unsigned) b.n_channels);
+    k.block = dim3(256);
+    return k;
+}
+
 void launch_clock(const DeviceBatch &b, hipStream_t s) {
-    if (sdrm_k3_lanes_for(b.n_channels, k3_forced_lanes()) == 16) {
-        launch_clock_as<16>(b, s);
-    } else {
-        launch_clock_as<64>(b, s);
-    }
-    if (b.max_symbols > 0) {
-        hipLaunchKernelGGL(k3_quantize, dim3((b.max_symbols + 1023) / 1024, (unsigned) b.n_channels), dim3(256), 0, s, b);
-    }
+    void *args[] = {(void *) &b};
+    launch_described(describe_clock(b), args, s);
+    launch_described(describe_quantize(b), args, s);
 }
 
 // ================================================================================================ probes

@@ -48,6 +48,19 @@ struct DeviceBatch {
     int any_dc;
 };
 
+// one kernel launch, described: what launch_* puts on a stream and what the explicitly built graph of the one-channel
+// blocking call holds as a node (func == nullptr: nothing to launch this call)
+struct KernelLaunch {
+    const void *func = nullptr;
+    dim3 grid = dim3(1), block = dim3(1);
+    size_t lds = 0;
+};
+KernelLaunch describe_front(const DeviceBatch &b);      // args: DeviceBatch, const sdrm_f2 *d_in, size_t in_stride
+KernelLaunch describe_hist_roll(const DeviceBatch &b);  // args: the same three
+KernelLaunch describe_dc(const DeviceBatch &b);         // args: DeviceBatch
+KernelLaunch describe_clock(const DeviceBatch &b);      // args: DeviceBatch
+KernelLaunch describe_quantize(const DeviceBatch &b);   // args: DeviceBatch
+
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s);
 bool front_waits_for_clock_start(int n_channels);
