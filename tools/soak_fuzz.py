@@ -105,5 +105,23 @@ while time.time() < t_end:
             if not np.array_equal(np.concatenate(got[c]), np.concatenate(exp)):
                 print("MISMATCH pipelined: seed %d channel %d cfg %s" % (seed, c, cfgs[c])); sys.exit(1)
         g.close()
+    if seed % 25 == 0:  # many channels: the 64-channel clock-stage workgroups, the DC / front-end placement holds
+        n_big = int(rng.choice([400, 1100, 2100]))
+        pool = cfgs[:6]
+        big = [pool[i % len(pool)] for i in range(n_big)]
+        g = binding.Batch(big)
+        if g.code == 0:
+            obig = [orc.Fsk(*c) for c in big]
+            pos = [int(rng.integers(0, 1000)) for _ in big]
+            for call in range(4):
+                lens = [int(rng.choice([0, 100, 1999, 4096, min(maxlen, 6000)])) for _ in big]
+                parts = [sigs[i % len(pool)][p:p + n] for i, (p, n) in enumerate(zip(pos, lens))]
+                pos = [p + n for p, n in zip(pos, lens)]
+                g8 = g.process(parts)
+                for i, o in enumerate(obig):
+                    if not np.array_equal(g8[i], o.process(parts[i])[0]):
+                        print("MISMATCH big batch: seed %d channels %d call %d channel %d cfg %s" % (seed, n_big, call, i, big[i])); sys.exit(1)
+                calls += 1
+            g.close()
     rounds += 1; seed += 1
 print("soak ok: %d rounds, %d batch calls, seeds up to %d, %.0f s" % (rounds, calls, seed - 1, budget))
