@@ -2,7 +2,8 @@
 Every round draws a batch of random configurations (as tests/test_gpu_fuzz.py), random signals -- GMSK, white noise over
 many decades, silence, denormal-scale and constant stretches spliced in -- and random call lengths up to 20000 samples;
 every third round also drives one plain fsk_demod handle with repeated lengths (the graph replay), every fourth the
-pinned-arena pipeline with three calls in flight.  Bit-exact or it stops.
+pinned-arena pipeline with three calls in flight, every fifth device-resident calls queued back to back, every 25th a batch
+of 400 to 2100 channels.  Bit-exact or it stops.
 python tools/soak_fuzz.py [seconds] [first seed]"""
 import os, sys, time
 import numpy as np
@@ -105,6 +106,33 @@ while time.time() < t_end:
             if not np.array_equal(np.concatenate(got[c]), np.concatenate(exp)):
                 print("MISMATCH pipelined: seed %d channel %d cfg %s" % (seed, c, cfgs[c])); sys.exit(1)
         g.close()
+    if seed % 5 == 1:  # device-resident input, several calls in flight on a side stream, only the last one fetched
+        import torch
+        n_ch = len(cfgs)
+        g = binding.Batch(cfgs)
+        stride = maxlen
+        lens_plan = [[int(rng.choice([0, 100, 1999, 4096, maxlen])) for _ in cfgs] for _ in range(int(rng.integers(2, 9)))]
+        bufs, pos = [], [0] * n_ch
+        for lens in lens_plan:
+            host = np.zeros((n_ch, 2 * stride), np.float32)
+            for c in range(n_ch):
+                part = sigs[c][pos[c]:pos[c] + lens[c]].view(np.float32)
+                host[c, :len(part)] = part
+                pos[c] += lens[c]
+            bufs.append(torch.from_numpy(host).cuda())
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for t, lens in zip(bufs, lens_plan):
+            g.process_device(t.data_ptr(), stride, lens, side.cuda_stream)
+        data, got_lens = g.fetch(maxlen)
+        for c in range(n_ch):
+            o = orc.Fsk(*cfgs[c]); p0 = 0; last = None
+            for lens in lens_plan:
+                last = o.process(sigs[c][p0:p0 + lens[c]])[0]; p0 += lens[c]
+            if got_lens[c] != len(last) or not np.array_equal(data[c, :got_lens[c]], last):
+                print("MISMATCH device-resident: seed %d channel %d cfg %s calls %d" % (seed, c, cfgs[c], len(lens_plan))); sys.exit(1)
+        g.close()
+        del bufs
     if seed % 25 == 0:  # many channels: the 64-channel clock-stage workgroups, the DC / front-end placement holds
         n_big = int(rng.choice([400, 1100, 2100]))
         pool = cfgs[:6]
