@@ -92,7 +92,7 @@ struct sdrm_batch_t {
     uint32_t sg_width = 0;        // soft-bit bytes it copies back
     sdrm_f2 *h_in_stage = nullptr;  // pinned staging for the caller's (pageable) buffer
     bool sg_broken = false;       // building or instantiating the graph failed once: stay on the plain path
-    size_t sg_prev_len = 0;       // length of the previous blocking call: a graph is captured when a length repeats
+    size_t sg_prev_len = 0;       // length of the previous blocking call: a graph is built when a length repeats
     int last_slot = -1;
     hipStream_t stream = nullptr;  // private stream of the host-buffer API
     sdrm::DeviceBatch dev = {};
@@ -886,12 +886,12 @@ extern "C" int sdrm_batch_process_nco(sdrm_batch *b, const sdrm_cf32 *const *inp
     return process_host(b, inputs, input_lens, outputs, output_lens, segments, n_segments);
 }
 
-// ---- one-channel blocking call through a captured graph ----------------------------------------------------------------
+// ---- one-channel blocking call through a replayed graph ----------------------------------------------------------------
 // The reference's own usage (one handle per DSP thread, perf_fsk_modem.c: 100 calls of 4096 samples) is bound by launch
 // and synchronisation overhead here, not by the kernels: eight enqueue calls and the gaps between five small kernels.
 // Everything that changes from call to call lives in memory the graph reads through fixed addresses -- the staged
 // input, the control record written by plan_call, the results -- so a graph built once per input length is replayed.
-// Grids and copy widths are captured for the most outputs a call of that length can have (the decimation phase moves
+// Grids and copy widths are those of the most outputs a call of that length can have (the decimation phase moves
 // nz by one between calls); workgroups beyond the call's own tile count leave at once.
 #define SDRM_GRAPH_MAX_SAMPLES 65536u
 static const int SG_SLOT = SDRM_CTL_SLOTS - 1;
