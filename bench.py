@@ -89,10 +89,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the demodulator has no CPU fallback)")
+    # one rank per GPU (RCCL).  SDRM_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer
+    # GPUs than ranks (ranks then share devices: a functional check, not a measurement)
+    backend = os.environ.get("SDRM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     C, N, R = args.channels_per_gpu, args.chunk, args.chunks_resident
     total_ch = C * world
