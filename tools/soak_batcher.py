@@ -53,7 +53,7 @@ while time.time() < t_end:
         for k in range(K):
             want = o.process(chunks[c][k])[0]
             if got[c][k] is None or not np.array_equal(got[c][k], want):
-                print("MISMATCH batcher: seed %d client %d buffer %d cfg %s sizes %s got %s want %d" % (seed, c, k, cfg, sizes[c], None if got[c][k] is None else len(got[c][k]), len(want)), flush=True); os._exit(1)
+                print("MISMATCH batcher: seed %d client %d buffer %d cfg %s sizes %s got %s want %d" % (seed, c, k, cfg, sizes[c], None if got[c][k] is None else len(got[c][k]), len(want)), flush=True); sys.exit(1)
             buffers += 1
     for c in range(len(cfgs)):
         bt.interrupt(c)
