@@ -1,6 +1,8 @@
 // sdrm_kernels.hip -- gfx950 kernels of the GMSK/FSK demodulation pipeline (exact mode).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile): no FMA contraction, IEEE
 // division, fp32 denormals preserved -- required for bit parity with the reference's CPU path.
+#include <atomic>
+
 #include "sdrm_launch.h"
 
 namespace sdrm {
@@ -348,16 +350,19 @@ __global__ __launch_bounds__(256) void k1_hist_roll(DeviceBatch b, const sdrm_f2
 // to the kernel's code object on ONE device, so what has been granted is remembered per device (a process that drives
 // several GPUs gets it right for each)
 struct lds_grant {
-    size_t bytes[16] = {};
+    std::atomic<size_t> bytes[16] = {};  // handles are created and used from many threads
 };
 template <typename K>
 static void allow_lds(K kernel, size_t bytes, lds_grant *granted) {
     int dev = 0;
     (void) hipGetDevice(&dev);
-    size_t &have = granted->bytes[dev & 15];
-    if (bytes > 64 * 1024 && bytes > have) {
+    std::atomic<size_t> &have = granted->bytes[dev & 15];
+    if (bytes > 64 * 1024 && bytes > have.load(std::memory_order_acquire)) {
+        // setting the attribute twice (two threads at once) is harmless; recording it before it is set would not be
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
-        have = bytes;
+        size_t seen = have.load(std::memory_order_relaxed);
+        while (seen < bytes && !have.compare_exchange_weak(seen, bytes, std::memory_order_release)) {
+        }
     }
 }
 
