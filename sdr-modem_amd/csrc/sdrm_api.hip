@@ -460,6 +460,11 @@ extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_
         HIP_TRY(hipMemset(b->d_nco_state + c, 0, sizeof(float)));
     }
     HIP_TRY(hipStreamSynchronize(nullptr));  // the memsets above have landed before a (non-blocking) pipeline stream runs
+    if (b->sg_exec != nullptr) {  // a graph built for the channel's previous parameters (grids, widths) is stale
+        (void) hipGraphExecDestroy(b->sg_exec);
+        b->sg_exec = nullptr;
+        b->sg_len = 0;
+    }
     b->any_nodc = false;
     for (const sdrm_chan_params &q : pl.params) {
         b->any_nodc = b->any_nodc || q.dc_len == 0;

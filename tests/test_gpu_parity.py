@@ -307,6 +307,23 @@ def test_reference_perf_configuration_maximum_buffer():
     d.close()
 
 
+def test_one_channel_batch_reset_between_graph_replays():
+    """a batch of one channel replays a graph for repeated call lengths; handing the channel to a new stream with other
+    parameters (sdrm_batch_reset_channel) must drop the graph built for the old ones"""
+    a = (48000, 4800, 5000, 2, 2000, True, 8192)
+    b_ = (48000, 9600, 5000, 1, 2000, False, 4096)  # shorter filters, no DC blocker, smaller buffer: fits the batch
+    g = binding.Batch([a])
+    for cfg, seed in ((a, 1), (b_, 2), (a, 3)):
+        if cfg is not a or seed == 3:
+            assert g.reset_channel(0, cfg) == 0
+        o = orc.Fsk(*cfg)
+        sig = siggen.gmsk_channel(seed, 5 * 4096, fs=cfg[0], baud=cfg[1])
+        for k in range(5):
+            part = sig[k * 4096:(k + 1) * 4096]
+            assert np.array_equal(g.process([part])[0], o.process(part)[0]), (cfg, k)
+    g.close()
+
+
 def test_call_longer_than_the_float_position_range():
     """The hand-scheduled symbol loop counts positions in a float's mantissa (1.5 * 2^23 + p, p < 2^22); a call with more
     samples than that takes the C++ form of the loop.  One 4.3 M-sample call (decimation 1, so the clock stage sees all of
