@@ -49,7 +49,7 @@ while time.time() < t_end:
     g = binding.Batch(cfgs, keep_soft=keep_soft)
     if g.code != 0:
         print("seed %d: batch create %d, skipped" % (seed, g.code)); seed += 1; continue
-    total = 7 * maxlen  # the pinned-arena round below makes seven calls of up to maxlen samples from position 0
+    total = 9 * maxlen  # the pinned-arena and device-resident rounds below make up to eight calls of up to maxlen samples from position 0
     sigs = [signal(rng, c, total, i) for i, c in enumerate(cfgs)]
     pos = [0] * len(cfgs)
     for call in range(6):
