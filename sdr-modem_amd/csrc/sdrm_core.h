@@ -72,7 +72,9 @@ SDRM_HD int sdrm_cvt_i32(float v) {
     return (fabsf(v) < 2147483648.0f) ? (int) v : SDRM_INT_MIN;
 }
 
-// reference src/math/fast_atan2f.c:87-157; tab = 257-entry arctan table (sdrm_tables.h)
+// reference src/math/fast_atan2f.c:87-157 in the reference's own shape (an if-tree); tab = 257-entry arctan table
+// (sdrm_tables.h).  The kernels run sdrm_fast_atan2f_flat below; this form is the readable statement of what that one
+// computes, and the CPU suite checks the two against each other and against the oracle.
 SDRM_HD float sdrm_fast_atan2f(float y, float x, const float *tab) {
     float ya = fabsf(y), xa = fabsf(x);
     if (!(ya > 0.0f || xa > 0.0f)) {
@@ -102,13 +104,6 @@ SDRM_HD float sdrm_fast_atan2f(float y, float x, const float *tab) {
         return (x >= 0.0f) ? half_pi_f - base : half_pi_f + base;
     }
     return (x >= 0.0f) ? -half_pi_f + base : -half_pi_f - base;
-}
-
-// reference src/dsp/quadrature_demod.c:65-67: gain * atan2(x[n] * conj(x[n-1]))
-SDRM_HD float sdrm_quad_sample(sdrm_f2 cur, sdrm_f2 prev, float gain, const float *tab) {
-    float re = cur.x * prev.x + cur.y * prev.y;
-    float im = cur.y * prev.x - cur.x * prev.y;
-    return gain * sdrm_fast_atan2f(im, re, tab);
 }
 
 // (double) z < TAN_MAP_RES (0.003921569, fast_atan2f.c:18,107) for a float z: the constant is not a float, so the test is

@@ -371,6 +371,13 @@ extern "C" void emu_fast_atan2f_flat(const float *y, const float *x, float *out,
     }
 }
 
+// the same in the reference's own shape (sdrm_fast_atan2f, the if-tree)
+extern "C" void emu_fast_atan2f_tree(const float *y, const float *x, float *out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        out[i] = sdrm_fast_atan2f(y[i], x[i], sdrm_atan_tab);
+    }
+}
+
 // stage taps for inspection
 extern "C" size_t emu_taps(EmuBatch *b, size_t c, int stage, float *dst, size_t cap) {
     const std::vector<float> &t = stage == 2 ? b->plan.design[c].taps2 : b->plan.design[c].taps1;

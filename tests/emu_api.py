@@ -35,6 +35,7 @@ def lib():
                                               C.c_size_t, C.POINTER(NcoSegment), C.c_size_t, C.POINTER(C.c_size_t)]
         L.emu_doppler_plan_stream.restype = C.c_size_t
         L.emu_fast_atan2f_flat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.emu_fast_atan2f_tree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.emu_taps.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
         L.emu_taps.restype = C.c_size_t
         L.emu_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FskInfo)]

@@ -75,6 +75,11 @@ def test_branch_free_arctangent_equals_the_reference_form():
     both_nan = np.isnan(out) & np.isnan(want)
     assert np.array_equal(out.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan])
     assert np.array_equal(np.isnan(out), np.isnan(want))
+    # and the if-tree form kept next to it (sdrm_fast_atan2f) says the same
+    tree = np.zeros(len(y), np.float32)
+    emu_api.lib().emu_fast_atan2f_tree(y.ctypes.data, x.ctypes.data, tree.ctypes.data, len(y))
+    both_nan = np.isnan(out) & np.isnan(tree)
+    assert np.array_equal(out.view(np.uint32)[~both_nan], tree.view(np.uint32)[~both_nan])
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c) for c in CONFIGS])
