@@ -6,12 +6,18 @@ Workload (BASELINE.json configs[2], the largest single-GPU configuration): 256 c
 channel per step (the reference's shipped buffer_size, src/resources/config.conf:11), inputs resident in HBM,
 streaming state carried across steps.  A "step" = one pass of the whole path (LPF1 -> quadrature demod -> LPF2 ->
 DC blocker -> M&M clock recovery -> int8 soft bits) over one chunk of every channel of this rank.
-Channels are independent, so N GPUs = N shards with no data-path collective (weak scaling); the only collective is
-the RCCL broadcast of the channel configuration from rank 0 at setup.
+Channels are independent, so N GPUs = N shards with no data-path collective (weak scaling, the same 256 channels per
+GPU at every N); the only collective is the RCCL broadcast of the channel configuration from rank 0 at setup.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+`python bench.py --gpus N` starts the N ranks itself (one per GPU) when no launcher has set RANK/WORLD_SIZE; under
+`python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.  Rank 0 prints ONE JSON line:
+the contract's fields, `roofline` (front-end kernel), `cpu_baseline`, and -- informative sub-blocks, outside the timed
+region -- `config3_sharded` (BASELINE configs[3]: 512 channels per GPU, N > 1 only), and at N = 1 `channel_sweep`,
+`end_to_end` (host buffers in, soft bits out: PCIe-inclusive), `config5` (mixed rates with per-channel Doppler) and
+`perf_fsk_modem_style`.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -23,7 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FS, BAUD, DEV, DECIM, TW, DC = 48000, 9600, 5000, 1, 2000, True
+T1, T2 = 117, 57       # the two filters' lengths at this configuration (53 fs / (22 tw), made odd)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# exact-mode arithmetic ceiling of the front-end: a separately rounded multiply and add per tap = two packed fp32
+# instructions per two component-MACs; 256 CUs x 4 SIMDs x 16 component-MACs per cycle at 2.4 GHz
+VALU_EXACT_MACS = 256 * 4 * 16 * 2.4e9
 DISTINCT = 32          # distinct seeded waveforms per rank; further channels are circular shifts of them
 SWEEP_STEPS = 48       # timed steps per extra channel count of the sweep
 
@@ -39,8 +49,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0)
     ap.add_argument("--verify", action="store_true", help="also check 2 channels of the last step against the oracle")
-    ap.add_argument("--sweep", type=str, default="1024,4096",
+    ap.add_argument("--sweep", type=str, default="512,1024,4096",
                     help="extra channel counts measured briefly at N=1 (reported under 'channel_sweep'); '' to skip")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / config5 / perf_fsk_modem_style / config3")
     ap.add_argument("--watchdog-seconds", type=float, default=900.0,
                     help="give up (exit code 3, message on stderr) if the whole run takes longer than this")
     return ap.parse_args()
@@ -65,8 +76,175 @@ def usable_cores():
     return max(1, n)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one per GPU, RCCL rendezvous on
+    127.0.0.1) BEFORE this process imports torch or touches the GPU, relay rank 0's JSON line, fail if any rank fails.
+    The parent never initialises HIP (a process that has must not be replaced or forked into GPU work on this pool)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + args.watchdog_seconds + 60.0
+    line, code = None, 0
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        for ln in out0.decode(errors="replace").splitlines():
+            if ln.startswith("{"):
+                line = ln
+        for p in procs:
+            rc = p.wait(timeout=max(1.0, deadline - time.time()))
+            code = code or rc
+    except subprocess.TimeoutExpired:
+        code = 3
+        sys.stderr.write("bench.py: ranks did not finish in time\n")
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # exactly the children started here
+    if line is None:
+        code = code or 4
+        sys.stderr.write("bench.py: rank 0 printed no result\n")
+    else:
+        print(line, flush=True)
+    sys.exit(code)
+
+
+def newest_traffic(channels, chunk):
+    """HBM bytes per k1_front launch from the newest committed PMC measurement that matches the workload
+    (profiles/*k1_front_traffic*.json, written by tools/pmc_k1.sh from separate FETCH_SIZE / WRITE_SIZE passes)."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*k1_front_traffic*.json"))):
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            continue
+        if tj.get("channels") == channels and tj.get("chunk") == chunk and tj.get("hbm_bytes_per_launch"):
+            key = str(tj.get("round", ""))
+            if best is None or key >= best[2]:
+                best = (tj["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), key)
+    return (best[0], best[1]) if best else (None, None)
+
+
+class Rig:
+    """the device-resident workload of one rank: C channels x `resident` chunks of synthetic GMSK in HBM + a batch"""
+
+    def __init__(self, torch, binding, siggen, dev, local_rank, cfgs, first_channel, chunk, resident, base=None):
+        self.torch, self.C, self.N, self.R = torch, len(cfgs), chunk, resident
+        n_total = resident * chunk
+        k = min(self.C, DISTINCT)
+        if base is None:
+            base = np.stack([siggen.gmsk_channel(first_channel + i, n_total, cfgs[i][0], cfgs[i][1]) for i in range(k)])
+        k = min(k, len(base))
+        self.base, self.k = base, k
+        base_t = torch.from_numpy(base[:k, :n_total].copy().view(np.float32).reshape(k, 2 * n_total)).to(dev)
+        self.x = torch.empty((self.C, 2 * n_total), dtype=torch.float32, device=dev)
+        for c in range(self.C):
+            self.x[c] = torch.roll(base_t[c % k], shifts=2 * 977 * (c // k))
+        del base_t
+        torch.cuda.synchronize()
+        self.batch = binding.Batch(cfgs, device=local_rank)
+        if self.batch.code != 0:
+            raise RuntimeError("sdrm_batch_create failed: %d" % self.batch.code)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.lens = [chunk] * self.C
+        self.n_total = n_total
+
+    def step(self, i):
+        off = (i % self.R) * self.N * 8  # bytes into each channel row
+        self.batch.process_device(self.x.data_ptr() + off, self.n_total, self.lens, self.stream)
+
+    def kernel_ms(self):
+        out = []
+        for which in range(3):
+            ms, n = self.batch.timing_read(which)
+            out.append(ms / max(n, 1))
+        return out
+
+    def close(self):
+        self.batch.close()
+        self.batch = None
+        del self.x
+        self.torch.cuda.empty_cache()
+
+
+def end_to_end(binding, siggen, channels, chunk, calls=24, slots=4):
+    """host buffers in, soft bits out (sdrm_batch_arena / _submit / _collect): every call copies its pinned slot to the
+    device, runs the path and copies the soft bits back; three calls in flight.  PCIe-inclusive -- never `value`."""
+    b = binding.Batch([(FS, BAUD, DEV, DECIM, TW, DC, chunk)] * channels)
+    if b.code != 0:
+        raise RuntimeError("create failed %d" % b.code)
+    arena = b.arena(slots)
+    base = np.stack([siggen.gmsk_channel(i, chunk) for i in range(8)]).view(np.float32)
+    for s in range(slots):
+        arena[s, :, :2 * chunk] = np.tile(np.roll(base, 2 * 977 * s, axis=1), (channels // 8, 1))
+    lens = [chunk] * channels
+    flight = 3
+    for k in range(4):
+        assert b.submit(k % slots, lens) == 0
+        b.collect(copy=False)
+    t0 = time.perf_counter()
+    for k in range(calls):
+        if k >= flight:
+            b.collect(copy=False)
+        assert b.submit(k % slots, lens) == 0
+    for k in range(min(flight, calls)):
+        b.collect(copy=False)
+    dt = (time.perf_counter() - t0) / calls
+    b.close()
+    return {"value": round(channels * chunk / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_call": round(dt * 1e3, 3),
+            "host_link_GBs": round(channels * chunk * 8 / dt / 1e9, 1), "channels": channels, "calls": calls,
+            "path": "sdrm_batch_arena/_submit/_collect: pinned arena slot -> one host-to-device copy per call -> kernels -> "
+                    "soft bits and counts back to pinned memory, 3 calls in flight (PCIe-inclusive)"}
+
+
+def config5(torch, binding, siggen, dev, channels, chunk, steps=24):
+    """BASELINE configs[4] in one GPU's share: half 240 kHz / 19200 baud (decimation 5), half 48 kHz / 1200 baud
+    (decimation 8), every channel corrected by its own Doppler ramp (three NCO batches per channel and call)."""
+    cfgs = [(240000, 19200, 5000, 5, 2000, True, chunk) if c % 2 == 0 else (48000, 1200, 5000, 8, 2000, True, chunk)
+            for c in range(channels)]
+    a = siggen.gmsk_channel(1, 2 * chunk, fs=240000, baud=19200)
+    b_ = siggen.gmsk_channel(2, 2 * chunk, fs=48000, baud=1200)
+    x = torch.from_numpy(np.stack([a if c % 2 == 0 else b_ for c in range(channels)]).view(np.float32)).to(dev)
+    b = binding.Batch(cfgs)
+    if b.code != 0:
+        raise RuntimeError("create failed %d" % b.code)
+    st = torch.cuda.current_stream().cuda_stream
+    lens = [chunk] * channels
+    segs = (binding.NcoSegment * (3 * channels))(*[binding.NcoSegment(c, n, -10000 + (80 * c) % 20000 + 500 * k)
+                                                   for c in range(channels)
+                                                   for k, n in enumerate((40000, 40000, chunk - 80000))])
+    for i in range(4):
+        b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens, segs, st)
+    torch.cuda.synchronize()
+    b.timing_enable(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens, segs, st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    km = [b.timing_read(w) for w in range(3)]
+    b.close()
+    del x
+    torch.cuda.empty_cache()
+    return {"value": round(channels * chunk / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+            "channels": channels, "steps": steps, "kernel_ms": [round(m / max(n, 1), 3) for m, n in km],
+            "workload": "half (240000,19200,5000,5,2000,dc) + half (48000,1200,5000,8,2000,dc), per-channel Doppler NCO "
+                        "(3 batches per channel and call), inputs in HBM"}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)
     # a wedged device queue must not hold the box until an outer limit expires: leave with a diagnostic instead
     import threading
 
@@ -87,13 +265,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the demodulator has no CPU fallback)")
     # one rank per GPU (RCCL).  SDRM_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer
     # GPUs than ranks (ranks then share devices: a functional check, not a measurement)
     backend = os.environ.get("SDRM_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if n_dev == 0:
+        sys.exit("bench.py needs a GPU (the demodulator has no CPU fallback)")
     if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
+        local_rank %= n_dev
+    elif world > n_dev:
+        sys.exit("bench.py: %d ranks but only %d GPUs on this node (SDRM_BENCH_BACKEND=gloo gives a functional run with "
+                 "shared devices)" % (world, n_dev))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the demodulator has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -104,35 +288,16 @@ def main():
 
     C, N, R = args.channels_per_gpu, args.chunk, args.chunks_resident
     total_ch = C * world
+    coll_dev = dev if backend == "nccl" else "cpu"  # RCCL broadcasts device tensors, gloo host tensors
 
     # --- configuration fan-out: rank 0 owns the channel table; RCCL broadcast (the only collective on this path)
     from sdr_modem_amd import shard
     table0 = [(FS, BAUD, DEV, DECIM, TW, DC, N)] * total_ch if rank == 0 else None
-    cfgs, lo, hi = shard.fanout_configs(table0, total_ch, device=dev)
+    cfgs, lo, hi = shard.fanout_configs(table0, total_ch, device=coll_dev)
     assert hi - lo == C
 
-    # --- synthetic input, resident in HBM: [C][R*N] complex64
-    n_total = R * N
-    first = rank * C
-    k = min(C, DISTINCT)
-    base = np.stack([siggen.gmsk_channel(first + i, n_total, FS, BAUD) for i in range(k)])
-    base_t = torch.from_numpy(base.view(np.float32).reshape(k, 2 * n_total)).to(dev)
-    x = torch.empty((C, 2 * n_total), dtype=torch.float32, device=dev)
-    for c in range(C):
-        x[c] = torch.roll(base_t[c % k], shifts=2 * 977 * (c // k))
-    del base_t
-    torch.cuda.synchronize()
-
-    batch = binding.Batch(cfgs, device=local_rank)
-    if batch.code != 0:
-        sys.exit("sdrm_batch_create failed: %d" % batch.code)
-    stream = torch.cuda.current_stream().cuda_stream
-    lens = [N] * C
-    base_ptr = x.data_ptr()
-
-    def step(i):
-        off = (i % R) * N * 8  # bytes into each channel row
-        batch.process_device(base_ptr + off, n_total, lens, stream)
+    rig = Rig(torch, binding, siggen, dev, local_rank, cfgs, rank * C, N, R)
+    batch = rig.batch
 
     def barrier():
         torch.cuda.synchronize()
@@ -140,24 +305,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for i in range(args.warmup):
-        step(i)
+        rig.step(i)
     barrier()
     batch.timing_enable(True)  # HIP events around each kernel, on the launch stream, inside the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        rig.step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
-    k_ms = []
-    for which in range(3):
-        ms, n = batch.timing_read(which)
-        k_ms.append(ms / max(n, 1))
+    k_ms = rig.kernel_ms()
     batch.timing_enable(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     samples_per_step = C * N * world
     msps = samples_per_step * args.steps / elapsed / 1e6
@@ -170,26 +335,45 @@ def main():
         verify = True
         for c in (0, C - 1):
             o = orc.Fsk(FS, BAUD, DEV, DECIM, TW, DC, N)
-            row = x[c].cpu().numpy().view(np.complex64)
+            row = rig.x[c].cpu().numpy().view(np.complex64)
             last = None
             for i in range(args.warmup + args.steps):
                 j = i % R
                 last, _ = o.process(row[j * N:(j + 1) * N])
             verify = verify and bool(np.array_equal(last, data[c, :olen[c]]))
 
-    out = None
+    row0 = rig.x[0].cpu().numpy().view(np.complex64)[:2 * N] if rank == 0 else None
+    base = rig.base
+    rig.close()
+
+    # --- BASELINE configs[3]: 4096 channels over 8 GPUs = 512 per GPU, same fan-out, its own short timed region
+    config3 = None
+    if world > 1 and not args.no_extras:
+        c3 = 512
+        table3 = [(FS, BAUD, DEV, DECIM, TW, DC, N)] * (c3 * world) if rank == 0 else None
+        cfgs3, lo3, hi3 = shard.fanout_configs(table3, c3 * world, device=coll_dev)
+        rig3 = Rig(torch, binding, siggen, dev, local_rank, cfgs3, rank * c3, N, 2, base=base)
+        for i in range(4):
+            rig3.step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(SWEEP_STEPS):
+            rig3.step(i)
+        barrier()
+        dt3 = max_over_ranks(time.perf_counter() - t0)
+        rig3.close()
+        config3 = {"value": round(c3 * world * N * SWEEP_STEPS / dt3 / 1e6, 1), "unit": "Msamples/s",
+                   "channels_total": c3 * world, "channels_per_gpu": c3, "steps": SWEEP_STEPS,
+                   "ms_per_step": round(dt3 / SWEEP_STEPS * 1e3, 3),
+                   "workload": "BASELINE configs[3] shape: %d channels sharded over %d GPUs, channel table broadcast from "
+                               "rank 0 over RCCL" % (c3 * world, world)}
+
     if rank == 0:
         front_ms = k_ms[0]
         achieved = (C * N * 8.0) / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "k1_front_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("channels") == C and tj.get("chunk") == N:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = newest_traffic(C, N)
+        macs_per_sample = 2 * T1 + T2
+        ceiling_gbs = VALU_EXACT_MACS / macs_per_sample * 8.0 / 1e9
         out = {
             "metric": "IQ Msamples/s demodulated (whole node), 48 kHz GMSK 9600 baud",
             "value": round(msps, 3),
@@ -203,7 +387,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic GMSK (BT 0.5, h 0.5, AWGN sigma 0.05; %d seeded waveforms per rank, further channels "
-                    "are circular shifts), resident in HBM" % k,
+                    "are circular shifts), resident in HBM" % min(C, DISTINCT),
             "config": {"workload": "BASELINE configs[2]: %d concurrent 48 kHz / 9600 baud GMSK channels per GPU, "
                                    "fsk_demod(48000,9600,5000,1,2000,dc), %d-sample chunks" % (C, N),
                        "channels_per_gpu": C, "chunk_samples": N, "mode": "exact (bit-identical to CPU reference)",
@@ -214,27 +398,33 @@ def main():
                           "clock_recovery": round(k_ms[2], 4)},
             "roofline": {"kernel": "k1_front (LPF1+quadrature demod+LPF2)", "bound": "hbm",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": C * N * 8,
                          # SURVEY 8d also defines the fused-pipeline figure: 8 B in + baud/fs B out per sample at the
                          # whole-path rate.  It is far below the front-end's because the step time is the clock
-                         # recovery chain (latency-bound, 4 waves), not a memory stream.
+                         # recovery chain (latency-bound), not a memory stream.
                          "whole_path_hbm_frac": round(msps * 1e6 / world * (8.0 + BAUD / FS / DECIM) / 1e9 / HBM_PEAK_GBS, 5),
-                         "valu_exact_ceiling_frac": round(35.9e12 / 291.0 * 8.0 / 1e9 / HBM_PEAK_GBS, 4),
+                         # what bit-exact arithmetic allows: 2 T1 + T2 separately rounded multiply-adds per sample on the
+                         # packed fp32 pipes (no FMA, no MFMA: both fuse)
+                         "exact_valu_ceiling": round(ceiling_gbs, 1),
+                         "exact_valu_ceiling_frac": round(ceiling_gbs / HBM_PEAK_GBS, 4),
+                         "frac_of_ceiling": round(achieved / ceiling_gbs, 4),
                          "note": "8 B of IQ read per input sample (SURVEY 8d LPF-stage HBM-read term). The kernel is "
                                  "fp32-VALU-bound: bit-exact parity needs a separately rounded multiply and add per tap "
-                                 "(v_pk_mul_f32 + v_pk_add_f32, measured 35.9 T component-MAC/s; 291 MAC per sample), "
-                                 "which caps it at valu_exact_ceiling_frac of the HBM peak"},
+                                 "(v_pk_mul_f32 + v_pk_add_f32: 16 component-MACs per SIMD and cycle; %d MACs per sample), "
+                                 "which caps it at exact_valu_ceiling GB/s of IQ" % macs_per_sample},
         }
         if verify is not None:
             out["verified_vs_oracle"] = verify
+        if config3 is not None:
+            out["config3_sharded"] = config3
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import orc
             cores = usable_cores()
-            row = x[0].cpu().numpy().view(np.complex64)[:2 * N]
-            one, _, _ = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), 1, min(2.0, args.cpu_seconds))
-            allc, secs, smp = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), cores, args.cpu_seconds)
+            cfg6 = (FS, BAUD, DEV, DECIM, TW, DC)
+            one, _, _ = orc.bench_fsk(row0, N, cfg6, 1, min(2.0, args.cpu_seconds))
+            allc, secs, smp = orc.bench_fsk(row0, N, cfg6, cores, args.cpu_seconds)
             out["cpu_baseline"] = {
                 "value": round(allc, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
                 "single_thread_value": round(one, 3),
@@ -244,13 +434,23 @@ def main():
             if orc.tuned_lib() is not None:
                 # second figure: the same code with SIMD dot products (per-lane partial sums, -O3 -mavx2 -mfma), standing in
                 # for libvolk's tuned kernels, which the reference uses outside its tests; not bit-exact, timing only
-                t_one, _, _ = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), 1, min(2.0, args.cpu_seconds), tuned=True)
-                t_all, _, _ = orc.bench_fsk(row, N, (FS, BAUD, DEV, DECIM, TW, DC), cores, args.cpu_seconds, tuned=True)
+                t_one, _, _ = orc.bench_fsk(row0, N, cfg6, 1, min(2.0, args.cpu_seconds), tuned=True)
+                t_all, _, _ = orc.bench_fsk(row0, N, cfg6, cores, args.cpu_seconds, tuned=True)
                 out["cpu_baseline"]["simd_stand_in"] = {
                     "value": round(t_all, 3), "single_thread_value": round(t_one, 3), "unit": "Msamples/s", "cores": cores,
                     "note": "oracle source built -O3 -mavx2 -mfma with vectorised FIR dot products (different summation "
                             "order: not the pinned arithmetic, never used as a checker)"}
-        if world == 1 and not args.no_cpu_baseline:
+                # third figure, when the box has it: the real libvolk's dot-product kernels behind the same loops
+                volk = orc.volk_attach()
+                if volk:
+                    v_one, _, _ = orc.bench_fsk(row0, N, cfg6, 1, min(2.0, args.cpu_seconds), tuned=True)
+                    v_all, _, _ = orc.bench_fsk(row0, N, cfg6, cores, args.cpu_seconds, tuned=True)
+                    orc.volk_detach()
+                    out["cpu_baseline"]["libvolk"] = {"value": round(v_all, 3), "single_thread_value": round(v_one, 3),
+                                                      "unit": "Msamples/s", "cores": cores, "library": volk}
+                else:
+                    out["cpu_baseline"]["libvolk"] = None  # dlopen("libvolk.so*") found nothing on this box
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             # the reference's own perf harness (test/perf_fsk_modem.c:70-98): one handle, 100 calls of 4096 samples
             # `re = (uint8_t) i, im = 0`, fsk_demod_create(48000, 4800, 5000, 2, 2000, true, 2016000); its published
             # figures are seconds per 100 calls on one CPU core.  One channel is one
@@ -278,48 +478,38 @@ def main():
                                            "note": "reference publishes 0.0368 s (MacBook Air M1) and 0.656 s (Raspberry "
                                                    "Pi 3) for this loop; includes the Python call overhead here"}
         if world == 1 and args.sweep:
-            # the named workload (256 channels) is bounded by the sequential clock-recovery chain of 4 waves; show how
+            # the named workload (256 channels) is bounded by the sequential clock-recovery chain of 16 waves; show how
             # the same pipeline fills the GPU with more channels (short runs, 2 resident chunks)
-            batch.close()
-            batch = None
-            del x
-            torch.cuda.empty_cache()
             sweep = {}
             for c2 in [int(v) for v in args.sweep.split(",") if v.strip()]:
                 try:
-                    x2 = torch.empty((c2, 4 * N), dtype=torch.float32, device=dev)
-                    seed = torch.from_numpy(base[:, :2 * N].copy().view(np.float32).reshape(k, 4 * N)).to(dev)
-                    for c in range(c2):
-                        x2[c] = torch.roll(seed[c % k], shifts=2 * 977 * (c // k))
-                    del seed
-                    b2 = binding.Batch([(FS, BAUD, DEV, DECIM, TW, DC, N)] * c2, device=local_rank)
-                    if b2.code != 0:
-                        raise RuntimeError("create failed %d" % b2.code)
-                    ln = [N] * c2
+                    r2 = Rig(torch, binding, siggen, dev, local_rank, [(FS, BAUD, DEV, DECIM, TW, DC, N)] * c2, 0, N, 2, base=base)
                     for i in range(2):
-                        b2.process_device(x2.data_ptr() + (i % 2) * N * 8, 2 * N, ln, stream)
+                        r2.step(i)
                     torch.cuda.synchronize()
-                    b2.timing_enable(True)
+                    r2.batch.timing_enable(True)
                     t0 = time.perf_counter()
                     for i in range(SWEEP_STEPS):
-                        b2.process_device(x2.data_ptr() + (i % 2) * N * 8, 2 * N, ln, stream)
+                        r2.step(i)
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
-                    km = [b2.timing_read(w) for w in range(3)]
-                    fr = km[0][0] / max(km[0][1], 1)
+                    km = r2.kernel_ms()
                     sweep[str(c2)] = {"value": round(c2 * N * SWEEP_STEPS / dt / 1e6, 1), "unit": "Msamples/s",
                                       "ms_per_step": round(dt / SWEEP_STEPS * 1e3, 3), "steps": SWEEP_STEPS,
-                                      "kernel_ms": [round(m / max(n, 1), 3) for m, n in km],
-                                      "front_hbm_frac": round(c2 * N * 8.0 / (fr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                    b2.close()
-                    del x2
-                    torch.cuda.empty_cache()
+                                      "kernel_ms": [round(m, 3) for m in km],
+                                      "front_hbm_frac": round(c2 * N * 8.0 / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    r2.close()
                 except Exception as exc:  # the sweep is informative only
                     sweep[str(c2)] = {"error": str(exc)[:200]}
             out["channel_sweep"] = sweep
+        if world == 1 and not args.no_extras:
+            for name, fn in (("end_to_end", lambda: end_to_end(binding, siggen, C, N)),
+                             ("config5", lambda: config5(torch, binding, siggen, dev, C, N))):
+                try:
+                    out[name] = fn()
+                except Exception as exc:  # informative sub-blocks: never cost the headline its line
+                    out[name] = {"error": str(exc)[:200]}
         print(json.dumps(out), flush=True)
-    if batch is not None:
-        batch.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

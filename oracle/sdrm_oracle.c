@@ -102,6 +102,42 @@ int orc_lowpass_taps(float gain, uint64_t fs, uint64_t fc, uint32_t tw, float **
 
 /* ------------------------------------------------------------------ FIR */
 
+#ifdef ORC_TUNED
+/* TIMING ONLY: when the box has the real libvolk (the reference's kernel library, an un-vendored system package), the
+ * tuned build can run the reference's own dot-product kernels behind the same loops (bench.py, cpu_baseline.libvolk).
+ * VOLK exports every kernel as a function-POINTER variable (`volk_32f_x2_dot_prod_32f_u` ...) whose first call picks
+ * the machine's best implementation, so calls go through the variable.  reference call sites: src/dsp/fir_filter.c:102,132 */
+#include <dlfcn.h>
+typedef void (*orc_volk_dot_fn)(float *result, const float *input, const float *taps, unsigned int n);
+static void *g_volk_handle;
+static orc_volk_dot_fn *g_volk_dot_f, *g_volk_dot_c;
+
+int orc_volk_attach(const char *path) {
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (h == NULL) {
+        return -1;
+    }
+    orc_volk_dot_fn *f = (orc_volk_dot_fn *) dlsym(h, "volk_32f_x2_dot_prod_32f_u");
+    orc_volk_dot_fn *c = (orc_volk_dot_fn *) dlsym(h, "volk_32fc_32f_dot_prod_32fc_u");
+    if (f == NULL || c == NULL || *f == NULL || *c == NULL) {
+        dlclose(h);
+        return -2;
+    }
+    g_volk_handle = h;
+    g_volk_dot_f = f;
+    g_volk_dot_c = c;
+    return 0;
+}
+
+void orc_volk_detach(void) {
+    g_volk_dot_f = g_volk_dot_c = NULL;
+    if (g_volk_handle != NULL) {
+        dlclose(g_volk_handle);
+        g_volk_handle = NULL;
+    }
+}
+#endif
+
 struct orc_fir {
     int decim;
     size_t ntaps;
@@ -174,7 +210,13 @@ void orc_fir_process(orc_fir *f, const float *input, size_t n, float **output, s
         /* TIMING STAND-IN ONLY (libsdrm_oracle_tuned.so, bench.py's second CPU figure): what libvolk's SIMD dot
          * products do instead of the generic kernels -- partial sums per vector lane, i.e. a different summation
          * order and therefore NOT the pinned arithmetic.  Never used as a checker. */
-        if (w == 1) {
+        if (g_volk_dot_f != NULL) { /* the real libvolk is attached: its kernels do the dot products */
+            if (w == 1) {
+                (*g_volk_dot_f)(&f->out[made], x, f->rev, (unsigned int) T);
+            } else {
+                (*g_volk_dot_c)(&f->out[2 * made], x, f->rev, (unsigned int) T);
+            }
+        } else if (w == 1) {
             float a[16] = {0};
             size_t j = 0;
             for (; j + 16 <= T; j += 16) {

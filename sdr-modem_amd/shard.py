@@ -25,8 +25,88 @@ def shard_range(total, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def fanout_configs(cfgs_rank0, total, device="cpu"):
-    """Broadcast the channel table from rank 0; return (this rank's configs, lo, hi)."""
+def filter_lengths(cfg):
+    """(T1, T2) of a channel: the reference's tap-count rule (src/dsp/lpf_taps.c:33-40, `53 fs / (22 tw)` made odd) applied
+    to the two filters fsk_demod_create designs (src/dsp/fsk_demod.c:36-47: LPF1 with a transition width of a tenth of the
+    Carson bandwidth -- the reference multiplies by the float constant 0.1f --, LPF2 with the request's)."""
+    fs, baud, dev, _decim, tw = int(cfg[0]), int(cfg[1]), int(cfg[2]), int(cfg[3]), int(cfg[4])
+    carson = abs(dev) + baud / 2.0
+    tw1 = int(float(torch.tensor(0.1, dtype=torch.float32)) * carson)
+
+    def ntaps(width):
+        n = int(53.0 * fs / (22.0 * max(width, 1)))
+        return n if n % 2 else n + 1
+    return ntaps(tw1), ntaps(tw)
+
+
+def channel_cost(cfg):
+    """Relative work of one channel per second of signal: the front-end's multiply-adds,
+    fs * (4 T1 + 2 T2 / d) -- complex LPF1 at the input rate plus real LPF2 at the decimated one."""
+    t1, t2 = filter_lengths(cfg)
+    return int(cfg[0]) * (4.0 * t1 + 2.0 * t2 / max(int(cfg[3]), 1))
+
+
+def shard_by_cost(cfgs, world):
+    """Contiguous channel blocks, one per rank, with the LARGEST block cost as small as contiguity allows (a mixed-rate
+    batch: a 240 kHz / 397-tap channel costs ten times a 48 kHz / 207-tap one, so equal counts are not equal work).
+    Classic linear partition: binary search on the bound, greedy fill; then the cuts are moved right while that lowers
+    the heavier neighbour without raising the bound, which evens out the light ranks.  Returns [(lo, hi)] * world."""
+    n = len(cfgs)
+    cost = [channel_cost(c) for c in cfgs]
+    if world <= 1 or n == 0:
+        return [(0, n)] + [(n, n)] * (max(world, 1) - 1)
+
+    def cuts_for(bound):
+        cuts, acc = [0], 0.0
+        for i, w in enumerate(cost):
+            if acc + w > bound and acc > 0.0:
+                cuts.append(i)
+                acc = 0.0
+            acc += w
+        cuts.append(n)
+        return cuts
+    lo_b, hi_b = max(cost), sum(cost)
+    for _ in range(60):
+        mid = 0.5 * (lo_b + hi_b)
+        if len(cuts_for(mid)) - 1 <= world:
+            hi_b = mid
+        else:
+            lo_b = mid
+    cuts = cuts_for(hi_b)
+    while len(cuts) - 1 < world:  # fewer blocks than ranks: split the heaviest block that can be split
+        sums = [sum(cost[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)]
+        order = sorted(range(len(sums)), key=lambda i: -sums[i])
+        for i in order:
+            if cuts[i + 1] - cuts[i] > 1:
+                half, acc, j = sums[i] / 2.0, 0.0, cuts[i]
+                while j < cuts[i + 1] - 1 and acc + cost[j] <= half:
+                    acc += cost[j]
+                    j += 1
+                cuts.insert(i + 1, max(j, cuts[i] + 1))
+                break
+        else:
+            cuts.insert(len(cuts) - 1, cuts[-1])  # nothing left to split: empty rank
+    # greedy fill leaves the last rank light: shift work towards it while the maximum does not grow
+    prefix = [0.0]
+    for w in cost:
+        prefix.append(prefix[-1] + w)
+    moved = True
+    while moved:
+        moved = False
+        for i in range(len(cuts) - 2, 0, -1):
+            left = prefix[cuts[i]] - prefix[cuts[i - 1]]
+            right = prefix[cuts[i + 1]] - prefix[cuts[i]]
+            if cuts[i] - cuts[i - 1] > 1:
+                w = cost[cuts[i] - 1]
+                if max(left - w, right + w) < max(left, right):
+                    cuts[i] -= 1
+                    moved = True
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+def fanout_configs(cfgs_rank0, total, device="cpu", balance="count"):
+    """Broadcast the channel table from rank 0; return (this rank's configs, lo, hi).  balance="cost": shards of equal
+    front-end work (shard_by_cost, computed by every rank from the same broadcast table) instead of equal counts."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     table = torch.zeros((total, FIELDS), dtype=torch.int64, device=device)
@@ -34,11 +114,14 @@ def fanout_configs(cfgs_rank0, total, device="cpu"):
         table.copy_(encode(cfgs_rank0))
     if world > 1:
         dist.broadcast(table, src=0)
-    lo, hi = shard_range(total, world, rank)
+    if balance == "cost":
+        lo, hi = shard_by_cost(decode(table.cpu()), world)[rank]
+    else:
+        lo, hi = shard_range(total, world, rank)
     return decode(table[lo:hi].cpu()), lo, hi
 
 
-def fanout_nco_segments(segments_rank0, total, device="cpu"):
+def fanout_nco_segments(segments_rank0, total, device="cpu", span=None):
     """Doppler pre-correction at node scale: rank 0 runs the orbit model and the planner for every channel
     of the node and holds the call's NCO batches as (global_channel, len, freq_hz), grouped by channel; one broadcast
     (a count, then an int64 table -- RCCL on GPUs, KB-sized) gives every rank the batches of its own channels, with
@@ -56,6 +139,6 @@ def fanout_nco_segments(segments_rank0, total, device="cpu"):
         table[:n].copy_(torch.tensor([[int(c), int(ln), int(f)] for c, ln, f in segments_rank0], dtype=torch.int64))
     if world > 1:
         dist.broadcast(table, src=0)
-    lo, hi = shard_range(total, world, rank)
+    lo, hi = span if span is not None else shard_range(total, world, rank)  # span: this rank's (lo, hi) of a cost-balanced table
     rows = table[:n].cpu().tolist()
     return [(int(c) - lo, int(ln), int(f)) for c, ln, f in rows if lo <= c < hi]

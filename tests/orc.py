@@ -347,6 +347,29 @@ def tuned_lib():
     return _TUNED or None
 
 
+def volk_attach(path=None):
+    """Put the box's real libvolk (when it has one) behind the tuned build's FIR loops: bench.py's cpu_baseline.libvolk,
+    timing only.  Returns the library name that loaded, or None."""
+    L = tuned_lib()
+    if L is None or not hasattr(L, "orc_volk_attach"):
+        return None
+    import ctypes.util
+    names = [path] if path else [ctypes.util.find_library("volk"), "libvolk.so", "libvolk.so.3.1", "libvolk.so.3.0",
+                                 "libvolk.so.2.5", "libvolk.so.2.4", "libvolk.so.2.2", "libvolk.so.2.0"]
+    L.orc_volk_attach.argtypes = [C.c_char_p]
+    for name in names:
+        if name and L.orc_volk_attach(name.encode()) == 0:
+            return name
+    return None
+
+
+def volk_detach():
+    L = tuned_lib()
+    if L is not None and hasattr(L, "orc_volk_detach"):
+        L.orc_volk_detach.restype = None
+        L.orc_volk_detach()
+
+
 def bench_fsk(iq, chunk, cfg, threads, min_seconds, tuned=False):
     fs, baud, dev, decim, tw, dc = cfg
     iq = np.ascontiguousarray(iq).view(np.float32)

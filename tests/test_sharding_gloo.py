@@ -56,6 +56,15 @@ def _worker(rank, world, port, ret):
             x = np.concatenate([osc.multiply(1500 - 100 * (lo + i), x[:2000]), osc.multiply(1490 - 100 * (lo + i), x[2000:])])
         want8, _ = orc.demod_stream(c[:6], x.view(np.complex64), n)
         ok = ok and np.array_equal(want8, got8[i])
+    # cost-balanced shards of a mixed-rate table: every rank derives the same cuts from the broadcast table
+    mix = None
+    if rank == 0:
+        mix = [(240000, 19200, 5000, 5, 2000, True, 4096)] * 6 + [(48000, 1200, 5000, 8, 2000, True, 4096)] * 18
+    cfgs_c, lo_c, hi_c = shard.fanout_configs(mix, 24, balance="cost")
+    spans = [None] * world
+    dist.all_gather_object(spans, (lo_c, hi_c, sum(shard.channel_cost(c) for c in cfgs_c)))
+    ok = ok and spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 24
+    ok = ok and max(s[2] for s in spans) / min(s[2] for s in spans) <= 1.15 and spans[0][1] - spans[0][0] < 12
     # every rank reports its range; rank 0 checks the shards tile [0, total)
     ranges = [None] * world
     dist.all_gather_object(ranges, (lo, hi, bool(ok)))
@@ -87,3 +96,34 @@ def test_shard_range_tiles_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_cost_balanced_shards_of_the_config5_mix():
+    """BASELINE configs[4]: 240 kHz / 19200 baud and 48 kHz / 1200 baud channels cost 5-10x apart; shards are balanced by
+    fs * (4 T1 + 2 T2 / d), contiguous, and tile the table."""
+    sys.path.insert(0, ROOT)
+    import sdrm_pkg
+    sdrm_pkg.load()
+    from sdr_modem_amd import shard
+    assert shard.filter_lengths((48000, 9600, 5000, 1, 2000, True, 1)) == (117, 57)       # SURVEY 8 table
+    assert shard.filter_lengths((240000, 19200, 5000, 1, 2000, True, 1)) == (397, 289)
+    assert shard.filter_lengths((48000, 1200, 5000, 1, 2000, True, 1)) == (207, 57)
+    assert shard.filter_lengths((192000, 40000, 5000, 1, 2000, True, 1)) == (185, 231)
+    for decims in ((5, 8), (1, 1)):
+        for total in (4096, 512, 100):
+            half = total // 2
+            cfgs = [(240000, 19200, 5000, decims[0], 2000, True, 131072)] * half + \
+                   [(48000, 1200, 5000, decims[1], 2000, True, 131072)] * (total - half)
+            for world in (2, 4, 8):
+                spans = shard.shard_by_cost(cfgs, world)
+                assert spans[0][0] == 0 and spans[-1][1] == total
+                assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+                costs = [sum(shard.channel_cost(c) for c in cfgs[a:b]) for a, b in spans]
+                # 100 channels over 8 ranks: one heavy channel is a seventh of a rank's share, granularity bounds the balance
+                assert max(costs) / min(costs) <= (1.15 if total >= 512 else 1.35), (decims, total, world, costs)
+                by_count = [sum(shard.channel_cost(c) for c in cfgs[slice(*shard.shard_range(total, world, r))]) for r in range(world)]
+                assert max(by_count) / min(by_count) > 3.0  # what equal counts would have given
+    # uniform tables fall back to equal counts; more ranks than channels leaves empty shards at the end
+    uni = [(48000, 9600, 5000, 1, 2000, True, 4096)] * 4096
+    assert shard.shard_by_cost(uni, 8) == [(512 * r, 512 * (r + 1)) for r in range(8)]
+    assert shard.shard_by_cost(uni[:3], 8)[:3] == [(0, 1), (1, 2), (2, 3)]
