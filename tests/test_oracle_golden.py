@@ -36,6 +36,12 @@ E2E = [
 ]
 
 
+# Off-by-one soft bits against the committed golden files: exactly the counts SURVEY.md 8(c) measured for the UNMODIFIED
+# reference sources with generic VOLK kernels in this container (the golden files were generated on the author's
+# machine; the reference compares at +-2, test_fsk_demod.c:47).  Any change of the oracle's arithmetic moves them.
+E2E_MISMATCHES = {"lucky7": 22, "lucky7_nodc": 35, "nusat": 1, "nan": 0}
+
+
 @pytest.mark.parametrize("name,cfg,inp,exp", E2E, ids=[e[0] for e in E2E])
 def test_e2e_golden_files(name, cfg, inp, exp):
     iq = np.fromfile(os.path.join(GOLDEN, inp), dtype=np.float32)
@@ -43,9 +49,58 @@ def test_e2e_golden_files(name, cfg, inp, exp):
     got, _ = orc.demod_stream(cfg, iq, 4096)  # 4096 = the harness's buffer, test_fsk_demod.c:20
     assert len(got) == len(want)
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
-    # the reference's own tolerance is 2 LSB (test_fsk_demod.c:47); the oracle is within 1
+    # the reference's own tolerance is 2 LSB (test_fsk_demod.c:47); the oracle is within 1, on exactly the symbols the
+    # reference itself misses
     assert diff.max() <= 1, (name, int(diff.max()))
-    assert (diff != 0).mean() < 0.005, (name, int((diff != 0).sum()))
+    assert int((diff != 0).sum()) == E2E_MISMATCHES[name], (name, int((diff != 0).sum()))
+
+
+# ---------------------------------------------------------------- second, independent restatement (numpy fp32)
+
+def _synthetic(fs, baud, n, seed):
+    import sdrm_pkg
+    sdrm_pkg.load()
+    from sdr_modem_amd import siggen
+    return siggen.gmsk_channel(seed, n, fs=fs, baud=baud).view(np.float32)
+
+
+NP_CASES = [
+    # name, config, input file or (fs, baud, samples, seed) of a synthetic GMSK stream, chunking of the C oracle
+    ("lucky7_9600_d1", (48000, 9600, 5000, 1, 2000, True), "lucky7.expected.cf32", 4096),
+    ("lucky7_4800_d2", (48000, 4800, 5000, 2, 2000, True), "lucky7.expected.cf32", 4096),
+    ("lucky7_4800_d2_nodc", (48000, 4800, 5000, 2, 2000, False), "lucky7.expected.cf32", 1000),
+    ("nusat", (192000, 40000, 5000, 1, 2000, True), "nusat.cf32", 4096),
+    ("config5_240k_19200_d5", (240000, 19200, 5000, 5, 2000, True), (240000, 19200, 60000, 11), 7777),
+    ("config5_48k_1200_d8", (48000, 1200, 5000, 8, 2000, True), (48000, 1200, 50000, 12), 4096),
+    ("bench_48k_9600", (48000, 9600, 5000, 1, 2000, True), (48000, 9600, 40000, 13), 131072),
+]
+
+
+@pytest.mark.parametrize("name,cfg,src,chunk", NP_CASES, ids=[c[0] for c in NP_CASES])
+def test_numpy_restatement_agrees_bit_for_bit(name, cfg, src, chunk):
+    """tests/np_oracle.py is written from SURVEY.md Appendix B and processes the whole stream at once; the C oracle is
+    written from the reference's stage files and works chunk by chunk with carried state.  Their FLOAT soft bits must be
+    the same bits (this also re-proves chunk invariance for samples per symbol < 8)."""
+    import np_oracle
+    iq = np.fromfile(os.path.join(GOLDEN, src), dtype=np.float32) if isinstance(src, str) else _synthetic(*src)
+    a8, af = np_oracle.demod_stream(cfg, iq)
+    b8, bf = orc.demod_stream(cfg, iq, chunk)
+    assert len(af) == len(bf) and len(af) > 100
+    assert np.array_equal(af.view(np.uint32), bf.view(np.uint32)), name
+    assert np.array_equal(a8, b8), name
+
+
+def test_numpy_restatement_tables_and_taps():
+    import np_oracle
+    # the arctan table is atan(i / 255) through "%.6e", its last two entries equal (fast_atan2f.c:23-67)
+    formula = np.array([float("%.6e" % np.arctan(min(i, 255) / 255.0)) for i in range(257)], dtype=np.float32)
+    assert np.array_equal(formula, np_oracle.ATAN)
+    # its tap design equals the reference's known answer (test/test_lpf_taps.c:28-41) and the C oracle's, bit for bit
+    v = VEC["test_lpf_taps.c:expected_taps"]
+    taps = np_oracle.design_taps(8000, 1750, 500)
+    assert np.abs(taps - np.array(v["values"], dtype=np.float32)).max() < 1e-4
+    for fs, fc, tw in ((48000, 9800, 980), (48000, 4800, 2000), (240000, 14600, 1460), (192000, 20000, 2000)):
+        assert np.array_equal(np_oracle.design_taps(fs, fc, tw).view(np.uint32), orc.lowpass_taps(fs, fc, tw)[1].view(np.uint32))
 
 
 @pytest.mark.parametrize("chunk", [1000, 2000, 4096, 96000])
