@@ -169,10 +169,9 @@ int sdrm_batch_timing_read(sdrm_batch *batch, int which, double *total_ms, uint6
 /* Stage probes for tests: run ONE stage of the device pipeline on a host vector (state-free where the
  * stage is). Return 0 on success. */
 int sdrm_probe_atan2(const float *y, const float *x, float *out, size_t n);
-int sdrm_probe_wave_scan(const float *terms, float carry_in, float *out, size_t n); /* in-order fp32 running sum */
-/* in-order scan flavour used by the probe and the DC kernel: 0 = hand-placed v_add_f32_dpp chain (default),
- * 1 = the same wave_shr data flow through the compiler's update_dpp builtin */
-void sdrm_set_scan_mode(int mode);
+/* sums[i] / length as the DC blocker computes it (reference src/dsp/dc_blocker.c:63): three instructions with a fall-back
+ * to the division proper for denormal / non-finite quotients; must equal the IEEE quotient bit for bit */
+int sdrm_probe_boxcar_div(const float *sums, uint32_t length, float *out, size_t n);
 
 /* Diagnostics (tools/k3_probe.py, tools/sweep_point.py; never needed for results).
  * sdrm_batch_k3_stamps: enable = 1 makes every call (enable = k > 1: only the k-th call from now) record cycle counts

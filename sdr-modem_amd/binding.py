@@ -57,7 +57,7 @@ EXPORTS = [
     "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt",
     "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
-    "sdrm_probe_atan2", "sdrm_probe_wave_scan", "sdrm_set_scan_mode", "sdrm_version", "sdrm_device_count",
+    "sdrm_probe_atan2", "sdrm_probe_boxcar_div", "sdrm_version", "sdrm_device_count",
     "sdrm_batch_k3_stamps", "sdrm_batch_timeline",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
     "interrupt_waiting_the_data", "destroy_queue",
@@ -141,9 +141,7 @@ def load():
     L.sdrm_batch_timing_enable.argtypes = [vp, C.c_int]
     L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sdrm_probe_atan2.argtypes = [vp, vp, vp, C.c_size_t]
-    L.sdrm_probe_wave_scan.argtypes = [vp, C.c_float, vp, C.c_size_t]
-    L.sdrm_set_scan_mode.argtypes = [C.c_int]
-    L.sdrm_set_scan_mode.restype = None
+    L.sdrm_probe_boxcar_div.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
     L.fsk_demod_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_uint8, C.c_uint32, C.c_bool, C.c_uint32,
                                    C.POINTER(vp)]
     L.fsk_demod_process.argtypes = [vp, C.c_size_t, C.POINTER(i8p), C.POINTER(C.c_size_t), vp]

@@ -16,9 +16,6 @@
 #include "sdrm_launch.h"
 #include "sdrm_tables.h"
 
-namespace sdrm {
-void set_scan_mode(int mode);
-}
 
 #define SDRM_CTL_SLOTS 8
 #define SDRM_RES_SETS 4    // pinned result sets of the pipelined host path
@@ -397,8 +394,11 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.out_stride = out_stride;
     d.t1_max = pl.t1_max;
     d.t2_max = pl.t2_max;
-    d.rx_cap = pl.rx_cap;
-    d.rs_cap = pl.rs_cap;
+    d.dc_hx_cap = pl.dc_hx_cap;
+    d.dc_l_cap = pl.dc_l_cap;
+    d.dc_group = pl.dc_group;
+    d.dc_rpitch = sdrm_k2_ring_pitch((pl.dc_l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK);
+    d.dc_lds = (uint32_t) pl.dc_lds_bytes();
     d.any_dc = any_dc;
     b->in_stride = pl.in_stride;
     *out = b;
@@ -1479,9 +1479,8 @@ extern "C" int sdrm_probe_atan2(const float *y, const float *x, float *out, size
     return 0;
 }
 
-static int g_probe_scan_mode = 0;
-
-extern "C" int sdrm_probe_wave_scan(const float *terms, float carry_in, float *out, size_t n) {
+// quotients of the DC blocker's boxcars: the three-instruction form with its fall-back, as the DC kernel runs it
+extern "C" int sdrm_probe_boxcar_div(const float *sums, uint32_t length, float *out, size_t n) {
     if (sdrm_device_count() <= 0) {
         fprintf(stderr, "<3>sdrmodem_hip: no HIP device available\n");
         return -ENODEV;
@@ -1489,8 +1488,8 @@ extern "C" int sdrm_probe_wave_scan(const float *terms, float carry_in, float *o
     float *dt = nullptr, *dout = nullptr;
     HIP_TRY(hipMalloc((void **) &dt, n * 4 + 4));
     HIP_TRY(hipMalloc((void **) &dout, n * 4 + 4));
-    HIP_TRY(hipMemcpy(dt, terms, n * 4, hipMemcpyHostToDevice));
-    sdrm::launch_probe_scan(dt, carry_in, dout, n, g_probe_scan_mode, nullptr);
+    HIP_TRY(hipMemcpy(dt, sums, n * 4, hipMemcpyHostToDevice));
+    sdrm::launch_probe_boxcar_div(dt, length, dout, n, nullptr);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
     (void) hipFree(dt);
@@ -1554,8 +1553,3 @@ extern "C" int sdrm_batch_timeline(sdrm_batch *b, int enable, unsigned long long
     return rows;
 }
 
-// selects the in-order scan flavour (0 = wave_shr DPP, 1 = row_shr DPP + readlane) for the probe and the DC kernel
-extern "C" void sdrm_set_scan_mode(int mode) {
-    g_probe_scan_mode = mode;
-    sdrm::set_scan_mode(mode);
-}

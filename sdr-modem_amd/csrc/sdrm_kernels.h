@@ -9,8 +9,8 @@
 //   K1 front  : LPF1 (complex FIR, T1 taps) -> quadrature demod -> LPF2 (real FIR, T2 taps, decimate d)
 //               grid (tiles, channels), 256 threads, IQ tile + halo staged in LDS        [parallel in time]
 //   K1h       : roll the raw-IQ history (T1+T2-1 samples per channel) for the next call
-//   K2 dc     : 4 cascaded boxcars + delay; one wave per channel, 64 consecutive samples per step,
-//               running sums as an in-order 64-lane DPP chain with carry hand-off          [sequential]
+//   K2 dc     : 4 cascaded boxcars + delay; a workgroup serves 16 channels: ONE chain wave runs every running sum
+//               (lane = stage x channel, one add per sample), five helper waves do the pointwise parts [sequential]
 //   K3 clock  : MMSE interpolator + Mueller&Mueller loop + int8; one lane per channel       [sequential]
 #ifndef SDRM_KERNELS_H
 #define SDRM_KERNELS_H
@@ -79,10 +79,9 @@ struct sdrm_chan_params {
     uint32_t hist_len;              // raw-IQ history carried between calls: T1 + T2 - 1 samples
     uint32_t tile_m;                // LPF2 outputs produced by one K1 tile
     uint32_t max_len;               // max_input_buffer_length
-    uint32_t rx_mask, rs_mask;      // DC ring sizes - 1 (input ring, stage rings)
     uint32_t dc_state_off;          // float offset of this channel's DC state in the dc state pool
     float quad_gain;
-    float dc_len_f;
+    float dc_len_f, dc_inv_len;     // (float) L and RN(1 / L): sdrm_boxcar_out_fast
     float omega_mid, omega_lim, gain_omega, gain_mu;
 };
 
@@ -416,6 +415,190 @@ SDRM_HD void sdrm_hist_roll(int tid, int nthreads, const sdrm_chan_params &p, co
     for (int j = tid; j < H; j += nthreads) {
         hist_next[j] = sdrm_ext_sample(in, hist_cur, H, (int) c.n_in - H + j);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ K2
+
+// DC blocker (reference src/dsp/dc_blocker.c:56-64, 105-119): four cascaded length-L boxcars, each
+//   t = u[n] - u[n-L];  acc = acc + t;  v[n] = acc / L          (acc: a strictly sequential fp32 recursion)
+// and out[n] = x[n - 2(L-1)] - v3[n].  Everything except `acc = acc + t` is pointwise.
+//
+// One workgroup serves up to 16 channels ("slots") with six waves:
+//   chain wave   lane = (stage, slot): reads the 64 terms of its block from its LDS row (16 x ds_read_b128), adds them
+//                one by one to its running sum and leaves four checkpoints {sum before the block, after 16, 32, 48 terms};
+//   feeder       terms of stage 0 from the front-end's output: t = x[n] - x[n-L];
+//   3 x stage    for stage s -> s+1: every lane takes 16 consecutive samples of one slot (4 lanes per block), rebuilds the
+//                running sums from its checkpoint with the SAME additions in the same order, divides, appends the
+//                quotients to the stage's delay ring in LDS, reads the delayed ones and writes the next stage's terms;
+//   output       the same for stage 3, then x[n - 2(L-1)] - v3[n] to global memory.
+// The stages run two blocks apart (stage s sums block it - 2s in iteration `it`, the helpers convert it in iteration
+// it + 1), one barrier per iteration; a row keeps three blocks (being written / being summed / being read).
+// A lone wave pays per instruction, not per lane: the chain wave's 64 additions serve 4 stages x 16 channels, where the
+// earlier in-order DPP chain spent 63 wave instructions on 64 samples of ONE stage of ONE channel.
+#define SDRM_K2_SLOTS 16
+#define SDRM_K2_BLK 64
+#define SDRM_K2_P 16      // consecutive samples per helper lane
+#define SDRM_K2_NBUF 3
+#define SDRM_K2_TSPITCH (SDRM_K2_NBUF * SDRM_K2_BLK + 4)  // floats per row: 49 sixteen-byte units (odd: conflict-free ds_read_b128 across rows)
+#define SDRM_K2_MIRROR 16  // the first 16 ring slots are repeated behind the ring: 16 delayed samples never wrap
+#define SDRM_K2_WAVES 6
+#define SDRM_K2_ROWS (4 * SDRM_K2_SLOTS)
+
+// per-slot constants (in LDS on the device)
+struct sdrm_k2_slot {
+    int chan;            // -1: no channel in this slot (or no DC blocker / absent from the call)
+    uint32_t L;          // boxcar length
+    uint32_t A;          // L rounded up to a block: ring slot of call-relative sample n is (A + n) mod rcap
+    uint32_t rcap;       // A + 64
+    uint32_t nz;         // samples of this call
+    uint32_t HX;         // 2 (L - 1): samples of x carried between calls
+    float Lf, invL;
+};
+
+// DC state of a channel in global memory: hx[hx_cap] (the last 2(L-1) samples of x, oldest first, at the FRONT of the
+// array), three tails of l_cap floats (the last L quotients of stages 0..2, oldest first), four running sums
+SDRM_HD float *sdrm_k2_state_tail(float *st, int ring, uint32_t hx_cap, uint32_t l_cap) { return st + hx_cap + (size_t) ring * l_cap; }
+SDRM_HD float *sdrm_k2_state_acc(float *st, uint32_t hx_cap, uint32_t l_cap) { return st + hx_cap + 3 * (size_t) l_cap; }
+SDRM_HD size_t sdrm_k2_state_floats(uint32_t hx_cap, uint32_t l_cap) { return (size_t) hx_cap + 3 * (size_t) l_cap + 8; }
+
+// floats between two rings in LDS (odd number of 16-byte units)
+SDRM_HD uint32_t sdrm_k2_ring_pitch(uint32_t rcap_max) { return rcap_max + SDRM_K2_MIRROR + 4; }
+
+SDRM_HD void sdrm_k2_slot_setup(sdrm_k2_slot &s, int chan, const sdrm_chan_params &p, uint32_t nz) {
+    s.chan = chan;
+    s.L = p.dc_len;
+    s.A = (p.dc_len + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK;
+    s.rcap = s.A + SDRM_K2_BLK;
+    s.nz = nz;
+    s.HX = 2 * (p.dc_len - 1);
+    s.Lf = p.dc_len_f;
+    s.invL = p.dc_inv_len;
+}
+
+// x[n] of this call: the front-end's output for n >= 0, the carried samples before
+SDRM_HD float sdrm_k2_x(const float *z, const float *hx, uint32_t HX, int n) { return n >= 0 ? z[n] : hx[(int) HX + n]; }
+
+// ring <- tail at the start of a call: the sample L - j before the call sits in slot A - L + j
+SDRM_HD void sdrm_k2_ring_load(float *ring, const sdrm_k2_slot &s, const float *tail, int tid, int nthreads) {
+    for (uint32_t j = tid; j < s.L; j += nthreads) {
+        const uint32_t slot = s.A - s.L + j;
+        ring[slot] = tail[j];
+        if (slot < SDRM_K2_MIRROR) {
+            ring[s.rcap + slot] = tail[j];
+        }
+    }
+}
+
+// tail <- ring at the end: the last L samples, i.e. call-relative nz - L .. nz - 1
+SDRM_HD void sdrm_k2_ring_save(const float *ring, const sdrm_k2_slot &s, float *tail, int tid, int nthreads) {
+    for (uint32_t j = tid; j < s.L; j += nthreads) {
+        tail[j] = ring[(s.A + s.nz - s.L + j) % s.rcap];
+    }
+}
+
+// ring slot of the first sample of block k
+SDRM_HD uint32_t sdrm_k2_block_slot(const sdrm_k2_slot &s, int k) { return (uint32_t) (((uint64_t) s.A + (uint64_t) k * SDRM_K2_BLK) % s.rcap); }
+
+// ---- chain wave: row = (stage, slot).  64 additions in order; checkpoints {before, after 16, 32, 48}; returns the sum after 64
+SDRM_HD float sdrm_k2_chain_block(const float *row_buf, float *check, float acc) {
+    check[0] = acc;
+    for (int g = 0; g < 4; g++) {
+        for (int i = 0; i < 16; i++) {
+            acc = acc + row_buf[16 * g + i];
+        }
+        if (g < 3) {
+            check[g + 1] = acc;
+        }
+    }
+    return acc;
+}
+
+// ---- feeder: the 16 terms of stage 0 a lane owns in block k (q = lane & 3): t = x[n] - x[n - L], 0 beyond the call's end
+SDRM_HD void sdrm_k2_feed(const sdrm_k2_slot &s, int k, int q, const float *z, const float *hx, float *row_buf) {
+    const int n0 = k * SDRM_K2_BLK + q * SDRM_K2_P;
+    for (int i = 0; i < SDRM_K2_P; i++) {
+        const int n = n0 + i;
+        float t = 0.0f;
+        if ((uint32_t) n < s.nz) {
+            t = sdrm_boxcar_term(z[n], sdrm_k2_x(z, hx, s.HX, n - (int) s.L));
+        }
+        row_buf[q * SDRM_K2_P + i] = t;
+    }
+}
+
+// the 16 quotients a lane owns: running sums rebuilt from the checkpoint, then sums / L
+SDRM_HD void sdrm_k2_quotients(const sdrm_k2_slot &s, const float *row_buf, float check, int q, float (&v)[SDRM_K2_P]) {
+    float acc = check;
+    float sums[SDRM_K2_P];
+    bool any_unsafe = false;
+    for (int i = 0; i < SDRM_K2_P; i++) {
+        acc = acc + row_buf[q * SDRM_K2_P + i];
+        sums[i] = acc;
+        bool unsafe;
+        v[i] = sdrm_boxcar_out_fast(acc, s.Lf, s.invL, &unsafe);
+        any_unsafe |= unsafe;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    any_unsafe = __any(any_unsafe);
+#endif
+    if (any_unsafe) {  // denormal / infinite / NaN quotients: the division proper (the same values wherever the short form is valid)
+        for (int i = 0; i < SDRM_K2_P; i++) {
+            v[i] = sdrm_boxcar_out(sums[i], s.Lf);
+        }
+    }
+}
+
+// ---- stage s -> s+1: quotients into the delay ring, delayed quotients out of it, terms of the next stage
+SDRM_HD void sdrm_k2_transition(const sdrm_k2_slot &s, int k, int q, const float *in_buf, float check, float *ring, float *out_buf) {
+    float v[SDRM_K2_P];
+    sdrm_k2_quotients(s, in_buf, check, q, v);
+    // Lanes past the channel's end leave the ring alone (another channel of the group may have many more blocks, and
+    // their garbage would run round the ring into the samples the next call needs); a lane that holds the end writes
+    // fewer than 16 slots beyond it, which the ring's 64 spare slots absorb.
+    if ((uint32_t) (k * SDRM_K2_BLK + q * SDRM_K2_P) >= s.nz) {
+        for (int i = 0; i < SDRM_K2_P; i++) {
+            out_buf[q * SDRM_K2_P + i] = 0.0f;
+        }
+        return;
+    }
+    const uint32_t base = sdrm_k2_block_slot(s, k) + (uint32_t) q * SDRM_K2_P;  // < rcap, a multiple of 16
+    for (int i = 0; i < SDRM_K2_P; i++) {
+        ring[base + i] = v[i];
+    }
+    if (base == 0) {
+        for (int i = 0; i < SDRM_K2_MIRROR; i++) {
+            ring[s.rcap + i] = v[i];
+        }
+    }
+    const uint32_t from = (base + s.rcap - s.L) % s.rcap;  // from + 15 < rcap + MIRROR
+    const int n0 = k * SDRM_K2_BLK + q * SDRM_K2_P;
+    for (int i = 0; i < SDRM_K2_P; i++) {
+        const float ud = ring[from + i];
+        out_buf[q * SDRM_K2_P + i] = ((uint32_t) (n0 + i) < s.nz) ? sdrm_boxcar_term(v[i], ud) : 0.0f;
+    }
+}
+
+// ---- output: x[n - 2(L-1)] - v3[n]; returns true when a result is not finite
+SDRM_HD bool sdrm_k2_output(const sdrm_k2_slot &s, int k, int q, const float *in_buf, float check, const float *z, const float *hx,
+                            float *out) {
+    float v[SDRM_K2_P];
+    sdrm_k2_quotients(s, in_buf, check, q, v);
+    const int n0 = k * SDRM_K2_BLK + q * SDRM_K2_P;
+    bool odd = false;
+    for (int i = 0; i < SDRM_K2_P; i++) {
+        const int n = n0 + i;
+        if ((uint32_t) n < s.nz) {
+            const float o = sdrm_k2_x(z, hx, s.HX, n - (int) s.HX) - v[i];
+            out[n] = o;
+            odd |= !(fabsf(o) < INFINITY);
+        }
+    }
+    return odd;
+}
+
+// new hx = the last HX samples of (hx ++ z[0 .. nz)): element j for j in [j0, j1) (the caller orders reads before writes)
+SDRM_HD float sdrm_k2_hx_source(const sdrm_k2_slot &s, const float *z, const float *hx, uint32_t j) {
+    return sdrm_k2_x(z, hx, s.HX, (int) s.nz - (int) s.HX + (int) j);
 }
 
 // ------------------------------------------------------------------------------------------------ K3

@@ -408,301 +408,218 @@ void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_strid
 
 // ================================================================================================ K2
 
-// In-order fp32 running sum across the 64 lanes of a wave: s[i] = fl(s[i-1] + t[i]), s[-1] = carry.
-// fp32 addition is not associative, so this is a chain of 63 dependent adds ("wavefront-prefix handoff"): each step
-// is ONE instruction, v_add_f32 with a DPP wave_shr:1 on its first source -- lane i adds its term to lane i-1's
-// partial sum; lane 0 has no source lane and (bound_ctrl off) keeps its value, which is already final.  After step k
-// lanes 0..k are final; finished lanes recompute the same value, unfinished lanes hold scratch.
-// MODE 0: hand-placed instruction chain (s_nop 1 = the 2 wait states a DPP read of a just-written VGPR needs).
-// MODE 1: the same data flow through the update_dpp builtin, scheduled by the compiler (v_mov + v_mov_dpp + v_add).
-template <int MODE>
-__device__ __forceinline__ float wave_inorder_sum(float t, float carry) {
-    float s = carry + t;  // lane 0 is final
-    if (MODE == 0) {
-        asm volatile(
-            ".rept 63\n\t"
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            ".endr"
-            : "+v"(s)
-            : "v"(t));
-    } else {
-        const int ci = __builtin_bit_cast(int, carry);
-#pragma unroll
-        for (int k = 1; k < 64; k++) {
-            int up = __builtin_amdgcn_update_dpp(ci, __builtin_bit_cast(int, s), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            s = __builtin_bit_cast(float, up) + t;
-        }
-    }
-    return s;
-}
-
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-
-// With several hundred channels a CU carries several DC workgroups, i.e. several chain waves per SIMD whose
-// 4-in-12-cycle adds add up to a busy vector unit, and a symbol loop of the clock stage sharing such a SIMD runs ~1.4x
-// slower (5.4 instead of 4.4 ms per chunk at 1024 channels).  From 384 channels on the DC kernel therefore asks for at
-// least 20 KB of LDS per workgroup: a clock-recovery workgroup holds 141 KB of a CU's 160 KB, so the two can then never
-// share a CU.  (With one DC workgroup per CU the sharing costs ~1 % and the exclusion is not worth its risk, below.)
-bool k2_keeps_off_clock_cus(int n_channels) { return n_channels >= 384; }
-
-size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap, int n_channels) {
-    const size_t need = ((size_t) rx_cap + 3 * (size_t) rs_cap) * sizeof(float);
-    const size_t floor_bytes = k2_keeps_off_clock_cus(n_channels) ? 20 * 1024 : 0;
-    return need < floor_bytes ? floor_bytes : need;
-}
-
-// The exclusion only helps if the clock stage of call k gets its CUs BEFORE the DC workgroups of call k+1 spread over
-// the chip -- both are released by the same event (the clock stage of call k-1 finishing) and the DC kernel is
-// dispatched ~25 us earlier; when it wins, the clock stage waits for DC workgroups to finish (+1 ms).  This one-wave
-// kernel sits in the DC stream in front of the DC kernel and sleeps ~100 us (of the 2 ms of slack that stage has).
+// A clock-recovery workgroup needs a CU's LDS nearly to itself (141 KB); a DC workgroup of sixteen channels holds ~105 KB,
+// so the two never share a CU.  The clock stage of call k and the DC stage of call k+1 are released by the same event
+// (the clock stage of call k-1 finishing); with many channels the DC grid would cover every CU before the clock
+// stage's workgroups are placed, which then wait for DC workgroups to finish.  This one-wave kernel in front of the DC
+// kernel gives the clock stage ~100 us of head start (of the slack the DC stage has).
 __global__ void k2_hold(int loops) {
     for (int i = 0; i < loops; i++) {
         __builtin_amdgcn_s_sleep(127);
     }
 }
 // The front-end of call k+2 and the clock stage of call k are both free to go when the clock stage of call k-1 ends.
-// A clock-recovery workgroup needs a CU's LDS nearly to itself; once the front-end's thousands of small workgroups are
-// streaming through the chip no CU ever has that much free, and the clock stage starts only when the front-end's grid
-// has drained (seen: every other call 0.5-1.2 ms late at 512 channels).  Half a hold in the front-end's stream lets
-// the clock stage place its workgroups first.
-// Measured with and without (ms per step, 131072-sample chunks): 384 channels 3.30 / 3.86, 512: 3.39 / 3.96, 768: 3.43 /
-// 4.34, 1024: 3.93 / 3.90; below (256: 3.22 / 3.10) the stages' phases happen to miss each other anyway and above
-// (1536: 5.46 / 5.24) the front-end is what the step waits for: neither is held.
+// Once the front-end's thousands of small workgroups are streaming through the chip no CU ever has 141 KB free, and the
+// clock stage starts only when the front-end's grid has drained (seen: every other call 0.5-1.2 ms late at 512 channels).
+// Half a hold in the front-end's stream lets the clock stage place its workgroups first.
 bool front_waits_for_clock_start(int n_channels) { return n_channels >= 384 && n_channels <= 1024; }
 void launch_front_hold(hipStream_t s) { hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 12); }
 
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s) {
-    if (b.any_dc && k2_keeps_off_clock_cus(b.n_channels)) {
+    if (b.any_dc && b.n_channels >= 2048) {
         hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 30);
     }
 }
 
-// What one stage wave of the DC blocker does, specialised per stage so that the loop over full 64-sample blocks carries
-// no stage or validity tests (a lone wave pays ~4 cycles per scalar instruction and ~25 per taken branch; the
-// generic loop spent as long on control flow as on the 63-step chain).  All four stages execute the same number of
-// barriers: 3*STAGE - 1 idle ones, one iteration that only prefetches, one per block, then idle ones up to nb + 9.
-struct k2_ctx {
-    float *lds;               // the channel's LDS area: input ring, then the three stage rings
-    uint32_t rx_cap, rs_cap;  // ring capacities (floats)
-    uint32_t mx, ms;          // ring masks of this channel
-    uint32_t L, nz, zbase;
-    float Lf;
-    const float *z;           // LPF2 output of this call (stage 0 feeds the input ring from it)
-    float *out;               // DC-free output (stage 3)
-    int lane;
-};
+// DC blocker: design in sdrm_kernels.h (K2).  Workgroup = dc_group channels (16 unless long boxcars need the LDS), six
+// waves: 0 chain, 1 feeder, 2..4 stage s -> s+1, 5 output.  Iteration `it` (one barrier each): the chain wave sums block
+// it - 2s of stage s; the feeder prepares block it + 1 of stage 0; the helper of stage s converts block it - 1 - 2s.
+typedef float k2_f4 __attribute__((ext_vector_type(4)));
 
-#define K2_SKEW 3
-#define K2_BARRIER() asm volatile("s_barrier" ::: "memory")
-// everything this wave issued to the LDS is at least one iteration old when this runs: the wait is free, and it is what
-// guarantees that the previous iteration's store is complete before the barrier after which its reader may look at it
-#define K2_SETTLE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-template <int STAGE, int MODE>
-__device__ __forceinline__ void k2_stage(const k2_ctx &k, float &acc, bool &odd) {
-    typedef float k2_f4 __attribute__((ext_vector_type(4)));
-    const int lane = k.lane;
-    const int nb = (int) ((k.nz + 63) / 64), nfull = (int) (k.nz / 64);
-    const uint32_t rin = STAGE == 0 ? 0u : k.rx_cap + (uint32_t) (STAGE - 1) * k.rs_cap;
-    const uint32_t m_in = STAGE == 0 ? k.mx : k.ms;
-    const uint32_t rout = k.rx_cap + (uint32_t) (STAGE < 3 ? STAGE : 0) * k.rs_cap;
-    float *rx = k.lds;
-    const k2_f4 *z4 = reinterpret_cast<const k2_f4 *>(k.z);  // rows start 256-byte aligned (z_stride % 64 == 0)
-    k2_f4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
-    float u_n = 0.0f, ud_n = 0.0f, xd_n = 0.0f;
-    // Stage 0 also feeds the input ring: every fourth block it commits four blocks that it loaded four iterations
-    // earlier (one float4 per lane) and issues the load of the four after those: a load has four iterations to land.
-    auto commit = [&](int first_block, const k2_f4 &v) {
-        const uint32_t n4 = (uint32_t) first_block * 64u + 4u * (uint32_t) lane;
-        const uint32_t pos4 = k.zbase + n4;
-        if (n4 < k.nz) rx[pos4 & k.mx] = v.x;
-        if (n4 + 1u < k.nz) rx[(pos4 + 1u) & k.mx] = v.y;
-        if (n4 + 2u < k.nz) rx[(pos4 + 2u) & k.mx] = v.z;
-        if (n4 + 3u < k.nz) rx[(pos4 + 3u) & k.mx] = v.w;
-    };
-    auto feed = [&](int blk) {  // blk % 4 == 0
-        commit(blk + 4, xq);
-        const uint32_t nn = ((uint32_t) blk + 8u) * 64u + 4u * (uint32_t) lane;
-        if (nn < k.nz) {
-            xq = z4[(blk + 8) * 16 + lane];
-        }
-    };
-    // inputs of block `blk` into registers: written by the previous stage two iterations ago (stage 0: by the feed)
-    auto prefetch = [&](int blk) {
-        const uint32_t pos = k.zbase + (uint32_t) blk * 64u + lane;
-        u_n = k.lds[rin + (pos & m_in)];
-        ud_n = k.lds[rin + ((pos - k.L) & m_in)];
-        if (STAGE == 3) {
-            xd_n = rx[(pos - 2 * (k.L - 1)) & k.mx];
-        }
-    };
-    // one block: `count` valid samples (64 except in the last block)
-    auto block = [&](int blk, int count, bool more) {
-        const uint32_t n = (uint32_t) blk * 64u + lane;
-        const uint32_t pos = k.zbase + n;
-        const bool valid = count == 64 || lane < count;
-        const float t = valid ? sdrm_boxcar_term(u_n, ud_n) : 0.0f;
-        const float xd = xd_n;
-        if (more) {
-            prefetch(blk + 1);
-        }
-        const float s = wave_inorder_sum<MODE>(t, acc);
-        acc = lane_bcast(s, count - 1);
-        const float v = sdrm_boxcar_out(s, k.Lf);
-        if (STAGE < 3) {
-            if (valid) {
-                k.lds[rout + (pos & k.ms)] = v;
-            }
-        } else if (valid) {
-            const float o = xd - v;
-            k.out[n] = o;
-            odd |= !(fabsf(o) < INFINITY);
-        }
-    };
-    if (STAGE == 0) {
-        if (4u * (uint32_t) lane < k.nz) {
-            const k2_f4 first = z4[lane];
-            commit(0, first);
-        }
-        if (256u + 4u * (uint32_t) lane < k.nz) {
-            xq = z4[64 + lane];
-        }
-        if (nb > 0) {
-            prefetch(0);
-        }
-    } else {
-        for (int i = 0; i < K2_SKEW * STAGE - 1; i++) {
-            K2_BARRIER();
-        }
-        if (nb > 0) {
-            prefetch(0);
-        }
-        K2_BARRIER();
-    }
-    for (int blk = 0; blk < nfull; blk++) {
-        K2_SETTLE();
-        if (STAGE == 0 && (blk & 3) == 0) {
-            feed(blk);
-        }
-        block(blk, 64, blk + 1 < nb);
-        K2_BARRIER();
-    }
-    if (nfull < nb) {
-        K2_SETTLE();
-        if (STAGE == 0 && (nfull & 3) == 0) {
-            feed(nfull);
-        }
-        block(nfull, (int) (k.nz - (uint32_t) nfull * 64u), false);
-        K2_BARRIER();
-    }
-    K2_SETTLE();
-    for (int i = 0; i < K2_SKEW * (3 - STAGE); i++) {
-        K2_BARRIER();
-    }
-}
-
-// One workgroup of four waves per channel, one wave per boxcar stage (reference src/dsp/dc_blocker.c:56-64,105-119:
-// four cascaded length-L boxcars, y = (u - u[-L]) + y_prev, out y/L; result x[n - 2(L-1)] - y4).
-// The stages form a software pipeline over 64-sample blocks: in iteration `it`, wave s works on block it - s.  Within a
-// block the pointwise parts are lane-parallel (lane = sample) and the running sum is the in-order 64-lane chain above;
-// a stage hands its block to the next one through an LDS ring (which is also that stage's delay line), one barrier per
-// iteration.  Rings and running sums persist in the channel's DC state between calls; the slot of stream sample n is
-// n & mask.
-template <int MODE>
-__global__ __launch_bounds__(256) void k2_dc(DeviceBatch b) {
+__global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     extern __shared__ __attribute__((aligned(16))) float k2_lds[];
-    const int c = blockIdx.x;
-    const sdrm_chan_params p = b.params[c];
-    if (p.dc_len == 0) {
-        return;
-    }
+    float *ts = k2_lds;                                            // [64 rows][TSPITCH]
+    float *check = ts + SDRM_K2_ROWS * SDRM_K2_TSPITCH;            // [64 rows][NBUF][4]
+    float *rings = check + SDRM_K2_ROWS * SDRM_K2_NBUF * 4;        // [3][group][ring pitch]
+    const uint32_t rpitch = b.dc_rpitch;
+    sdrm_k2_slot *slots = reinterpret_cast<sdrm_k2_slot *>(rings + 3 * (size_t) b.dc_group * rpitch);
+    __shared__ int nb_sh;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c0 = blockIdx.x * b.dc_group;
     tl_mark(b, 1, 0);
-    const sdrm_chunk_ctl ctl = b.ctl[c];
-    const int lane = threadIdx.x & 63;
-    const int stage = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    float *rx = k2_lds;
-    float *rs[3] = {rx + b.rx_cap, rx + b.rx_cap + b.rs_cap, rx + b.rx_cap + 2 * b.rs_cap};
-    const uint32_t mx = p.rx_mask, ms = p.rs_mask;
-    float *st = b.dc_state + p.dc_state_off;
-    float *st_rx = st, *st_r0 = st_rx + (mx + 1), *st_r1 = st_r0 + (ms + 1), *st_r2 = st_r1 + (ms + 1);
-    float *st_acc = st_r2 + (ms + 1);
-    for (uint32_t k = threadIdx.x; k <= mx; k += 256) {
-        rx[k] = st_rx[k];
-    }
-    for (uint32_t k = threadIdx.x; k <= ms; k += 256) {
-        rs[0][k] = st_r0[k];
-        rs[1][k] = st_r1[k];
-        rs[2][k] = st_r2[k];
-    }
-    float acc = st_acc[stage];
-    __syncthreads();
-    __builtin_amdgcn_s_setprio(2);  // latency-bound chains: issue ahead of the front-end's waves on a shared SIMD
 
-    k2_ctx k;
-    k.lds = k2_lds;
-    k.rx_cap = b.rx_cap;
-    k.rs_cap = b.rs_cap;
-    k.mx = mx;
-    k.ms = ms;
-    k.L = p.dc_len;
-    k.nz = ctl.nz;
-    k.zbase = ctl.zbase;
-    k.Lf = p.dc_len_f;
-    k.z = b.z + (size_t) c * b.z_stride;
-    k.out = b.dcout + (size_t) c * b.z_stride;
-    k.lane = lane;
-    bool odd = false;
-    const bool stamp = b.k3_stamps != nullptr && blockIdx.x == 0;  // diagnostics: this channel's cycles per iteration
-    const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    if (stage == 0) {
-        k2_stage<0, MODE>(k, acc, odd);
-    } else if (stage == 1) {
-        k2_stage<1, MODE>(k, acc, odd);
-    } else if (stage == 2) {
-        k2_stage<2, MODE>(k, acc, odd);
-    } else {
-        k2_stage<3, MODE>(k, acc, odd);
+    // ---- set-up: slot constants, zeroed term rows, delay rings from the channels' tails
+    if (tid == 0) {
+        nb_sh = 0;
     }
-    __syncthreads();  // all rings final before they go back to the channel's state
-    if (stamp && lane == 0 && stage == 0) {
+    for (int i = tid; i < SDRM_K2_ROWS * SDRM_K2_TSPITCH; i += blockDim.x) {
+        ts[i] = 0.0f;
+    }
+    __syncthreads();
+    if (tid < SDRM_K2_SLOTS) {
+        sdrm_k2_slot s;
+        s.chan = -1;
+        s.L = 1; s.A = 64; s.rcap = 128; s.nz = 0; s.HX = 0; s.Lf = 1.0f; s.invL = 1.0f;
+        const int c = c0 + tid;
+        if (tid < b.dc_group && c < b.n_channels) {
+            const sdrm_chan_params p = b.params[c];
+            const sdrm_chunk_ctl ctl = b.ctl[c];
+            if (p.dc_len != 0 && ctl.absent == 0) {
+                sdrm_k2_slot_setup(s, c, p, ctl.nz);
+                atomicMax(&nb_sh, (int) ((ctl.nz + SDRM_K2_BLK - 1) / SDRM_K2_BLK));
+            }
+        }
+        slots[tid] = s;
+    }
+    __syncthreads();
+    const int nb = nb_sh;
+    if (nb == 0) {
+        return;  // nothing to do for any channel of the group: states stay as they are
+    }
+    const int slot_h = lane >> 2, q = lane & 3;           // helper lanes: 4 lanes per slot, 16 samples each
+    const sdrm_k2_slot hs = slots[slot_h];
+    const bool h_on = hs.chan >= 0;
+    float *st_h = b.dc_state + (h_on ? b.params[hs.chan].dc_state_off : 0);
+    const float *z_h = b.z + (size_t) (h_on ? hs.chan : 0) * b.z_stride;
+    const float *hx_h = st_h;
+    if (wave >= 2 && wave <= 4) {
+        // a stage helper owns ring (wave - 2) of every slot: all of a slot's lanes fill it
+        for (int sl = 0; sl < b.dc_group; sl++) {
+            const sdrm_k2_slot s = slots[sl];
+            if (s.chan >= 0) {
+                float *st = b.dc_state + b.params[s.chan].dc_state_off;
+                sdrm_k2_ring_load(rings + ((size_t) (wave - 2) * b.dc_group + sl) * rpitch, s,
+                                  sdrm_k2_state_tail(st, wave - 2, b.dc_hx_cap, b.dc_l_cap), lane, 64);
+            }
+        }
+    }
+    const unsigned long long t_begin = (b.k3_stamps != nullptr && blockIdx.x == 0) ? __builtin_amdgcn_s_memtime() : 0;
+
+    // ---- roles
+    float acc = 0.0f;          // chain wave: running sum of row (stage, slot) = lane
+    bool odd = false;
+    if (wave == 0) {
+        const sdrm_k2_slot s = slots[lane & (SDRM_K2_SLOTS - 1)];
+        if (s.chan >= 0) {
+            acc = sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4];
+        }
+        __builtin_amdgcn_s_setprio(3);  // one dependent chain: issue ahead of whatever shares the SIMD
+    } else if (wave == 1) {
+        if (h_on) {
+            sdrm_k2_feed(hs, 0, q, z_h, hx_h, ts + (0 * SDRM_K2_SLOTS + slot_h) * SDRM_K2_TSPITCH);  // block 0 of stage 0
+        }
+    }
+    __syncthreads();
+    const int n_it = nb + 7;
+    for (int it = 0; it < n_it; it++) {
+        if (wave == 0) {
+            const int k = it - 2 * (lane >> 4);
+            if (k >= 0 && k < nb) {
+                const int buf = k % SDRM_K2_NBUF;
+                const k2_f4 *row = reinterpret_cast<const k2_f4 *>(ts + lane * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK);
+                k2_f4 t[16];
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    t[g] = row[g];
+                }
+                k2_f4 cp;
+                cp.x = acc;
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    acc = acc + t[g].x;
+                    acc = acc + t[g].y;
+                    acc = acc + t[g].z;
+                    acc = acc + t[g].w;
+                    if (g == 3) cp.y = acc;
+                    if (g == 7) cp.z = acc;
+                    if (g == 11) cp.w = acc;
+                }
+                *reinterpret_cast<k2_f4 *>(check + (lane * SDRM_K2_NBUF + buf) * 4) = cp;
+            }
+        } else if (wave == 1) {
+            const int k = it + 1;
+            if (k < nb && h_on) {
+                sdrm_k2_feed(hs, k, q, z_h, hx_h, ts + (0 * SDRM_K2_SLOTS + slot_h) * SDRM_K2_TSPITCH + (k % SDRM_K2_NBUF) * SDRM_K2_BLK);
+            }
+        } else {
+            const int stage = wave - 2;  // 0..3: converts the sums of this stage
+            const int k = it - 1 - 2 * stage;
+            if (k >= 0 && k < nb && h_on) {
+                const int buf = k % SDRM_K2_NBUF;
+                const int row = stage * SDRM_K2_SLOTS + slot_h;
+                const float *in_buf = ts + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK;
+                const float cp = check[(row * SDRM_K2_NBUF + buf) * 4 + q];
+                if (stage < 3) {
+                    sdrm_k2_transition(hs, k, q, in_buf, cp, rings + ((size_t) stage * b.dc_group + slot_h) * rpitch,
+                                       ts + (row + SDRM_K2_SLOTS) * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK);
+                } else {
+                    odd |= sdrm_k2_output(hs, k, q, in_buf, cp, z_h, hx_h, b.dcout + (size_t) hs.chan * b.z_stride);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- state back: running sums, ring tails, carried samples of x
+    if (wave == 0) {
+        const sdrm_k2_slot s = slots[lane & (SDRM_K2_SLOTS - 1)];
+        if (s.chan >= 0) {
+            sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4] = acc;
+        }
+    } else if (wave >= 2 && wave <= 4) {
+        for (int sl = 0; sl < b.dc_group; sl++) {
+            const sdrm_k2_slot s = slots[sl];
+            if (s.chan >= 0) {
+                float *st = b.dc_state + b.params[s.chan].dc_state_off;
+                sdrm_k2_ring_save(rings + ((size_t) (wave - 2) * b.dc_group + sl) * rpitch, s,
+                                  sdrm_k2_state_tail(st, wave - 2, b.dc_hx_cap, b.dc_l_cap), lane, 64);
+            }
+        }
+    }
+    if (wave == 5 && odd && h_on) {
+        b.nonfinite[hs.chan] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
+    }
+    // hx <- last HX samples of (hx ++ z): a slot at a time by all threads; when the call is shorter than HX the new array
+    // overlaps the old one shifted by nz, so every round reads before anybody writes (and later rounds read further up)
+    for (int sl = 0; sl < b.dc_group; sl++) {
+        const sdrm_k2_slot s = slots[sl];
+        if (s.chan < 0 || s.nz == 0) {
+            continue;
+        }
+        float *hx = b.dc_state + b.params[s.chan].dc_state_off;
+        const float *z = b.z + (size_t) s.chan * b.z_stride;
+        for (uint32_t j0 = 0; j0 < s.HX; j0 += blockDim.x) {
+            const uint32_t j = j0 + tid;
+            float v = 0.0f;
+            if (j < s.HX) {
+                v = sdrm_k2_hx_source(s, z, hx, j);
+            }
+            __syncthreads();
+            if (j < s.HX) {
+                hx[j] = v;
+            }
+        }
+    }
+    if (b.k3_stamps != nullptr && blockIdx.x == 0 && tid == 0) {
         unsigned long long *k2s = b.k3_stamps + SDRM_STAMP_K3_WAVES(b.n_channels) * 4 + 8;  // after the K3 and K1 records
         k2s[8] = __builtin_amdgcn_s_memtime() - t_begin;
-        k2s[9] = (unsigned long long) ((ctl.nz + 63) / 64 + 3 * K2_SKEW);
-    }
-    if (odd) {
-        b.nonfinite[c] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
-    }
-    for (uint32_t k = threadIdx.x; k <= mx; k += 256) {
-        st_rx[k] = rx[k];
-    }
-    for (uint32_t k = threadIdx.x; k <= ms; k += 256) {
-        st_r0[k] = rs[0][k];
-        st_r1[k] = rs[1][k];
-        st_r2[k] = rs[2][k];
-    }
-    if (lane == 0) {
-        st_acc[stage] = acc;
+        k2s[9] = (unsigned long long) n_it;
     }
     tl_mark(b, 1, 1);
 }
-
-static int g_scan_mode = 0;
 
 KernelLaunch describe_dc(const DeviceBatch &b) {
     KernelLaunch k;
     if (!b.any_dc) {
         return k;
     }
-    k.lds = k2_lds_bytes(b.rx_cap, b.rs_cap, b.n_channels);
-    static lds_grant granted0, granted1;
-    allow_lds(k2_dc<0>, k.lds, &granted0);
-    allow_lds(k2_dc<1>, k.lds, &granted1);
-    k.func = g_scan_mode == 0 ? reinterpret_cast<const void *>(k2_dc<0>) : reinterpret_cast<const void *>(k2_dc<1>);
-    k.grid = dim3((unsigned) b.n_channels);
-    k.block = dim3(256);
+    k.lds = b.dc_lds;
+    static lds_grant granted;
+    allow_lds(k2_dc, k.lds, &granted);
+    k.func = reinterpret_cast<const void *>(k2_dc);
+    k.grid = dim3((unsigned) ((b.n_channels + b.dc_group - 1) / b.dc_group));
+    k.block = dim3(64 * SDRM_K2_WAVES);
     return k;
 }
 
@@ -1234,35 +1151,28 @@ __global__ void probe_atan2(const float *y, const float *x, const float *tab, fl
     }
 }
 
-template <int MODE>
-__global__ void probe_scan(const float *terms, float carry, float *out, size_t n) {
-    const int lane = threadIdx.x;
-    for (size_t n0 = 0; n0 < n; n0 += 64) {
-        const size_t i = n0 + lane;
-        const bool valid = i < n;
-        const int last = (int) ((n - n0 < 64 ? n - n0 : 64) - 1);
-        float t = valid ? terms[i] : 0.0f;
-        float s = wave_inorder_sum<MODE>(t, carry);
-        carry = lane_bcast(s, last);
-        if (valid) {
-            out[i] = s;
-        }
+// the quotient form of the DC kernel, one value per lane (16 per lane there: the fall-back is taken per wave either way)
+__global__ void probe_boxcar_div(const float *sums, float len_f, float inv_len, float *out, size_t n) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const float a = i < n ? sums[i] : 0.0f;
+    bool unsafe;
+    float v = sdrm_boxcar_out_fast(a, len_f, inv_len, &unsafe);
+    if (__any(unsafe)) {
+        v = sdrm_boxcar_out(a, len_f);
     }
+    if (i < n) {
+        out[i] = v;
+    }
+}
+
+void launch_probe_boxcar_div(const float *d_sums, uint32_t length, float *d_out, size_t n, hipStream_t s) {
+    unsigned blocks = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(probe_boxcar_div, dim3(blocks ? blocks : 1), dim3(256), 0, s, d_sums, (float) length, 1.0f / (float) length, d_out, n);
 }
 
 void launch_probe_atan2(const float *d_y, const float *d_x, const float *d_tab, float *d_out, size_t n, hipStream_t s) {
     unsigned blocks = (unsigned) ((n + 255) / 256);
     hipLaunchKernelGGL(probe_atan2, dim3(blocks ? blocks : 1), dim3(256), 0, s, d_y, d_x, d_tab, d_out, n);
 }
-
-void launch_probe_scan(const float *d_terms, float carry, float *d_out, size_t n, int mode, hipStream_t s) {
-    if (mode == 0) {
-        hipLaunchKernelGGL(probe_scan<0>, dim3(1), dim3(64), 0, s, d_terms, carry, d_out, n);
-    } else {
-        hipLaunchKernelGGL(probe_scan<1>, dim3(1), dim3(64), 0, s, d_terms, carry, d_out, n);
-    }
-}
-
-void set_scan_mode(int mode) { g_scan_mode = mode; }
 
 }  // namespace sdrm

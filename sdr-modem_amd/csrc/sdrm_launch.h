@@ -44,7 +44,9 @@ struct DeviceBatch {
     uint32_t max_tiles;              // K1 grid.x for this call
     uint32_t max_symbols;            // upper bound of any channel's symbol count this call (k3_quantize grid)
     uint32_t t1_max, t2_max;         // size K1's LDS
-    uint32_t rx_cap, rs_cap;         // DC ring capacities (floats) sizing K2's LDS
+    uint32_t dc_hx_cap, dc_l_cap;    // DC state geometry (sdrm_kernels.h, K2)
+    uint32_t dc_group, dc_rpitch;    // channels per DC workgroup, floats between two of its delay rings in LDS
+    uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
 };
 
@@ -65,7 +67,6 @@ size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s);
 bool front_waits_for_clock_start(int n_channels);
 void launch_front_hold(hipStream_t s);
-size_t k2_lds_bytes(uint32_t rx_cap, uint32_t rs_cap, int n_channels);
 
 void launch_nco_phase(const DeviceBatch &b, hipStream_t s);
 void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);
@@ -78,8 +79,8 @@ void launch_dc(const DeviceBatch &b, hipStream_t s);
 void launch_clock(const DeviceBatch &b, hipStream_t s);
 
 // test probes
+void launch_probe_boxcar_div(const float *d_sums, uint32_t length, float *d_out, size_t n, hipStream_t s);
 void launch_probe_atan2(const float *d_y, const float *d_x, const float *d_tab, float *d_out, size_t n, hipStream_t s);
-void launch_probe_scan(const float *d_terms, float carry, float *d_out, size_t n, int mode, hipStream_t s);
 
 }  // namespace sdrm
 

@@ -11,16 +11,18 @@ namespace sdrm {
 
 static uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
-static uint32_t pow2_at_least(uint32_t v) {
-    uint32_t p = 64;
-    while (p < v) {
-        p <<= 1;
-    }
-    return p;
+// LDS of the DC kernel: term rows and checkpoints of 4 stages x 16 slots, three delay rings per channel of the group,
+// the slots' constants
+static size_t dc_lds_bytes_for(uint32_t l_cap, uint32_t group) {
+    const uint32_t rcap = (l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK;
+    return ((size_t) SDRM_K2_ROWS * SDRM_K2_TSPITCH + (size_t) SDRM_K2_ROWS * SDRM_K2_NBUF * 4 +
+            3 * (size_t) group * sdrm_k2_ring_pitch(rcap)) * sizeof(float) + SDRM_K2_SLOTS * sizeof(sdrm_k2_slot) + 64;
 }
 
+size_t BatchPlan::dc_lds_bytes() const { return dc_lds_bytes_for(dc_l_cap, dc_group); }
+
 // everything of a channel's device parameters that follows from its design alone (no offsets into shared storage)
-static int params_from_design(const ChannelDesign &d, sdrm_chan_params &p, uint32_t *rx, uint32_t *rs) {
+static int params_from_design(const ChannelDesign &d, sdrm_chan_params &p) {
     memset(&p, 0, sizeof(p));
     p.T1 = (uint32_t) d.taps1.size();
     p.T2 = (uint32_t) d.taps2.size();
@@ -40,16 +42,9 @@ static int params_from_design(const ChannelDesign &d, sdrm_chan_params &p, uint3
     p.omega_lim = d.omega_lim;
     p.gain_omega = d.gain_omega;
     p.gain_mu = d.gain_mu;
-    *rx = *rs = 0;
     if (p.dc_len) {
         p.dc_len_f = (float) p.dc_len;
-        // The four stage waves of K2 run three 64-sample blocks apart and prefetch one block ahead: a stage ring
-        // covers its delay plus the blocks between its writer and its reader; the input ring is also fed up to 8
-        // blocks ahead of the first stage and read 2(L-1) behind the last one.
-        *rs = pow2_at_least(p.dc_len + 4 * 64);
-        *rx = pow2_at_least(2 * (p.dc_len - 1) + 17 * 64);
-        p.rs_mask = *rs - 1;
-        p.rx_mask = *rx - 1;
+        p.dc_inv_len = 1.0f / p.dc_len_f;  // correctly rounded reciprocal: sdrm_boxcar_out_fast
     }
     return 0;
 }
@@ -78,8 +73,7 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
     for (size_t c = 0; c < n; c++) {
         const ChannelDesign &d = plan.design[c];
         sdrm_chan_params &p = plan.params[c];
-        uint32_t rx = 0, rs = 0;
-        int code = params_from_design(d, p, &rx, &rs);
+        int code = params_from_design(d, p);
         if (code != 0) {
             return code;
         }
@@ -103,8 +97,7 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
         }
         if (p.dc_len) {
             plan.any_dc = 1;
-            plan.rx_cap = std::max(plan.rx_cap, rx);
-            plan.rs_cap = std::max(plan.rs_cap, rs);
+            plan.dc_l_cap = std::max(plan.dc_l_cap, p.dc_len);
         }
         plan.t1_max = std::max(plan.t1_max, p.T1);
         plan.t2_max = std::max(plan.t2_max, p.T2);
@@ -113,7 +106,17 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
     }
     // every channel gets a DC state region of the batch's largest size, so that a channel can later be given any
     // configuration the batch's geometry holds (replan_channel)
-    plan.dc_region_floats = plan.any_dc ? (size_t) plan.rx_cap + 3 * (size_t) plan.rs_cap + 8 : 0;
+    plan.dc_hx_cap = plan.any_dc ? 2 * (plan.dc_l_cap - 1) : 0;
+    plan.dc_region_floats = plan.any_dc ? sdrm_k2_state_floats(plan.dc_hx_cap, plan.dc_l_cap) : 0;
+    // sixteen channels per DC workgroup while their delay rings fit beside the term rows (150 KB of the CU's 160)
+    plan.dc_group = SDRM_K2_SLOTS;
+    while (plan.dc_group > 1 && dc_lds_bytes_for(plan.dc_l_cap, plan.dc_group) > 150 * 1024) {
+        plan.dc_group /= 2;
+    }
+    if (plan.any_dc && dc_lds_bytes_for(plan.dc_l_cap, plan.dc_group) > 160 * 1024) {
+        fprintf(stderr, "<3>DC blocker of %u samples does not fit the device\n", plan.dc_l_cap);
+        return -ENOTSUP;
+    }
     for (size_t c = 0; c < n; c++) {
         plan.params[c].dc_state_off = (uint32_t) (c * plan.dc_region_floats);
     }
@@ -138,14 +141,13 @@ int replan_channel(BatchPlan &plan, size_t c, const sdrm_fsk_config &cfg, std::v
         return code;
     }
     sdrm_chan_params p;
-    uint32_t rx = 0, rs = 0;
-    code = params_from_design(d, p, &rx, &rs);
+    code = params_from_design(d, p);
     if (code != 0) {
         return code;
     }
     // the batch's geometry (LDS sizes, strides, buffers) was fixed when it was created
     if (p.T1 > plan.t1_max || p.T2 > plan.t2_max || p.hist_len > plan.hist_stride || p.max_len > plan.in_stride ||
-        p.max_len + 64 > plan.z_stride || (p.dc_len && (!plan.any_dc || rx > plan.rx_cap || rs > plan.rs_cap))) {
+        p.max_len + 64 > plan.z_stride || (p.dc_len && (!plan.any_dc || p.dc_len > plan.dc_l_cap))) {
         fprintf(stderr, "<3>configuration does not fit the batch it is assigned to (filters of %u / %u taps, DC length %u, "
                         "buffer %u)\n", p.T1, p.T2, p.dc_len, p.max_len);
         return -ENOTSUP;

@@ -21,12 +21,14 @@ struct BatchPlan {
     std::vector<float> tap_pool;  // reversed taps of every distinct filter, 8-float aligned
     // geometry shared by the whole batch
     uint32_t t1_max = 0, t2_max = 0, hist_stride = 0, z_stride = 0, out_stride = 0, in_stride = 0;
-    uint32_t rx_cap = 64, rs_cap = 64;
+    uint32_t dc_l_cap = 0, dc_hx_cap = 0;  // longest boxcar of the batch and its 2(L-1) carried samples: size every channel's DC state
+    uint32_t dc_group = SDRM_K2_SLOTS;     // channels per DC workgroup: 16 unless the delay rings of that many would not fit in LDS
     size_t dc_state_floats = 0, dc_region_floats = 0;  // every channel owns a region of the largest size
     size_t private_taps_base = 0, private_taps_slot = 0;  // per-channel tap slots behind the shared pool (replan_channel)
     int any_dc = 0;
     // streaming bookkeeping that depends on input lengths only (kept on the host)
     std::vector<uint32_t> phase, parity, zbase;
+    size_t dc_lds_bytes() const;  // dynamic LDS of the DC kernel for this batch
 };
 
 // 0, or the error of design_channel() / -ENOTSUP for geometry the tiles cannot hold

@@ -4,12 +4,12 @@
 // hand-off, decimation phase, ring indexing and the clock loop's block-wise execution against the oracle without
 // a GPU.  It is NOT a fallback: the product library never links or loads this file.
 //
-// K2 (DC blocker) is wave-level code on the GPU (DPP chain); here the same ring layout and block structure are
-// walked with a plain sequential running sum.
+// K2 (DC blocker): the kernel's six roles are driven from the same per-lane bodies, iteration by iteration.
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../sdr-modem_amd/csrc/sdrm_plan.h"
@@ -119,43 +119,108 @@ static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
     }
 }
 
+// K2: the device's roles (chain wave, feeder, three stage helpers, output; sdrm_kernels.h) driven lane by lane in the
+// kernel's iteration order.  Within an iteration the six waves run concurrently on the device and touch disjoint
+// buffers; here they run one after the other, in alternating order from iteration to iteration, so that a dependence
+// between two roles inside one iteration would show up as a wrong result.
 static void emu_dc(EmuBatch *b) {
     const BatchPlan &pl = b->plan;
-    for (size_t c = 0; c < pl.params.size(); c++) {
-        const sdrm_chan_params &p = pl.params[c];
-        if (p.dc_len == 0) continue;
-        const sdrm_chunk_ctl &ctl = b->ctl[c];
-        const uint32_t mx = p.rx_mask, ms = p.rs_mask, L = p.dc_len;
-        float *st = b->dcstate.data() + p.dc_state_off;
-        float *rx = st, *r[3] = {rx + (mx + 1), rx + (mx + 1) + (ms + 1), rx + (mx + 1) + 2 * (ms + 1)};
-        float *acc = rx + (mx + 1) + 3 * (ms + 1);
-        const float *z = b->z.data() + c * pl.z_stride;
-        float *out = b->dcout.data() + c * pl.z_stride;
-        for (uint32_t n0 = 0; n0 < ctl.nz; n0 += 64) {
-            const uint32_t cnt = ctl.nz - n0 < 64 ? ctl.nz - n0 : 64;
-            float u[64], xdd[64];
-            for (uint32_t l = 0; l < cnt; l++) {
-                u[l] = z[n0 + l];
-                rx[(ctl.zbase + n0 + l) & mx] = u[l];
+    if (!pl.any_dc) return;
+    const int C = (int) pl.params.size();
+    const int G = (int) pl.dc_group;
+    const uint32_t rcap_max = (pl.dc_l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK;
+    const uint32_t rpitch = sdrm_k2_ring_pitch(rcap_max);
+    std::vector<float> ts(SDRM_K2_ROWS * SDRM_K2_TSPITCH), check(SDRM_K2_ROWS * SDRM_K2_NBUF * 4), rings(3 * (size_t) G * rpitch);
+    for (int c0 = 0; c0 < C; c0 += G) {
+        std::fill(ts.begin(), ts.end(), 0.0f);
+        std::fill(check.begin(), check.end(), NAN);
+        std::fill(rings.begin(), rings.end(), NAN);
+        sdrm_k2_slot slots[SDRM_K2_SLOTS];
+        int nb = 0;
+        for (int sl = 0; sl < SDRM_K2_SLOTS; sl++) {
+            sdrm_k2_slot &s = slots[sl];
+            s.chan = -1;
+            s.L = 1; s.A = 64; s.rcap = 128; s.nz = 0; s.HX = 0; s.Lf = 1.0f; s.invL = 1.0f;
+            const int c = c0 + sl;
+            if (sl < G && c < C && pl.params[c].dc_len != 0 && b->ctl[c].absent == 0) {
+                sdrm_k2_slot_setup(s, c, pl.params[c], b->ctl[c].nz);
+                nb = std::max(nb, (int) ((b->ctl[c].nz + SDRM_K2_BLK - 1) / SDRM_K2_BLK));
             }
-            for (uint32_t l = 0; l < cnt; l++) xdd[l] = rx[(ctl.zbase + n0 + l - 2 * (L - 1)) & mx];
-            for (int s = 0; s < 4; s++) {
-                float *ring_in = (s == 0) ? rx : r[s - 1];
-                const uint32_t m_in = (s == 0) ? mx : ms;
-                float t[64];
-                for (uint32_t l = 0; l < cnt; l++) t[l] = sdrm_boxcar_term(u[l], ring_in[(ctl.zbase + n0 + l - L) & m_in]);
-                float run = acc[s];
-                for (uint32_t l = 0; l < cnt; l++) {
-                    run = run + t[l];
-                    u[l] = sdrm_boxcar_out(run, p.dc_len_f);
+        }
+        if (nb == 0) continue;
+        float acc[SDRM_K2_ROWS];
+        for (int r = 0; r < SDRM_K2_ROWS; r++) {
+            const sdrm_k2_slot &s = slots[r & (SDRM_K2_SLOTS - 1)];
+            acc[r] = s.chan >= 0 ? sdrm_k2_state_acc(b->dcstate.data() + pl.params[s.chan].dc_state_off, pl.dc_hx_cap, pl.dc_l_cap)[r >> 4] : 0.0f;
+        }
+        for (int ring = 0; ring < 3; ring++)
+            for (int sl = 0; sl < G; sl++)
+                if (slots[sl].chan >= 0)
+                    for (int lane = 0; lane < 64; lane++)
+                        sdrm_k2_ring_load(rings.data() + ((size_t) ring * G + sl) * rpitch, slots[sl],
+                                          sdrm_k2_state_tail(b->dcstate.data() + pl.params[slots[sl].chan].dc_state_off, ring, pl.dc_hx_cap, pl.dc_l_cap), lane, 64);
+        auto chan_z = [&](const sdrm_k2_slot &s) { return b->z.data() + (size_t) s.chan * pl.z_stride; };
+        auto chan_hx = [&](const sdrm_k2_slot &s) { return b->dcstate.data() + pl.params[s.chan].dc_state_off; };
+        auto role = [&](int wave, int it) {
+            for (int lane = 0; lane < 64; lane++) {
+                const int slot_h = lane >> 2, q = lane & 3;
+                const sdrm_k2_slot &hs = slots[slot_h];
+                if (wave == 0) {
+                    const int k = it - 2 * (lane >> 4);
+                    if (k >= 0 && k < nb) {
+                        const int buf = k % SDRM_K2_NBUF;
+                        acc[lane] = sdrm_k2_chain_block(ts.data() + lane * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK,
+                                                        check.data() + (lane * SDRM_K2_NBUF + buf) * 4, acc[lane]);
+                    }
+                } else if (wave == 1) {
+                    const int k = it + 1;
+                    if (k < nb && hs.chan >= 0)
+                        sdrm_k2_feed(hs, k, q, chan_z(hs), chan_hx(hs), ts.data() + slot_h * SDRM_K2_TSPITCH + (k % SDRM_K2_NBUF) * SDRM_K2_BLK);
+                } else {
+                    const int stage = wave - 2, k = it - 1 - 2 * stage;
+                    if (k >= 0 && k < nb && hs.chan >= 0) {
+                        const int buf = k % SDRM_K2_NBUF, row = stage * SDRM_K2_SLOTS + slot_h;
+                        const float *in_buf = ts.data() + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK;
+                        const float cp = check[(row * SDRM_K2_NBUF + buf) * 4 + q];
+                        if (stage < 3) {
+                            sdrm_k2_transition(hs, k, q, in_buf, cp, rings.data() + ((size_t) stage * G + slot_h) * rpitch,
+                                               ts.data() + (row + SDRM_K2_SLOTS) * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK);
+                        } else if (sdrm_k2_output(hs, k, q, in_buf, cp, chan_z(hs), chan_hx(hs), b->dcout.data() + (size_t) hs.chan * pl.z_stride)) {
+                            b->nonfinite[hs.chan] = 1u;
+                        }
+                    }
                 }
-                acc[s] = run;
-                if (s < 3)
-                    for (uint32_t l = 0; l < cnt; l++) r[s][(ctl.zbase + n0 + l) & ms] = u[l];
             }
-            for (uint32_t l = 0; l < cnt; l++) {
-                out[n0 + l] = xdd[l] - u[l];
-                if (!(fabsf(out[n0 + l]) < INFINITY)) b->nonfinite[c] = 1u;
+        };
+        for (int sl = 0; sl < G; sl++)
+            if (slots[sl].chan >= 0)
+                for (int q = 0; q < 4; q++) sdrm_k2_feed(slots[sl], 0, q, chan_z(slots[sl]), chan_hx(slots[sl]), ts.data() + sl * SDRM_K2_TSPITCH);
+        for (int it = 0; it < nb + 7; it++) {
+            if (it & 1) {
+                for (int w = SDRM_K2_WAVES - 1; w >= 0; w--) role(w, it);
+            } else {
+                for (int w = 0; w < SDRM_K2_WAVES; w++) role(w, it);
+            }
+        }
+        for (int r = 0; r < SDRM_K2_ROWS; r++) {
+            const sdrm_k2_slot &s = slots[r & (SDRM_K2_SLOTS - 1)];
+            if (s.chan >= 0) sdrm_k2_state_acc(b->dcstate.data() + pl.params[s.chan].dc_state_off, pl.dc_hx_cap, pl.dc_l_cap)[r >> 4] = acc[r];
+        }
+        for (int ring = 0; ring < 3; ring++)
+            for (int sl = 0; sl < G; sl++)
+                if (slots[sl].chan >= 0)
+                    for (int lane = 0; lane < 64; lane++)
+                        sdrm_k2_ring_save(rings.data() + ((size_t) ring * G + sl) * rpitch, slots[sl],
+                                          sdrm_k2_state_tail(b->dcstate.data() + pl.params[slots[sl].chan].dc_state_off, ring, pl.dc_hx_cap, pl.dc_l_cap), lane, 64);
+        const uint32_t T = 64 * SDRM_K2_WAVES;
+        for (int sl = 0; sl < G; sl++) {
+            const sdrm_k2_slot &s = slots[sl];
+            if (s.chan < 0 || s.nz == 0) continue;
+            float *hx = b->dcstate.data() + pl.params[s.chan].dc_state_off;
+            std::vector<float> v(T);
+            for (uint32_t j0 = 0; j0 < s.HX; j0 += T) {  // a round: every thread reads, barrier, every thread writes
+                for (uint32_t t = 0; t < T && j0 + t < s.HX; t++) v[t] = sdrm_k2_hx_source(s, chan_z(s), hx, j0 + t);
+                for (uint32_t t = 0; t < T && j0 + t < s.HX; t++) hx[j0 + t] = v[t];
             }
         }
     }
@@ -395,4 +460,26 @@ extern "C" void emu_info(EmuBatch *b, size_t c, sdrm_fsk_info *info) {
     info->gain_omega = d.gain_omega;
     info->gain_mu = d.gain_mu;
     info->omega_lim = d.omega_lim;
+}
+
+// sdrm_boxcar_out_fast against the division it stands for: every fp32 significand at biased exponent `bexp`, both signs.
+// Returns the number of quotients that differ where the short form did not raise its flag; *unsafe_count = flagged ones.
+extern "C" uint64_t emu_check_boxcar_div(uint32_t length, uint32_t bexp, uint64_t *unsafe_count) {
+    const float lf = (float) length, inv = 1.0f / lf;
+    uint64_t bad = 0, uns = 0;
+    for (uint32_t sign = 0; sign < 2; sign++) {
+        for (uint32_t m = 0; m < (1u << 23); m++) {
+            const float a = sdrm_from_bits((sign << 31) | (bexp << 23) | m);
+            bool unsafe;
+            const float got = sdrm_boxcar_out_fast(a, lf, inv, &unsafe);
+            if (unsafe) {
+                uns++;
+                continue;
+            }
+            const float want = sdrm_boxcar_out(a, lf);
+            if (sdrm_bits(got) != sdrm_bits(want) && !(got != got && want != want)) bad++;
+        }
+    }
+    if (unsafe_count) *unsafe_count = uns;
+    return bad;
 }

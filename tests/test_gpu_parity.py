@@ -70,25 +70,25 @@ def test_probe_fast_atan2_bit_exact():
     assert np.array_equal(np.isnan(out), np.isnan(want))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_probe_inorder_wave_scan_is_the_sequential_fp32_sum(mode):
-    """mode 0 = hand-placed v_add_f32_dpp chain, mode 1 = the same data flow through the update_dpp builtin"""
+@pytest.mark.parametrize("length", [32, 80, 154, 160, 400, 1280, 3968])
+def test_probe_boxcar_quotient_is_the_ieee_division(length):
+    """the DC blocker's `sum / L` (reference src/dsp/dc_blocker.c:63) as the kernel computes it: reciprocal multiply + two
+    FMAs, the division proper when the quotient is denormal or not finite -- the IEEE quotient bit for bit"""
     L = binding.load()
-    L.sdrm_set_scan_mode(mode)
-    rng = np.random.default_rng(mode)
-    for n in (1, 63, 64, 65, 1000, 4096 + 17):
-        t = (rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)).astype(np.float32)
-        t[n // 2] = 1e-41  # denormal term must not be flushed
-        out = np.zeros(n, np.float32)
-        carry = np.float32(0.37)
-        assert L.sdrm_probe_wave_scan(t.ctypes.data, carry, out.ctypes.data, n) == 0
-        want = np.zeros(n, np.float32)
-        acc = carry
-        for i in range(n):
-            acc = np.float32(t[i] + acc)
-            want[i] = acc
-        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (mode, n)
-    L.sdrm_set_scan_mode(0)
+    rng = np.random.default_rng(length)
+    n = 1 << 20
+    a = (rng.standard_normal(n) * 10.0 ** rng.uniform(-44, 38, n)).astype(np.float32)
+    edge = np.array([0.0, -0.0, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, -3.4028235e38, np.inf, -np.inf, np.nan,
+                     length, 0.5 * length * 1.4e-45, 1.5 * length * 1.4e-45, 2.5 * length * 1.4e-45], dtype=np.float32)
+    a[:len(edge)] = edge
+    a[len(edge):len(edge) + 4096] = (np.arange(4096) * length * np.float32(1.4e-45) * 0.5).astype(np.float32)  # ties among denormals
+    out = np.zeros(n, np.float32)
+    assert L.sdrm_probe_boxcar_div(a.ctypes.data, length, out.ctypes.data, n) == 0
+    with np.errstate(all="ignore"):
+        want = (a / np.float32(length)).astype(np.float32)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(out), nan)
+    assert np.array_equal(out.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
 
 
 def test_design_parameters_match_oracle():
@@ -229,6 +229,86 @@ def test_batch_256_channels_bit_exact_and_independent():
     lens = np.array([len(outs[1][c]) for c in range(C_)])
     assert np.all(np.abs(lens - N / 5) < 40)
     g.close()
+
+
+@pytest.mark.parametrize("channels", [512, 1100])
+def test_many_channel_batches_bit_exact(channels):
+    """BASELINE configs[3] gives every GPU 512 channels; 1100 is past the 1024-channel switch of the clock stage's
+    workgroup shape (64 channels per workgroup at native size), not a multiple of any workgroup size, with a second
+    configuration mixed in (different filters, decimation and DC length inside one DC workgroup).  Three calls (full,
+    short, ragged) so that every stage's state crosses call boundaries; 24 spot channels against the oracle, float
+    and int8 soft bits bit for bit; every other channel against its twin (same waveform: same bits)."""
+    N = 8192
+    cfg_a = (48000, 9600, 5000, 1, 2000, True)
+    cfg_b = (48000, 4800, 5000, 2, 2000, True)
+    distinct = 24
+    cfgs = [(cfg_b if (c % distinct) % 5 == 3 else cfg_a) + (N,) for c in range(channels)]
+    base = [siggen.gmsk_channel(100 + i, 2 * N + 700, fs=cfgs[i][0], baud=cfgs[i][1]) for i in range(distinct)]
+    g = binding.Batch(cfgs, keep_soft=True)
+    assert g.code == 0
+    oracles = [orc.Fsk(*cfgs[i]) for i in range(distinct)]
+    spots = list(range(channels - distinct, channels))  # the last 24 channels: partial workgroups of every stage
+    for lo, n in ((0, N), (N, 700), (N + 700, N - 1)):
+        lens = [n if c % 11 else max(0, n - 33) for c in range(channels)]
+        parts = [base[c % distinct][lo:lo + lens[c]] for c in range(channels)]
+        g8 = g.process(parts)
+        want = {}
+        for c in spots:
+            o8, of = oracles[c % distinct].process(parts[c]) if (c % distinct, lens[c]) not in want else want[(c % distinct, lens[c])]
+            want[(c % distinct, lens[c])] = (o8, of)
+        for c in spots:
+            o8, of = want[(c % distinct, lens[c])]
+            assert_same(of, g.last_soft(c), o8, g8[c], where="%d channels, ch %d" % (channels, c))
+        # twins: channels with the same waveform and the same lengths so far produce the same bits
+        first = {}
+        for c in range(channels):
+            key = (c % distinct, c % 11 == 0)
+            if key in first:
+                assert np.array_equal(g8[c], g8[first[key]]), (channels, c, first[key])
+            else:
+                first[key] = c
+    g.close()
+
+
+def test_config_fanout_over_rccl_when_the_node_has_two_gpus():
+    """the only collective of the path is the broadcast of the channel table from rank 0 -- RCCL
+    (torch.distributed backend "nccl") on GPUs.  Needs two devices; the world-size-2 gloo test covers the logic on CPU."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the RCCL fan-out needs two")
+    code = r"""
+import os, sys
+sys.path.insert(0, os.environ["SDRM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SDRM_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import sdrm_pkg; sdrm_pkg.load()
+from sdr_modem_amd import binding, shard, siggen
+import orc
+rank = int(os.environ["RANK"]); torch.cuda.set_device(rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+table = [(48000, 9600, 5000, 1, 2000, True, 4096)] * 5 + [(48000, 4800, 5000, 2, 2000, False, 4096)] * 4 if rank == 0 else None
+cfgs, lo, hi = shard.fanout_configs(table, 9, device=torch.device("cuda", rank))
+b = binding.Batch(cfgs, device=rank)
+sigs = [siggen.gmsk_channel(lo + i, 4096, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+got = b.process(sigs)
+ok = all(np.array_equal(orc.demod_stream(c[:6], s, 4096)[0], g) for c, s, g in zip(cfgs, sigs, got))
+flags = [None, None]
+dist.all_gather_object(flags, (lo, hi, bool(ok)))
+dist.barrier(); dist.destroy_process_group()
+if rank == 0:
+    assert flags[0][:2] == (0, 5) and flags[1][:2] == (5, 9) and flags[0][2] and flags[1][2], flags
+"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SDRM_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
 
 
 def test_mixed_batch_with_ragged_lengths():

@@ -298,3 +298,22 @@ def test_absent_channel_keeps_its_state_while_an_empty_call_does_not():
         assert np.array_equal(a, b)
         extra += len(a)
     assert extra > 0
+
+
+def test_boxcar_quotient_short_form_is_the_ieee_division():
+    """sdrm_boxcar_out_fast (csrc/sdrm_core.h): q0 = a * RN(1/L), one FMA for the residual, one for the correction -- must be
+    a / L bit for bit whenever it does not ask for the division proper (reference src/dsp/dc_blocker.c:63).  Every
+    significand, both signs, at a normal exponent for the lengths of the named configurations; at the exponents where the
+    quotient turns denormal the flag must be up instead.  (tools/dc_div_sweep.cpp: all lengths 32..3968, 74e9 quotients.)"""
+    import ctypes as C
+    lib = emu_api.lib()
+    lib.emu_check_boxcar_div.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.emu_check_boxcar_div.restype = C.c_uint64
+    for length in (80, 154, 160, 400, 800, 1280):
+        uns = C.c_uint64()
+        assert lib.emu_check_boxcar_div(length, 127, C.byref(uns)) == 0, length
+        assert uns.value == 0
+        assert lib.emu_check_boxcar_div(length, 1, C.byref(uns)) == 0, length   # quotients below the normal range
+        assert uns.value == 2 * (1 << 23)
+        assert lib.emu_check_boxcar_div(length, 255, C.byref(uns)) == 0          # infinities and NaN
+        assert uns.value == 2 * (1 << 23)
