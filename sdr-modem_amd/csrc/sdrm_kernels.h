@@ -425,23 +425,28 @@ SDRM_HD void sdrm_hist_roll(int tid, int nthreads, const sdrm_chan_params &p, co
 //
 // One workgroup serves up to 16 channels ("slots") with six waves:
 //   chain wave   lane = (stage, slot): reads the 64 terms of its block from its LDS row (16 x ds_read_b128), adds them
-//                one by one to its running sum and leaves four checkpoints {sum before the block, after 16, 32, 48 terms};
+//                one by one to its running sum and leaves a checkpoint every P terms {sum before the block, after P, 2P, ..};
 //   feeder       terms of stage 0 from the front-end's output: t = x[n] - x[n-L];
-//   3 x stage    for stage s -> s+1: every lane takes 16 consecutive samples of one slot (4 lanes per block), rebuilds the
-//                running sums from its checkpoint with the SAME additions in the same order, divides, appends the
-//                quotients to the stage's delay ring in LDS, reads the delayed ones and writes the next stage's terms;
+//   3 x stage    for stage s -> s+1: every lane takes P consecutive samples of one slot, rebuilds the running sums from
+//                its checkpoint with the SAME additions in the same order, divides, appends the quotients to the stage's
+//                delay ring in LDS, reads the delayed ones and writes the next stage's terms;
 //   output       the same for stage 3, then x[n - 2(L-1)] - v3[n] to global memory.
+// (a helper role is 16 / P waves: a wave covers P slots with 64 / P lanes each)
 // The stages run two blocks apart (stage s sums block it - 2s in iteration `it`, the helpers convert it in iteration
 // it + 1), one barrier per iteration; a row keeps three blocks (being written / being summed / being read).
 // A lone wave pays per instruction, not per lane: the chain wave's 64 additions serve 4 stages x 16 channels, where the
 // earlier in-order DPP chain spent 63 wave instructions on 64 samples of ONE stage of ONE channel.
 #define SDRM_K2_SLOTS 16
 #define SDRM_K2_BLK 64
-#define SDRM_K2_P 16      // consecutive samples per helper lane
+#ifndef SDRM_K2_P
+#define SDRM_K2_P 16      // consecutive samples per helper lane (16: one wave per helper role, 8: two)
+#endif
+#define SDRM_K2_LPS (SDRM_K2_BLK / SDRM_K2_P)    // helper lanes per slot and block = checkpoints per row and block
+#define SDRM_K2_WPR (SDRM_K2_SLOTS / SDRM_K2_P)  // waves per helper role (a wave covers P slots)
 #define SDRM_K2_NBUF 3
 #define SDRM_K2_TSPITCH (SDRM_K2_NBUF * SDRM_K2_BLK + 4)  // floats per row: 49 sixteen-byte units (odd: conflict-free ds_read_b128 across rows)
 #define SDRM_K2_MIRROR 16  // the first 16 ring slots are repeated behind the ring: 16 delayed samples never wrap
-#define SDRM_K2_WAVES 6
+#define SDRM_K2_WAVES (1 + 5 * SDRM_K2_WPR)  // chain, feeder, three stage helpers, output
 #define SDRM_K2_ROWS (4 * SDRM_K2_SLOTS)
 
 // per-slot constants (in LDS on the device)
@@ -499,21 +504,18 @@ SDRM_HD void sdrm_k2_ring_save(const float *ring, const sdrm_k2_slot &s, float *
 // ring slot of the first sample of block k
 SDRM_HD uint32_t sdrm_k2_block_slot(const sdrm_k2_slot &s, int k) { return (uint32_t) (((uint64_t) s.A + (uint64_t) k * SDRM_K2_BLK) % s.rcap); }
 
-// ---- chain wave: row = (stage, slot).  64 additions in order; checkpoints {before, after 16, 32, 48}; returns the sum after 64
+// ---- chain wave: row = (stage, slot).  64 additions in order; checkpoints {before, after P, 2P, ..}; returns the sum after 64
 SDRM_HD float sdrm_k2_chain_block(const float *row_buf, float *check, float acc) {
-    check[0] = acc;
-    for (int g = 0; g < 4; g++) {
-        for (int i = 0; i < 16; i++) {
-            acc = acc + row_buf[16 * g + i];
-        }
-        if (g < 3) {
-            check[g + 1] = acc;
+    for (int g = 0; g < SDRM_K2_LPS; g++) {
+        check[g] = acc;
+        for (int i = 0; i < SDRM_K2_P; i++) {
+            acc = acc + row_buf[SDRM_K2_P * g + i];
         }
     }
     return acc;
 }
 
-// ---- feeder: the 16 terms of stage 0 a lane owns in block k (q = lane & 3): t = x[n] - x[n - L], 0 beyond the call's end
+// ---- feeder: the P terms of stage 0 a lane owns in block k (q = lane % LPS): t = x[n] - x[n - L], 0 beyond the call's end
 SDRM_HD void sdrm_k2_feed(const sdrm_k2_slot &s, int k, int q, const float *z, const float *hx, float *row_buf) {
     const int n0 = k * SDRM_K2_BLK + q * SDRM_K2_P;
     for (int i = 0; i < SDRM_K2_P; i++) {
@@ -526,7 +528,7 @@ SDRM_HD void sdrm_k2_feed(const sdrm_k2_slot &s, int k, int q, const float *z, c
     }
 }
 
-// the 16 quotients a lane owns: running sums rebuilt from the checkpoint, then sums / L
+// the P quotients a lane owns: running sums rebuilt from the checkpoint, then sums / L
 SDRM_HD void sdrm_k2_quotients(const sdrm_k2_slot &s, const float *row_buf, float check, int q, float (&v)[SDRM_K2_P]) {
     float acc = check;
     float sums[SDRM_K2_P];
@@ -554,23 +556,23 @@ SDRM_HD void sdrm_k2_transition(const sdrm_k2_slot &s, int k, int q, const float
     sdrm_k2_quotients(s, in_buf, check, q, v);
     // Lanes past the channel's end leave the ring alone (another channel of the group may have many more blocks, and
     // their garbage would run round the ring into the samples the next call needs); a lane that holds the end writes
-    // fewer than 16 slots beyond it, which the ring's 64 spare slots absorb.
+    // fewer than P slots beyond it, which the ring's 64 spare slots absorb.
     if ((uint32_t) (k * SDRM_K2_BLK + q * SDRM_K2_P) >= s.nz) {
         for (int i = 0; i < SDRM_K2_P; i++) {
             out_buf[q * SDRM_K2_P + i] = 0.0f;
         }
         return;
     }
-    const uint32_t base = sdrm_k2_block_slot(s, k) + (uint32_t) q * SDRM_K2_P;  // < rcap, a multiple of 16
+    const uint32_t base = sdrm_k2_block_slot(s, k) + (uint32_t) q * SDRM_K2_P;  // < rcap, a multiple of P
     for (int i = 0; i < SDRM_K2_P; i++) {
         ring[base + i] = v[i];
     }
-    if (base == 0) {
-        for (int i = 0; i < SDRM_K2_MIRROR; i++) {
-            ring[s.rcap + i] = v[i];
+    if (base < SDRM_K2_MIRROR) {
+        for (int i = 0; i < SDRM_K2_P; i++) {
+            ring[s.rcap + base + i] = v[i];
         }
     }
-    const uint32_t from = (base + s.rcap - s.L) % s.rcap;  // from + 15 < rcap + MIRROR
+    const uint32_t from = (base + s.rcap - s.L) % s.rcap;  // from + P - 1 < rcap + MIRROR
     const int n0 = k * SDRM_K2_BLK + q * SDRM_K2_P;
     for (int i = 0; i < SDRM_K2_P; i++) {
         const float ud = ring[from + i];

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile): no FMA contraction, IEEE
 // division, fp32 denormals preserved -- required for bit parity with the reference's CPU path.
 #include <atomic>
+#include <type_traits>
 
 #include "sdrm_launch.h"
 
@@ -434,13 +435,113 @@ void launch_dc_hold(const DeviceBatch &b, hipStream_t s) {
 // DC blocker: design in sdrm_kernels.h (K2).  Workgroup = dc_group channels (16 unless long boxcars need the LDS), six
 // waves: 0 chain, 1 feeder, 2..4 stage s -> s+1, 5 output.  Iteration `it` (one barrier each): the chain wave sums block
 // it - 2s of stage s; the feeder prepares block it + 1 of stage 0; the helper of stage s converts block it - 1 - 2s.
+// The helpers below compute what sdrm_k2_feed / _transition / _output (sdrm_kernels.h, also run by the CPU emulation)
+// state, with 16-byte LDS accesses, the global loads of the next block in flight while this one is worked on, and the
+// ring position kept incrementally instead of by division.
 typedef float k2_f4 __attribute__((ext_vector_type(4)));
+// One barrier per iteration hands LDS blocks from role to role: the wave's own LDS traffic must have landed, its global
+// loads (the NEXT block's operands, into registers) and stores stay in flight -- __syncthreads() would wait for those too
+// and expose a full memory latency per iteration.
+#define K2_HANDOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+struct k2_lane {
+    sdrm_k2_slot s;
+    int q;               // which P-sample piece of a block this lane owns
+    const float *z;      // the channel's front-end output of this call
+    const float *hx;     // its carried samples of x
+    float *out;          // its DC-free output
+    bool on;
+};
+#define K2_P SDRM_K2_P
+#define K2_V4 (SDRM_K2_P / 4)  // 16-byte pieces per lane
+
+// P consecutive floats, 16-byte aligned (LDS rows and ring slots of whole lanes, z rows at lane starts)
+__device__ __forceinline__ void k2_load_p(const float *src, float (&v)[K2_P]) {
+    const k2_f4 *p = reinterpret_cast<const k2_f4 *>(src);
+#pragma unroll
+    for (int g = 0; g < K2_V4; g++) {
+        const k2_f4 t = p[g];
+        v[4 * g] = t.x;
+        v[4 * g + 1] = t.y;
+        v[4 * g + 2] = t.z;
+        v[4 * g + 3] = t.w;
+    }
+}
+__device__ __forceinline__ void k2_store_p(float *dst, const float (&v)[K2_P]) {
+    k2_f4 *d = reinterpret_cast<k2_f4 *>(dst);
+#pragma unroll
+    for (int g = 0; g < K2_V4; g++) {
+        d[g] = k2_f4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    }
+}
+// P consecutive floats from an 8-byte aligned address (x[n - 2(L-1)]: the delay is even)
+__device__ __forceinline__ void k2_load_p8(const float *src, float (&v)[K2_P]) {
+    typedef float k2_f2 __attribute__((ext_vector_type(2)));
+    const k2_f2 *p = reinterpret_cast<const k2_f2 *>(src);
+#pragma unroll
+    for (int g = 0; g < K2_P / 2; g++) {
+        const k2_f2 t = p[g];
+        v[2 * g] = t.x;
+        v[2 * g + 1] = t.y;
+    }
+}
+// the same from an address that is only 4-byte aligned (delayed samples: the delay is any number)
+__device__ __forceinline__ void k2_load_p_any(const float *src, bool aligned, float (&v)[K2_P]) {
+    if (aligned) {
+        k2_load_p(src, v);
+    } else {
+#pragma unroll
+        for (int i = 0; i < K2_P; i++) v[i] = src[i];
+    }
+}
+
+// P consecutive samples x[m0 .. m0+P-1] of the channel's input stream (m0 may be negative: carried samples)
+__device__ __forceinline__ void k2_load_x(const k2_lane &L, int m0, float (&v)[K2_P]) {
+    if (m0 >= 0) {
+        k2_load_p_any(L.z + m0, (m0 & 3) == 0, v);
+    } else if (m0 + K2_P <= 0) {
+        const float *p = L.hx + ((int) L.s.HX + m0);
+#pragma unroll
+        for (int i = 0; i < K2_P; i++) v[i] = p[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < K2_P; i++) v[i] = sdrm_k2_x(L.z, L.hx, L.s.HX, m0 + i);
+    }
+}
+
+// the P quotients of a lane: running sums rebuilt from the checkpoint (the chain wave's additions, in its order), / L.
+// sdrm_boxcar_out_fast's `unsafe` test for all of them at once: a running sum that is not finite stays so (Inf + x, NaN + x),
+// so the lane's LAST sum tells; a zero or denormal quotient shows in the smallest |sum| (|sum| < 2^-100 is far above
+// what gives a denormal quotient for any length up to 4096, and costs nothing but the division it then takes).
+__device__ __forceinline__ void k2_quotients(const k2_lane &L, const float (&t)[K2_P], float cp, float (&v)[K2_P]) {
+    float sums[K2_P];
+    float acc = cp;
+#pragma unroll
+    for (int i = 0; i < K2_P; i++) {
+        acc = acc + t[i];
+        sums[i] = acc;
+        const float q0 = acc * L.s.invL;
+        const float r = fmaf(-q0, L.s.Lf, acc);
+        v[i] = fmaf(r, L.s.invL, q0);
+    }
+    float lo = fabsf(sums[0]);
+#pragma unroll
+    for (int i = 1; i < K2_P; i++) {
+        lo = fminf(lo, fabsf(sums[i]));  // v_min3_f32 with |.| modifiers: two sums per instruction
+    }
+    const bool unsafe = !(fabsf(acc) < INFINITY) | (lo < 7.888609e-31f);
+    if (__any(unsafe)) {
+#pragma unroll
+        for (int i = 0; i < K2_P; i++) v[i] = sdrm_boxcar_out(sums[i], L.s.Lf);
+    }
+}
 
 __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     extern __shared__ __attribute__((aligned(16))) float k2_lds[];
-    float *ts = k2_lds;                                            // [64 rows][TSPITCH]
-    float *check = ts + SDRM_K2_ROWS * SDRM_K2_TSPITCH;            // [64 rows][NBUF][4]
-    float *rings = check + SDRM_K2_ROWS * SDRM_K2_NBUF * 4;        // [3][group][ring pitch]
+    float *ts = k2_lds;                                                  // [64 rows][TSPITCH]
+    float *check = ts + SDRM_K2_ROWS * SDRM_K2_TSPITCH;                  // [64 rows][NBUF][LPS]
+    float *xdt = check + SDRM_K2_ROWS * SDRM_K2_NBUF * SDRM_K2_LPS;      // [16 slots][2][64]: x[n - 2(L-1)] for the output role
+    float *rings = xdt + SDRM_K2_SLOTS * 2 * SDRM_K2_BLK;                // [3][group][ring pitch]
     const uint32_t rpitch = b.dc_rpitch;
     sdrm_k2_slot *slots = reinterpret_cast<sdrm_k2_slot *>(rings + 3 * (size_t) b.dc_group * rpitch);
     __shared__ int nb_sh;
@@ -477,43 +578,172 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     if (nb == 0) {
         return;  // nothing to do for any channel of the group: states stay as they are
     }
-    const int slot_h = lane >> 2, q = lane & 3;           // helper lanes: 4 lanes per slot, 16 samples each
-    const sdrm_k2_slot hs = slots[slot_h];
-    const bool h_on = hs.chan >= 0;
-    float *st_h = b.dc_state + (h_on ? b.params[hs.chan].dc_state_off : 0);
-    const float *z_h = b.z + (size_t) (h_on ? hs.chan : 0) * b.z_stride;
-    const float *hx_h = st_h;
-    if (wave >= 2 && wave <= 4) {
-        // a stage helper owns ring (wave - 2) of every slot: all of a slot's lanes fill it
-        for (int sl = 0; sl < b.dc_group; sl++) {
+    // roles: wave 0 = chain; then WPR waves each of feeder, stage 0, 1, 2, output; a helper wave covers P slots
+    const int role = wave == 0 ? 0 : 1 + (wave - 1) / SDRM_K2_WPR;      // 0 chain, 1 feeder, 2..4 stage (role - 2), 5 output
+    const int sub = wave == 0 ? 0 : (wave - 1) % SDRM_K2_WPR;
+    k2_lane L;
+    const int slot_h = sub * SDRM_K2_P + lane / SDRM_K2_LPS;
+    L.s = slots[slot_h];
+    L.q = lane % SDRM_K2_LPS;
+    L.on = L.s.chan >= 0;
+    L.hx = b.dc_state + (L.on ? b.params[L.s.chan].dc_state_off : 0);
+    L.z = b.z + (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
+    L.out = b.dcout + (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
+    if (role >= 2 && role <= 4) {
+        // the stage helper of a slot owns that slot's ring of its stage: the wave fills its P rings one at a time
+        for (int i = 0; i < SDRM_K2_P; i++) {
+            const int sl = sub * SDRM_K2_P + i;
             const sdrm_k2_slot s = slots[sl];
-            if (s.chan >= 0) {
+            if (sl < b.dc_group && s.chan >= 0) {
                 float *st = b.dc_state + b.params[s.chan].dc_state_off;
-                sdrm_k2_ring_load(rings + ((size_t) (wave - 2) * b.dc_group + sl) * rpitch, s,
-                                  sdrm_k2_state_tail(st, wave - 2, b.dc_hx_cap, b.dc_l_cap), lane, 64);
+                sdrm_k2_ring_load(rings + ((size_t) (role - 2) * b.dc_group + sl) * rpitch, s,
+                                  sdrm_k2_state_tail(st, role - 2, b.dc_hx_cap, b.dc_l_cap), lane, 64);
             }
         }
     }
     const unsigned long long t_begin = (b.k3_stamps != nullptr && blockIdx.x == 0) ? __builtin_amdgcn_s_memtime() : 0;
 
-    // ---- roles
-    float acc = 0.0f;          // chain wave: running sum of row (stage, slot) = lane
+    float acc = 0.0f;                // chain wave: running sum of row (stage, slot) = lane
     bool odd = false;
-    if (wave == 0) {
+    uint32_t bslot = L.s.A;          // stage helpers: ring slot of the block they convert next (block 0: A)
+    const int n_lane = L.q * K2_P;   // first sample of this lane inside a block
+    const int nz = (int) L.s.nz;
+    // delayed samples may be fetched before this block's quotients are stored when they cannot be among them
+    const bool early = __all(!L.on || L.s.L >= (uint32_t) SDRM_K2_BLK);
+    if (role == 0) {
         const sdrm_k2_slot s = slots[lane & (SDRM_K2_SLOTS - 1)];
         if (s.chan >= 0) {
             acc = sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4];
         }
         __builtin_amdgcn_s_setprio(3);  // one dependent chain: issue ahead of whatever shares the SIMD
-    } else if (wave == 1) {
-        if (h_on) {
-            sdrm_k2_feed(hs, 0, q, z_h, hx_h, ts + (0 * SDRM_K2_SLOTS + slot_h) * SDRM_K2_TSPITCH);  // block 0 of stage 0
+    } else if (role == 1) {
+        if (L.on) {
+            sdrm_k2_feed(L.s, 0, L.q, L.z, L.hx, ts + slot_h * SDRM_K2_TSPITCH);  // block 0 of stage 0
         }
     }
     __syncthreads();
     const int n_it = nb + 7;
-    for (int it = 0; it < n_it; it++) {
-        if (wave == 0) {
+    const bool stamp = b.k3_stamps != nullptr && blockIdx.x == 0;  // diagnostics: cycles each role works per iteration
+    unsigned long long busy = 0;
+#ifdef SDRM_K2_DEBUG_STAGE
+    unsigned long long dbg[4] = {0, 0, 0, 0};
+#endif
+    // Interior iterations take straight-line code: every lane of the wave has a channel, its block lies wholly inside
+    // the call, nothing comes from the carried samples, delayed quotients sit at 16-byte boundaries.  Everything else
+    // (the first and last blocks, ragged batches, odd delays, partial groups) takes the predicated code below.
+    int nz_min = nz, l_max = (int) L.s.L, hx_max = (int) L.s.HX;
+    bool all_on = L.on;
+    {
+        const sdrm_k2_slot *sp = slots + (role == 0 ? 0 : sub * SDRM_K2_P);
+        for (int i = 0; i < (role == 0 ? SDRM_K2_SLOTS : SDRM_K2_P); i++) {
+            nz_min = min(nz_min, (int) sp[i].nz);
+            l_max = max(l_max, (int) sp[i].L);
+            hx_max = max(hx_max, (int) sp[i].HX);
+            all_on = all_on && sp[i].chan >= 0;
+        }
+    }
+    const int nb_full = all_on ? nz_min / SDRM_K2_BLK : 0;  // blocks 0 .. nb_full-1 are whole for every slot of the wave
+    const bool l_mod4 = __all((L.s.L & 3u) == 0);           // x[n-L] and the delayed quotients at 16-byte boundaries
+    const bool fast_wave = all_on && early && l_mod4;
+    // Every role runs its own copy of the iteration loop (the same number of barriers in each): the roles then share no
+    // control flow, and the compiler's bookkeeping of outstanding loads and stores of one role (the feeder's operands in
+    // flight across the barrier, the output role's stores) cannot make another role wait for them.
+    const int role_rt = role;
+    auto body = [&](auto role_c, int it, unsigned long long w0) {
+        constexpr int R = decltype(role_c)::value;  // 0 chain, 1 feeder, 2 any of the three stages, 5 output
+        const int role = R == 2 ? role_rt : R;
+        if (R == 2) {
+            __builtin_assume(role >= 2 && role <= 4);
+        }
+        (void) w0;
+        if (role == 0 && it >= 6 && it < nb_full) {
+            // ---- chain, all four stages inside their calls: no lane stays out
+            const int ks = it - 2 * (lane >> 4);
+            const int buf = ks % SDRM_K2_NBUF;
+            const k2_f4 *row = reinterpret_cast<const k2_f4 *>(ts + lane * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK);
+            k2_f4 t[16];
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                t[g] = row[g];
+            }
+            float cp[SDRM_K2_LPS];
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                if ((4 * g) % K2_P == 0) cp[(4 * g) / K2_P] = acc;
+                acc = acc + t[g].x;
+                acc = acc + t[g].y;
+                acc = acc + t[g].z;
+                acc = acc + t[g].w;
+            }
+            k2_f4 *cdst = reinterpret_cast<k2_f4 *>(check + (lane * SDRM_K2_NBUF + buf) * SDRM_K2_LPS);
+#pragma unroll
+            for (int g = 0; g < SDRM_K2_LPS / 4; g++) {
+                cdst[g] = k2_f4{cp[4 * g], cp[4 * g + 1], cp[4 * g + 2], cp[4 * g + 3]};
+            }
+        } else if (role >= 2 && role <= 4 && fast_wave && it - 1 - 2 * (role - 2) >= 0 && it - 1 - 2 * (role - 2) < nb_full) {
+            // ---- stage s -> s + 1, whole block
+            const int stage = role - 2;
+            const int k = it - 1 - 2 * stage;
+            const int buf = k % SDRM_K2_NBUF;
+            const int row = stage * SDRM_K2_SLOTS + slot_h;
+            float *ring = rings + ((size_t) stage * b.dc_group + slot_h) * rpitch;
+            const uint32_t base = bslot + (uint32_t) n_lane;
+            int from = (int) base - (int) L.s.L;
+            from += from < 0 ? (int) L.s.rcap : 0;
+            float t[K2_P], v[K2_P], dl[K2_P];
+            k2_load_p(ts + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK + n_lane, t);
+            const float cp = check[(row * SDRM_K2_NBUF + buf) * SDRM_K2_LPS + L.q];
+            k2_load_p(ring + from, dl);
+#ifdef SDRM_K2_DEBUG_STAGE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long d1 = __builtin_amdgcn_s_memtime();
+#endif
+            k2_quotients(L, t, cp, v);
+#ifdef SDRM_K2_DEBUG_STAGE
+            asm volatile("" : "+v"(v[0]), "+v"(v[15]));
+            const unsigned long long d2 = __builtin_amdgcn_s_memtime();
+#endif
+            k2_store_p(ring + base, v);
+            if (base < SDRM_K2_MIRROR) {
+                k2_store_p(ring + L.s.rcap + base, v);
+            }
+#ifdef SDRM_K2_DEBUG_STAGE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long d3 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+            for (int i = 0; i < K2_P; i++) t[i] = sdrm_boxcar_term(v[i], dl[i]);
+            k2_store_p(ts + (row + SDRM_K2_SLOTS) * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK + n_lane, t);
+            bslot += SDRM_K2_BLK;
+            bslot -= bslot >= L.s.rcap ? L.s.rcap : 0u;
+#ifdef SDRM_K2_DEBUG_STAGE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long d4 = __builtin_amdgcn_s_memtime();
+            if (stamp && role == 2) {
+                dbg[0] += d1 - w0; dbg[1] += d2 - d1; dbg[2] += d3 - d2; dbg[3] += d4 - d3;
+            }
+#endif
+        } else if (role == 5 && all_on && it - 7 >= 0 && it - 7 < nb_full) {
+            // ---- output, whole block
+            const int k = it - 7;
+            const int buf = k % SDRM_K2_NBUF;
+            const int row = 3 * SDRM_K2_SLOTS + slot_h;
+            const int n0 = k * SDRM_K2_BLK + n_lane;
+            float t[K2_P], v[K2_P], xd[K2_P], o[K2_P];
+            k2_load_p(ts + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK + n_lane, t);
+            const float cp = check[(row * SDRM_K2_NBUF + buf) * SDRM_K2_LPS + L.q];
+            k2_load_p(xdt + (slot_h * 2 + (k & 1)) * SDRM_K2_BLK + n_lane, xd);
+            k2_quotients(L, t, cp, v);
+            float probe = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K2_P; i++) {
+                o[i] = xd[i] - v[i];
+                probe = fmaf(o[i], 0.0f, probe);  // NaN as soon as one of them is not finite
+            }
+            k2_store_p(L.out + n0, o);
+            odd |= probe != probe;
+        } else
+        if (role == 0) {
             const int k = it - 2 * (lane >> 4);
             if (k >= 0 && k < nb) {
                 const int buf = k % SDRM_K2_NBUF;
@@ -523,62 +753,260 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
                 for (int g = 0; g < 16; g++) {
                     t[g] = row[g];
                 }
-                k2_f4 cp;
-                cp.x = acc;
+                float cp[SDRM_K2_LPS];
 #pragma unroll
                 for (int g = 0; g < 16; g++) {
+                    if ((4 * g) % K2_P == 0) cp[(4 * g) / K2_P] = acc;
                     acc = acc + t[g].x;
                     acc = acc + t[g].y;
                     acc = acc + t[g].z;
                     acc = acc + t[g].w;
-                    if (g == 3) cp.y = acc;
-                    if (g == 7) cp.z = acc;
-                    if (g == 11) cp.w = acc;
                 }
-                *reinterpret_cast<k2_f4 *>(check + (lane * SDRM_K2_NBUF + buf) * 4) = cp;
+                k2_f4 *cdst = reinterpret_cast<k2_f4 *>(check + (lane * SDRM_K2_NBUF + buf) * SDRM_K2_LPS);
+#pragma unroll
+                for (int g = 0; g < SDRM_K2_LPS / 4; g++) {
+                    cdst[g] = k2_f4{cp[4 * g], cp[4 * g + 1], cp[4 * g + 2], cp[4 * g + 3]};
+                }
             }
-        } else if (wave == 1) {
-            const int k = it + 1;
-            if (k < nb && h_on) {
-                sdrm_k2_feed(hs, k, q, z_h, hx_h, ts + (0 * SDRM_K2_SLOTS + slot_h) * SDRM_K2_TSPITCH + (k % SDRM_K2_NBUF) * SDRM_K2_BLK);
-            }
-        } else {
-            const int stage = wave - 2;  // 0..3: converts the sums of this stage
+        } else if (role <= 4) {
+            // ---- stage s -> s + 1
+            const int stage = role - 2;
             const int k = it - 1 - 2 * stage;
-            if (k >= 0 && k < nb && h_on) {
+            if (k >= 0 && k < nb && L.on) {
                 const int buf = k % SDRM_K2_NBUF;
                 const int row = stage * SDRM_K2_SLOTS + slot_h;
-                const float *in_buf = ts + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK;
-                const float cp = check[(row * SDRM_K2_NBUF + buf) * 4 + q];
-                if (stage < 3) {
-                    sdrm_k2_transition(hs, k, q, in_buf, cp, rings + ((size_t) stage * b.dc_group + slot_h) * rpitch,
-                                       ts + (row + SDRM_K2_SLOTS) * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK);
+                float *ring = rings + ((size_t) stage * b.dc_group + slot_h) * rpitch;
+                const int n0 = k * SDRM_K2_BLK + n_lane;
+                const uint32_t base = bslot + (uint32_t) n_lane;
+                int from = (int) base - (int) L.s.L;
+                from += from < 0 ? (int) L.s.rcap : 0;
+                const bool dl_aligned = __all((from & 3) == 0);
+                float t[K2_P], v[K2_P], dl[K2_P];
+                k2_load_p(ts + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK + n_lane, t);
+                const float cp = check[(row * SDRM_K2_NBUF + buf) * SDRM_K2_LPS + L.q];
+                if (early) {
+                    k2_load_p_any(ring + from, dl_aligned, dl);
+                }
+                k2_quotients(L, t, cp, v);
+                if (n0 < nz) {
+                    k2_store_p(ring + base, v);
+                    if (base < SDRM_K2_MIRROR) {
+                        k2_store_p(ring + L.s.rcap + base, v);
+                    }
+                    if (!early) {
+                        k2_load_p_any(ring + from, dl_aligned, dl);
+                    }
+#pragma unroll
+                    for (int i = 0; i < K2_P; i++) t[i] = (n0 + i < nz) ? sdrm_boxcar_term(v[i], dl[i]) : 0.0f;
                 } else {
-                    odd |= sdrm_k2_output(hs, k, q, in_buf, cp, z_h, hx_h, b.dcout + (size_t) hs.chan * b.z_stride);
+#pragma unroll
+                    for (int i = 0; i < K2_P; i++) t[i] = 0.0f;
+                }
+                k2_store_p(ts + (row + SDRM_K2_SLOTS) * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK + n_lane, t);
+                bslot += SDRM_K2_BLK;
+                bslot -= bslot >= L.s.rcap ? L.s.rcap : 0u;
+            }
+        } else {
+            // ---- output: x[n - 2(L-1)] - v3[n]
+            const int k = it - 7;
+            if (k >= 0 && k < nb && L.on) {
+                const int buf = k % SDRM_K2_NBUF;
+                const int row = 3 * SDRM_K2_SLOTS + slot_h;
+                const int n0 = k * SDRM_K2_BLK + n_lane;
+                float t[K2_P], v[K2_P];
+                k2_load_p(ts + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK + n_lane, t);
+                k2_quotients(L, t, check[(row * SDRM_K2_NBUF + buf) * SDRM_K2_LPS + L.q], v);
+                if (n0 < nz) {
+                    float o[K2_P], xd[K2_P];
+                    k2_load_p(xdt + (slot_h * 2 + (k & 1)) * SDRM_K2_BLK + n_lane, xd);
+                    float probe = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < K2_P; i++) {
+                        o[i] = xd[i] - v[i];
+                        probe = fmaf(o[i], 0.0f, probe);  // NaN as soon as one of them is not finite
+                    }
+                    if (n0 + K2_P <= nz) {
+                        k2_store_p(L.out + n0, o);
+                        odd |= probe != probe;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < K2_P; i++) {
+                            if (n0 + i < nz) {
+                                L.out[n0 + i] = o[i];
+                                odd |= !(fabsf(o[i]) < INFINITY);
+                            }
+                        }
+                    }
                 }
             }
         }
-        __syncthreads();
+    };
+    auto run = [&](auto role_c) {
+        for (int it = 0; it < n_it; it++) {
+            const unsigned long long w0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            body(role_c, it, w0);
+            if (stamp) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the role's LDS traffic is part of its work
+                busy += __builtin_amdgcn_s_memtime() - w0;
+            }
+            K2_HANDOVER();
+        }
+    };
+    if (role == 0) {
+        run(std::integral_constant<int, 0>{});
+    } else if (role == 1) {
+        // ---- feeder.  The only role that reads global memory in the loop, and it writes none.  A lane takes four 4-sample
+        // pieces 16 samples apart (a load instruction then covers 64 contiguous bytes of every channel row) of
+        //   a = x[n], b = x[n-L] for block it + 1 of stage 0, and c = x[n - 2(L-1)] for block it - 6 of the output role;
+        // iteration `it` consumes what was loaded two iterations earlier (two register sets, so that a memory latency
+        // longer than an iteration stays hidden) and issues the loads for iteration it + 2 behind it.
+        struct feed_set {
+            float a[K2_P], b[K2_P], c[K2_P];
+        };
+        typedef float k2_f2 __attribute__((ext_vector_type(2)));
+        const int piece = 4 * SDRM_K2_LPS;  // samples between two pieces of a lane
+        auto x4 = [&](int m, float *v) {    // x[m .. m+3]: any alignment, maybe carried samples
+            if (m >= 0 && (m & 3) == 0) {
+                const k2_f4 t = *reinterpret_cast<const k2_f4 *>(L.z + m);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                for (int e = 0; e < 4; e++) v[e] = sdrm_k2_x(L.z, L.hx, L.s.HX, m + e);
+            }
+        };
+        // any iteration: operands fetched and used on the spot (the first and last blocks, ragged or partial groups)
+        auto feed_generic = [&](int it) {
+            const int k = it + 1, ko = it - 6;
+            if (!L.on) {
+                return;
+            }
+            for (int g = 0; g < K2_V4; g++) {
+                const int n = k * SDRM_K2_BLK + g * piece + 4 * L.q;
+                if (k < nb) {
+                    float va[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (n < nz) {
+                        x4(n, va);
+                        x4(n - (int) L.s.L, vb);
+                    }
+                    k2_f4 t;
+                    t.x = (n < nz) ? sdrm_boxcar_term(va[0], vb[0]) : 0.0f;
+                    t.y = (n + 1 < nz) ? sdrm_boxcar_term(va[1], vb[1]) : 0.0f;
+                    t.z = (n + 2 < nz) ? sdrm_boxcar_term(va[2], vb[2]) : 0.0f;
+                    t.w = (n + 3 < nz) ? sdrm_boxcar_term(va[3], vb[3]) : 0.0f;
+                    *reinterpret_cast<k2_f4 *>(ts + slot_h * SDRM_K2_TSPITCH + (k % SDRM_K2_NBUF) * SDRM_K2_BLK + g * piece + 4 * L.q) = t;
+                }
+                const int no = ko * SDRM_K2_BLK + g * piece + 4 * L.q;
+                if (ko >= 0 && ko < nb && no < nz) {
+                    float vc[4];
+                    x4(no - (int) L.s.HX, vc);
+                    *reinterpret_cast<k2_f4 *>(xdt + (slot_h * 2 + (ko & 1)) * SDRM_K2_BLK + g * piece + 4 * L.q) = k2_f4{vc[0], vc[1], vc[2], vc[3]};
+                }
+            }
+        };
+        // interior iterations [f0, f1): whole blocks of every slot, nothing from the carried samples, x[n-L] 16-byte aligned
+        auto feed_load = [&](int it, feed_set &S) {
+            const float *za = L.z + (it + 1) * SDRM_K2_BLK + 4 * L.q, *zb = za - (int) L.s.L;
+            const float *zc = L.z + (it - 6) * SDRM_K2_BLK + 4 * L.q - (int) L.s.HX;
+#pragma unroll
+            for (int g = 0; g < K2_V4; g++) {
+                const k2_f4 ta = *reinterpret_cast<const k2_f4 *>(za + g * piece);
+                const k2_f4 tb = *reinterpret_cast<const k2_f4 *>(zb + g * piece);
+                S.a[4 * g] = ta.x; S.a[4 * g + 1] = ta.y; S.a[4 * g + 2] = ta.z; S.a[4 * g + 3] = ta.w;
+                S.b[4 * g] = tb.x; S.b[4 * g + 1] = tb.y; S.b[4 * g + 2] = tb.z; S.b[4 * g + 3] = tb.w;
+            }
+#pragma unroll
+            for (int g = 0; g < K2_V4; g++) {  // the delay 2(L-1) is even: 8-byte pieces
+                const k2_f2 lo = *reinterpret_cast<const k2_f2 *>(zc + g * piece), hi = *reinterpret_cast<const k2_f2 *>(zc + g * piece + 2);
+                S.c[4 * g] = lo.x; S.c[4 * g + 1] = lo.y; S.c[4 * g + 2] = hi.x; S.c[4 * g + 3] = hi.y;
+            }
+        };
+        auto feed_use = [&](int it, const feed_set &S) {
+            float *dt = ts + slot_h * SDRM_K2_TSPITCH + ((it + 1) % SDRM_K2_NBUF) * SDRM_K2_BLK + 4 * L.q;
+            float *dx = xdt + (slot_h * 2 + ((it - 6) & 1)) * SDRM_K2_BLK + 4 * L.q;
+#pragma unroll
+            for (int g = 0; g < K2_V4; g++) {
+                k2_f4 t;
+                t.x = sdrm_boxcar_term(S.a[4 * g], S.b[4 * g]);
+                t.y = sdrm_boxcar_term(S.a[4 * g + 1], S.b[4 * g + 1]);
+                t.z = sdrm_boxcar_term(S.a[4 * g + 2], S.b[4 * g + 2]);
+                t.w = sdrm_boxcar_term(S.a[4 * g + 3], S.b[4 * g + 3]);
+                *reinterpret_cast<k2_f4 *>(dt + g * piece) = t;
+                *reinterpret_cast<k2_f4 *>(dx + g * piece) = k2_f4{S.c[4 * g], S.c[4 * g + 1], S.c[4 * g + 2], S.c[4 * g + 3]};
+            }
+        };
+        int f0 = max((l_max + SDRM_K2_BLK - 1) / SDRM_K2_BLK - 1, (hx_max + SDRM_K2_BLK - 1) / SDRM_K2_BLK + 6), f1 = nb_full - 1;
+        if (!(all_on && l_mod4) || f1 - f0 < 8) {
+            f0 = f1 = 0;
+        }
+        unsigned long long w0 = 0;
+        auto begin_iter = [&]() { w0 = stamp ? __builtin_amdgcn_s_memtime() : 0; };
+        auto end_iter = [&]() {
+            if (stamp) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                busy += __builtin_amdgcn_s_memtime() - w0;
+            }
+            K2_HANDOVER();
+        };
+        int it = 0;
+        for (; it < n_it && it < f0; it++) {
+            begin_iter();
+            feed_generic(it);
+            end_iter();
+        }
+        if (f1 > f0) {
+            // two register sets: iteration `it` uses what was loaded two iterations earlier, then reloads its set for it + 2
+            feed_set ev, od;
+            feed_load(it, ev);
+            feed_load(it + 1, od);
+            while (it + 3 < f1) {
+                begin_iter();
+                feed_use(it, ev);
+                feed_load(it + 2, ev);
+                end_iter();
+                begin_iter();
+                feed_use(it + 1, od);
+                feed_load(it + 3, od);
+                end_iter();
+                it += 2;
+            }
+            begin_iter();
+            feed_use(it, ev);
+            end_iter();
+            begin_iter();
+            feed_use(it + 1, od);
+            end_iter();
+            it += 2;
+        }
+        for (; it < n_it; it++) {
+            begin_iter();
+            feed_generic(it);
+            end_iter();
+        }
+    } else if (role <= 4) {
+        run(std::integral_constant<int, 2>{});
+    } else {
+        run(std::integral_constant<int, 5>{});
     }
+    __syncthreads();
 
     // ---- state back: running sums, ring tails, carried samples of x
-    if (wave == 0) {
+    if (role == 0) {
         const sdrm_k2_slot s = slots[lane & (SDRM_K2_SLOTS - 1)];
         if (s.chan >= 0) {
             sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4] = acc;
         }
-    } else if (wave >= 2 && wave <= 4) {
-        for (int sl = 0; sl < b.dc_group; sl++) {
+    } else if (role >= 2 && role <= 4) {
+        for (int i = 0; i < SDRM_K2_P; i++) {
+            const int sl = sub * SDRM_K2_P + i;
             const sdrm_k2_slot s = slots[sl];
-            if (s.chan >= 0) {
+            if (sl < b.dc_group && s.chan >= 0) {
                 float *st = b.dc_state + b.params[s.chan].dc_state_off;
-                sdrm_k2_ring_save(rings + ((size_t) (wave - 2) * b.dc_group + sl) * rpitch, s,
-                                  sdrm_k2_state_tail(st, wave - 2, b.dc_hx_cap, b.dc_l_cap), lane, 64);
+                sdrm_k2_ring_save(rings + ((size_t) (role - 2) * b.dc_group + sl) * rpitch, s,
+                                  sdrm_k2_state_tail(st, role - 2, b.dc_hx_cap, b.dc_l_cap), lane, 64);
             }
         }
     }
-    if (wave == 5 && odd && h_on) {
-        b.nonfinite[hs.chan] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
+    if (role == 5 && odd && L.on) {
+        b.nonfinite[L.s.chan] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
     }
     // hx <- last HX samples of (hx ++ z): a slot at a time by all threads; when the call is shorter than HX the new array
     // overlaps the old one shifted by nz, so every round reads before anybody writes (and later rounds read further up)
@@ -606,6 +1034,15 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         k2s[8] = __builtin_amdgcn_s_memtime() - t_begin;
         k2s[9] = (unsigned long long) n_it;
     }
+    if (stamp && lane == 0 && (wave == 0 || (wave - 1) % SDRM_K2_WPR == 0)) {
+        b.k3_stamps[SDRM_STAMP_K3_WAVES(b.n_channels) * 4 + 8 + role] = busy;  // six roles: words 0..5 of the DC record
+    }
+#ifdef SDRM_K2_DEBUG_STAGE
+    if (stamp && lane == 0 && role == 2) {  // stage 0's segments over the other roles' words (debug build only)
+        b.k3_stamps[SDRM_STAMP_K3_WAVES(b.n_channels) * 4 + 8 + 6] = dbg[0] | (dbg[1] << 32);
+        b.k3_stamps[SDRM_STAMP_K3_WAVES(b.n_channels) * 4 + 8 + 7] = dbg[2] | (dbg[3] << 32);
+    }
+#endif
     tl_mark(b, 1, 1);
 }
 

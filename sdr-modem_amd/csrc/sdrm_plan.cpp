@@ -11,12 +11,12 @@ namespace sdrm {
 
 static uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
-// LDS of the DC kernel: term rows and checkpoints of 4 stages x 16 slots, three delay rings per channel of the group,
+// LDS of the DC kernel: term rows and checkpoints of 4 stages x 16 slots, the delayed-input tile, three delay rings per channel of the group,
 // the slots' constants
 static size_t dc_lds_bytes_for(uint32_t l_cap, uint32_t group) {
     const uint32_t rcap = (l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK;
-    return ((size_t) SDRM_K2_ROWS * SDRM_K2_TSPITCH + (size_t) SDRM_K2_ROWS * SDRM_K2_NBUF * 4 +
-            3 * (size_t) group * sdrm_k2_ring_pitch(rcap)) * sizeof(float) + SDRM_K2_SLOTS * sizeof(sdrm_k2_slot) + 64;
+    return ((size_t) SDRM_K2_ROWS * SDRM_K2_TSPITCH + (size_t) SDRM_K2_ROWS * SDRM_K2_NBUF * SDRM_K2_LPS +
+            (size_t) SDRM_K2_SLOTS * 2 * SDRM_K2_BLK + 3 * (size_t) group * sdrm_k2_ring_pitch(rcap)) * sizeof(float) + SDRM_K2_SLOTS * sizeof(sdrm_k2_slot) + 64;
 }
 
 size_t BatchPlan::dc_lds_bytes() const { return dc_lds_bytes_for(dc_l_cap, dc_group); }

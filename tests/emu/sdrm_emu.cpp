@@ -130,7 +130,7 @@ static void emu_dc(EmuBatch *b) {
     const int G = (int) pl.dc_group;
     const uint32_t rcap_max = (pl.dc_l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK;
     const uint32_t rpitch = sdrm_k2_ring_pitch(rcap_max);
-    std::vector<float> ts(SDRM_K2_ROWS * SDRM_K2_TSPITCH), check(SDRM_K2_ROWS * SDRM_K2_NBUF * 4), rings(3 * (size_t) G * rpitch);
+    std::vector<float> ts(SDRM_K2_ROWS * SDRM_K2_TSPITCH), check(SDRM_K2_ROWS * SDRM_K2_NBUF * SDRM_K2_LPS), rings(3 * (size_t) G * rpitch);
     for (int c0 = 0; c0 < C; c0 += G) {
         std::fill(ts.begin(), ts.end(), 0.0f);
         std::fill(check.begin(), check.end(), NAN);
@@ -161,16 +161,18 @@ static void emu_dc(EmuBatch *b) {
                                           sdrm_k2_state_tail(b->dcstate.data() + pl.params[slots[sl].chan].dc_state_off, ring, pl.dc_hx_cap, pl.dc_l_cap), lane, 64);
         auto chan_z = [&](const sdrm_k2_slot &s) { return b->z.data() + (size_t) s.chan * pl.z_stride; };
         auto chan_hx = [&](const sdrm_k2_slot &s) { return b->dcstate.data() + pl.params[s.chan].dc_state_off; };
-        auto role = [&](int wave, int it) {
-            for (int lane = 0; lane < 64; lane++) {
-                const int slot_h = lane >> 2, q = lane & 3;
+        // role 0 = chain (one wave), roles 1..5 = feeder, stages 0..2, output (SDRM_K2_WPR waves each, a wave covers P slots)
+        auto role = [&](int role_id, int it) {
+            for (int lane = 0; lane < (role_id == 0 ? 64 : 64 * SDRM_K2_WPR); lane++) {
+                const int slot_h = lane / SDRM_K2_LPS, q = lane % SDRM_K2_LPS;
                 const sdrm_k2_slot &hs = slots[slot_h];
+                const int wave = role_id;
                 if (wave == 0) {
                     const int k = it - 2 * (lane >> 4);
                     if (k >= 0 && k < nb) {
                         const int buf = k % SDRM_K2_NBUF;
                         acc[lane] = sdrm_k2_chain_block(ts.data() + lane * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK,
-                                                        check.data() + (lane * SDRM_K2_NBUF + buf) * 4, acc[lane]);
+                                                        check.data() + (lane * SDRM_K2_NBUF + buf) * SDRM_K2_LPS, acc[lane]);
                     }
                 } else if (wave == 1) {
                     const int k = it + 1;
@@ -181,7 +183,7 @@ static void emu_dc(EmuBatch *b) {
                     if (k >= 0 && k < nb && hs.chan >= 0) {
                         const int buf = k % SDRM_K2_NBUF, row = stage * SDRM_K2_SLOTS + slot_h;
                         const float *in_buf = ts.data() + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK;
-                        const float cp = check[(row * SDRM_K2_NBUF + buf) * 4 + q];
+                        const float cp = check[(row * SDRM_K2_NBUF + buf) * SDRM_K2_LPS + q];
                         if (stage < 3) {
                             sdrm_k2_transition(hs, k, q, in_buf, cp, rings.data() + ((size_t) stage * G + slot_h) * rpitch,
                                                ts.data() + (row + SDRM_K2_SLOTS) * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK);
@@ -194,12 +196,12 @@ static void emu_dc(EmuBatch *b) {
         };
         for (int sl = 0; sl < G; sl++)
             if (slots[sl].chan >= 0)
-                for (int q = 0; q < 4; q++) sdrm_k2_feed(slots[sl], 0, q, chan_z(slots[sl]), chan_hx(slots[sl]), ts.data() + sl * SDRM_K2_TSPITCH);
+                for (int q = 0; q < SDRM_K2_LPS; q++) sdrm_k2_feed(slots[sl], 0, q, chan_z(slots[sl]), chan_hx(slots[sl]), ts.data() + sl * SDRM_K2_TSPITCH);
         for (int it = 0; it < nb + 7; it++) {
             if (it & 1) {
-                for (int w = SDRM_K2_WAVES - 1; w >= 0; w--) role(w, it);
+                for (int w = 5; w >= 0; w--) role(w, it);
             } else {
-                for (int w = 0; w < SDRM_K2_WAVES; w++) role(w, it);
+                for (int w = 0; w < 6; w++) role(w, it);
             }
         }
         for (int r = 0; r < SDRM_K2_ROWS; r++) {

@@ -44,4 +44,8 @@ for w in range(min(waves, 2)):
           "%.3f ms at %.0f MHz" % (w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1), ticks / 1e5, (stg + drn) / max(ticks, 1) * 100))
 print("cycles per iteration, all %d consumer waves: %s" % (waves, " ".join("%.0f" % (int(out[w][1]) / max(int(out[w][3]), 1)) for w in range(waves))))
 if k2[9]:
-    print("K2 channel 0: %d iterations, %.0f cycles each (the 63-step chain alone is 756)" % (k2[9], k2[8] / k2[9]))
+    print("K2 workgroup 0: %d iterations, %.0f cycles each; busy per iteration: chain %.0f, feeder %.0f, stages %.0f %.0f %.0f, output %.0f" % (
+        k2[9], k2[8] / k2[9], *[k2[w] / k2[9] for w in range(6)]))
+    if k2[6]:
+        print("   stage 0 segments (debug build): reads %.0f, quotients %.0f, ring store %.0f, terms + store %.0f" % (
+            (k2[6] & 0xffffffff) / k2[9], (k2[6] >> 32) / k2[9], (k2[7] & 0xffffffff) / k2[9], (k2[7] >> 32) / k2[9]))
