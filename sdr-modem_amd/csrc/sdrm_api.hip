@@ -77,6 +77,12 @@ struct sdrm_batch_t {
     // The three stages of consecutive calls overlap: each stage has its own stream, the stage-to-stage buffers
     // (z, dcout) are double buffered, and events order producer -> consumer and buffer reuse.
     hipStream_t s_front = nullptr, s_dc = nullptr, s_clock = nullptr;
+    // Small batches: a grid of idle-spinning waves beside every clock-stage launch (sdrm_kernels.hip, k3_company)
+    hipStream_t s_company = nullptr;
+    hipEvent_t ev_company = nullptr;
+    uint32_t *d_k3_done = nullptr;   // clock-stage workgroups finished, all launches
+    uint32_t k3_done_target = 0;     // what the counter reads when the launch enqueued last has finished
+    int company_blocks = 0;
     float *d_z2 = nullptr, *d_dcout2 = nullptr;
     bool any_nodc = false;
     bool serial = false;
@@ -163,8 +169,12 @@ static void batch_free(sdrm_batch_t *b) {
             }
         }
     }
-    hipStream_t streams[4] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock,
-                              b->s_nco != b->s_front ? b->s_nco : nullptr};
+    hipStream_t streams[5] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock,
+                              b->s_nco != b->s_front ? b->s_nco : nullptr, b->s_company};
+    if (b->ev_company) {
+        (void) hipEventDestroy(b->ev_company);
+    }
+    (void) hipFree(b->d_k3_done);
     for (hipStream_t st : streams) {
         if (st) {
             (void) hipStreamDestroy(st);
@@ -359,6 +369,19 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     } else {
         e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
         e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
+        // company for the clock stage while the batch is too small to keep the chip busy by itself (at 1024 channels the
+        // front-end does); SDRM_K3_COMPANY="blocks,first,last" overrides (blocks 0: none)
+        int blocks = 4096, lo = 32, hi = 768;
+        if (const char *env = getenv("SDRM_K3_COMPANY")) {
+            sscanf(env, "%d,%d,%d", &blocks, &lo, &hi);
+        }
+        if (blocks > 0 && (int) n_channels >= lo && (int) n_channels <= hi) {
+            b->company_blocks = blocks;
+            e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
+            e = e ? e : hipEventCreateWithFlags(&b->ev_company, hipEventDisableTiming);
+            e = e ? e : hipMalloc((void **) &b->d_k3_done, 64);
+            e = e ? e : hipMemset(b->d_k3_done, 0, 64);
+        }
     }
     for (int i = 0; i < SDRM_CTL_SLOTS && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
@@ -740,6 +763,14 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     }
     if (b->timing) {
         timing_begin(b, 2, b->s_clock, &ev);
+    }
+    if (b->company_blocks > 0) {
+        // starts when the clock stage may start, leaves when the clock stage's last workgroup has
+        d.k3_done = b->d_k3_done;
+        b->k3_done_target += sdrm::clock_workgroups(d);
+        HIP_TRY(hipEventRecord(b->ev_company, b->s_clock));
+        HIP_TRY(hipStreamWaitEvent(b->s_company, b->ev_company, 0));
+        sdrm::launch_clock_company(d, b->k3_done_target, b->company_blocks, b->s_company);
     }
     sdrm::launch_clock(d, b->s_clock);
     if (b->timing) {

@@ -276,6 +276,9 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
         return;
     }
     tl_mark(b, 0, 0);
+#ifndef SDRM_K1_NOPRIO
+    __builtin_amdgcn_s_setprio(1);  // ahead of the clock stage's companion waves (priority 0) wherever they share a SIMD
+#endif
     const sdrm_chan_params p = b.params[c];
     sdrm_f2 *xs = reinterpret_cast<sdrm_f2 *>(k1_lds);
     float *qs = reinterpret_cast<float *>(xs);  // aliases the raw tile: written only after every LPF1 read (barrier)
@@ -423,7 +426,14 @@ __global__ void k2_hold(int loops) {
 // Once the front-end's thousands of small workgroups are streaming through the chip no CU ever has 141 KB free, and the
 // clock stage starts only when the front-end's grid has drained (seen: every other call 0.5-1.2 ms late at 512 channels).
 // Half a hold in the front-end's stream lets the clock stage place its workgroups first.
-bool front_waits_for_clock_start(int n_channels) { return n_channels >= 384 && n_channels <= 1024; }
+bool front_waits_for_clock_start(int n_channels) {
+    static const char *e = getenv("SDRM_FRONT_HOLD");  // measurements: "lo,hi" channel range (default 128..1024)
+    int lo = 128, hi = 1024;
+    if (e != nullptr) {
+        sscanf(e, "%d,%d", &lo, &hi);
+    }
+    return n_channels >= lo && n_channels <= hi;
+}
 void launch_front_hold(hipStream_t s) { hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 12); }
 
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s) {
@@ -649,14 +659,15 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     // control flow, and the compiler's bookkeeping of outstanding loads and stores of one role (the feeder's operands in
     // flight across the barrier, the output role's stores) cannot make another role wait for them.
     const int role_rt = role;
-    auto body = [&](auto role_c, int it, unsigned long long w0) {
-        constexpr int R = decltype(role_c)::value;  // 0 chain, 1 feeder, 2 any of the three stages, 5 output
+    auto body = [&](auto role_c, auto fast_c, int it, unsigned long long w0) {
+        constexpr int R = decltype(role_c)::value;  // 0 chain, 2 any of the three stages, 5 output (the feeder has its own loops)
+        constexpr bool FAST = decltype(fast_c)::value;  // interior iteration: straight-line code
         const int role = R == 2 ? role_rt : R;
         if (R == 2) {
             __builtin_assume(role >= 2 && role <= 4);
         }
         (void) w0;
-        if (role == 0 && it >= 6 && it < nb_full) {
+        if (FAST && role == 0) {
             // ---- chain, all four stages inside their calls: no lane stays out
             const int ks = it - 2 * (lane >> 4);
             const int buf = ks % SDRM_K2_NBUF;
@@ -680,7 +691,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
             for (int g = 0; g < SDRM_K2_LPS / 4; g++) {
                 cdst[g] = k2_f4{cp[4 * g], cp[4 * g + 1], cp[4 * g + 2], cp[4 * g + 3]};
             }
-        } else if (role >= 2 && role <= 4 && fast_wave && it - 1 - 2 * (role - 2) >= 0 && it - 1 - 2 * (role - 2) < nb_full) {
+        } else if (FAST && role >= 2 && role <= 4) {
             // ---- stage s -> s + 1, whole block
             const int stage = role - 2;
             const int k = it - 1 - 2 * stage;
@@ -723,7 +734,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
                 dbg[0] += d1 - w0; dbg[1] += d2 - d1; dbg[2] += d3 - d2; dbg[3] += d4 - d3;
             }
 #endif
-        } else if (role == 5 && all_on && it - 7 >= 0 && it - 7 < nb_full) {
+        } else if (FAST && role == 5) {
             // ---- output, whole block
             const int k = it - 7;
             const int buf = k % SDRM_K2_NBUF;
@@ -742,6 +753,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
             }
             k2_store_p(L.out + n0, o);
             odd |= probe != probe;
+        } else if (FAST) {
         } else
         if (role == 0) {
             const int k = it - 2 * (lane >> 4);
@@ -842,14 +854,37 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         }
     };
     auto run = [&](auto role_c) {
-        for (int it = 0; it < n_it; it++) {
+        constexpr int R = decltype(role_c)::value;
+        // interior iterations of this role: its block lies wholly inside every slot's call (and, for the stage helpers,
+        // the delays allow the straight-line form)
+        int lo = 0, hi = 0;
+        if (R == 0) {
+            lo = 6, hi = nb_full;
+        } else if (R == 2 && fast_wave) {
+            lo = 1 + 2 * (role_rt - 2), hi = nb_full + lo;
+        } else if (R == 5 && all_on) {
+            lo = 7, hi = nb_full + 7;
+        }
+        hi = min(hi, n_it);
+        lo = min(lo, hi);
+        auto one = [&](auto fast_c, int it) {
             const unsigned long long w0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            body(role_c, it, w0);
+            body(role_c, fast_c, it, w0);
             if (stamp) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the role's LDS traffic is part of its work
                 busy += __builtin_amdgcn_s_memtime() - w0;
             }
             K2_HANDOVER();
+        };
+        int it = 0;
+        for (; it < lo; it++) {
+            one(std::false_type{}, it);
+        }
+        for (; it < hi; it++) {
+            one(std::true_type{}, it);
+        }
+        for (; it < n_it; it++) {
+            one(std::false_type{}, it);
         }
     };
     if (role == 0) {
@@ -1160,6 +1195,12 @@ size_t k3_lds_bytes(int lanes) {
 // stored behind the loads.
 //   v64..v88 are scratch (named, so that halves of the 64-bit pairs can be addressed); everything else is allocated
 //   by the compiler.  exec is narrowed as lanes run out of samples and restored on exit.
+#ifndef SDRM_K3_LOOP_SKEW
+#define SDRM_K3_LOOP_SKEW 0
+#endif
+#define K3_STR2(x) #x
+#define K3_STR(x) K3_STR2(x)
+#define K3_LOOP_SKEW ".rept " K3_STR(SDRM_K3_LOOP_SKEW) "\n\ts_nop 0\n\t.endr\n\t"
 template <bool CAP>
 __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, uint32_t col_addr, uint32_t bank_addr,
                                                 uint32_t &off, uint32_t off_end, const float *out_base, uint32_t ring_mask) {
@@ -1196,6 +1237,10 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         "v_mov_b32 v87, %[last]\n\t" \
         "v_and_b32 v86, %[sgn], %[last]\n\t" \
         "v_mov_b32 v88, %[off]\n" \
+        /* the loop starts on a 64-byte boundary (+ SDRM_K3_LOOP_SKEW s_nops): a hand-scheduled stream of 4- and 8-byte */ \
+        /* instructions runs ~15 % slower when code in front of it moves it by 4 bytes (2.58 -> 2.96 ms per chunk seen) */ \
+        ".p2align 6\n\t" \
+        K3_LOOP_SKEW \
         "1:\n\t" \
         /* eight symbols per trip: the taken branch back costs a lone wave ~25 cycles */ \
         K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
@@ -1308,6 +1353,10 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         nz_sh[lane] = L.nz;
         dc_sh[lane] = uses_dc;
     }
+    __shared__ unsigned hw_sh;  // diagnostics: where the producer wave runs (HW_ID: SIMD in bits 5:4, CU 11:8, SE 15:13)
+    if (producer && lane == 0) {
+        hw_sh = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, whole register
+    }
     __syncthreads();
     const int my_nz = nz_sh[lane];
     const int my_dc = dc_sh[lane];
@@ -1322,6 +1371,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     }
     const bool uniform = same_src && nrows == G::lanes;
     const int nblocks = (max_nz + G::block - 1) / G::block;
+
 
     if (producer) {
         const float *row0 = (__builtin_amdgcn_readfirstlane(my_dc) ? b.dcout : b.z) + (size_t) c0 * b.z_stride;
@@ -1483,11 +1533,13 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         }
     }
     if (b.k3_stamps && lane == 0) {  // diagnostic only: cycles waiting for the producer vs in the symbol loops
-        b.k3_stamps[blockIdx.x * 4 + 0] = t_wait;
+        b.k3_stamps[blockIdx.x * 4 + 0] = (t_wait & 0xffffffffull) | ((real0 & 0xffffffffull) << 32);  // + when this wave's loop began (100 MHz ticks)
         b.k3_stamps[blockIdx.x * 4 + 1] = t_drain;
         // steps in the low half, 100 MHz ticks of the whole loop in the high half (shader clock = cycles / time)
         b.k3_stamps[blockIdx.x * 4 + 2] = (unsigned long long) nblocks | ((__builtin_amdgcn_s_memrealtime() - real0) << 32);
-        b.k3_stamps[blockIdx.x * 4 + 3] = n_iter;
+        // iterations, and in the upper bits the HW_ID of the consumer wave (bits 47:32) and of the producer wave (63:48)
+        b.k3_stamps[blockIdx.x * 4 + 3] = (n_iter & 0xffffffffull) | ((unsigned long long) (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffu) << 32) |
+                                          ((unsigned long long) (hw_sh & 0xffffu) << 48);
     }
 #undef K3_DRAIN
     if (absent) {
@@ -1505,6 +1557,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         cs->poison = flagged;      // the carried samples come from this call's stream
         b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
         b.out_len[c] = L.oo;
+    }
+    if (b.k3_done != nullptr && lane == 0) {
+        atomicAdd(b.k3_done, 1u);  // the companion grid (k3_company) leaves when every workgroup of this launch has
     }
     tl_mark(b, 2, 1);
 }
@@ -1567,6 +1622,42 @@ KernelLaunch describe_quantize(const DeviceBatch &b) {
     k.block = dim3(256);
     return k;
 }
+
+// Company for the clock stage.  A wave that is (nearly) alone on the chip runs a dependent chain slower than the same
+// wave on a busy chip: with 256 channels the clock stage is 16 consumer waves, and some of them -- different ones from
+// run to run -- took 245-260 cycles per symbol instead of 220, until other waves were issuing VECTOR instructions all over
+// the chip.  Measured (tools/k3_ab.py, ms per 131072-sample chunk of 256 channels): 2.96-2.98 alone; beside 256 / 1024 /
+// 2048 / 4096 one-wave workgroups that execute one v_mov per 32 s_nop 7: 2.86 / 2.73 / 2.64 / 2.58, every consumer wave
+// then at 218-220 cycles per symbol; one v_mov per s_nop: 2.53 (the front-end beside it 0.70 instead of 0.55 ms, which
+// matters only where it is the longer stage).  Waves that run nothing but s_nop, or s_sleep, change nothing; a solid
+// stream of v_add takes the consumers' issue slots and helps nothing either; extra waves inside the clock stage's own
+// workgroups (its CUs hold nothing else: its rings take the LDS) do not help: what counts is sparse vector activity on every
+// compute unit -- presumably what keeps the chip's power management from parking parts of it.  Round 1's DC blocker, one
+// busy workgroup per channel on every CU, was that company without anybody knowing; the lane-dense one is not.
+// So small batches get a companion grid on a side stream beside each clock-stage launch: no LDS, no memory traffic but a
+// look at the counter the clock stage's workgroups bump when they finish, every ~50 us, and a bound on its life.
+#ifndef SDRM_K3_COMPANY_NOPS
+#define SDRM_K3_COMPANY_NOPS 1   // s_nop 7 between two vector instructions of a companion wave
+#endif
+#define SDRM_K3_COMPANY_REPS (64 / SDRM_K3_COMPANY_NOPS)
+__global__ __launch_bounds__(64) void k3_company(const uint32_t *done, uint32_t target, int max_rounds) {
+    float a = threadIdx.x;
+    for (int i = 0; i < max_rounds; i++) {
+        for (int j = 0; j < 48; j++) {  // ~50 us between two looks at the counter (4096 waves looking: keep it rare)
+            asm volatile(".rept " K3_STR(SDRM_K3_COMPANY_REPS) "\n\tv_mov_b32 %0, %0\n\t.rept " K3_STR(SDRM_K3_COMPANY_NOPS) "\n\ts_nop 7\n\t.endr\n\t.endr" : "+v"(a));
+        }
+        if ((int32_t) (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) {
+            break;
+        }
+    }
+}
+
+void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, hipStream_t s) {
+    // max_rounds: ~6 ms at most, whatever happens to the counter
+    hipLaunchKernelGGL(k3_company, dim3((unsigned) blocks), dim3(64), 0, s, b.k3_done, target, 120);
+}
+
+unsigned clock_workgroups(const DeviceBatch &b) { return describe_clock(b).grid.x; }
 
 void launch_clock(const DeviceBatch &b, hipStream_t s) {
     void *args[] = {(void *) &b};

@@ -48,6 +48,7 @@ struct DeviceBatch {
     uint32_t dc_group, dc_rpitch;    // channels per DC workgroup, floats between two of its delay rings in LDS
     uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
+    uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching
 };
 
 // one kernel launch, described: what launch_* puts on a stream and what the explicitly built graph of the one-channel
@@ -77,6 +78,8 @@ void launch_dc(const DeviceBatch &b, hipStream_t s);
 // words of the front-end, then 10 of the DC blocker
 #define SDRM_STAMP_K3_WAVES(n_channels) (((n_channels) + 15) / 16)
 void launch_clock(const DeviceBatch &b, hipStream_t s);
+void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, hipStream_t s);
+unsigned clock_workgroups(const DeviceBatch &b);
 
 // test probes
 void launch_probe_boxcar_div(const float *d_sums, uint32_t length, float *d_out, size_t n, hipStream_t s);

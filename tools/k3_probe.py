@@ -37,8 +37,16 @@ out = out[:slots * 4].reshape(slots, 4)
 if k1[4]:
     print("K1 per workgroup (cycles): load %.0f, lpf1 %.0f, quad %.0f, lpf2+store %.0f  (%d workgroups)" % (
         k1[0] / k1[4], k1[1] / k1[4], k1[2] / k1[4], k1[3] / k1[4], k1[4]))
+starts = [int(out[w][0]) >> 32 for w in range(waves)]
+print("loop start of each consumer wave, us after the first: %s" % " ".join("%.0f" % ((s - min(starts)) / 100.0) for s in starts))
+hw = [(int(out[w][3]) >> 32) & 0xffff for w in range(waves)]
+hwp = [(int(out[w][3]) >> 48) & 0xffff for w in range(waves)]
+for w in range(waves):
+    out[w][3] = int(out[w][3]) & 0xffffffff
+print("consumer/producer SIMD, CU, SE per workgroup: %s" % " ".join("%d/%d:%d:%d" % ((hw[w] >> 4) & 3, (hwp[w] >> 4) & 3, (hw[w] >> 8) & 15, (hw[w] >> 13) & 7) for w in range(waves)))
 for w in range(min(waves, 2)):
     stg, drn, packed, it = [int(v) for v in out[w]]
+    stg &= 0xffffffff
     nb, ticks = packed & 0xffffffff, packed >> 32
     print("wave %d: wait-for-producer %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration, "
           "%.3f ms at %.0f MHz" % (w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1), ticks / 1e5, (stg + drn) / max(ticks, 1) * 100))
