@@ -212,6 +212,11 @@ void sdrm_batcher_put(sdrm_batcher *batcher, size_t channel, const sdrm_cf32 *bu
 void sdrm_batcher_take(sdrm_batcher *batcher, size_t channel, int8_t **output, size_t *output_len);
 void sdrm_batcher_complete(sdrm_batcher *batcher, size_t channel);
 void sdrm_batcher_interrupt(sdrm_batcher *batcher, size_t channel);
+/* the channel's consumer is gone for good (write error, client torn down): closes the channel like the poison pill and
+ * discards everything of it that has not been taken, finished or not, so that the shared rounds retire and the other
+ * clients keep moving -- in the reference a dead consumer only fills its own queue (src/queue.c).  The slot can be
+ * handed to a new client with sdrm_batcher_reset_channel afterwards. */
+void sdrm_batcher_abandon(sdrm_batcher *batcher, size_t channel);
 /* A channel changes hands (one client leaves, another arrives): waits until everything put on the channel has been
  * consumed, lets the rounds in flight finish, then resets the channel as sdrm_batch_reset_channel does (config NULL =
  * same configuration) and reopens it if it had been interrupted.  Other channels keep their streams. */

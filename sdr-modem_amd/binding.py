@@ -54,7 +54,7 @@ EXPORTS = [
     "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
     "sdrm_batch_process_nco", "sdrm_batch_process_device_nco", "sdrm_batch_last_mixed",
     "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect", "sdrm_batch_reset_channel",
-    "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt",
+    "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt", "sdrm_batcher_abandon",
     "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_boxcar_div", "sdrm_version", "sdrm_device_count",
@@ -80,6 +80,8 @@ def bind_batcher(L):
     L.sdrm_batcher_complete.restype = None
     L.sdrm_batcher_interrupt.argtypes = [vp, C.c_size_t]
     L.sdrm_batcher_interrupt.restype = None
+    L.sdrm_batcher_abandon.argtypes = [vp, C.c_size_t]
+    L.sdrm_batcher_abandon.restype = None
     L.sdrm_batcher_reset_channel.argtypes = [vp, C.c_size_t, C.POINTER(FskConfig)]
     L.sdrm_batcher_channels.argtypes = [vp]
     L.sdrm_batcher_channels.restype = C.c_size_t
@@ -392,6 +394,9 @@ class Batcher:
 
     def interrupt(self, channel):
         self.L.sdrm_batcher_interrupt(self.h, channel)
+
+    def abandon(self, channel):
+        self.L.sdrm_batcher_abandon(self.h, channel)
 
     def rounds(self):
         return int(self.L.sdrm_batcher_rounds(self.h))

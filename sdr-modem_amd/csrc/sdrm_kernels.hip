@@ -626,7 +626,10 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
             acc = sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4];
         }
         __builtin_amdgcn_s_setprio(3);  // one dependent chain: issue ahead of whatever shares the SIMD
-    } else if (role == 1) {
+    } else {
+        __builtin_amdgcn_s_setprio(1);  // the helpers: ahead of the clock stage's companion waves (priority 0)
+    }
+    if (role == 1) {
         if (L.on) {
             sdrm_k2_feed(L.s, 0, L.q, L.z, L.hx, ts + slot_h * SDRM_K2_TSPITCH);  // block 0 of stage 0
         }

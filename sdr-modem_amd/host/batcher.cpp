@@ -41,6 +41,7 @@ int Batcher::init() {
     next_put_.assign(n_, 0);
     mine_.assign(n_, std::deque<uint64_t>());
     closed_.assign(n_, 0);
+    abandoned_.assign(n_, 0);
     doppler_.assign(n_, Doppler());
     open_ = n_;
     thread_ = std::thread(&Batcher::run, this);
@@ -137,6 +138,9 @@ void Batcher::take(size_t c, int8_t **out, size_t *len) {
     }
     std::unique_lock<std::mutex> lk(m_);
     for (;;) {
+        if (abandoned_[c]) {
+            return;  // the channel was given up: nothing is delivered any more
+        }
         if (!mine_[c].empty()) {
             Round &rd = round(mine_[c].front());
             if (rd.state == DONE) {
@@ -206,6 +210,41 @@ void Batcher::interrupt(size_t c) {
     cv_result_.notify_all();
 }
 
+// finished rounds at the head of an abandoned channel's list count as consumed (the batcher thread calls this again
+// whenever a round finishes)
+void Batcher::drop_done_locked(size_t c) {
+    bool dropped = false;
+    while (!mine_[c].empty() && round(mine_[c].front()).state == DONE) {
+        round(mine_[c].front()).unconsumed--;
+        mine_[c].pop_front();
+        dropped = true;
+    }
+    if (dropped) {
+        retire_locked();
+        if (mine_[c].empty() && reset_waiters_ > 0) {
+            cv_result_.notify_all();
+        }
+    }
+}
+
+void Batcher::abandon(size_t c) {
+    if (c >= n_) {
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> g(m_);
+        if (!closed_[c]) {
+            closed_[c] = 1;
+            open_--;
+        }
+        abandoned_[c] = 1;
+        drop_done_locked(c);
+    }
+    cv_work_.notify_all();
+    cv_space_.notify_all();
+    cv_result_.notify_all();
+}
+
 int Batcher::reset_channel(size_t c, const sdrm_fsk_config *cfg) {
     if (c >= n_) {
         return -1;
@@ -269,6 +308,7 @@ void Batcher::run() {
             lk.lock();
             if (code == 0 && closed_[req->channel]) {
                 closed_[req->channel] = 0;  // the slot serves a new client
+                abandoned_[req->channel] = 0;
                 open_++;
             }
             req->code = code;
@@ -305,6 +345,11 @@ void Batcher::run() {
                 inflight_.erase(std::find(inflight_.begin(), inflight_.end(), r));
                 cv_result_.notify_all();
                 retire_locked();
+                for (size_t c = 0; c < n_; c++) {
+                    if (abandoned_[c]) {
+                        drop_done_locked(c);
+                    }
+                }
             }
             continue;
         }
@@ -325,6 +370,11 @@ void Batcher::run() {
             inflight_.pop_front();
             cv_result_.notify_all();
             retire_locked();
+            for (size_t c = 0; c < n_; c++) {
+                if (abandoned_[c]) {
+                    drop_done_locked(c);  // nobody will take these
+                }
+            }
             continue;
         }
         if (stopping_) {
@@ -367,6 +417,12 @@ extern "C" int sdrm_batcher_reset_channel(sdrm_batcher *b, size_t channel, const
 extern "C" void sdrm_batcher_interrupt(sdrm_batcher *b, size_t channel) {
     if (b != nullptr) {
         reinterpret_cast<sdrm::Batcher *>(b)->interrupt(channel);
+    }
+}
+
+extern "C" void sdrm_batcher_abandon(sdrm_batcher *b, size_t channel) {
+    if (b != nullptr) {
+        reinterpret_cast<sdrm::Batcher *>(b)->abandon(channel);
     }
 }
 

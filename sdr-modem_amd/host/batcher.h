@@ -52,6 +52,10 @@ public:
     void take(size_t channel, int8_t **out, size_t *len);
     void complete(size_t channel);
     void interrupt(size_t channel);
+    // the channel's consumer is gone (socket or disk error, client torn down): close the channel as interrupt() does
+    // and throw away everything of it that nobody will take any more, including what the device has not finished yet,
+    // so that its rounds retire and the other channels keep moving (a dead consumer in the reference only fills its own queue)
+    void abandon(size_t channel);
     void set_doppler(size_t channel, doppler_plan_fn fn, void *planner);
     // hand the channel to a new client: waits until everything put on it has been consumed, drains the device, resets
     // the channel (cfg may be NULL = same configuration) and reopens it after a poison pill
@@ -60,6 +64,7 @@ public:
     uint64_t rounds_launched() const { return launched_; }
 
 private:
+    void drop_done_locked(size_t channel);
     enum State { FREE, FILLING, SUBMITTED, DONE };
     struct Round {
         uint64_t id = 0;
@@ -91,6 +96,7 @@ private:
     std::vector<uint64_t> next_put_;
     std::vector<std::deque<uint64_t>> mine_;  // rounds holding an unconsumed buffer of the channel, oldest first
     std::vector<uint8_t> closed_;
+    std::vector<uint8_t> abandoned_;  // closed, and its undelivered results are discarded as they arrive
     size_t open_ = 0;
     struct Doppler {
         doppler_plan_fn fn = nullptr;

@@ -103,6 +103,9 @@ static void *batched_main(void *arg) {
             break;
         }
     }
+    /* whatever made the loop end, nobody takes this client's results any more: let the shared rounds go (the reference's
+     * worker leaves its own queue to fill up, src/dsp_worker.c:56-64,83-101; here the rounds belong to every client) */
+    sdrm_batcher_abandon(w->batcher, w->channel);
     printf("[%d] dsp_worker stopped\n", w->id);
     return NULL;
 }

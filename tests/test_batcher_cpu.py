@@ -220,3 +220,43 @@ def test_channel_changes_hands_while_the_others_keep_streaming():
     assert np.array_equal(bt.take(1), ob.process(sb[4096:])[0])
     assert bt.reset_channel(1, (48000, 1200, 5000, 1, 2000, True, 4096)) != 0  # 207-tap filter: larger than the batch's
     bt.close()
+
+
+def test_a_dead_consumer_does_not_stall_the_other_clients():
+    """A client whose consumer is gone (socket or disk error: the worker leaves its loop) must not hold the shared rounds:
+    in the reference a dead consumer only fills its own queue (src/queue.c:99-154).  Channel 1 puts two buffers and never
+    takes them; after sdrm_batcher_abandon its rounds retire, channel 0 streams on past the number of rounds the batcher
+    owns, and the slot can be handed to a new client, whose stream starts clean."""
+    cfgs = [CFG_A, CFG_A]
+    n = 12  # more buffers than the batcher has rounds (4): they have to be recycled
+    sig0 = siggen.gmsk_channel(0, 4096 * n)
+    sig1 = siggen.gmsk_channel(1, 4096 * 4)
+    chunks0 = [sig0[k * 4096:(k + 1) * 4096] for k in range(n)]
+    bt = emu_api.emu_batcher(cfgs, slots=4, max_wait_us=2000, blocking=True)
+    bt.put(1, sig1[:4096])
+    bt.put(1, sig1[4096:8192])
+    bt.abandon(1)  # consumer of channel 1 died: nobody will ever take those two
+    assert bt.take(1) is None
+    got = []
+
+    def client0():
+        for k in range(n):
+            bt.put(0, chunks0[k])
+            got.append(bt.take(0))
+
+    t = threading.Thread(target=client0)
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "channel 0 is stuck behind the dead client's rounds"
+    exp = oracle_stream(CFG_A, chunks0)
+    assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    # the slot serves a new client: reset returns (nothing of the old one is waited for) and the stream starts from scratch
+    done = []
+    r = threading.Thread(target=lambda: done.append(bt.reset_channel(1, None)))
+    r.start()
+    r.join(30)
+    assert not r.is_alive() and done == [0]
+    sig_b = siggen.gmsk_channel(7, 4096)
+    bt.put(1, sig_b)
+    assert np.array_equal(bt.take(1), oracle_stream(CFG_A, [sig_b])[0])
+    bt.close()
