@@ -73,6 +73,12 @@ typedef struct {
 #define SDRM_FLAG_KEEP_SOFT_F32 1u /* the caller reads the float soft bits (clock-recovery output) of a call; the stage
                                     * produces them in any case, the int8 output is converted from them */
 
+#define SDRM_FLAG_FAST_FMA 2u      /* OPT-IN fast mode: both low-pass filters accumulate with fused multiply-adds (half the
+                                    * vector instructions of the front-end).  NOT the reference's arithmetic: the soft
+                                    * bits differ from the CPU path in the last place on a few per cent of the symbols
+                                    * (~3e-4 RMS, SURVEY.md finding 2) and are held to the reference's own +-2 LSB test
+                                    * tolerance (test/test_fsk_demod.c:47), not to bit equality.  Never the default. */
+
 /* device < 0: current HIP device.  Returns 0, -ENOMEM, -1 (bad parameters), -ENODEV (no usable GPU),
  * -ENOTSUP (samples-per-symbol outside the supported range). */
 int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels, int device, uint32_t flags, sdrm_batch **batch);

@@ -423,6 +423,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.dc_rpitch = sdrm_k2_ring_pitch((pl.dc_l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK);
     d.dc_lds = (uint32_t) pl.dc_lds_bytes();
     d.any_dc = any_dc;
+    d.fast_fma = (flags & SDRM_FLAG_FAST_FMA) ? 1 : 0;
     b->in_stride = pl.in_stride;
     *out = b;
     return 0;

@@ -143,10 +143,19 @@ SDRM_HD sdrm_f2 sdrm_ext_sample(const sdrm_f2 *in, const sdrm_f2 *hist, int hist
     return *p;
 }
 
+// One tap of a dot product.  EXACT (the default, what every parity claim rests on): product and sum rounded separately, as
+// the reference's VOLK generic kernels do.  FUSED (opt-in, SDRM_FLAG_FAST_FMA): one fused multiply-add -- half the
+// vector instructions, and NOT the reference's bits: the soft bits then differ in the last place on a few per cent of
+// the symbols, which the reference's own tests tolerate at +-2 LSB of the int8 output (test/test_fsk_demod.c:47).
+template <bool FUSED>
+SDRM_HD float sdrm_mac(float acc, float x, float t) {
+    return FUSED ? fmaf(x, t, acc) : acc + x * t;
+}
+
 // K sequential taps on N adjacent outputs of a unit-stride FIR, register blocked: for every output the
 // taps are visited in increasing j, one fp32 multiply and one fp32 add each -- the reference's order
 // (fir_filter.c:100-105 / :130-135 with VOLK generic dot products).
-template <int N, int K>
+template <int N, int K, bool FUSED = false>
 SDRM_HD void sdrm_fir_block_c(const sdrm_f2 *xs, const float *taps, int ntaps, sdrm_f2 (&acc)[N]) {
     int j0 = 0;
     for (; j0 + K <= ntaps; j0 += K) {
@@ -160,8 +169,8 @@ SDRM_HD void sdrm_fir_block_c(const sdrm_f2 *xs, const float *taps, int ntaps, s
             const float tp = taps[j0 + u];
 #pragma unroll
             for (int r = 0; r < N; r++) {
-                acc[r].x = acc[r].x + w[r + u].x * tp;
-                acc[r].y = acc[r].y + w[r + u].y * tp;
+                acc[r].x = sdrm_mac<FUSED>(acc[r].x, w[r + u].x, tp);
+                acc[r].y = sdrm_mac<FUSED>(acc[r].y, w[r + u].y, tp);
             }
         }
     }
@@ -170,8 +179,8 @@ SDRM_HD void sdrm_fir_block_c(const sdrm_f2 *xs, const float *taps, int ntaps, s
 #pragma unroll
         for (int r = 0; r < N; r++) {
             sdrm_f2 v = xs[j0 + r];
-            acc[r].x = acc[r].x + v.x * tp;
-            acc[r].y = acc[r].y + v.y * tp;
+            acc[r].x = sdrm_mac<FUSED>(acc[r].x, v.x, tp);
+            acc[r].y = sdrm_mac<FUSED>(acc[r].y, v.y, tp);
         }
     }
 }
@@ -211,7 +220,13 @@ SDRM_HD sdrm_v2 sdrm_v2_make(float a, float b) {
     sdrm_v2 v = {a, b};
     return v;
 }
-SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) { return acc + x * t; }
+template <bool FUSED = false>
+SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) {
+    if (FUSED) {
+        return sdrm_v2_make(fmaf(x.x, t, acc.x), fmaf(x.y, t, acc.y));
+    }
+    return acc + x * t;
+}
 #else
 struct sdrm_v2 {
     float x, y;
@@ -220,10 +235,11 @@ SDRM_HD sdrm_v2 sdrm_v2_make(float a, float b) {
     sdrm_v2 v = {a, b};
     return v;
 }
+template <bool FUSED = false>
 SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) {
     sdrm_v2 r;
-    r.x = acc.x + x.x * t;
-    r.y = acc.y + x.y * t;
+    r.x = sdrm_mac<FUSED>(acc.x, x.x, t);
+    r.y = sdrm_mac<FUSED>(acc.y, x.y, t);
     return r;
 }
 #endif
@@ -232,7 +248,7 @@ SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) {
 // packed multiply and one packed add per pair and tap (half the VALU instructions of sdrm_fir_block_r; per output the
 // operations and their order are unchanged).  The window is kept twice, as even-aligned pairs (x[2k], x[2k+1]) and as
 // odd-aligned pairs (x[2k+1], x[2k+2]), so that every pair operand is a register pair whatever the tap's parity.
-template <int N, int K>
+template <int N, int K, bool FUSED = false>
 SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, float (&acc)[N]) {
     constexpr int P = N / 2;
     constexpr int W = N + K - 1;  // window floats per step
@@ -259,12 +275,12 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const int i = 2 * p + u;
-                pa[p] = sdrm_v2_mac(pa[p], (i & 1) ? wo[i / 2] : we[i / 2], tp);
+                pa[p] = sdrm_v2_mac<FUSED>(pa[p], (i & 1) ? wo[i / 2] : we[i / 2], tp);
             }
             if (N & 1) {
                 const int i = N - 1 + u;
                 const float x = (i & 1) ? we[i / 2].y : we[i / 2].x;
-                tail = tail + x * tp;
+                tail = sdrm_mac<FUSED>(tail, x, tp);
             }
         }
     }
@@ -280,7 +296,7 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
         const float tp = taps[j0];
 #pragma unroll
         for (int r = 0; r < N; r++) {
-            acc[r] = acc[r] + xs[j0 + r] * tp;
+            acc[r] = sdrm_mac<FUSED>(acc[r], xs[j0 + r], tp);
         }
     }
 }
@@ -322,6 +338,7 @@ SDRM_HD void sdrm_k1_phase_load(int tid, const sdrm_k1_tile &t, const sdrm_f2 *i
 }
 
 // phase 1: LPF1 on R adjacent positions (reference src/dsp/fir_filter.c:123-144 via lpf.c:38-40)
+template <bool FUSED = false>
 SDRM_HD void sdrm_k1_phase_lpf1(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps1_rev,
                                 const sdrm_f2 *xs, sdrm_f2 *bnd, sdrm_k1_regs &regs) {
 #pragma unroll
@@ -330,7 +347,7 @@ SDRM_HD void sdrm_k1_phase_lpf1(int tid, const sdrm_k1_tile &t, const sdrm_chan_
         regs.y[r].y = 0.0f;
     }
     if (tid * SDRM_K1_R < t.ny) {
-        sdrm_fir_block_c<SDRM_K1_R, SDRM_K1_U>(xs + tid * SDRM_K1_R, taps1_rev, (int) p.T1, regs.y);
+        sdrm_fir_block_c<SDRM_K1_R, SDRM_K1_U, FUSED>(xs + tid * SDRM_K1_R, taps1_rev, (int) p.T1, regs.y);
     }
     bnd[tid] = regs.y[SDRM_K1_R - 1];
 }
@@ -362,6 +379,7 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
 }
 
 // phase 3: LPF2 with decimation (reference src/dsp/fir_filter.c:93-114), results to global z
+template <bool FUSED = false>
 SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps2_rev,
                                 const float *qs, float *zs, uint32_t *nonfinite_flag) {
     const int base = tid * SDRM_K1_RZ;
@@ -374,7 +392,7 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
         acc[r] = 0.0f;
     }
     if (p.decim == 1) {
-        sdrm_fir_block_rp<SDRM_K1_RZ, SDRM_K1_U>(qs + base, taps2_rev, (int) p.T2, acc);
+        sdrm_fir_block_rp<SDRM_K1_RZ, SDRM_K1_U, FUSED>(qs + base, taps2_rev, (int) p.T2, acc);
     } else {
         const int d = (int) p.decim;
         for (int j = 0; j < (int) p.T2; j++) {
@@ -383,7 +401,7 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
             for (int r = 0; r < SDRM_K1_RZ; r++) {
                 int ol = base + r;
                 float v = (ol < t.m) ? qs[ol * d + j] : 0.0f;
-                acc[r] = acc[r] + v * tp;
+                acc[r] = sdrm_mac<FUSED>(acc[r], v, tp);
             }
         }
     }

@@ -267,6 +267,8 @@ size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) {
 
 // grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
 // per-thread boundary samples | arctan table.
+// FUSED: the opt-in fast mode (SDRM_FLAG_FAST_FMA): both filters' taps as fused multiply-adds.  Never the default.
+template <bool FUSED>
 __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
                                                             size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
@@ -319,13 +321,13 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     __syncthreads();
     unsigned long long t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_regs regs;
-    sdrm_k1_phase_lpf1(tid, t, p, taps1, xs, bnd, regs);
+    sdrm_k1_phase_lpf1<FUSED>(tid, t, p, taps1, xs, bnd, regs);
     __syncthreads();
     unsigned long long t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_quad(tid, t, p, tab, bnd, regs, qs);
     __syncthreads();
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    sdrm_k1_phase_lpf2(tid, t, p, taps2, qs, zs, b.nonfinite + c);
+    sdrm_k1_phase_lpf2<FUSED>(tid, t, p, taps2, qs, zs, b.nonfinite + c);
     __syncthreads();
     sdrm_k1_phase_store(tid, t, zs, b.z + (size_t) c * b.z_stride);
     tl_mark(b, 0, 1);
@@ -383,10 +385,15 @@ KernelLaunch describe_front(const DeviceBatch &b) {
     if (b.max_tiles == 0) {
         return k;
     }
-    static lds_grant granted;
+    static lds_grant granted, granted_fused;
     k.lds = k1_lds_bytes(b.t1_max, b.t2_max);
-    allow_lds(k1_front, k.lds, &granted);
-    k.func = reinterpret_cast<const void *>(k1_front);
+    if (b.fast_fma) {
+        allow_lds(k1_front<true>, k.lds, &granted_fused);
+        k.func = reinterpret_cast<const void *>(k1_front<true>);
+    } else {
+        allow_lds(k1_front<false>, k.lds, &granted);
+        k.func = reinterpret_cast<const void *>(k1_front<false>);
+    }
     k.grid = dim3(b.max_tiles, (unsigned) b.n_channels);
     k.block = dim3(SDRM_K1_THREADS);
     return k;
