@@ -207,11 +207,134 @@ struct sdrm_mm_consts {
 };
 
 // ---- NCO (next scope row f-1; reference src/dsp/sig_source.c:43-58) ----
+// The reference computes the oscillator sample as (float) cos((double) phase), (float) sin((double) phase) with the
+// host's libm (sig_source.c:46).  Two double-precision implementations of cos agree to an ulp or two of a double, not
+// bit for bit, and where the value lies next to a rounding boundary of fp32 (a "midpoint": probability 2^-29 per ulp
+// of disagreement) the float results differ in the last place -- the device's math library did on ~1e-5 of the samples.
+// So: evaluate fast; when the double lies within 16 ulp of an fp32 midpoint, evaluate again in double-double (~100 bits)
+// and round THAT to fp32.  The result is the correctly rounded float of the exact cosine; a libm returns the same float
+// unless its own double error (glibc: < 0.55 ulp) carries it across the midpoint, i.e. on ~1e-9 of the samples.
+struct sdrm_dd {
+    double hi, lo;
+};
+SDRM_HD sdrm_dd sdrm_dd_make(double hi, double lo) {
+    sdrm_dd r;
+    r.hi = hi;
+    r.lo = lo;
+    return r;
+}
+SDRM_HD sdrm_dd sdrm_two_sum(double a, double b) {  // a + b exactly (Knuth)
+    const double s = a + b, bb = s - a;
+    return sdrm_dd_make(s, (a - (s - bb)) + (b - bb));
+}
+SDRM_HD sdrm_dd sdrm_quick_two_sum(double a, double b) {  // |a| >= |b|
+    const double s = a + b;
+    return sdrm_dd_make(s, b - (s - a));
+}
+SDRM_HD sdrm_dd sdrm_two_prod(double a, double b) {  // a * b exactly
+    const double p = a * b;
+    return sdrm_dd_make(p, fma(a, b, -p));
+}
+SDRM_HD sdrm_dd sdrm_dd_add(sdrm_dd a, sdrm_dd b) {
+    sdrm_dd s = sdrm_two_sum(a.hi, b.hi);
+    const sdrm_dd t = sdrm_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = sdrm_quick_two_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return sdrm_quick_two_sum(s.hi, s.lo);
+}
+SDRM_HD sdrm_dd sdrm_dd_mul(sdrm_dd a, sdrm_dd b) {
+    sdrm_dd p = sdrm_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return sdrm_quick_two_sum(p.hi, p.lo);
+}
+
+// sin(x), cos(x) to ~2^-100 for |x| < 2^20 (an fp32 phase is far below that): x - k pi/2 with pi/2 in three 33-bit
+// pieces (each product with k is exact) and a tail, then the Taylor series in double-double on |r| <= pi/4.
+SDRM_HD void sdrm_sincos_dd(double x, sdrm_dd *sn, sdrm_dd *cs) {
+    static const double S[14][2] = {
+        {-0x1.5555555555555p-3, -0x1.5555555555555p-57}, {0x1.1111111111111p-7, 0x1.1111111111111p-63},
+        {-0x1.a01a01a01a01ap-13, -0x1.a01a01a01a01ap-73}, {0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73},
+        {-0x1.ae64567f544e4p-26, 0x1.c062e06d1f209p-80}, {0x1.6124613a86d09p-33, 0x1.f28e0cc748ebep-87},
+        {-0x1.ae7f3e733b81fp-41, -0x1.1d8656b0ee8cbp-97}, {0x1.952c77030ad4ap-49, 0x1.ac981465ddc6cp-103},
+        {-0x1.2f49b46814157p-57, -0x1.2650f61dbdcb4p-112}, {0x1.71b8ef6dcf572p-66, -0x1.d043ae40c4647p-120},
+        {-0x1.761b41316381ap-75, 0x1.3423c7d91404fp-130}, {0x1.3f3ccdd165fa9p-84, -0x1.58ddadf344487p-139},
+        {-0x1.d1ab1c2dccea3p-94, -0x1.054d0c78aea14p-149}, {0x1.259f98b4358adp-103, 0x1.eaf8c39dd9bc5p-157}};
+    static const double Cc[14][2] = {
+        {-0x1.0000000000000p-1, 0.0}, {0x1.5555555555555p-5, 0x1.5555555555555p-59},
+        {-0x1.6c16c16c16c17p-10, 0x1.f49f49f49f49fp-65}, {0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76},
+        {-0x1.27e4fb7789f5cp-22, -0x1.cbbc05b4fa99ap-76}, {0x1.1eed8eff8d898p-29, -0x1.2aec959e14c06p-83},
+        {-0x1.93974a8c07c9dp-37, -0x1.05d6f8a2efd1fp-92}, {0x1.ae7f3e733b81fp-45, 0x1.1d8656b0ee8cbp-101},
+        {-0x1.6827863b97d97p-53, -0x1.eec01221a8b0bp-107}, {0x1.e542ba4020225p-62, 0x1.ea72b4afe3c2fp-120},
+        {-0x1.0ce396db7f853p-70, 0x1.aebcdbd20331cp-124}, {0x1.f2cf01972f578p-80, -0x1.9ada5fcc1ab14p-135},
+        {-0x1.88e85fc6a4e5ap-89, 0x1.71c37ebd16540p-143}, {0x1.0a18a2635085dp-98, 0x1.b9e2e28e1aa54p-153}};
+    const double P1 = 0x1.921fb54400000p+0, P2 = 0x1.0b4611a600000p-34, P3 = 0x1.3198a2e000000p-69, P4 = 0x1.b839a252049c1p-104;
+    const double k = rint(x * 0x1.45f306dc9c883p-1);  // x * 2/pi
+    sdrm_dd r = sdrm_two_sum(x, -(k * P1));             // k * P1 is exact (33-bit piece, |k| < 2^20)
+    r = sdrm_dd_add(r, sdrm_dd_make(-(k * P2), 0.0));
+    r = sdrm_dd_add(r, sdrm_dd_make(-(k * P3), 0.0));
+    r = sdrm_dd_add(r, sdrm_two_prod(-k, P4));
+    const sdrm_dd z = sdrm_dd_mul(r, r);
+    sdrm_dd ps = sdrm_dd_make(S[13][0], S[13][1]), pc = sdrm_dd_make(Cc[13][0], Cc[13][1]);
+    for (int n = 12; n >= 0; n--) {
+        ps = sdrm_dd_add(sdrm_dd_make(S[n][0], S[n][1]), sdrm_dd_mul(z, ps));
+        pc = sdrm_dd_add(sdrm_dd_make(Cc[n][0], Cc[n][1]), sdrm_dd_mul(z, pc));
+    }
+    const sdrm_dd s0 = sdrm_dd_add(r, sdrm_dd_mul(sdrm_dd_mul(r, z), ps));        // r + r^3 (S1 + z (S2 + ...))
+    const sdrm_dd c0 = sdrm_dd_add(sdrm_dd_make(1.0, 0.0), sdrm_dd_mul(z, pc));    // 1 + z (C1 + z (C2 + ...))
+    const int q = (int) ((long long) k & 3);
+    const sdrm_dd ns = sdrm_dd_make(-s0.hi, -s0.lo), nc = sdrm_dd_make(-c0.hi, -c0.lo);
+    *sn = q == 0 ? s0 : (q == 1 ? c0 : (q == 2 ? ns : nc));
+    *cs = q == 0 ? c0 : (q == 1 ? ns : (q == 2 ? nc : s0));
+}
+
+// the float nearest to hi + lo (ties to even), for values in fp32's normal range
+SDRM_HD float sdrm_dd_to_f32(sdrm_dd v) {
+    const float f = (float) v.hi;
+    const double r = (v.hi - (double) f) + v.lo;  // v - f: the first difference is exact
+    const uint32_t fb = sdrm_bits(f);
+    const bool up_is_away = (f >= 0.0f);  // for f > 0 the next float up is the one of larger magnitude
+    const float f_up = sdrm_from_bits(up_is_away ? fb + 1u : fb - 1u), f_dn = sdrm_from_bits(up_is_away ? fb - 1u : fb + 1u);
+    const double half_up = ((double) f_up - (double) f) * 0.5, half_dn = ((double) f - (double) f_dn) * 0.5;
+    const bool even = (fb & 1u) == 0u;
+    if (r > half_up || (r == half_up && !even)) {
+        return f_up;
+    }
+    if (-r > half_dn || (-r == half_dn && !even)) {
+        return f_dn;
+    }
+    return f;
+}
+
+// does rounding this double to fp32 depend on the double's last few bits?  (29 bits are dropped; the boundary is their half)
+SDRM_HD bool sdrm_f32_rounding_is_fragile(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t b = __builtin_bit_cast(uint64_t, a);
+#else
+    uint64_t b;
+    memcpy(&b, &a, sizeof(b));
+#endif
+    const int64_t d = (int64_t) (b & 0x1fffffffull) - 0x10000000ll;
+    return d >= -16 && d <= 16;
+}
+
 // the oscillator sample for an fp32 phase: cos/sin evaluated in double on it, rounded to fp32 (amplitude 1)
 SDRM_HD sdrm_f2 sdrm_nco_sample(float phase) {
     sdrm_f2 s;
-    s.x = (float) cos((double) phase);
-    s.y = (float) sin((double) phase);
+    const double x = (double) phase, c = cos(x), sn = sin(x);
+    s.x = (float) c;
+    s.y = (float) sn;
+    const bool fc = sdrm_f32_rounding_is_fragile(c), fs = sdrm_f32_rounding_is_fragile(sn);
+    if ((fc | fs) && fabs(x) < 1048576.0 && fabs(c) > 1e-30 && fabs(sn) > 1e-30) {
+        sdrm_dd es, ec;
+        sdrm_sincos_dd(x, &es, &ec);
+        if (fc) {
+            s.x = sdrm_dd_to_f32(ec);
+        }
+        if (fs) {
+            s.y = sdrm_dd_to_f32(es);
+        }
+    }
     return s;
 }
 

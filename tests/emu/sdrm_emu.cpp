@@ -485,3 +485,32 @@ extern "C" uint64_t emu_check_boxcar_div(uint32_t length, uint32_t bexp, uint64_
     if (unsafe_count) *unsafe_count = uns;
     return bad;
 }
+
+// NCO sample helpers for the CPU suite: the double-double sin/cos, and a sweep that counts, over `n` consecutive fp32
+// phases starting at `first_bits`, how often the fragile path was taken and how often the result differs from the host
+// libm's (float) cos / (float) sin
+extern "C" void emu_sincos_dd(double x, double *out4) {
+    sdrm_dd s, c;
+    sdrm_sincos_dd(x, &s, &c);
+    out4[0] = s.hi; out4[1] = s.lo; out4[2] = c.hi; out4[3] = c.lo;
+}
+extern "C" void emu_nco_sample(float phase, float *out2) {
+    const sdrm_f2 v = sdrm_nco_sample(phase);
+    out2[0] = v.x; out2[1] = v.y;
+}
+extern "C" void emu_nco_sweep(uint32_t first_bits, uint32_t n, uint32_t stride, uint64_t *fragile, uint64_t *differ,
+                              float *fragile_phases, uint32_t cap) {
+    uint64_t fr = 0, df = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const float ph = sdrm_from_bits(first_bits + i * stride);
+        const double x = (double) ph, c = cos(x), s = sin(x);
+        if (sdrm_f32_rounding_is_fragile(c) || sdrm_f32_rounding_is_fragile(s)) {
+            if (fr < cap) fragile_phases[fr] = ph;
+            fr++;
+        }
+        const sdrm_f2 v = sdrm_nco_sample(ph);
+        if (sdrm_bits(v.x) != sdrm_bits((float) c) || sdrm_bits(v.y) != sdrm_bits((float) s)) df++;
+    }
+    *fragile = fr;
+    *differ = df;
+}

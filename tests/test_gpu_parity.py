@@ -628,9 +628,10 @@ NCO_TOL = 0.01  # the reference's own tolerance for the corrected IQ (test/utils
 
 
 def test_doppler_corrected_iq_matches_reference_golden_file():
-    """test/test_doppler.c:37-76 through the device NCO: lucky7.cf32 -> lucky7.expected.cf32.  cos/sin come from the
-    device's double-precision math library instead of glibc: tolerance 0.01 as in the reference; we also require the
-    values to be bit-identical to the oracle for at least 99.99 % of the samples."""
+    """test/test_doppler.c:37-76 through the device NCO: lucky7.cf32 -> lucky7.expected.cf32 at the reference's 0.01, and
+    bit for bit the oracle's corrected IQ: where the device's double cos/sin lies next to an fp32 rounding boundary the
+    sample is re-evaluated in double-double and rounded once (csrc/sdrm_core.h, sdrm_nco_sample), which is what the host
+    libm's (float) cos gives on all but ~1e-9 of the phases."""
     iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.complex64)
     want = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.float32)
     chunk = 2000  # the reference harness reads 2000 samples at a time; the interpolated shift advances per call
@@ -647,9 +648,7 @@ def test_doppler_corrected_iq_matches_reference_golden_file():
     got, ref = np.concatenate(got), np.concatenate(ref)
     assert len(got) == len(want)
     assert np.abs(got - want).max() < NCO_TOL
-    assert np.abs(got - ref).max() < 1e-6
-    same = np.mean(got.view(np.uint32) == ref.view(np.uint32))
-    assert same > 0.9999, same
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     g.close()
 
 
@@ -666,10 +665,7 @@ def test_doppler_then_demod_soft_bits_match_oracle():
         o8, of = o.process(d.process(part.view(np.float32)))
         g8 = g.process_nco([part], planner.plan(0, len(part)))[0]
         gf = g.last_soft(0)
-        assert len(of) == len(gf)
-        rms = float(np.sqrt(np.mean((of.astype(np.float64) - gf) ** 2))) if len(of) else 0.0
-        assert rms <= RMS_TOL, rms
-        assert np.abs(o8.astype(np.int32) - g8.astype(np.int32)).max() <= 2  # reference tolerance, test_fsk_demod.c:47
+        assert_same(of, gf, o8, g8, where="offset %d" % off)  # corrected IQ identical => soft bits identical
     g.close()
 
 
@@ -697,11 +693,7 @@ def test_mixed_rate_batch_with_per_channel_doppler_ramp():
             if odops[i] is not None:
                 x = odops[i].process(x)
             o8, of = o.process(x)
-            gf = g.last_soft(i)
-            assert len(of) == len(gf), i
-            if len(of):
-                assert float(np.sqrt(np.mean((of.astype(np.float64) - gf) ** 2))) <= RMS_TOL, i
-            assert np.abs(o8.astype(np.int32) - g8[i].astype(np.int32)).max(initial=0) <= 2, i
+            assert_same(of, g.last_soft(i), o8, g8[i], where="call %d channel %d" % (call, i))
     g.close()
 
 
@@ -743,10 +735,7 @@ def test_nco_ragged_batches_and_large_steps_match_oracle():
                 assert len(got) == 0, (call, c)
                 continue
             assert len(got) == len(want[c]), (call, c)
-            assert np.abs(got - want[c]).max() < 1e-6, (call, c)
-            total += len(got)
-            same += int(np.sum(got.view(np.uint32) == want[c].view(np.uint32)))
-    assert same / total > 0.9999, same / total
+            assert np.array_equal(got.view(np.uint32), want[c].view(np.uint32)), (call, c)
     g.close()
 
 
@@ -769,9 +758,7 @@ def test_dsp_worker_with_doppler_callback():
     o = orc.Fsk(48000, 4800, 5000, 2, 2000, True, 4096)
     d = orc.Doppler(48000, shifts, 4096)
     want = np.concatenate([o.process(d.process(iq[off:off + 4096].view(np.float32)))[0] for off in range(0, len(iq), 4096)])
-    assert len(got) == len(want)
-    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 2
-    assert np.mean(got == want) > 0.999
+    assert np.array_equal(got, want)
 
 
 # ---------------------------------------------------------------- next row f-3: per-GPU batcher behind many clients

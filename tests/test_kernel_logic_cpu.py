@@ -317,3 +317,42 @@ def test_boxcar_quotient_short_form_is_the_ieee_division():
         assert uns.value == 2 * (1 << 23)
         assert lib.emu_check_boxcar_div(length, 255, C.byref(uns)) == 0          # infinities and NaN
         assert uns.value == 2 * (1 << 23)
+
+
+def test_nco_sample_is_the_correctly_rounded_float_of_the_exact_cosine():
+    """sdrm_nco_sample (csrc/sdrm_core.h; reference src/dsp/sig_source.c:46): where (float) cos((double) phase) hangs on the
+    last bits of the double, the sample is re-evaluated in double-double and rounded once.  Here on the host: the
+    double-double sin/cos against 300-bit arithmetic, and a sweep of 2^25 consecutive phases -- every one equal to the
+    host libm's float, the fragile ones checked to be the correctly rounded float of the exact value."""
+    import ctypes as C
+    import mpmath as mp
+    mp.mp.prec = 300
+    lib = emu_api.lib()
+    lib.emu_sincos_dd.argtypes = [C.c_double, C.POINTER(C.c_double)]
+    lib.emu_nco_sweep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
+    lib.emu_nco_sample.argtypes = [C.c_float, C.POINTER(C.c_float)]
+    rng = np.random.default_rng(3)
+    xs = list(rng.uniform(-7, 7, 300).astype(np.float32)) + [1e-30, -1e-20, np.float32(np.pi / 2), np.float32(np.pi), 6.2831855,
+                                                             -6.2831855, 1000.5, -54321.25, 1048575.0]
+    for x in xs:
+        out = (C.c_double * 4)()
+        lib.emu_sincos_dd(float(x), out)
+        for got, true in ((mp.mpf(out[0]) + mp.mpf(out[1]), mp.sin(mp.mpf(float(x)))), (mp.mpf(out[2]) + mp.mpf(out[3]), mp.cos(mp.mpf(float(x))))):
+            assert abs(got - true) <= abs(true) * mp.mpf(2) ** -100, (float(x), float(got))
+    fragile_total, phases = 0, []
+    for first in (0x3f000000, 0x40490fdb - (1 << 22), 0xc0000000, 0x40c00000):  # around 0.5, pi, -2, 6
+        fr, df = C.c_uint64(), C.c_uint64()
+        buf = np.zeros(256, np.float32)
+        lib.emu_nco_sweep(first, 1 << 23, 1, C.byref(fr), C.byref(df), buf.ctypes.data, 256)
+        assert df.value == 0  # the host libm's float everywhere
+        fragile_total += fr.value
+        phases += list(buf[:min(fr.value, 256)])
+    assert fragile_total > 0  # the sweep did meet roundings that hang on the double's last bits (2^-29 x 33 per value)
+    for ph in phases:
+        out = (C.c_float * 2)()
+        lib.emu_nco_sample(float(ph), out)
+        for got, fn in ((out[0], mp.cos), (out[1], mp.sin)):
+            true = fn(mp.mpf(float(ph)))
+            f = np.float32(float(true))
+            best = min([np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))], key=lambda v: abs(mp.mpf(float(v)) - true))
+            assert np.float32(got) == best, float(ph)

@@ -1,7 +1,7 @@
 """Soak of the Doppler pre-correction (NCO phase recursion + mix) against the oracle: random channel counts (one to three
 phase workgroups, partly filled), sampling rates, ragged inputs, batches that end anywhere, empty batches, channels that skip
-the correction, shifts beyond the sampling rate.  The corrected IQ must equal the oracle's within 1e-6 (the device's double
-cos/sin and glibc's differ in the last bit on < 0.01 % of samples), i.e. the phases are the oracle's sample for sample.
+the correction, shifts beyond the sampling rate.  The corrected IQ must equal the oracle's within 1e-6 and the number of floats that differ at all is counted (the
+oscillator samples are the correctly rounded floats of the exact cos/sin: a libm differs on ~1e-9 of them).
 python tools/soak_nco.py [seconds] [first seed]"""
 import os, sys, time
 import numpy as np
@@ -60,4 +60,5 @@ while time.time() < t_end:
             total += len(got); same += int(np.sum(got.view(np.uint32) == want[c].view(np.uint32)))
     g.close()
     rounds += 1; seed += 1
-print("nco soak ok: %d rounds, %.1f M corrected samples, %.5f %% bit-identical, %.0f s" % (rounds, total / 1e6, 100.0 * same / max(total, 1), budget), flush=True)
+print("nco soak ok: %d rounds, %.1f M corrected floats (%.1f M samples), %d differ from the oracle's (%.2e), %.0f s" % (
+    rounds, total / 1e6, total / 2e6, total - same, (total - same) / max(total, 1), budget), flush=True)
