@@ -46,6 +46,12 @@ int fsk_demod_create(uint64_t sampling_freq, uint32_t baud_rate, int64_t deviati
 void fsk_demod_process(const sdrm_cf32 *input, size_t input_len, int8_t **output, size_t *output_len,
                        fsk_demod *demod);
 void fsk_demod_destroy(fsk_demod *demod);
+/* The reference's process() is void.  If the device path fails under a handle, the handle enters a sticky error state: a
+ * "<3>" message on stderr once, *output_len = 0 on this and every later call.  sdrm_fsk_demod_error returns the handle's
+ * sticky code (0 = healthy, negative errno otherwise); sdrm_last_error the code of the calling thread's last failed
+ * fsk_demod_process.  The worker mirror ends that client, as the reference does on I/O errors (src/dsp_worker.c:56-64). */
+int sdrm_fsk_demod_error(const fsk_demod *demod);
+int sdrm_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * (1) Batched extension (not in the reference): C channels, each with its own fsk_demod_create()
@@ -111,6 +117,10 @@ int sdrm_batch_process_device(sdrm_batch *batch, const void *d_input, size_t in_
  * the host until they are there. */
 int sdrm_batch_wait(sdrm_batch *batch, void *stream);
 int sdrm_batch_sync(sdrm_batch *batch);
+/* The call reads d_input on the batch's own front-end stream, AFTER sdrm_batch_process_device has returned: refilling or
+ * freeing the buffer on `stream` right away (a caching allocator reusing the block) would race it.  This makes `stream`
+ * wait (on the device) until the latest call has consumed its input -- the front-end and the history roll, not the rest. */
+int sdrm_batch_wait_input(sdrm_batch *batch, void *stream);
 /* device pointers: int8 soft bits [C][out_stride], per-channel counts uint32[C], float soft bits or NULL */
 int sdrm_batch_device_outputs(sdrm_batch *batch, void **d_out_i8, size_t *out_stride, void **d_out_len,
                               void **d_out_f32);

@@ -54,7 +54,7 @@ EXPORTS = [
     "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read",
     "sdrm_batch_process_nco", "sdrm_batch_process_device_nco", "sdrm_batch_last_mixed",
     "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect", "sdrm_batch_reset_channel",
-    "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt", "sdrm_batcher_abandon",
+    "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt", "sdrm_batcher_abandon", "sdrm_fsk_demod_error", "sdrm_last_error", "sdrm_batch_wait_input",
     "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_boxcar_div", "sdrm_version", "sdrm_device_count",
@@ -123,6 +123,7 @@ def load():
     L.sdrm_batch_last_soft.argtypes = [vp, C.c_size_t, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdrm_batch_fetch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdrm_batch_wait.argtypes = [vp, vp]
+    L.sdrm_batch_wait_input.argtypes = [vp, vp]
     L.sdrm_batch_sync.argtypes = [vp]
     L.sdrm_batch_process_nco.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(NcoSegment), C.c_size_t,
                                          C.POINTER(i8p), C.POINTER(C.c_size_t)]

@@ -214,6 +214,9 @@ static void batch_free(sdrm_batch_t *b) {
     if (b->d_outlen_b) {
         (void) hipFree(b->d_outlen_b);
     }
+    if (b->dev.k3_stamps) {
+        (void) hipFree(b->dev.k3_stamps);
+    }
     if (b->d_timeline) {
         (void) hipFree(b->d_timeline);
     }
@@ -799,6 +802,18 @@ extern "C" int sdrm_batch_wait(sdrm_batch *b, void *stream) {
     return 0;
 }
 
+// make `stream` wait until the most recent call has READ its input (front-end and history roll done): the caller may
+// then refill or free the input buffer on that stream without waiting for the rest of the call
+extern "C" int sdrm_batch_wait_input(sdrm_batch *b, void *stream) {
+    if (b == nullptr) {
+        return -1;
+    }
+    if (b->last_slot >= 0) {
+        HIP_TRY(hipStreamWaitEvent((hipStream_t) stream, b->ev_front[b->last_slot], 0));
+    }
+    return 0;
+}
+
 // block the host until every enqueued call has finished
 extern "C" int sdrm_batch_sync(sdrm_batch *b) {
     if (b == nullptr) {
@@ -1351,7 +1366,12 @@ struct fsk_demod_t {
     size_t slot;
     uint32_t max_len;
     int8_t *out;  // the handle's own copy of its last result (valid until its next call, as in the reference)
+    int error;    // sticky: the device path failed under this handle (every later call produces nothing)
 };
+
+static thread_local int g_last_error = 0;
+extern "C" int sdrm_last_error(void) { return g_last_error; }
+extern "C" int sdrm_fsk_demod_error(const fsk_demod *demod) { return demod ? demod->error : -1; }
 
 namespace {
 struct SharedPool {
@@ -1378,6 +1398,11 @@ bool shared_attach(fsk_demod_t *d, const sdrm_fsk_config &cfg) {
             g_pool.failed = true;
         } else {
             g_pool.used.assign((size_t) n, 0);
+            // a round waits for every OPEN channel: slots without a handle stay closed (the reset that attaches a handle
+            // reopens its slot), so that a round is launched as soon as the live handles have delivered
+            for (size_t s = 0; s < (size_t) n; s++) {
+                sdrm_batcher_abandon(g_pool.bt, s);
+            }
         }
     }
     if (g_pool.bt == nullptr) {
@@ -1435,8 +1460,26 @@ extern "C" int fsk_demod_create(uint64_t sampling_freq, uint32_t baud_rate, int6
     return 0;
 }
 
+// The reference's process() returns void and cannot fail.  A device failure here must neither look like "no symbols
+// this time" for ever after nor take the whole server down with every other client attached: the handle goes into a
+// sticky error state ("<3>" message once, *output_len = 0 from then on, sdrm_fsk_demod_error() / sdrm_last_error() tell),
+// and the worker above ends THAT client, as the reference does on a socket or disk error (src/dsp_worker.c:56-64, 83-101).
+static void demod_failed(fsk_demod *demod, int code, const char *what) {
+    if (demod->error == 0) {
+        fprintf(stderr, "<3>sdrmodem_hip: fsk_demod_process: %s (code %d); this handle produces nothing from now on\n", what, code);
+    }
+    demod->error = code ? code : -EIO;
+    g_last_error = demod->error;
+}
+
 extern "C" void fsk_demod_process(const sdrm_cf32 *input, size_t input_len, int8_t **output, size_t *output_len,
                                   fsk_demod *demod) {
+    if (demod->error != 0) {
+        *output = demod->out;
+        *output_len = 0;
+        g_last_error = demod->error;
+        return;
+    }
     if (demod->shared != nullptr) {
         *output = demod->out;
         *output_len = 0;
@@ -1449,8 +1492,8 @@ extern "C" void fsk_demod_process(const sdrm_cf32 *input, size_t input_len, int8
         sdrm_batcher_put(demod->shared, demod->slot, input, input_len);
         sdrm_batcher_take(demod->shared, demod->slot, &soft, &n);
         if (soft == nullptr) {
-            fprintf(stderr, "<3>sdrmodem_hip: the shared batcher went away under fsk_demod_process\n");
-            abort();
+            demod_failed(demod, -EPIPE, "the shared batcher went away");
+            return;
         }
         memcpy(demod->out, soft, n);
         sdrm_batcher_complete(demod->shared, demod->slot);
@@ -1463,9 +1506,10 @@ extern "C" void fsk_demod_process(const sdrm_cf32 *input, size_t input_len, int8
     size_t olens[1] = {0};
     int code = sdrm_batch_process(demod->batch, ins, lens, outs, olens);
     if (code != 0) {
-        // the reference's process() cannot fail; a dead GPU must not look like "no symbols"
-        fprintf(stderr, "<3>sdrmodem_hip: fsk_demod_process failed on the device (code %d)\n", code);
-        abort();
+        demod_failed(demod, code, "the device call failed");
+        *output = nullptr;
+        *output_len = 0;
+        return;
     }
     *output = outs[0];
     *output_len = olens[0];
@@ -1478,6 +1522,7 @@ extern "C" void fsk_demod_destroy(fsk_demod *demod) {
     if (demod->shared != nullptr) {
         std::lock_guard<std::mutex> g(g_pool.m);
         g_pool.used[demod->slot] = 0;  // the next handle that takes the slot resets it
+        sdrm_batcher_abandon(demod->shared, demod->slot);  // rounds stop waiting for this slot; nothing of it is kept
     }
     if (demod->batch != nullptr) {
         batch_free(demod->batch);

@@ -1564,7 +1564,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         cs->mu = L.st.mu;
         cs->omega = L.st.omega;
         cs->last = L.st.last;
-        cs->poison = flagged;      // the carried samples come from this call's stream
+        // the carried samples come from this call's stream; a loop state that is no longer finite (an Inf sample makes
+        // omega and mu NaN two symbols later) keeps the channel off the finite-only fast path until it is reset
+        cs->poison = (flagged != 0 || !(fabsf(L.st.mu) < INFINITY) || !(fabsf(L.st.omega) < INFINITY) || !(fabsf(L.st.last) < INFINITY)) ? 1u : 0u;
         b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
         b.out_len[c] = L.oo;
     }

@@ -381,7 +381,13 @@ void Batcher::run() {
             break;
         }
         if (fresh && rd.contributed > 0 && rd.writers == 0) {
+#ifdef SDRM_TSAN_BUILD
+            // gcc 11's ThreadSanitizer does not intercept pthread_cond_clockwait (what a steady_clock deadline becomes) and
+            // then loses track of the mutex: the sanitizer build waits on the system clock instead (tests/san/run.sh)
+            cv_work_.wait_until(lk, std::chrono::system_clock::now() + (rd.first + std::chrono::microseconds(max_wait_us_) - std::chrono::steady_clock::now()));
+#else
             cv_work_.wait_until(lk, rd.first + std::chrono::microseconds(max_wait_us_));
+#endif
         } else {
             cv_work_.wait(lk);
         }

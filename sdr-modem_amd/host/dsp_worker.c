@@ -144,6 +144,13 @@ static void *worker_main(void *arg) {
             soft_len = olens[0];
         } else if (w->demod != NULL) {
             fsk_demod_process(iq, iq_len, &soft, &soft_len, w->demod);
+            if (sdrm_fsk_demod_error(w->demod) != 0) {
+                /* the device path failed under this client's handle: end this client, like a socket or disk error
+                 * does in the reference (src/dsp_worker.c:56-64, 83-101); the others keep running */
+                complete_buffer_processing(w->inbox);
+                fprintf(stderr, "<3>[%d] demodulation failed on the device\n", w->id);
+                break;
+            }
         }
         if (soft == NULL) {
             complete_buffer_processing(w->inbox);

@@ -320,7 +320,8 @@ static void emu_clock_as(EmuBatch *b) {
             cs.mu = L.st.mu;
             cs.omega = L.st.omega;
             cs.last = L.st.last;
-            cs.poison = flagged[l];
+            cs.poison = (flagged[l] != 0 || !(fabsf(lanes[l].st.mu) < INFINITY) || !(fabsf(lanes[l].st.omega) < INFINITY) ||
+                         !(fabsf(lanes[l].st.last) < INFINITY)) ? 1u : 0u;  // as the kernel: a non-finite loop state stays off the fast path
             b->nonfinite[c] = 0;
             b->outlen[c] = L.oo;
         }

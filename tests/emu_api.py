@@ -20,7 +20,8 @@ def lib():
     global _LIB
     if _LIB is None:
         subprocess.check_call(["make", "-s", "-C", EMU_DIR], stdout=subprocess.DEVNULL)
-        L = C.CDLL(os.path.join(EMU_DIR, "libsdrm_emu.so"))
+        # SDRM_EMU_LIB: another build of the same sources (tests/san/run.sh: AddressSanitizer / UBSan)
+        L = C.CDLL(os.environ.get("SDRM_EMU_LIB") or os.path.join(EMU_DIR, "libsdrm_emu.so"))
         L.emu_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.POINTER(C.c_void_p)]
         L.emu_reset_channel.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FskConfig)]
         L.emu_destroy.argtypes = [C.c_void_p]

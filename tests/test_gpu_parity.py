@@ -250,6 +250,15 @@ def test_nan_inf_denormal_inputs():
     run_stream((48000, 9600, 5000, 1, 2000, True), iq[10000:], [4096, 4096], 4096)
 
 
+def test_inf_sample_followed_by_many_clean_calls():
+    """the loop state stays non-finite after an Inf sample: the device keeps the channel on its general path (sticky
+    poison) and follows the oracle through the clean calls behind it"""
+    iq = siggen.gmsk_channel(9, 10 * 4096)
+    iq[3000] = np.inf + 0j
+    run_stream((48000, 9600, 5000, 1, 2000, False), iq, [4096] * 10, 4096)
+    run_stream((48000, 9600, 5000, 1, 2000, True), iq, [4096] * 10, 4096)
+
+
 def test_oversize_input_gives_no_output(capfd):
     d = binding.FskDemod(48000, 9600, 5000, 1, 2000, True, 100)
     assert len(d.process(siggen.gmsk_channel(1, 101))) == 0

@@ -156,6 +156,16 @@ def test_nan_and_inf_inputs_no_dc():
     run_both((48000, 9600, 5000, 1, 2000, False), iq, [4096] * 4, 4096)
 
 
+def test_inf_sample_followed_by_many_clean_calls():
+    """An Inf (not NaN) sample makes omega and mu NaN a few symbols later; the calls after it carry no flagged sample any
+    more, but the loop state is still not finite: the channel has to stay on the general (NaN-aware) path until it is reset
+    (the finite-only loop assumes every symbol advances by at least one sample).  Same stream as the oracle throughout."""
+    iq = siggen.gmsk_channel(9, 10 * 4096)
+    iq[3000] = np.inf + 0j
+    run_both((48000, 9600, 5000, 1, 2000, False), iq, [4096] * 10, 4096)
+    run_both((48000, 9600, 5000, 1, 2000, True), iq, [4096] * 10, 4096)
+
+
 def test_batch_of_mixed_channels_is_independent():
     cfgs = [(48000, 9600, 5000, 1, 2000, True, 8192), (48000, 4800, 5000, 2, 2000, False, 8192),
             (240000, 19200, 5000, 5, 2000, True, 8192)] * 23  # 69 channels: two K3 waves, one partial
