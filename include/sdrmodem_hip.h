@@ -293,6 +293,21 @@ void dsp_worker_shutdown(void *arg, void *data);
 bool dsp_worker_find_by_id(void *id, void *data);
 void dsp_worker_destroy(void *data);
 
+/* ---- wire framing of the RX path (reference src/api.h:8-27, api.proto:35-49,69-72, src/api_utils.c:82-108).
+ * Header = {u8 protocol version 0, u8 type, u32 body length in network order}.  The server answers an RxRequest with a
+ * Response and then streams the worker's soft bits raw on the same socket (src/tcp_server.c:677, src/dsp_worker.c:93-95):
+ * sdrm_wire_write_response + a dsp_worker created with that socket and demod_destination SOCKET reproduce those bytes.
+ * sdrm_wire_decode_rx_request fills the request half of a worker configuration from an RxRequest body (0 / -1). */
+#define SDRM_WIRE_PROTOCOL_VERSION 0
+#define SDRM_WIRE_TYPE_RX_REQUEST 0
+#define SDRM_WIRE_TYPE_SHUTDOWN 1
+#define SDRM_WIRE_TYPE_RESPONSE 2
+#define SDRM_WIRE_STATUS_SUCCESS 0
+#define SDRM_WIRE_STATUS_FAILURE 1
+int sdrm_wire_write_response(int socket, uint32_t status, uint32_t details);
+int sdrm_wire_read_header(int socket, uint8_t *type, uint32_t *message_length);
+int sdrm_wire_decode_rx_request(const uint8_t *body, size_t len, sdrm_worker_config *config, int *has_doppler);
+
 #ifdef __cplusplus
 }
 #endif

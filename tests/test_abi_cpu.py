@@ -140,3 +140,69 @@ def test_queue_blocking_put_waits_for_a_free_slot():
     assert np.array_equal(q.take(), b)
     q.complete()
     q.close()
+
+
+# ---------------------------------------------------------------- wire framing
+
+def _varint(v):
+    out = bytearray()
+    v &= (1 << 64) - 1
+    while True:
+        b = v & 0x7f
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _field(num, value):
+    """proto2 field: int -> varint, bytes -> length-delimited"""
+    if isinstance(value, bytes):
+        return _varint(num << 3 | 2) + _varint(len(value)) + value
+    return _varint(num << 3) + _varint(value)
+
+
+def test_wire_response_bytes_and_header_round_trip():
+    """reference src/api.h:23-27 (packed header: version, type, u32 length in network order) and src/api_utils.c:82-108
+    (Response{status, details}, both required and therefore always serialised): the bytes a reference client reads"""
+    import socket
+    L = binding.load()
+    L.sdrm_wire_write_response.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+    L.sdrm_wire_read_header.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]
+    a, b = socket.socketpair()
+    assert L.sdrm_wire_write_response(a.fileno(), 0, 7) == 0        # SUCCESS, details = client id 7 (tcp_server.c:677)
+    assert b.recv(64) == bytes([0, 2, 0, 0, 0, 4, 0x08, 0x00, 0x10, 0x07])
+    assert L.sdrm_wire_write_response(a.fileno(), 1, 300) == 0      # FAILURE, a two-byte varint
+    assert b.recv(64) == bytes([0, 2, 0, 0, 0, 5, 0x08, 0x01, 0x10, 0xac, 0x02])
+    b.sendall(bytes([0, 0, 0, 0, 1, 44]) + bytes(300))               # an RxRequest header announcing 300 bytes
+    t, n = C.c_uint8(), C.c_uint32()
+    assert L.sdrm_wire_read_header(a.fileno(), C.byref(t), C.byref(n)) == 0 and (t.value, n.value) == (0, 300)
+    a.recv(300)
+    b.sendall(bytes([9, 0, 0, 0, 0, 0]))                             # wrong protocol version
+    assert L.sdrm_wire_read_header(a.fileno(), C.byref(t), C.byref(n)) == -2
+    b.close()
+    assert L.sdrm_wire_read_header(a.fileno(), C.byref(t), C.byref(n)) == -1  # peer gone
+    a.close()
+
+
+def test_wire_rx_request_fields_reach_the_worker_configuration():
+    """api.proto:35-49: the fields src/dsp_worker.c:120-163 reads, decoded without protobuf-c; unknown fields are skipped,
+    a missing required field or another modem type is an error"""
+    L = binding.load()
+    L.sdrm_wire_decode_rx_request.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(binding.WorkerConfig), C.POINTER(C.c_int)]
+    fsk = _field(1, -5000) + _field(2, 2000) + _field(3, 1)            # deviation (int64, negative), transition width, dc
+    doppler = _field(1, b"LUCKY-7") + _field(2, 1) + _field(3, 2) + _field(4, 3)
+    body = (_field(1, 437525000) + _field(2, 48000) + _field(3, 1) + _field(4, -12000) + _field(5, 1) + _field(6, 4800) +
+            _field(7, 2) + _field(8, 1) + _field(9, doppler) + _field(10, fsk) + _field(99, 12345) + _field(98, b"future"))
+    cfg, dop = binding.WorkerConfig(), C.c_int(-1)
+    buf = (C.c_uint8 * len(body)).from_buffer_copy(body)
+    assert L.sdrm_wire_decode_rx_request(buf, len(body), C.byref(cfg), C.byref(dop)) == 0
+    assert (cfg.rx_sampling_freq, cfg.demod_baud_rate, cfg.demod_decimation, cfg.demod_destination) == (48000, 4800, 2, 1)
+    assert (cfg.demod_fsk_deviation, cfg.demod_fsk_transition_width, cfg.demod_fsk_use_dc_block, cfg.rx_dump_file) == (-5000, 2000, True, True)
+    assert dop.value == 1
+    short = _field(1, 1) + _field(2, 48000) + _field(3, 0) + _field(4, 0) + _field(5, 1) + _field(6, 4800) + _field(7, 2)  # no destination
+    buf = (C.c_uint8 * len(short)).from_buffer_copy(short)
+    assert L.sdrm_wire_decode_rx_request(buf, len(short), C.byref(cfg), C.byref(dop)) == -1
+    bad = body[:len(body) - 3]                                        # truncated in the middle of a field
+    buf = (C.c_uint8 * len(bad)).from_buffer_copy(bad)
+    assert L.sdrm_wire_decode_rx_request(buf, len(bad), C.byref(cfg), C.byref(dop)) == -1

@@ -748,6 +748,68 @@ def test_nco_ragged_batches_and_large_steps_match_oracle():
     g.close()
 
 
+def test_rx_client_on_a_socket_gets_the_response_and_then_the_soft_bits():
+    """what an RX client of the reference sees on its socket -- the Response (src/api_utils.c:82-108, sent at
+    src/tcp_server.c:677) and behind it the raw int8 soft bits the worker writes (src/dsp_worker.c:93-95) -- produced by
+    the wire helper + a GPU worker configured from a hand-encoded RxRequest (api.proto:35-49), on a socketpair."""
+    import socket
+    import threading
+    L = binding.load()
+    L.sdrm_wire_write_response.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+    L.sdrm_wire_decode_rx_request.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(binding.WorkerConfig), C.POINTER(C.c_int)]
+
+    def varint(v):
+        out = bytearray()
+        v &= (1 << 64) - 1
+        while True:
+            b = v & 0x7f
+            v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+
+    def field(num, value):
+        return (varint(num << 3 | 2) + varint(len(value)) + value) if isinstance(value, bytes) else varint(num << 3) + varint(value)
+
+    fsk = field(1, 5000) + field(2, 2000) + field(3, 1)
+    body = (field(1, 437525000) + field(2, 48000) + field(3, 0) + field(4, 0) + field(5, 1) + field(6, 4800) + field(7, 2) +
+            field(8, 1) + field(10, fsk))  # destination SOCKET
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    server, client = socket.socketpair()
+    received = bytearray()
+
+    def reader():
+        while True:
+            chunk = client.recv(65536)
+            if not chunk:
+                break
+            received.extend(chunk)
+
+    t = threading.Thread(target=reader)
+    t.start()
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = binding.WorkerConfig()
+        buf = (C.c_uint8 * len(body)).from_buffer_copy(body)
+        assert L.sdrm_wire_decode_rx_request(buf, len(body), C.byref(cfg), None) == 0
+        cfg.buffer_size, cfg.queue_size, cfg.rx_file_source, cfg.base_path = 4096, 4, True, tmp.encode()  # the server_config half
+        w = C.c_void_p()
+        assert L.dsp_worker_create(21, server.fileno(), C.byref(cfg), C.byref(w)) == 0
+        assert L.sdrm_wire_write_response(server.fileno(), 0, 21) == 0
+        for off in range(0, len(iq), 4096):
+            part = np.ascontiguousarray(iq[off:off + 4096]).view(np.float32)
+            L.dsp_worker_put(part.ctypes.data, len(part) // 2, w)
+        L.dsp_worker_destroy(w)
+    server.close()
+    t.join(30)
+    client.close()
+    assert bytes(received[:10]) == bytes([0, 2, 0, 0, 0, 4, 0x08, 0x00, 0x10, 21])
+    got = np.frombuffer(bytes(received[10:]), dtype=np.int8)
+    want, _ = orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq, 4096)
+    assert np.array_equal(got, want)
+    golden = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.s8"), dtype=np.int8)
+    assert len(got) == len(golden) and np.abs(got.astype(np.int32) - golden.astype(np.int32)).max() <= 2  # test_fsk_demod.c:47
+
+
 def test_dsp_worker_with_doppler_callback():
     """the worker's Doppler leg (reference src/dsp_worker.c:65-71): shifts come from a per-second callback"""
     L = binding.load()
