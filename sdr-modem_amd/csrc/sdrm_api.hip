@@ -709,6 +709,10 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
             HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[prev2], 0));  // channels without DC: K3 reads z
         }
     }
+    int dc_first_loops = 0;
+    if (!b->serial && i >= 1 && d.any_dc && sdrm::front_waits_for_dc_start((int) C, &dc_first_loops)) {
+        sdrm::launch_front_hold_for_dc(dc_first_loops, b->s_front);  // the previous call's DC stage places its workgroups first
+    }
     if (!b->serial && i >= 3 && sdrm::front_waits_for_clock_start((int) C)) {
         // let the clock stage of call i-2 (released by the end of call i-3's) take its CUs before this grid floods the chip
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[(i + SDRM_CTL_SLOTS - 3) % SDRM_CTL_SLOTS], 0));

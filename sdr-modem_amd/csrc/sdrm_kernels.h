@@ -62,14 +62,17 @@ struct sdrm_k3_geom {
 #ifndef SDRM_K3_BANKPITCH
 #define SDRM_K3_BANKPITCH 12  // floats between two rows of the MMSE bank copy in LDS (48 B: rows start on 16 different bank offsets instead of 8)
 #endif
-// channels per workgroup for a batch of n channels: 16 while that holds at most a quarter of the CUs (the other stages
-// need the rest from ~1000 channels on), else 64.  Measured (ms per step, 131072-sample chunks; lanes 64 / 32 / 16 / 8):
-// 256 channels 3.96 / 3.18 / 3.09 / 3.07, 1024: 4.67 / 4.37 / 3.88 / 4.46, 2048: 6.98 / 7.08 / 7.46 / 8.94.
+// channels per workgroup for a batch of n channels (round 1, ms per step, 131072-sample chunks; lanes 64 / 32 / 16 / 8:
+// 256 channels 3.96 / 3.18 / 3.09 / 3.07, 1024: 4.67 / 4.37 / 3.88 / 4.46)
 static inline int sdrm_k3_lanes_for(int n_channels, int forced) {
-    if (forced == 16 || forced == 64) {
+    if (forced == 16 || forced == 32 || forced == 64) {
         return forced;
     }
-    return n_channels <= 1024 ? 16 : 64;
+    // Measured per batch size (round 2, tools/k3_ab.py, ms per call of 131072 samples per channel; 16 / 32 / 64 channels
+    // per workgroup): 1280 channels 3.28 / 3.82 / 4.48, 1536: 4.02 / 3.81 / 4.62, 2048: 5.50 / 4.87 / 4.84,
+    // 3072: 8.18 / 7.21 / 7.20, 4096: 10.8 / 9.56 / 9.17.  Few channels per workgroup = more waves on the latency chain
+    // but more CUs whose LDS the front-end cannot use; the crossovers sit where the front-end becomes the longer stage.
+    return n_channels <= 1280 ? 16 : (n_channels <= 2048 ? 32 : 64);
 }
 
 // immutable per-channel parameters (device array, one per channel)

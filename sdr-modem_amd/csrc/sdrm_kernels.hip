@@ -443,6 +443,24 @@ bool front_waits_for_clock_start(int n_channels) {
 }
 void launch_front_hold(hipStream_t s) { hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 12); }
 
+// With thousands of channels a DC workgroup (~110 KB of LDS, eleven waves) cannot start on a CU that holds more than one
+// front-end workgroup (35 KB, four waves, a quarter of the register file each), and the front-end's grid of the NEXT
+// call -- released at the same moment, when this call's front-end ends -- refills every CU as fast as it drains: the
+// DC stage then starts only when that grid is nearly through (9.4 ms for 1.5 ms of work at 4096 channels).  The next
+// front-end therefore waits until the DC grid (itself held back ~100 us for the clock stage, launch_dc_hold) has taken
+// its CUs; it fills what is left, one workgroup per CU while the DC blocker runs, four afterwards.
+// SDRM_DC_FIRST="channels,loops" overrides from where this applies and how long (0: never).
+bool front_waits_for_dc_start(int n_channels, int *loops) {
+    static const char *e = getenv("SDRM_DC_FIRST");
+    int lo = 1536, n = 60;
+    if (e != nullptr) {
+        sscanf(e, "%d,%d", &lo, &n);
+    }
+    *loops = n;
+    return lo > 0 && n_channels >= lo;
+}
+void launch_front_hold_for_dc(int loops, hipStream_t s) { hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, loops); }
+
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s) {
     if (b.any_dc && b.n_channels >= 2048) {
         hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 30);
@@ -1126,7 +1144,8 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // hand-scheduled loop below (k3_drain_finite), otherwise the C++ form of the same arithmetic.  One barrier per step
 // hands block k to the consumer while block k+1 is written.
 size_t k3_lds_bytes(int lanes) {
-    const size_t rings = lanes == 16 ? (size_t) 16 * sdrm_k3_geom<16>::cpitch : (size_t) 64 * sdrm_k3_geom<64>::cpitch;
+    const size_t rings = lanes == 16 ? (size_t) 16 * sdrm_k3_geom<16>::cpitch
+                                     : (lanes == 32 ? (size_t) 32 * sdrm_k3_geom<32>::cpitch : (size_t) 64 * sdrm_k3_geom<64>::cpitch);
     return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_WAVE) * sizeof(float);
 }
 
@@ -1621,7 +1640,8 @@ int k3_forced_lanes() {
 }
 
 KernelLaunch describe_clock(const DeviceBatch &b) {
-    return sdrm_k3_lanes_for(b.n_channels, k3_forced_lanes()) == 16 ? describe_clock_as<16>(b) : describe_clock_as<64>(b);
+    const int lanes = sdrm_k3_lanes_for(b.n_channels, k3_forced_lanes());
+    return lanes == 16 ? describe_clock_as<16>(b) : (lanes == 32 ? describe_clock_as<32>(b) : describe_clock_as<64>(b));
 }
 
 KernelLaunch describe_quantize(const DeviceBatch &b) {

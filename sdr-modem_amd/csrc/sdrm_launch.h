@@ -68,6 +68,8 @@ KernelLaunch describe_quantize(const DeviceBatch &b);   // args: DeviceBatch
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s);
 bool front_waits_for_clock_start(int n_channels);
+bool front_waits_for_dc_start(int n_channels, int *loops);
+void launch_front_hold_for_dc(int loops, hipStream_t s);
 void launch_front_hold(hipStream_t s);
 
 void launch_nco_phase(const DeviceBatch &b, hipStream_t s);

@@ -3,6 +3,7 @@
 
 #include <errno.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -110,6 +111,12 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
     plan.dc_region_floats = plan.any_dc ? sdrm_k2_state_floats(plan.dc_hx_cap, plan.dc_l_cap) : 0;
     // sixteen channels per DC workgroup while their delay rings fit beside the term rows (150 KB of the CU's 160)
     plan.dc_group = SDRM_K2_SLOTS;
+    if (const char *e = getenv("SDRM_DC_GROUP")) {  // measurements: channels per DC workgroup (a power of two <= 16)
+        const int g = atoi(e);
+        if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) {
+            plan.dc_group = (uint32_t) g;
+        }
+    }
     while (plan.dc_group > 1 && dc_lds_bytes_for(plan.dc_l_cap, plan.dc_group) > 150 * 1024) {
         plan.dc_group /= 2;
     }

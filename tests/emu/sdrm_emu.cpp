@@ -331,8 +331,11 @@ static void emu_clock_as(EmuBatch *b) {
 // the workgroup shape the library would launch for this batch (same policy, same SDRM_K3_LANES override)
 static void emu_clock(EmuBatch *b) {
     const char *e = getenv("SDRM_K3_LANES");
-    if (sdrm_k3_lanes_for((int) b->plan.params.size(), e ? atoi(e) : 0) == 16) {
+    const int lanes = sdrm_k3_lanes_for((int) b->plan.params.size(), e ? atoi(e) : 0);
+    if (lanes == 16) {
         emu_clock_as<16>(b);
+    } else if (lanes == 32) {
+        emu_clock_as<32>(b);
     } else {
         emu_clock_as<64>(b);
     }
