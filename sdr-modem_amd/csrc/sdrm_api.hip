@@ -372,11 +372,28 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     } else {
         e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
         e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
-        // company for the clock stage while the batch is too small to keep the chip busy by itself (at 1024 channels the
-        // front-end does); SDRM_K3_COMPANY="blocks,first,last" overrides (blocks 0: none)
+        // company for the clock stage while the batch is too small to keep the chip busy by itself: the front-end of a
+        // full-length call must be expected to take well under the clock stage's time (at 1024 channels of the bench
+        // workload it does not, nor with the 397-tap filters of 240 kHz channels: BASELINE configs[4] in one GPU's share
+        // ran 2.53 ms per call with the companion grid and 1.94 without).  Estimates: the front-end's multiply-adds at the
+        // rate it reaches beside the other stages (18.4 T/s: 0.53 ms for 256 x 131072 samples of 291), the clock stage's
+        // longest symbol sequence at 97 ns per symbol (220 cycles at 2.27 GHz).
+        // SDRM_K3_COMPANY="blocks,first,last" overrides grid and channel range (blocks 0: none)
         int blocks = 4096, lo = 32, hi = 768;
         if (const char *env = getenv("SDRM_K3_COMPANY")) {
             sscanf(env, "%d,%d,%d", &blocks, &lo, &hi);
+        } else {
+            double macs = 0.0, symbols = 0.0;
+            for (size_t c = 0; c < C; c++) {
+                const double n = (double) cfgs[c].max_input_buffer_length;
+                const double d = cfgs[c].decimation ? (double) cfgs[c].decimation : 1.0;
+                macs += n * (2.0 * pl.params[c].T1 + pl.params[c].T2 / d);
+                const double sym = cfgs[c].sampling_freq ? n * (double) cfgs[c].baud_rate / (double) cfgs[c].sampling_freq : 0.0;
+                symbols = sym > symbols ? sym : symbols;
+            }
+            if (macs / 18.4e12 > 0.7 * symbols * 97e-9) {
+                blocks = 0;
+            }
         }
         if (blocks > 0 && (int) n_channels >= lo && (int) n_channels <= hi) {
             b->company_blocks = blocks;

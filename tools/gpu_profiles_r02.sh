@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 evidence for profiles/: rocprofv3 kernel stats of the bench command, PMC passes (separate: SQ, FETCH_SIZE,
 # WRITE_SIZE) over tools/stage_times.py at 256 and 4096 channels, kernel stats of the 1024 / 4096 sweep points and of the
-# mixed-rate Doppler workload.  Everything lands under gpurun_out/r02/; tools/collect_profiles_r02.py copies summaries.
+# mixed-rate Doppler workload.  Everything lands under gpurun_out/r02/; summaries are then copied into profiles/ by hand.
 set +e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -24,6 +24,7 @@ pmc() { # tag channels name counters...
 for ch in 256 4096; do
   pmc c$ch $ch sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
   pmc c$ch $ch sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+  pmc c$ch $ch grbm GRBM_GUI_ACTIVE GRBM_COUNT
   pmc c$ch $ch fetch FETCH_SIZE
   pmc c$ch $ch write WRITE_SIZE
 done
