@@ -261,6 +261,14 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
         pa[p] = sdrm_v2_make(acc[2 * p], acc[2 * p + 1]);
     }
     float tail = (N & 1) ? acc[N - 1] : 0.0f;
+    // the odd-aligned pairs are READ from LDS as pairs (a load costs no vector instruction) instead of being assembled from
+    // the even-aligned ones with register moves (13 per 6 taps: 2 % of the front-end's vector instructions); the compiler
+    // must not see that xo is xs + 1, or it shares the loads again
+    int one = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(one));  // the offset, not the pointer: the pointer must stay recognisable as an LDS address
+#endif
+    const float *xo = xs + one;
     int j0 = 0;
     for (; j0 + K <= ntaps; j0 += K) {
         sdrm_v2 we[(W + 1) / 2], wo[(W + 1) / 2];
@@ -270,7 +278,7 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
         }
 #pragma unroll
         for (int k = 0; 2 * k + 2 < W; k++) {
-            wo[k] = sdrm_v2_make(xs[j0 + 2 * k + 1], xs[j0 + 2 * k + 2]);
+            wo[k] = sdrm_v2_make(xo[j0 + 2 * k], xo[j0 + 2 * k + 1]);
         }
 #pragma unroll
         for (int u = 0; u < K; u++) {
@@ -316,20 +324,42 @@ SDRM_HD void sdrm_k1_phase_load(int tid, const sdrm_k1_tile &t, const sdrm_f2 *i
     // that the loads are in flight together; longer halos take the plain loop
     constexpr int DEPTH = SDRM_K1_R + 1;
     sdrm_f2 v[DEPTH];
+    if (t.x_first >= 0 && t.nx >= (DEPTH - 1) * SDRM_K1_THREADS) {
+        // every tile but a call's first and last: the whole tile lies in the caller's buffer and only the last of the
+        // DEPTH rows is partial -- one uniform base and constant offsets, no per-sample address arithmetic or selection
+        // (the general form below spends ~9 vector instructions per load on them: 2.4 % of the kernel's)
+        const sdrm_f2 *src = in + t.x_first + tid;
+        const bool last = tid + (DEPTH - 1) * SDRM_K1_THREADS < t.nx;
 #pragma unroll
-    for (int i = 0; i < DEPTH; i++) {
-        const int k = tid + i * SDRM_K1_THREADS;
-        v[i].x = 0.0f;
-        v[i].y = 0.0f;
-        if (k < t.nx) {
-            v[i] = sdrm_ext_sample(in, hist, hist_len, t.x_first + k);
+        for (int i = 0; i < DEPTH - 1; i++) {
+            v[i] = src[i * SDRM_K1_THREADS];
         }
-    }
+        if (last) {
+            v[DEPTH - 1] = src[(DEPTH - 1) * SDRM_K1_THREADS];
+        }
 #pragma unroll
-    for (int i = 0; i < DEPTH; i++) {
-        const int k = tid + i * SDRM_K1_THREADS;
-        if (k < t.nx) {
-            xs[k] = v[i];
+        for (int i = 0; i < DEPTH - 1; i++) {
+            xs[tid + i * SDRM_K1_THREADS] = v[i];
+        }
+        if (last) {
+            xs[tid + (DEPTH - 1) * SDRM_K1_THREADS] = v[DEPTH - 1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < DEPTH; i++) {
+            const int k = tid + i * SDRM_K1_THREADS;
+            v[i].x = 0.0f;
+            v[i].y = 0.0f;
+            if (k < t.nx) {
+                v[i] = sdrm_ext_sample(in, hist, hist_len, t.x_first + k);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DEPTH; i++) {
+            const int k = tid + i * SDRM_K1_THREADS;
+            if (k < t.nx) {
+                xs[k] = v[i];
+            }
         }
     }
     for (int k = tid + DEPTH * SDRM_K1_THREADS; k < t.nx; k += SDRM_K1_THREADS) {
@@ -424,6 +454,25 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
 
 // the tile's LPF2 outputs, staged by sdrm_k1_phase_lpf2, written with consecutive lanes on consecutive samples
 SDRM_HD void sdrm_k1_phase_store(int tid, const sdrm_k1_tile &t, const float *zs, float *z_out) {
+    float *dst = z_out + t.o_lo + tid;
+    const float *src = zs + tid;
+    constexpr int FULL = SDRM_K1_RZ - 1;  // rows of 256 outputs a full tile certainly has (it has NY - (T2 - 1) - 1 outputs)
+    if (t.m >= FULL * SDRM_K1_THREADS) {
+        // constant offsets from one base: no per-sample address arithmetic
+        float v[FULL];
+#pragma unroll
+        for (int i = 0; i < FULL; i++) {
+            v[i] = src[i * SDRM_K1_THREADS];
+        }
+#pragma unroll
+        for (int i = 0; i < FULL; i++) {
+            dst[i * SDRM_K1_THREADS] = v[i];
+        }
+        for (int i = tid + FULL * SDRM_K1_THREADS; i < t.m; i += SDRM_K1_THREADS) {
+            z_out[t.o_lo + i] = zs[i];
+        }
+        return;
+    }
     for (int i = tid; i < t.m; i += SDRM_K1_THREADS) {
         z_out[t.o_lo + i] = zs[i];
     }
