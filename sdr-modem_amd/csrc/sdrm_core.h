@@ -126,15 +126,18 @@ SDRM_HD float sdrm_fast_atan2f_flat(float y, float x, const float *tab) {
     const float z = (wide ? ya : xa) / (wide ? xa : ya);
     const float a = z * 255.0f;
 #if defined(__HIP_DEVICE_COMPILE__)
-    int ia;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(ia) : "v"(a));  // NaN -> 0, no undefined behaviour for the compiler to use
-    const int idx = ia & 0xff;
+    // z is a quotient smaller / larger, i.e. in [0, 1], or NaN: a is in [0, 255] or NaN, the conversion gives 0..255 (NaN:
+    // 0) and `& 0xff` has nothing to do; a - (float) idx = a - floor(a) is v_fract_f32 (both exact; NaN stays NaN)
+    int idx;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(idx) : "v"(a));  // NaN -> 0, no undefined behaviour for the compiler to use
+    const float frac = __builtin_amdgcn_fractf(a);
 #else
     const int idx = sdrm_cvt_i32(a) & 0xff;
+    const float frac = a - (float) idx;
 #endif
     const float t0 = tab[idx];
     const float t1 = tab[idx + 1];
-    const float interp = t0 + (t1 - t0) * (a - (float) idx);
+    const float interp = t0 + (t1 - t0) * frac;
     const float base = (z < sdrm_from_bits(SDRM_TAN_MAP_RES_UP_BITS)) ? z : interp;
     const bool xp = x >= 0.0f, yp = y >= 0.0f;
     const float pi_f = 3.14159265358979323846f;

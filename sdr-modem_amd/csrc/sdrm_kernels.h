@@ -385,29 +385,47 @@ SDRM_HD void sdrm_k1_phase_lpf1(int tid, const sdrm_k1_tile &t, const sdrm_chan_
     bnd[tid] = regs.y[SDRM_K1_R - 1];
 }
 
-// phase 2: quadrature demod (reference src/dsp/quadrature_demod.c:57-73) into LDS
+// phase 2: quadrature demod (reference src/dsp/quadrature_demod.c:57-73) into LDS.  qs[-1] must be a valid slot: sample
+// k of the tile goes to qs[k], and the tile's first thread also writes its k = -1 (the predecessor-less sample nobody
+// reads); every thread stores all of its R samples -- positions past the tile's last needed sample (nq) hold finite
+// values nobody reads either, and NY - 2 < NY + QPAD -- so the stores are one base address plus constants and no
+// per-sample predicate (which also made the compiler sink half of the arctangent, with its constants re-made per sample,
+// into fifteen predicated blocks: 51 -> 40 vector instructions per sample).
 SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *tab,
                                 const sdrm_f2 *bnd, const sdrm_k1_regs &regs, float *qs) {
+    (void) t;
     sdrm_f2 prev;
     prev.x = 0.0f;
     prev.y = 0.0f;
     if (tid > 0) {
         prev = bnd[tid - 1];
     }
-    // all of the thread's samples first, unconditionally (threads past the tile's end hold zeros): fifteen independent
-    // chains the compiler can interleave, so that the table reads and the reciprocals wait for each other's work
+#if defined(__HIP_DEVICE_COMPILE__)
+    int zero = 0;
+    asm volatile("" : "+s"(zero));  // keeps the table's LDS address one scalar (else: base + constant, an add per sample)
+    tab += zero;
+#endif
+    // all of the thread's samples (threads past the tile's end hold zeros): fifteen independent chains the compiler can
+    // interleave, so that the table reads and the reciprocals wait for each other's work
     float q[SDRM_K1_R];
 #pragma unroll
     for (int r = 0; r < SDRM_K1_R; r++) {
-        q[r] = sdrm_quad_sample_flat(regs.y[r], prev, p.quad_gain, tab);
-        prev = regs.y[r];
+        sdrm_f2 cur = regs.y[r];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the LPF1 accumulators stay (re, im) register pairs: left to itself the compiler vectorises this phase ACROSS
+        // samples and pays for the layout it then wants with ~70 register moves inside the LPF1 tap loop
+        sdrm_v2 pair = sdrm_v2_make(cur.x, cur.y);
+        asm volatile("" : "+v"(pair));
+        cur.x = pair.x;
+        cur.y = pair.y;
+#endif
+        q[r] = sdrm_quad_sample_flat(cur, prev, p.quad_gain, tab);
+        prev = cur;
     }
+    float *dst = qs + tid * SDRM_K1_R - 1;
 #pragma unroll
     for (int r = 0; r < SDRM_K1_R; r++) {
-        int k = tid * SDRM_K1_R + r - 1;
-        if (k >= 0 && k < t.nq) {
-            qs[k] = q[r];
-        }
+        dst[r] = q[r];
     }
 }
 

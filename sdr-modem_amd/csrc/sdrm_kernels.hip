@@ -283,8 +283,8 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
 #endif
     const sdrm_chan_params p = b.params[c];
     sdrm_f2 *xs = reinterpret_cast<sdrm_f2 *>(k1_lds);
-    float *qs = reinterpret_cast<float *>(xs);  // aliases the raw tile: written only after every LPF1 read (barrier)
-    float *zs = qs + SDRM_K1_NY + SDRM_K1_QPAD;  // LPF2 outputs of the tile, behind the demodulated samples
+    float *qs = reinterpret_cast<float *>(xs) + 1;  // aliases the raw tile: written only after every LPF1 read (barrier); qs[-1] exists
+    float *zs = qs + SDRM_K1_NY + SDRM_K1_QPAD - 1;  // LPF2 outputs of the tile, behind the demodulated samples
     sdrm_f2 *bnd = reinterpret_cast<sdrm_f2 *>(k1_lds + SDRM_K1_XS_BYTES(b.t1_max));
     float *tab = reinterpret_cast<float *>(bnd + SDRM_K1_THREADS);
 
