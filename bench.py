@@ -130,8 +130,8 @@ def newest_traffic(channels, chunk):
         if tj.get("channels") == channels and tj.get("chunk") == chunk and tj.get("hbm_bytes_per_launch"):
             key = str(tj.get("round", ""))
             if best is None or key >= best[2]:
-                best = (tj["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), key)
-    return (best[0], best[1]) if best else (None, None)
+                best = (tj["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), key, tj)
+    return (best[0], best[1], best[3]) if best else (None, None, {})
 
 
 class Rig:
@@ -371,7 +371,7 @@ def main():
     if rank == 0:
         front_ms = k_ms[0]
         achieved = (C * N * 8.0) / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
-        traffic, traffic_src = newest_traffic(C, N)
+        traffic, traffic_src, pmc = newest_traffic(C, N)
         macs_per_sample = 2 * T1 + T2
         ceiling_gbs = VALU_EXACT_MACS / macs_per_sample * 8.0 / 1e9
         out = {
@@ -409,6 +409,16 @@ def main():
                          "exact_valu_ceiling": round(ceiling_gbs, 1),
                          "exact_valu_ceiling_frac": round(ceiling_gbs / HBM_PEAK_GBS, 4),
                          "frac_of_ceiling": round(achieved / ceiling_gbs, 4),
+                         # from the same PMC passes as `traffic` (not live): the shader clock the kernel really ran at
+                         # (GRBM_GUI_ACTIVE / duration; the chip lowers it under this load), the share of those cycles
+                         # in which the vector pipes were issuing (SQ_INSTS_VALU x 4 / SIMDs), and the share of the
+                         # issued vector instructions that are the filters' own multiplies and adds
+                         "pmc": {"shader_clock_ghz": pmc.get("shader_clock_ghz"), "valu_issue_busy": pmc.get("valu_issue_busy"),
+                                 "sq_insts_valu": pmc.get("sq_insts_valu"),
+                                 "fir_share_of_valu": (round(C * N * macs_per_sample / 64.0 / pmc["sq_insts_valu"], 4)
+                                                       if pmc.get("sq_insts_valu") else None),
+                                 "frac_of_ceiling_at_measured_clock": (round(achieved / (ceiling_gbs * pmc["shader_clock_ghz"] / 2.4), 4)
+                                                                       if pmc.get("shader_clock_ghz") else None)},
                          "note": "8 B of IQ read per input sample (SURVEY 8d LPF-stage HBM-read term). The kernel is "
                                  "fp32-VALU-bound: bit-exact parity needs a separately rounded multiply and add per tap "
                                  "(v_pk_mul_f32 + v_pk_add_f32: 16 component-MACs per SIMD and cycle; %d MACs per sample), "
