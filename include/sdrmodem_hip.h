@@ -13,8 +13,9 @@
  *      sdrm_doppler_*    the reference's Doppler batching (per-second shifts from the caller's orbit model) for the
  *                        device-side NCO in front of the demodulator.
  *
- * Every entry point fails loudly (non-zero return / abort message on stderr with the "<3>" systemd
- * prefix the reference uses) when no HIP device is usable: there is NO CPU fallback in this library.
+ * Every entry point fails loudly (non-zero return and a message on stderr with the "<3>" systemd prefix the
+ * reference uses; the void fsk_demod_process puts its handle into a sticky error state, see below) when no HIP
+ * device is usable or the device path fails: there is NO CPU fallback in this library, and nothing in it aborts.
  */
 #ifndef SDRMODEM_HIP_H
 #define SDRMODEM_HIP_H

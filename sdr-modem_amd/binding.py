@@ -1,7 +1,7 @@
 """ctypes binding of csrc/libsdrmodem_hip.so (include/sdrmodem_hip.h).  Thin: every call goes straight to the C-ABI.
 
-No fallback: load() raises when the shared library is absent, and the C-ABI itself returns -ENODEV / aborts with a
-"<3>" message when no HIP device is usable.
+No fallback: load() raises when the shared library is absent, and the C-ABI itself returns -ENODEV with a "<3>" message
+when no HIP device is usable (a failing plain handle goes into its sticky error state; nothing aborts).
 """
 import ctypes as C
 import errno

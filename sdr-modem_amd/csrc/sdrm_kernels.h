@@ -10,7 +10,7 @@
 //               grid (tiles, channels), 256 threads, IQ tile + halo staged in LDS        [parallel in time]
 //   K1h       : roll the raw-IQ history (T1+T2-1 samples per channel) for the next call
 //   K2 dc     : 4 cascaded boxcars + delay; a workgroup serves 16 channels: ONE chain wave runs every running sum
-//               (lane = stage x channel, one add per sample), five helper waves do the pointwise parts [sequential]
+//               (lane = stage x channel, one add per sample), five helper roles of two waves do the pointwise parts [sequential]
 //   K3 clock  : MMSE interpolator + Mueller&Mueller loop + int8; one lane per channel       [sequential]
 #ifndef SDRM_KERNELS_H
 #define SDRM_KERNELS_H
@@ -511,7 +511,7 @@ SDRM_HD void sdrm_hist_roll(int tid, int nthreads, const sdrm_chan_params &p, co
 //   t = u[n] - u[n-L];  acc = acc + t;  v[n] = acc / L          (acc: a strictly sequential fp32 recursion)
 // and out[n] = x[n - 2(L-1)] - v3[n].  Everything except `acc = acc + t` is pointwise.
 //
-// One workgroup serves up to 16 channels ("slots") with six waves:
+// One workgroup serves up to 16 channels ("slots") with 1 + 5 x (16 / P) waves (eleven with P = 8):
 //   chain wave   lane = (stage, slot): reads the 64 terms of its block from its LDS row (16 x ds_read_b128), adds them
 //                one by one to its running sum and leaves a checkpoint every P terms {sum before the block, after P, 2P, ..};
 //   feeder       terms of stage 0 from the front-end's output: t = x[n] - x[n-L];
