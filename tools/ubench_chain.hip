@@ -57,6 +57,27 @@ __global__ __launch_bounds__(64) void k(float *out, unsigned long long *stamps, 
             asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tds_read2_b64 v[40:43], %3 offset0:1 offset1:2\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 16) : "v40", "v41", "v42", "v43");
         } else if (MODE == 18) {  // 4 adds per LDS read: does the read's cost hide behind VALU work?
             asm volatile(".rept 256\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tds_read_b64 v[40:41], %3\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 16) : "v40", "v41");
+        } else if (MODE == 22) {  // quad-broadcast DPP add, dependent through the NON-DPP operand (the DPP source is old)
+            asm volatile(".rept 256\n\tv_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, %1, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(s) : "v"(t));
+        } else if (MODE == 23) {  // the dot product of the clock stage in quad form: pk_mul, s_nop 1, 8 broadcast adds
+            asm volatile(".rept 102\n\tv_pk_mul_f32 v[40:41], %1, %2\n\ts_nop 1\n\t"
+                         "v_add_f32_dpp %0, v40, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, v40, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, v40, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, v40, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, v41, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, v41, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, v41, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, v41, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(s) : "v"(pk), "v"(pk1) : "v40", "v41");
+        } else if (MODE == 24) {  // the same in today's form: 4 pk_mul, 8 plain adds (12 instructions)
+            asm volatile(".rept 85\n\tv_pk_mul_f32 v[40:41], %1, %2\n\tv_pk_mul_f32 v[42:43], %1, %2\n\t"
+                         "v_add_f32 %0, 0, v40\n\tv_add_f32 %0, v41, %0\n\tv_add_f32 %0, v42, %0\n\tv_add_f32 %0, v43, %0\n\t"
+                         "v_pk_mul_f32 v[44:45], %1, %2\n\tv_pk_mul_f32 v[46:47], %1, %2\n\t"
+                         "v_add_f32 %0, v44, %0\n\tv_add_f32 %0, v45, %0\n\tv_add_f32 %0, v46, %0\n\tv_add_f32 %0, v47, %0\n\t.endr"
+                         : "+v"(s) : "v"(pk), "v"(pk1) : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
         } else if (MODE == 19) {  // byte store per 8 adds
             asm volatile(".rept 128\n\t.rept 8\n\tv_add_f32 %0, %0, %2\n\t.endr\n\tglobal_store_byte %3, %0, %4\n\t.endr" : "+v"(s), "+v"(t2) : "v"(t), "v"(idx * 4096), "s"(out) : "memory");
         } else if (MODE == 20) {  // two interleaved in-order DPP chains (each gives the other its wait states)
@@ -111,6 +132,9 @@ int main() {
         run<10>("64-instr loop, 4-byte", blocks, 200, 1024);
         run<11>("64-instr loop, 8-byte", blocks, 200, 1024);
         run<12>("add + idle s_waitcnt", blocks, 200, 512);
+        run<22>("quad-bcast dpp add chain", blocks, 200, 1024);
+        run<23>("dot8 quad form (11 instr)", blocks, 200, 102);
+        run<24>("dot8 today (12 instr)", blocks, 200, 85);
         run<20>("2 DPP chains interleaved", blocks, 200, 512);
         run<21>("4 DPP chains interleaved", blocks, 200, 256);
         run<13>("add + ds_read_b64", blocks, 200, 256);
