@@ -678,10 +678,14 @@ def test_doppler_then_demod_soft_bits_match_oracle():
     g.close()
 
 
-def test_mixed_rate_batch_with_per_channel_doppler_ramp():
-    """BASELINE config 5 in miniature: 240 kHz / 19200 baud and 48 kHz / 1200 baud channels (decimated to sps < 8), each
-    with its own linear Doppler ramp (+-10 kHz over the run, piecewise-constant per <= 1 s batch), some uncorrected."""
-    cfgs = ([(240000, 19200, 5000, 5, 2000, True, 60000)] * 3 + [(48000, 1200, 5000, 8, 2000, True, 60000)] * 3) * 2
+@pytest.mark.parametrize("decims", [(5, 8), (1, 1)], ids=["decimated", "undecimated_tail_quirk"])
+def test_mixed_rate_batch_with_per_channel_doppler_ramp(decims):
+    """BASELINE config 5 in miniature: 240 kHz / 19200 baud and 48 kHz / 1200 baud channels, each with its own linear
+    Doppler ramp (+-10 kHz over the run, piecewise-constant per <= 1 s batch), some uncorrected.  Decimated to fewer than 8
+    samples per symbol, and undecimated (12.5 and 40 samples per symbol, DC lengths 400 and 1280): there the reference's
+    clock stage re-emits a symbol at chunk edges (clock_recovery_mm.c:127-133), which the device must reproduce call by
+    call behind the oscillator."""
+    cfgs = ([(240000, 19200, 5000, decims[0], 2000, True, 60000)] * 3 + [(48000, 1200, 5000, decims[1], 2000, True, 60000)] * 3) * 2
     n_calls, n = 3, 60000
     sigs = [siggen.gmsk_channel(i, n_calls * n, fs=c[0], baud=c[1], carrier_offset_hz=0.0) for i, c in enumerate(cfgs)]
     ramps = [(lambda k, i=i: -10000.0 + 2500.0 * k + 37.0 * i) if i % 3 else None for i in range(len(cfgs))]
