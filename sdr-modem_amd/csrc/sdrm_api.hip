@@ -444,10 +444,6 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.dc_lds = (uint32_t) pl.dc_lds_bytes();
     d.any_dc = any_dc;
     d.fast_fma = (flags & SDRM_FLAG_FAST_FMA) ? 1 : 0;
-    {
-        const char *pe = getenv("SDRM_K3_PAIR");  // measurements: 0 = the one-channel symbol loop only
-        d.k3_pair = pe != nullptr ? atoi(pe) : 1;
-    }
     b->in_stride = pl.in_stride;
     *out = b;
     return 0;

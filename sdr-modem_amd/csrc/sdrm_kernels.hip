@@ -1323,141 +1323,6 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     L.st.inc = inc;
 }
 
-// TWO channels per lane, half a symbol apart (round 2).  The symbol loop above is bound by what one wave can issue (~4.4
-// cycles per instruction) PLUS one LDS round trip per symbol (~60 cycles) that nothing of the same channel can cover: the
-// operand addresses need the loop state the symbol just produced.  A second, independent channel can: lane l of the
-// lower half of the wave's channels also runs channel l + LANES/2, its symbol placed between the first channel's operand
-// loads and their use, so each channel's LDS latency passes while the other channel computes.  Same instructions per
-// symbol and channel as k3_drain_finite (the assembler macro K3P is that symbol, registers by number), ~150 instead of
-// ~220 cycles per symbol and channel.  A lane stays in the loop while BOTH channels have a symbol to do (exec &= both
-// conditions, once per pair of symbols); whatever one channel has left when the other runs out of staged samples -- a
-// symbol or two when they share a symbol rate -- is done by the one-channel loop behind it.  Only for waves whose output
-// buffers cannot fill up within the block (the CAP = false case above).
-//   scratch: v64..v88 first channel ("A"), v96..v120 second ("B"), v90 / v91 constants, s[74:75] A's loop condition
-#define K3P_MACRO \
-    ".macro K3P b, acc, last, mu, omega, pm, off, gg, ll, mid, limm, col, cnd\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_pk_mul_f32 v[\\b+2:\\b+3], v[\\b+2:\\b+3], v[\\b+10:\\b+11]\n\t" \
-    "v_pk_mul_f32 v[\\b+4:\\b+5], v[\\b+4:\\b+5], v[\\b+12:\\b+13]\n\t" \
-    "v_add_f32 \\acc, 0, v[\\b+2]\n\t" \
-    "v_add_f32 \\acc, v[\\b+3], \\acc\n\t" \
-    "v_add_f32 \\acc, v[\\b+4], \\acc\n\t" \
-    "v_add_f32 \\acc, v[\\b+5], \\acc\n\t" \
-    "s_waitcnt lgkmcnt(4)\n\t" \
-    "v_pk_mul_f32 v[\\b+6:\\b+7], v[\\b+6:\\b+7], v[\\b+14:\\b+15]\n\t" \
-    "v_pk_mul_f32 v[\\b+8:\\b+9], v[\\b+8:\\b+9], v[\\b+16:\\b+17]\n\t" \
-    "v_add_f32 \\acc, v[\\b+6], \\acc\n\t" \
-    "v_add_f32 \\acc, v[\\b+7], \\acc\n\t" \
-    "v_add_f32 \\acc, v[\\b+8], \\acc\n\t" \
-    "v_add_f32 \\acc, v[\\b+9], \\acc\n\t" \
-    "v_xor_b32 v[\\b+20], \\acc, v[\\b+22]\n\t" \
-    "v_bfi_b32 v[\\b+19], s78, 1.0, \\acc\n\t" \
-    "v_fma_f32 v[\\b+20], -v[\\b+19], \\last, v[\\b+20]\n\t" \
-    "v_pk_mul_f32 v[\\b+0:\\b+1], v[\\b+20:\\b+21], \\gg op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
-    "v_add_f32 \\omega, \\omega, v[\\b+0]\n\t" \
-    "v_sub_f32 v[\\b+20], \\omega, \\mid\n\t" \
-    "v_pk_add_f32 v[\\b+20:\\b+21], v[\\b+20:\\b+21], \\ll op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
-    "v_sub_f32_e64 v[\\b+21], |v[\\b+20]|, |v[\\b+21]|\n\t" \
-    "v_fma_f32 \\omega, v[\\b+21], 0.5, \\mid\n\t" \
-    "v_add_f32 \\mu, \\mu, \\omega\n\t" \
-    "v_add_f32 \\mu, \\mu, v[\\b+1]\n\t" \
-    "v_floor_f32 v[\\b+21], \\mu\n\t" \
-    "v_sub_f32 \\mu, \\mu, v[\\b+21]\n\t" \
-    "v_add_f32 \\pm, \\pm, v[\\b+21]\n\t" \
-    "v_fma_f32 v[\\b+1], \\mu, v90, v91\n\t" \
-    "v_and_b32 v[\\b+0], %[m255], \\pm\n\t" \
-    "v_mad_u32_u24 v[\\b+1], v[\\b+1], %[rowb], %[bias]\n\t" \
-    "v_lshl_add_u32 v[\\b+0], v[\\b+0], 3, \\col\n\t" \
-    "ds_read_b128 v[\\b+2:\\b+5], v[\\b+1]\n\t" \
-    "ds_read2_b64 v[\\b+10:\\b+13], v[\\b+0] offset0:3 offset1:5\n\t" \
-    "ds_read_b128 v[\\b+6:\\b+9], v[\\b+1] offset:16\n\t" \
-    "ds_read2_b64 v[\\b+14:\\b+17], v[\\b+0] offset0:7 offset1:9\n\t" \
-    "v_cmp_lt_f32_e64 \\cnd, \\pm, \\limm\n\t" \
-    "v_and_b32 v[\\b+22], s79, \\acc\n\t" \
-    "global_store_dword \\off, \\acc, %[out]\n\t" \
-    "v_add_u32 \\off, 4, \\off\n\t" \
-    ".endm\n\t" \
-    /* operands of a channel's first symbol */ \
-    ".macro K3PFIRST b, mu, pm, col, last, off\n\t" \
-    "v_and_b32 v[\\b+0], %[m255], \\pm\n\t" \
-    "v_lshl_add_u32 v[\\b+0], v[\\b+0], 3, \\col\n\t" \
-    "v_fma_f32 v[\\b+1], \\mu, v90, v91\n\t" \
-    "v_mad_u32_u24 v[\\b+1], v[\\b+1], %[rowb], %[bias]\n\t" \
-    "ds_read_b128 v[\\b+2:\\b+5], v[\\b+1]\n\t" \
-    "ds_read2_b64 v[\\b+10:\\b+13], v[\\b+0] offset0:3 offset1:5\n\t" \
-    "ds_read_b128 v[\\b+6:\\b+9], v[\\b+1] offset:16\n\t" \
-    "ds_read2_b64 v[\\b+14:\\b+17], v[\\b+0] offset0:7 offset1:9\n\t" \
-    "v_mov_b32 v[\\b+23], \\last\n\t" \
-    "v_and_b32 v[\\b+22], s79, \\last\n\t" \
-    "v_mov_b32 v[\\b+24], \\off\n\t" \
-    ".endm\n\t" \
-    /* after the loop: the floor of the channel's last symbol, and which register holds that symbol */ \
-    ".macro K3PLAST b, last, off, flr\n\t" \
-    "v_mov_b32 \\flr, v[\\b+21]\n\t" \
-    "v_xor_b32 v[\\b+24], v[\\b+24], \\off\n\t" \
-    "v_and_b32 v[\\b+24], 4, v[\\b+24]\n\t" \
-    "v_cmp_eq_u32 vcc, 4, v[\\b+24]\n\t" \
-    "s_nop 1\n\t" \
-    "v_cndmask_b32 \\last, v[\\b+23], v[\\b+18], vcc\n\t" \
-    ".endm\n\t"
-// one trip = a symbol of each channel; consecutive trips swap the accumulator and the previous-symbol register
-#define K3P_TRIP(ACCA, LASTA, ACCB, LASTB) \
-    "K3P 64, " ACCA ", " LASTA ", %[muA], %[omegaA], %[pmA], %[offA], %[ggA], %[llA], %[midA], %[limmA], %[colA], s[74:75]\n\t" \
-    "K3P 96, " ACCB ", " LASTB ", %[muB], %[omegaB], %[pmB], %[offB], %[ggB], %[llB], %[midB], %[limmB], %[colB], vcc\n\t" \
-    "s_and_b64 vcc, vcc, s[74:75]\n\t" \
-    "s_and_b64 exec, exec, vcc\n\t"
-
-struct k3_half {  // one channel's loop state and constants as the pair loop takes them
-    float mu, omega, last, pm, limm, flr, mid;
-    uint32_t off, col;
-    float g_omega, g_mu, lim;
-};
-
-__device__ __forceinline__ void k3_drain_pair(k3_half &A, k3_half &B, uint32_t bank_addr, const float *out_base, uint32_t ring_mask) {
-    const uint32_t bias = bank_addr - 0x400000u * (SDRM_K3_BANKPITCH * 4u);
-    typedef float k3_f2 __attribute__((ext_vector_type(2)));
-    const k3_f2 ggA = {A.g_omega, A.g_mu}, ggB = {B.g_omega, B.g_mu};
-    const k3_f2 llA = {A.lim, -A.lim}, llB = {B.lim, -B.lim};
-    unsigned long long saved_exec;
-    asm volatile(
-        K3P_MACRO
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b32 s78, 0x7fffffff\n\t"
-        "s_mov_b32 s79, 0x80000000\n\t"
-        "v_mov_b32 v90, 0x43000000\n\t"  /* 128.0 */
-        "v_mov_b32 v91, 0x4b400000\n\t"  /* 1.5 * 2^23 */
-        "K3PFIRST 64, %[muA], %[pmA], %[colA], %[lastA], %[offA]\n\t"
-        "K3PFIRST 96, %[muB], %[pmB], %[colB], %[lastB], %[offB]\n\t"
-        ".p2align 6\n\t"
-        "1:\n\t"
-        K3P_TRIP("v82", "v87", "v114", "v119")
-        "s_cbranch_execz 2f\n\t"
-        K3P_TRIP("v87", "v82", "v119", "v114")
-        "s_cbranch_execz 2f\n\t"
-        K3P_TRIP("v82", "v87", "v114", "v119")
-        "s_cbranch_execz 2f\n\t"
-        K3P_TRIP("v87", "v82", "v119", "v114")
-        "s_cbranch_execnz 1b\n"
-        "2:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        "K3PLAST 64, %[lastA], %[offA], %[flrA]\n\t"
-        "K3PLAST 96, %[lastB], %[offB], %[flrB]\n\t"
-        ".purgem K3P\n\t"
-        ".purgem K3PFIRST\n\t"
-        ".purgem K3PLAST\n\t"
-        : [muA] "+v"(A.mu), [omegaA] "+v"(A.omega), [lastA] "+v"(A.last), [pmA] "+v"(A.pm), [offA] "+v"(A.off), [flrA] "+v"(A.flr),
-          [muB] "+v"(B.mu), [omegaB] "+v"(B.omega), [lastB] "+v"(B.last), [pmB] "+v"(B.pm), [offB] "+v"(B.off), [flrB] "+v"(B.flr),
-          [sv] "=&s"(saved_exec)
-        : [limmA] "v"(A.limm), [colA] "v"(A.col), [ggA] "v"(ggA), [llA] "v"(llA), [midA] "v"(A.mid),
-          [limmB] "v"(B.limm), [colB] "v"(B.col), [ggB] "v"(ggB), [llB] "v"(llB), [midB] "v"(B.mid),
-          [bias] "s"(bias), [out] "s"(out_base), [m255] "s"(ring_mask), [rowb] "n"(SDRM_K3_BANKPITCH * 4)
-        : "memory", "vcc", "s74", "s75", "s78", "s79", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
-          "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v90", "v91", "v96", "v97", "v98",
-          "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
-          "v115", "v116", "v117", "v118", "v119", "v120");
-}
-
 template <int LANES>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     typedef sdrm_k3_geom<LANES> G;
@@ -1658,25 +1523,6 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     const uint32_t bank_addr = (uint32_t) (uintptr_t) (lds_cf) bank_rev;
     unsigned long long t_wait = 0, t_drain = 0, n_iter = 0;
     const unsigned long long real0 = b.k3_stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz reference clock
-    // two channels per lane: lane l of the lower half of the wave's channels also runs its partner l ^ H through the
-    // pair loop; the partner's constants are fetched once, its loop state per block (ds_bpermute), and handed back
-    constexpr int H = G::lanes / 2;
-    const int partner = (lane ^ H) << 2;  // ds_bpermute takes byte addresses
-#define K3_FROM_PARTNER_F(x) __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, (float) (x))))
-#define K3_FROM_PARTNER_I(x) __builtin_amdgcn_ds_bpermute(partner, (int) (x))
-    const bool pair_wave = b.k3_pair != 0 && wave_clean && positions_fit && nrows > H;
-    k3_half hb;  // the partner's side, held by the lower lane
-    hb.mu = hb.omega = hb.last = hb.pm = hb.limm = hb.flr = hb.mid = hb.g_omega = hb.g_mu = hb.lim = 0.0f;
-    hb.off = hb.col = 0;
-    int keptB = 0;
-    if (pair_wave) {
-        hb.mid = K3_FROM_PARTNER_F(L.k.omega_mid);
-        hb.lim = K3_FROM_PARTNER_F(L.k.omega_lim);
-        hb.g_omega = K3_FROM_PARTNER_F(L.k.gain_omega);
-        hb.g_mu = K3_FROM_PARTNER_F(L.k.gain_mu);
-        hb.col = (uint32_t) K3_FROM_PARTNER_I(col_addr);
-        keptB = K3_FROM_PARTNER_I(L.kept);
-    }
     for (int k = 0; k <= nblocks; k++) {
         // k == nblocks: nothing new, only drains what the carried history alone allows (nz == 0 case)
         unsigned long long t0 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -1688,61 +1534,6 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         avail = avail < L.nz ? avail : L.nz;
         const uint32_t lim = active ? sdrm_k3_limit(L, avail) : 0u;
         const uint32_t oo0 = L.oo;
-        if (pair_wave) {
-            // the pair loop has no output-buffer test: both channels need a ring's worth of room (see below)
-            const bool mine = sdrm_k3_can_step(L, lim) && L.k.omega_mid - L.k.omega_lim >= 1.0f &&
-                              off_end - off > 4u * ((uint32_t) G::ring + 8u);
-            const bool theirs = K3_FROM_PARTNER_I(mine ? 1 : 0) != 0;
-            hb.mu = K3_FROM_PARTNER_F(L.st.mu);
-            hb.omega = K3_FROM_PARTNER_F(L.st.omega);
-            hb.last = K3_FROM_PARTNER_F(L.st.last);
-            const int iiB = K3_FROM_PARTNER_I(L.st.ii);
-            const int limB = K3_FROM_PARTNER_I((int) lim);
-            hb.off = (uint32_t) K3_FROM_PARTNER_I(off);
-            const bool ran = lane < H && mine && theirs;
-            int iiB_new = iiB, incB_new = 0;
-            if (ran) {
-                k3_half ha;
-                ha.mu = L.st.mu;
-                ha.omega = L.st.omega;
-                ha.last = L.st.last;
-                ha.pm = SDRM_RINT_MAGIC + (float) (L.st.ii - L.kept);
-                ha.limm = SDRM_RINT_MAGIC + (float) ((int) lim - L.kept);
-                ha.flr = 0.0f;
-                ha.mid = L.k.omega_mid;
-                ha.off = off;
-                ha.col = col_addr;
-                ha.g_omega = L.k.gain_omega;
-                ha.g_mu = L.k.gain_mu;
-                ha.lim = L.k.omega_lim;
-                hb.pm = SDRM_RINT_MAGIC + (float) (iiB - keptB);
-                hb.limm = SDRM_RINT_MAGIC + (float) (limB - keptB);
-                hb.flr = 0.0f;
-                k3_drain_pair(ha, hb, bank_addr, wg_out, (uint32_t) (G::ring - 1));
-                L.st.mu = ha.mu;
-                L.st.omega = ha.omega;
-                L.st.last = ha.last;
-                L.st.ii = (int) (ha.pm - SDRM_RINT_MAGIC) + L.kept;
-                L.st.inc = (int) ha.flr;
-                off = ha.off;
-                iiB_new = (int) (hb.pm - SDRM_RINT_MAGIC) + keptB;
-                incB_new = (int) hb.flr;
-            }
-            // hand the partner's state back (the upper lane of a pair that ran takes it)
-            const bool take = K3_FROM_PARTNER_I(ran ? 1 : 0) != 0 && lane >= H;
-            const float mu_b = K3_FROM_PARTNER_F(hb.mu), omega_b = K3_FROM_PARTNER_F(hb.omega), last_b = K3_FROM_PARTNER_F(hb.last);
-            const int ii_b = K3_FROM_PARTNER_I(iiB_new), inc_b = K3_FROM_PARTNER_I(incB_new);
-            const uint32_t off_b = (uint32_t) K3_FROM_PARTNER_I(hb.off);
-            if (take) {
-                L.st.mu = mu_b;
-                L.st.omega = omega_b;
-                L.st.last = last_b;
-                L.st.ii = ii_b;
-                L.st.inc = inc_b;
-                off = off_b;
-            }
-            L.oo = (off - off_base) / (uint32_t) sizeof(float);
-        }
         if (wave_clean && positions_fit) {
             if (sdrm_k3_can_step(L, lim)) {
                 // every symbol consumes at least one sample when omega cannot fall below 1, and a call never has more

@@ -50,7 +50,6 @@ struct DeviceBatch {
     int any_dc;
     int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching
-    int k3_pair;                     // clock stage: two channels per lane in the symbol loop (k3_drain_pair); 0 = one (SDRM_K3_PAIR=0)
 };
 
 // one kernel launch, described: what launch_* puts on a stream and what the explicitly built graph of the one-channel
