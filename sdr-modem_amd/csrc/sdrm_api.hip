@@ -83,6 +83,7 @@ struct sdrm_batch_t {
     uint32_t *d_k3_done = nullptr;   // clock-stage workgroups finished, all launches
     uint32_t k3_done_target = 0;     // what the counter reads when the launch enqueued last has finished
     int company_blocks = 0;
+    int company_rounds = 120;        // bound on the companion grid's life, in ~50 us looks at the counter
     float *d_z2 = nullptr, *d_dcout2 = nullptr;
     bool any_nodc = false;
     bool serial = false;
@@ -394,6 +395,9 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
             if (macs / 18.4e12 > 0.7 * symbols * 97e-9) {
                 blocks = 0;
             }
+            // the grid lives as long as a full-length call's clock stage may take (half as long again), at least ~1 ms
+            const double rounds = symbols * 97e-9 * 1.5 / 50e-6 + 20.0;
+            b->company_rounds = rounds > 4000.0 ? 4000 : (int) rounds;
         }
         if (blocks > 0 && (int) n_channels >= lo && (int) n_channels <= hi) {
             b->company_blocks = blocks;
@@ -795,7 +799,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         b->k3_done_target += sdrm::clock_workgroups(d);
         HIP_TRY(hipEventRecord(b->ev_company, b->s_clock));
         HIP_TRY(hipStreamWaitEvent(b->s_company, b->ev_company, 0));
-        sdrm::launch_clock_company(d, b->k3_done_target, b->company_blocks, b->s_company);
+        sdrm::launch_clock_company(d, b->k3_done_target, b->company_blocks, b->company_rounds, b->s_company);
     }
     sdrm::launch_clock(d, b->s_clock);
     if (b->timing) {

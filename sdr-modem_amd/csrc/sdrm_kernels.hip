@@ -1684,9 +1684,9 @@ __global__ __launch_bounds__(64) void k3_company(const uint32_t *done, uint32_t 
     }
 }
 
-void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, hipStream_t s) {
-    // max_rounds: ~6 ms at most, whatever happens to the counter
-    hipLaunchKernelGGL(k3_company, dim3((unsigned) blocks), dim3(64), 0, s, b.k3_done, target, 120);
+void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, int max_rounds, hipStream_t s) {
+    // max_rounds x ~50 us bounds the grid's life whatever happens to the counter
+    hipLaunchKernelGGL(k3_company, dim3((unsigned) blocks), dim3(64), 0, s, b.k3_done, target, max_rounds);
 }
 
 unsigned clock_workgroups(const DeviceBatch &b) { return describe_clock(b).grid.x; }

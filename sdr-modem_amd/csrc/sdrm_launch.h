@@ -81,7 +81,7 @@ void launch_dc(const DeviceBatch &b, hipStream_t s);
 // words of the front-end, then 10 of the DC blocker
 #define SDRM_STAMP_K3_WAVES(n_channels) (((n_channels) + 15) / 16)
 void launch_clock(const DeviceBatch &b, hipStream_t s);
-void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, hipStream_t s);
+void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, int max_rounds, hipStream_t s);
 unsigned clock_workgroups(const DeviceBatch &b);
 
 // test probes
