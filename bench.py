@@ -206,29 +206,53 @@ def end_to_end(binding, siggen, channels, chunk, calls=24, slots=4):
                     "soft bits and counts back to pinned memory, 3 calls in flight (PCIe-inclusive)"}
 
 
-def config5(torch, binding, siggen, dev, channels, chunk, steps=24):
-    """BASELINE configs[4] in one GPU's share: half 240 kHz / 19200 baud (decimation 5), half 48 kHz / 1200 baud
-    (decimation 8), every channel corrected by its own Doppler ramp (three NCO batches per channel and call)."""
-    cfgs = [(240000, 19200, 5000, 5, 2000, True, chunk) if c % 2 == 0 else (48000, 1200, 5000, 8, 2000, True, chunk)
-            for c in range(channels)]
+def config5_table(total, chunk):
+    """BASELINE configs[4]: half 240 kHz / 19200 baud (decimation 5), half 48 kHz / 1200 baud (decimation 8).  One GPU's
+    share interleaves them; a node-wide table keeps each source's channels together (heavy block first), which is what
+    the cost-balanced contiguous shards are for."""
+    return [(240000, 19200, 5000, 5, 2000, True, chunk) if c < total // 2 else (48000, 1200, 5000, 8, 2000, True, chunk)
+            for c in range(total)]
+
+
+def config5_segments(channels, chunk):
+    """three NCO batches per channel and call on the channel's own Doppler ramp: (global_channel, len, freq_hz)"""
+    return [(c, n, -10000 + (80 * c) % 20000 + 500 * k) for c in channels for k, n in enumerate((40000, 40000, chunk - 80000))]
+
+
+def config5(torch, binding, siggen, dev, cfgs, chunk, steps=24, plan_step=None, local_rank=-1):
+    """BASELINE configs[4]: every channel corrected by its own Doppler ramp (three NCO batches per channel and call) in
+    front of the demodulator.  `plan_step()` returns the call's batches as [(local_channel, len, freq_hz)] -- with N > 1
+    ranks that is the per-call fan-out from rank 0 (shard.fanout_nco_segments), inside the timed loop."""
+    channels = len(cfgs)
     a = siggen.gmsk_channel(1, 2 * chunk, fs=240000, baud=19200)
     b_ = siggen.gmsk_channel(2, 2 * chunk, fs=48000, baud=1200)
-    x = torch.from_numpy(np.stack([a if c % 2 == 0 else b_ for c in range(channels)]).view(np.float32)).to(dev)
-    b = binding.Batch(cfgs)
+    x = torch.from_numpy(np.stack([a if c[0] == 240000 else b_ for c in cfgs]).view(np.float32)).to(dev)
+    b = binding.Batch(cfgs, device=local_rank)
     if b.code != 0:
         raise RuntimeError("create failed %d" % b.code)
     st = torch.cuda.current_stream().cuda_stream
     lens = [chunk] * channels
-    segs = (binding.NcoSegment * (3 * channels))(*[binding.NcoSegment(c, n, -10000 + (80 * c) % 20000 + 500 * k)
-                                                   for c in range(channels)
-                                                   for k, n in enumerate((40000, 40000, chunk - 80000))])
+
+    def step(i):
+        mine = plan_step()
+        segs = (binding.NcoSegment * max(len(mine), 1))(*[binding.NcoSegment(*s) for s in mine])
+        b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens, segs, st, n_segments=len(mine))
     for i in range(4):
-        b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens, segs, st)
+        step(i)
     torch.cuda.synchronize()
     b.timing_enable(True)
+    return b, x, step
+
+
+def config5_single(torch, binding, siggen, dev, channels, chunk, steps=24):
+    """configs[4] in one GPU's share (N = 1): the two kinds of channel interleaved, batches planned locally"""
+    cfgs = [(240000, 19200, 5000, 5, 2000, True, chunk) if c % 2 == 0 else (48000, 1200, 5000, 8, 2000, True, chunk)
+            for c in range(channels)]
+    mine = config5_segments(range(channels), chunk)
+    b, x, step = config5(torch, binding, siggen, dev, cfgs, chunk, steps, plan_step=lambda: mine)
     t0 = time.perf_counter()
     for i in range(steps):
-        b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens, segs, st)
+        step(i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     km = [b.timing_read(w) for w in range(3)]
@@ -368,6 +392,35 @@ def main():
                    "workload": "BASELINE configs[3] shape: %d channels sharded over %d GPUs, channel table broadcast from "
                                "rank 0 over RCCL" % (c3 * world, world)}
 
+    # --- BASELINE configs[4]: mixed rates with per-channel Doppler over the node: cost-balanced shards of the table
+    # (a 240 kHz / 397-tap channel weighs ten 48 kHz ones), the call's NCO batches planned on rank 0 and fanned out
+    # with the same partition before every call -- the path's second (KB-sized) collective, inside the timed loop
+    config5s = None
+    if world > 1 and not args.no_extras:
+        tot5 = 256 * world
+        table5 = config5_table(tot5, N) if rank == 0 else None
+        part5 = shard.fanout_configs(table5, tot5, device=coll_dev, balance="cost")
+        segs5 = config5_segments(range(tot5), N) if rank == 0 else None
+        b5, x5, step5 = config5(torch, binding, siggen, dev, part5.cfgs, N,
+                                plan_step=lambda: shard.fanout_nco_segments(segs5, part5, device=coll_dev), local_rank=local_rank)
+        steps5 = 24
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps5):
+            step5(i)
+        barrier()
+        dt5 = max_over_ranks(time.perf_counter() - t0)
+        b5.close()
+        del x5
+        torch.cuda.empty_cache()
+        counts = [None] * world
+        dist.all_gather_object(counts, len(part5))
+        config5s = {"value": round(tot5 * N * steps5 / dt5 / 1e6, 1), "unit": "Msamples/s", "channels_total": tot5,
+                    "channels_per_rank": counts, "balance": "cost", "steps": steps5, "ms_per_step": round(dt5 / steps5 * 1e3, 3),
+                    "workload": "BASELINE configs[4] shape: %d x (240000,19200,5000,5,2000,dc) + %d x (48000,1200,5000,8,2000,dc) "
+                                "over %d GPUs, shards balanced by front-end cost, per-channel Doppler batches planned on rank 0 "
+                                "and broadcast before every call" % (tot5 // 2, tot5 - tot5 // 2, world)}
+
     if rank == 0:
         front_ms = k_ms[0]
         achieved = (C * N * 8.0) / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
@@ -428,6 +481,8 @@ def main():
             out["verified_vs_oracle"] = verify
         if config3 is not None:
             out["config3_sharded"] = config3
+        if config5s is not None:
+            out["config5_sharded"] = config5s
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import orc
@@ -537,7 +592,7 @@ def main():
             except Exception as exc:
                 out["roofline_fast"] = {"error": str(exc)[:200]}
             for name, fn in (("end_to_end", lambda: end_to_end(binding, siggen, C, N)),
-                             ("config5", lambda: config5(torch, binding, siggen, dev, C, N))):
+                             ("config5", lambda: config5_single(torch, binding, siggen, dev, C, N))):
                 try:
                     out[name] = fn()
                 except Exception as exc:  # informative sub-blocks: never cost the headline its line

@@ -304,13 +304,15 @@ class Batch:
         if code != 0:
             raise RuntimeError("sdrm_batch_process_device failed: %d" % code)
 
-    def process_device_nco(self, d_ptr, in_stride, lens, segments, stream=None):
-        """device-resident call with Doppler pre-correction; segments: ctypes array of NcoSegment or list of tuples"""
+    def process_device_nco(self, d_ptr, in_stride, lens, segments, stream=None, n_segments=None):
+        """device-resident call with Doppler pre-correction; segments: ctypes array of NcoSegment (n_segments of it, all
+        by default) or list of tuples"""
         arr = (C.c_size_t * self.n)(*[int(x) for x in lens])
         if not isinstance(segments, C.Array):
+            n_segments = len(segments)
             segments = (NcoSegment * max(len(segments), 1))(*[NcoSegment(*t) for t in segments])
-        code = self.L.sdrm_batch_process_device_nco(self.h, C.c_void_p(d_ptr), in_stride, arr, segments, len(segments),
-                                                    C.c_void_p(stream or 0))
+        code = self.L.sdrm_batch_process_device_nco(self.h, C.c_void_p(d_ptr), in_stride, arr, segments,
+                                                    len(segments) if n_segments is None else n_segments, C.c_void_p(stream or 0))
         if code != 0:
             raise RuntimeError("sdrm_batch_process_device_nco failed: %d" % code)
 

@@ -15,6 +15,8 @@
 #ifndef SDRM_KERNELS_H
 #define SDRM_KERNELS_H
 
+#include <stdio.h>
+
 #include "sdrm_core.h"
 
 #define SDRM_K1_THREADS 256
@@ -42,7 +44,7 @@
 // longer rings = longer staging steps, i.e. fewer hand-overs (barrier, limits, loop entry with its exposed first loads)
 // per symbol, and LDS instructions that move a quarter of the data.  A lone wave pays per instruction, not per lane:
 // with 16 of the consumer's 64 lanes in use a symbol costs ~257 cycles instead of ~312 (64 lanes), at the price of four
-// times as many CUs held.  sdrm_k3_lanes_for() picks per batch size.
+// times as many CUs held.  sdrm_k3_shape_for() picks per batch size.
 #define SDRM_K3_WAVE 64     // lanes of the staging wave (lane = time)
 #define SDRM_K3_PRE 3       // mirror slots below slot 0 (a symbol reads up to 3 samples before its window)
 #define SDRM_K3_POST 8      // mirror slots above slot RING-1 (a window is 8 samples)
@@ -50,29 +52,61 @@
 // starting anywhere are elements s, s+2, s+4, s+6: two ds_read2_b64 instead of four ds_read2_b32 (an LDS instruction
 // costs a lone wave ~12 cycles of issue whatever its width, tools/ubench_chain.hip; a 16-byte read that is only 4-byte
 // aligned is served, but in 64 cycles: tools/ubench_lds_unaligned.hip).
-template <int LANES>
+template <int LANES, int RING = 16384 / LANES>
 struct sdrm_k3_geom {
     static constexpr int lanes = LANES;
-    static constexpr int ring = 16384 / LANES;           // per-channel sample ring in LDS (power of two): 4 staging blocks
+    static constexpr int ring = RING;                    // per-channel sample ring in LDS (power of two): 4 staging blocks
     static constexpr int block = ring / 4;               // samples staged per channel per step
     static constexpr int segs = block / SDRM_K3_WAVE;    // 64-sample row segments per channel and step
     static constexpr int rows = SDRM_K3_PRE + ring + SDRM_K3_POST;
-    static constexpr int cpitch = 2 * rows;              // floats between two channels' rings (22 mod 64 for every LANES: conflict-free b64 reads)
+    static constexpr int cpitch = 2 * rows;              // floats between two channels' rings (22 mod 64 for every power-of-two ring: conflict-free b64 reads)
 };
 #ifndef SDRM_K3_BANKPITCH
 #define SDRM_K3_BANKPITCH 12  // floats between two rows of the MMSE bank copy in LDS (48 B: rows start on 16 different bank offsets instead of 8)
 #endif
+// Workgroup shape of the clock stage: channels per workgroup x ring length.  Two families:
+//   FULL shapes (lanes x ring = 16384 samples: 16 x 1024, 32 x 512, 64 x 256) fill a CU's LDS (141 KB), which keeps every
+//   other stage's workgroups off that CU: the symbol loop has its SIMD to itself.  Right while the clock stage is the
+//   longest stage (few channels).
+//   SLIM shapes (16 x 256: 41 KB, 16 x 512 / 32 x 256: 74 KB) leave room for front-end workgroups (35 KB each) on the same
+//   CU.  With thousands of channels the front-end is the longest stage and a FULL clock stage both takes whole CUs away
+//   from it and cannot place its own workgroups while the front-end's grid streams through the chip (no CU ever has
+//   141 KB free): measured in round 2 as 8.45 ms for a 3.76 ms kernel.  A slim workgroup starts wherever one front-end
+//   workgroup has left, and costs the front-end one of its four slots on that CU instead of all of them.
+struct sdrm_k3_shape {
+    int lanes, ring;
+};
+SDRM_HD bool sdrm_k3_shape_ok(int lanes, int ring) {
+    return (lanes == 16 && (ring == 1024 || ring == 512 || ring == 256)) || (lanes == 32 && (ring == 512 || ring == 256)) ||
+           (lanes == 64 && ring == 256);
+}
 // channels per workgroup for a batch of n channels (round 1, ms per step, 131072-sample chunks; lanes 64 / 32 / 16 / 8:
 // 256 channels 3.96 / 3.18 / 3.09 / 3.07, 1024: 4.67 / 4.37 / 3.88 / 4.46)
-static inline int sdrm_k3_lanes_for(int n_channels, int forced) {
-    if (forced == 16 || forced == 32 || forced == 64) {
-        return forced;
+static inline sdrm_k3_shape sdrm_k3_shape_for(int n_channels, int forced_lanes, int forced_ring) {
+    if (forced_lanes == 16 || forced_lanes == 32 || forced_lanes == 64) {
+        sdrm_k3_shape f = {forced_lanes, forced_ring ? forced_ring : 16384 / forced_lanes};
+        if (sdrm_k3_shape_ok(f.lanes, f.ring)) {
+            return f;
+        }
     }
     // Measured per batch size (round 2, tools/k3_ab.py, ms per call of 131072 samples per channel; 16 / 32 / 64 channels
-    // per workgroup): 1280 channels 3.28 / 3.82 / 4.48, 1536: 4.02 / 3.81 / 4.62, 2048: 5.50 / 4.87 / 4.84,
+    // per workgroup, full shapes): 1280 channels 3.28 / 3.82 / 4.48, 1536: 4.02 / 3.81 / 4.62, 2048: 5.50 / 4.87 / 4.84,
     // 3072: 8.18 / 7.21 / 7.20, 4096: 10.8 / 9.56 / 9.17.  Few channels per workgroup = more waves on the latency chain
     // but more CUs whose LDS the front-end cannot use; the crossovers sit where the front-end becomes the longer stage.
-    return n_channels <= 1280 ? 16 : (n_channels <= 2048 ? 32 : 64);
+    sdrm_k3_shape s = {16, 1024};
+    if (n_channels > 1280) {
+        s.lanes = n_channels <= 2048 ? 32 : 64;
+        s.ring = 16384 / s.lanes;
+    }
+    return s;
+}
+// "lanes" or "lanesxring" (SDRM_K3_LANES=16x256): tests and measurements force one workgroup shape
+static inline void sdrm_k3_parse_shape(const char *text, int *lanes, int *ring) {
+    *lanes = 0;
+    *ring = 0;
+    if (text != nullptr) {
+        sscanf(text, "%dx%d", lanes, ring);
+    }
 }
 
 // immutable per-channel parameters (device array, one per channel)

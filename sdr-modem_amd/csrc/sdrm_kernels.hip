@@ -1130,7 +1130,7 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 
 // ================================================================================================ K3
 
-// One lane per channel, LANES (16 or 64, sdrm_k3_lanes_for) channels per CONSUMER wave (reference
+// One lane per channel, LANES (16, 32 or 64: sdrm_k3_shape_for) channels per CONSUMER wave (reference
 // src/dsp/clock_recovery_mm.c:78-139 per lane); a second PRODUCER wave of the same workgroup stages the samples, so the
 // two overlap.
 // Producer: per step, a block (a quarter ring: 256 or 64 samples) of each of the workgroup's channels goes from global
@@ -1143,9 +1143,8 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // conversion is k3_quantize's, behind this kernel).  Without NaN/Inf in the wave's channels the consumer runs the
 // hand-scheduled loop below (k3_drain_finite), otherwise the C++ form of the same arithmetic.  One barrier per step
 // hands block k to the consumer while block k+1 is written.
-size_t k3_lds_bytes(int lanes) {
-    const size_t rings = lanes == 16 ? (size_t) 16 * sdrm_k3_geom<16>::cpitch
-                                     : (lanes == 32 ? (size_t) 32 * sdrm_k3_geom<32>::cpitch : (size_t) 64 * sdrm_k3_geom<64>::cpitch);
+size_t k3_lds_bytes(int lanes, int ring) {
+    const size_t rings = (size_t) lanes * 2 * (SDRM_K3_PRE + ring + SDRM_K3_POST);
     return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_WAVE) * sizeof(float);
 }
 
@@ -1323,9 +1322,9 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     L.st.inc = inc;
 }
 
-template <int LANES>
+template <int LANES, int RING>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
-    typedef sdrm_k3_geom<LANES> G;
+    typedef sdrm_k3_geom<LANES, RING> G;
     extern __shared__ __attribute__((aligned(16))) float k3_lds[];
     float *bank_rev = k3_lds;                       // [129*8] at LDS offset 0: a row is two aligned ds_read_b128
     float *ring = bank_rev + ((129 * SDRM_K3_BANKPITCH + 3) & ~3);  // [LANES][CPITCH]
@@ -1622,26 +1621,34 @@ __global__ __launch_bounds__(256) void k3_quantize(DeviceBatch b) {
     }
 }
 
-template <int LANES>
+template <int LANES, int RING>
 static KernelLaunch describe_clock_as(const DeviceBatch &b) {
     KernelLaunch k;
     static lds_grant granted;
-    k.lds = k3_lds_bytes(LANES);
-    allow_lds(k3_clock<LANES>, k.lds, &granted);
-    k.func = reinterpret_cast<const void *>(k3_clock<LANES>);
+    k.lds = k3_lds_bytes(LANES, RING);
+    allow_lds(k3_clock<LANES, RING>, k.lds, &granted);
+    k.func = reinterpret_cast<const void *>(k3_clock<LANES, RING>);
     k.grid = dim3((unsigned) ((b.n_channels + LANES - 1) / LANES));
     k.block = dim3(128);
     return k;
 }
 
-int k3_forced_lanes() {
-    const char *e = getenv("SDRM_K3_LANES");  // tests and measurements: force one workgroup shape (read per launch)
-    return e ? atoi(e) : 0;
+sdrm_k3_shape k3_shape(const DeviceBatch &b) {
+    int lanes = 0, ring = 0;
+    sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring);  // tests and measurements: force one workgroup shape (read per launch)
+    return sdrm_k3_shape_for(b.n_channels, lanes, ring);
 }
 
 KernelLaunch describe_clock(const DeviceBatch &b) {
-    const int lanes = sdrm_k3_lanes_for(b.n_channels, k3_forced_lanes());
-    return lanes == 16 ? describe_clock_as<16>(b) : (lanes == 32 ? describe_clock_as<32>(b) : describe_clock_as<64>(b));
+    const sdrm_k3_shape sh = k3_shape(b);
+    switch (sh.lanes * 10000 + sh.ring) {
+        case 16 * 10000 + 1024: return describe_clock_as<16, 1024>(b);
+        case 16 * 10000 + 512: return describe_clock_as<16, 512>(b);
+        case 16 * 10000 + 256: return describe_clock_as<16, 256>(b);
+        case 32 * 10000 + 512: return describe_clock_as<32, 512>(b);
+        case 32 * 10000 + 256: return describe_clock_as<32, 256>(b);
+        default: return describe_clock_as<64, 256>(b);
+    }
 }
 
 KernelLaunch describe_quantize(const DeviceBatch &b) {

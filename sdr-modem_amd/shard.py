@@ -104,9 +104,26 @@ def shard_by_cost(cfgs, world):
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+class Shard:
+    """This rank's part of a fanned-out channel table: its configs and the global range [lo, hi) they came from.
+    Unpacks as (cfgs, lo, hi).  The NCO fan-out takes the SAME object, so that the batches a rank keeps are always
+    those of the channels it was given (a cost-balanced table has other cuts than an equal-count one)."""
+
+    def __init__(self, cfgs, lo, hi, total, world, rank, balance):
+        self.cfgs, self.lo, self.hi = cfgs, lo, hi
+        self.total, self.world, self.rank, self.balance = total, world, rank, balance
+
+    def __iter__(self):
+        return iter((self.cfgs, self.lo, self.hi))
+
+    def __len__(self):
+        return self.hi - self.lo
+
+
 def fanout_configs(cfgs_rank0, total, device="cpu", balance="count"):
-    """Broadcast the channel table from rank 0; return (this rank's configs, lo, hi).  balance="cost": shards of equal
-    front-end work (shard_by_cost, computed by every rank from the same broadcast table) instead of equal counts."""
+    """Broadcast the channel table from rank 0; return this rank's Shard (unpacks as configs, lo, hi).  balance="cost":
+    shards of equal front-end work (shard_by_cost, computed by every rank from the same broadcast table) instead of
+    equal counts."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     table = torch.zeros((total, FIELDS), dtype=torch.int64, device=device)
@@ -116,16 +133,21 @@ def fanout_configs(cfgs_rank0, total, device="cpu", balance="count"):
         dist.broadcast(table, src=0)
     if balance == "cost":
         lo, hi = shard_by_cost(decode(table.cpu()), world)[rank]
-    else:
+    elif balance == "count":
         lo, hi = shard_range(total, world, rank)
-    return decode(table[lo:hi].cpu()), lo, hi
+    else:
+        raise ValueError("balance must be 'count' or 'cost'")
+    return Shard(decode(table[lo:hi].cpu()), lo, hi, total, world, rank, balance)
 
 
-def fanout_nco_segments(segments_rank0, total, device="cpu", span=None):
+def fanout_nco_segments(segments_rank0, shard, device="cpu"):
     """Doppler pre-correction at node scale: rank 0 runs the orbit model and the planner for every channel
     of the node and holds the call's NCO batches as (global_channel, len, freq_hz), grouped by channel; one broadcast
     (a count, then an int64 table -- RCCL on GPUs, KB-sized) gives every rank the batches of its own channels, with
-    the channel index rebased to the rank's shard.  Returns this rank's list of (local_channel, len, freq_hz)."""
+    the channel index rebased to the rank's shard.  `shard` is what fanout_configs returned on this rank (required: the
+    batches kept are those of exactly the channels the rank was given).  Returns [(local_channel, len, freq_hz)]."""
+    if not isinstance(shard, Shard):
+        raise TypeError("fanout_nco_segments needs the Shard returned by fanout_configs")
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     count = torch.zeros(1, dtype=torch.int64, device=device)
@@ -139,6 +161,6 @@ def fanout_nco_segments(segments_rank0, total, device="cpu", span=None):
         table[:n].copy_(torch.tensor([[int(c), int(ln), int(f)] for c, ln, f in segments_rank0], dtype=torch.int64))
     if world > 1:
         dist.broadcast(table, src=0)
-    lo, hi = span if span is not None else shard_range(total, world, rank)  # span: this rank's (lo, hi) of a cost-balanced table
+    lo, hi = shard.lo, shard.hi
     rows = table[:n].cpu().tolist()
     return [(int(c) - lo, int(ln), int(f)) for c, ln, f in rows if lo <= c < hi]

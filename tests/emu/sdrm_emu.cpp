@@ -228,9 +228,9 @@ static void emu_dc(EmuBatch *b) {
     }
 }
 
-template <int LANES>
+template <int LANES, int RING>
 static void emu_clock_as(EmuBatch *b) {
-    typedef sdrm_k3_geom<LANES> G;
+    typedef sdrm_k3_geom<LANES, RING> G;
     const BatchPlan &pl = b->plan;
     const int C = (int) pl.params.size();
     std::vector<float> ring(G::lanes * G::cpitch);
@@ -330,14 +330,16 @@ static void emu_clock_as(EmuBatch *b) {
 
 // the workgroup shape the library would launch for this batch (same policy, same SDRM_K3_LANES override)
 static void emu_clock(EmuBatch *b) {
-    const char *e = getenv("SDRM_K3_LANES");
-    const int lanes = sdrm_k3_lanes_for((int) b->plan.params.size(), e ? atoi(e) : 0);
-    if (lanes == 16) {
-        emu_clock_as<16>(b);
-    } else if (lanes == 32) {
-        emu_clock_as<32>(b);
-    } else {
-        emu_clock_as<64>(b);
+    int lanes = 0, ring = 0;
+    sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring);
+    const sdrm_k3_shape sh = sdrm_k3_shape_for((int) b->plan.params.size(), lanes, ring);
+    switch (sh.lanes * 10000 + sh.ring) {
+        case 16 * 10000 + 1024: emu_clock_as<16, 1024>(b); break;
+        case 16 * 10000 + 512: emu_clock_as<16, 512>(b); break;
+        case 16 * 10000 + 256: emu_clock_as<16, 256>(b); break;
+        case 32 * 10000 + 512: emu_clock_as<32, 512>(b); break;
+        case 32 * 10000 + 256: emu_clock_as<32, 256>(b); break;
+        default: emu_clock_as<64, 256>(b); break;
     }
 }
 

@@ -104,12 +104,12 @@ def test_design_parameters_match_oracle():
     g.close()
 
 
-@pytest.mark.parametrize("lanes", [16, 32, 64])
+@pytest.mark.parametrize("lanes", ["16", "32", "64", "16x512", "16x256", "32x256"])
 def test_clock_stage_workgroup_shapes(lanes, monkeypatch):
     """The clock stage runs with 16 channels per workgroup (256-sample steps) up to 1024 channels and with 64 (64-sample
     steps) beyond; SDRM_K3_LANES forces a shape.  Both shapes, both builds (float soft bits kept / int8 only, i.e. the C++
     loop and the hand-scheduled one), ragged chunks of one stream and a ragged 69-channel mixed batch with NaN input."""
-    monkeypatch.setenv("SDRM_K3_LANES", str(lanes))
+    monkeypatch.setenv("SDRM_K3_LANES", lanes)
     iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
     chunks = [0, 1, 7, 100, 255, 256, 257, 3839, 5000, 9000, 1, 8191, 12000, 64, 63, 65, 1]
     assert run_stream((48000, 9600, 5000, 1, 2000, True), iq, chunks, 12000) > 0
@@ -325,36 +325,62 @@ def test_many_channel_batches_bit_exact(channels):
     g.close()
 
 
-def test_config_fanout_over_rccl_when_the_node_has_two_gpus():
-    """the only collective of the path is the broadcast of the channel table from rank 0 -- RCCL
-    (torch.distributed backend "nccl") on GPUs.  Needs two devices; the world-size-2 gloo test covers the logic on CPU."""
-    import subprocess
-    import sys
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("one GPU on this box: the RCCL fan-out needs two")
-    code = r"""
+_FANOUT_RANK = r"""
 import os, sys
 sys.path.insert(0, os.environ["SDRM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SDRM_ROOT"], "tests"))
 import numpy as np, torch, torch.distributed as dist
 import sdrm_pkg; sdrm_pkg.load()
 from sdr_modem_amd import binding, shard, siggen
 import orc
-rank = int(os.environ["RANK"]); torch.cuda.set_device(rank)
-dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+rank = int(os.environ["RANK"]); backend = os.environ["SDRM_TEST_BACKEND"]
+dev_index = rank % torch.cuda.device_count()     # gloo: the ranks share the box's devices
+torch.cuda.set_device(dev_index)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index)); coll = torch.device("cuda", dev_index)
+else:
+    dist.init_process_group(backend); coll = "cpu"
+# leg 1: equal-count shards of a 9-channel table (BASELINE configs[3] in miniature), every shard on the HIP path
 table = [(48000, 9600, 5000, 1, 2000, True, 4096)] * 5 + [(48000, 4800, 5000, 2, 2000, False, 4096)] * 4 if rank == 0 else None
-cfgs, lo, hi = shard.fanout_configs(table, 9, device=torch.device("cuda", rank))
-b = binding.Batch(cfgs, device=rank)
+cfgs, lo, hi = shard.fanout_configs(table, 9, device=coll)
+b = binding.Batch(cfgs, device=dev_index)
 sigs = [siggen.gmsk_channel(lo + i, 4096, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
 got = b.process(sigs)
 ok = all(np.array_equal(orc.demod_stream(c[:6], s, 4096)[0], g) for c, s, g in zip(cfgs, sigs, got))
+b.close()
+# leg 2: BASELINE configs[4] in miniature -- cost-balanced shards of a mixed-rate table, the call's Doppler batches planned
+# on rank 0 for the whole node and fanned out with the SAME partition; every rank corrects and demodulates its channels
+n = 6000
+mix = [(240000, 19200, 5000, 5, 2000, True, n)] * 4 + [(48000, 1200, 5000, 8, 2000, True, n)] * 12 if rank == 0 else None
+part = shard.fanout_configs(mix, 16, device=coll, balance="cost")
+segs0 = [(c, ln, f) for c in range(16) if c % 3 for ln, f in ((2500, 900 - 40 * c), (n - 2500, 905 - 40 * c))] if rank == 0 else None
+mine = shard.fanout_nco_segments(segs0, part, device=coll)
+b2 = binding.Batch(part.cfgs, device=dev_index)
+sig2 = [siggen.gmsk_channel(50 + part.lo + i, n, fs=c[0], baud=c[1]) for i, c in enumerate(part.cfgs)]
+got2 = b2.process_nco(sig2, mine)
+ok2 = len(mine) == 2 * sum(1 for c in range(part.lo, part.hi) if c % 3)
+for i, c in enumerate(part.cfgs):
+    gc = part.lo + i
+    x = sig2[i].view(np.float32)
+    if gc % 3:
+        osc = orc.Nco(1.0, c[0], n)
+        x = np.concatenate([osc.multiply(900 - 40 * gc, x[:5000]), osc.multiply(905 - 40 * gc, x[5000:])])
+    ok2 = ok2 and np.array_equal(orc.demod_stream(c[:6], x.view(np.complex64), n)[0], got2[i])
+b2.close()
 flags = [None, None]
-dist.all_gather_object(flags, (lo, hi, bool(ok)))
+dist.all_gather_object(flags, (lo, hi, bool(ok), part.lo, part.hi, bool(ok2)))
 dist.barrier(); dist.destroy_process_group()
 if rank == 0:
     assert flags[0][:2] == (0, 5) and flags[1][:2] == (5, 9) and flags[0][2] and flags[1][2], flags
+    # the four 240 kHz channels weigh as much as the twelve 48 kHz ones: the cost cut is not the middle of the table
+    assert flags[0][3] == 0 and flags[0][4] == flags[1][3] and flags[1][4] == 16 and flags[0][4] < 8, flags
+    assert flags[0][5] and flags[1][5], flags
 """
+
+
+def _two_ranks(code, extra_env):
     import socket
+    import subprocess
+    import sys
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -362,8 +388,55 @@ if rank == 0:
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SDRM_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env))
-    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    return [p.wait(timeout=900) for p in procs]
+
+
+def test_config_and_doppler_fanout_across_two_ranks_on_the_device():
+    """the only collectives of the path are the broadcast of the channel table from rank 0 and, with Doppler
+    correction, of the call's NCO batches.  Two ranks, each demodulating its shard on the HIP path against the oracle:
+    equal-count shards (configs[3] shape) and cost-balanced shards of a mixed-rate table with the NCO fan-out
+    (configs[4] shape).  Over RCCL (backend "nccl") when the node has two GPUs; on a one-GPU box the two ranks share
+    cuda:0 and rendezvous over gloo -- the same rank code, spawn and collectives, a functional run."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    assert _two_ranks(_FANOUT_RANK, {"SDRM_TEST_BACKEND": backend}) == [0, 0]
+
+
+def test_bench_with_two_ranks_runs_the_sharded_path(tmp_path):
+    """`python bench.py --gpus 2` the way a user (or the driver, through torch.distributed.run) starts it: the parent
+    spawns two fresh ranks before anything touches the GPU, rank 0 broadcasts the channel table, every rank runs its
+    shard, the timing is the maximum over ranks, and config3_sharded / config5_sharded repeat that for BASELINE
+    configs[3] and configs[4].  On a one-GPU box SDRM_BENCH_BACKEND=gloo lets the two ranks share cuda:0: functional,
+    not a measurement."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    if torch.cuda.device_count() < 2:
+        env["SDRM_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--no-cpu-baseline", "--sweep", "", "--channels-per-gpu", "64", "--chunks-resident", "2"],
+                         env=env, stdout=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.returncode
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config3_sharded"]["channels_total"] == 1024 and res["config3_sharded"]["value"] > 0
+    c5 = res["config5_sharded"]
+    assert c5["channels_total"] == 512 and c5["value"] > 0 and c5["balance"] == "cost"
+    assert sum(c5["channels_per_rank"]) == 512 and c5["channels_per_rank"][0] < 256  # the heavy channels come first
+    (tmp_path / "bench_gloo2.json").write_text(lines[0])
+    keep = os.environ.get("SDRM_KEEP_BENCH_LINE")  # tools/gpu_round3.sh keeps the line for profiles/
+    if keep:
+        with open(keep, "w") as f:
+            f.write(lines[0] + "\n")
 
 
 def test_mixed_batch_with_ragged_lengths():

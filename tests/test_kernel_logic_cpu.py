@@ -107,11 +107,11 @@ def test_ragged_chunks_cross_tiles_and_phases():
         assert run_both(cfg, iq, chunks, 12000) <= len(iq)
 
 
-@pytest.mark.parametrize("lanes", [16, 32, 64])
+@pytest.mark.parametrize("lanes", ["16", "32", "64", "16x512", "16x256", "32x256"])
 def test_clock_stage_workgroup_shapes(lanes, monkeypatch):
     """the clock stage's two workgroup shapes (16 channels x 256-sample steps, 64 x 64; SDRM_K3_LANES forces one) stage
     and drain the same samples: ragged chunks around both step sizes"""
-    monkeypatch.setenv("SDRM_K3_LANES", str(lanes))
+    monkeypatch.setenv("SDRM_K3_LANES", lanes)
     iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
     chunks = [0, 1, 7, 100, 255, 256, 257, 1023, 1024, 1025, 3839, 5000, 9000, 1, 8191, 12000, 64, 63, 65, 1]
     for cfg in [(48000, 9600, 5000, 1, 2000, True), (48000, 4800, 5000, 2, 2000, False)]:

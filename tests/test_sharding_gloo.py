@@ -27,8 +27,9 @@ def _worker(rank, world, port, ret):
     table = None
     if rank == 0:
         table = [(48000, 9600, 5000, 1, 2000, True, 4096)] * 4 + [(48000, 4800, 5000, 2, 2000, False, 4096)] * 3
-    cfgs, lo, hi = shard.fanout_configs(table, total)
-    ok = len(cfgs) == hi - lo
+    part = shard.fanout_configs(table, total)
+    cfgs, lo, hi = part
+    ok = len(cfgs) == hi - lo == len(part)
     e = emu_api.EmuBatch(cfgs)
     ok = ok and e.code == 0
     sigs = [siggen.gmsk_channel(lo + i, 4096, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
@@ -44,7 +45,7 @@ def _worker(rank, world, port, ret):
         for c in range(total):
             if c % 2 == 0:  # every other channel is corrected, in two batches
                 segs0 += [(c, 1000, 1500 - 100 * c), (c, n - 1000, 1490 - 100 * c)]
-    mine = shard.fanout_nco_segments(segs0, total)
+    mine = shard.fanout_nco_segments(segs0, part)
     ok = ok and all(0 <= ch < hi - lo for ch, _, _ in mine)
     ok = ok and sorted(set(ch + lo for ch, _, _ in mine)) == [c for c in range(lo, hi) if c % 2 == 0]
     e2 = emu_api.EmuBatch(cfgs)
@@ -60,7 +61,18 @@ def _worker(rank, world, port, ret):
     mix = None
     if rank == 0:
         mix = [(240000, 19200, 5000, 5, 2000, True, 4096)] * 6 + [(48000, 1200, 5000, 8, 2000, True, 4096)] * 18
-    cfgs_c, lo_c, hi_c = shard.fanout_configs(mix, 24, balance="cost")
+    part_c = shard.fanout_configs(mix, 24, balance="cost")
+    cfgs_c, lo_c, hi_c = part_c
+    # the NCO fan-out takes the partition itself: with a cost-balanced table every rank keeps the batches of exactly
+    # the channels it was given (equal-count cuts would hand rank 1 the batches of channels rank 0 demodulates)
+    segs_c = [(c, 4096, 100 * c) for c in range(24)] if rank == 0 else None
+    mine_c = shard.fanout_nco_segments(segs_c, part_c)
+    ok = ok and [(ch + lo_c, f) for ch, _, f in mine_c] == [(c, 100 * c) for c in range(lo_c, hi_c)]
+    try:
+        shard.fanout_nco_segments(segs_c, 24)
+        ok = False  # a bare channel count is no partition
+    except TypeError:
+        pass
     spans = [None] * world
     dist.all_gather_object(spans, (lo_c, hi_c, sum(shard.channel_cost(c) for c in cfgs_c)))
     ok = ok and spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 24
