@@ -216,7 +216,8 @@ def config5_table(total, chunk):
 
 def config5_segments(channels, chunk):
     """three NCO batches per channel and call on the channel's own Doppler ramp: (global_channel, len, freq_hz)"""
-    return [(c, n, -10000 + (80 * c) % 20000 + 500 * k) for c in channels for k, n in enumerate((40000, 40000, chunk - 80000))]
+    return np.array([(c, n, -10000 + (80 * c) % 20000 + 500 * k) for c in channels for k, n in enumerate((40000, 40000, chunk - 80000))],
+                    dtype=np.int64).reshape(-1, 3)
 
 
 def config5(torch, binding, siggen, dev, cfgs, chunk, steps=24, plan_step=None, local_rank=-1):
@@ -233,10 +234,10 @@ def config5(torch, binding, siggen, dev, cfgs, chunk, steps=24, plan_step=None, 
     st = torch.cuda.current_stream().cuda_stream
     lens = [chunk] * channels
 
+    lens_c = (binding.C.c_size_t * channels)(*lens)
+
     def step(i):
-        mine = plan_step()
-        segs = (binding.NcoSegment * max(len(mine), 1))(*[binding.NcoSegment(*s) for s in mine])
-        b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens, segs, st, n_segments=len(mine))
+        b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens_c, plan_step(), st)
     for i in range(4):
         step(i)
     torch.cuda.synchronize()
@@ -402,7 +403,7 @@ def main():
         part5 = shard.fanout_configs(table5, tot5, device=coll_dev, balance="cost")
         segs5 = config5_segments(range(tot5), N) if rank == 0 else None
         b5, x5, step5 = config5(torch, binding, siggen, dev, part5.cfgs, N,
-                                plan_step=lambda: shard.fanout_nco_segments(segs5, part5, device=coll_dev), local_rank=local_rank)
+                                plan_step=lambda: shard.fanout_nco_segments(segs5, part5, device=coll_dev, as_array=True, capacity=4 * tot5), local_rank=local_rank)
         steps5 = 24
         barrier()
         t0 = time.perf_counter()

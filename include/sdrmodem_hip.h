@@ -186,6 +186,10 @@ int sdrm_batch_timing_read(sdrm_batch *batch, int which, double *total_ms, uint6
 /* Stage probes for tests: run ONE stage of the device pipeline on a host vector (state-free where the
  * stage is). Return 0 on success. */
 int sdrm_probe_atan2(const float *y, const float *x, float *out, size_t n);
+/* the front-end's discriminator phase as the kernel runs it -- out[i] = gain * fast_atan2f(y[i] conj(y[i-1])) for a stream
+ * of n complex samples (interleaved re, im; y[-1] = 0), reference src/dsp/quadrature_demod.c:57-73 -- including the
+ * kernel's choice, per wave of 960 samples, between its short form and the general one (fast_waves[w], may be NULL) */
+int sdrm_probe_quad(const float *iq, size_t n, float gain, float *out, uint32_t *fast_waves);
 /* sums[i] / length as the DC blocker computes it (reference src/dsp/dc_blocker.c:63): three instructions with a fall-back
  * to the division proper for denormal / non-finite quotients; must equal the IEEE quotient bit for bit */
 int sdrm_probe_boxcar_div(const float *sums, uint32_t length, float *out, size_t n);

@@ -34,6 +34,9 @@ class NcoSegment(C.Structure):
     _fields_ = [("channel", C.c_uint32), ("len", C.c_uint32), ("freq_hz", C.c_int64)]
 
 
+NCO_DTYPE = np.dtype([("channel", "<u4"), ("len", "<u4"), ("freq_hz", "<i8")])  # sdrm_nco_segment
+assert NCO_DTYPE.itemsize == C.sizeof(NcoSegment)
+
 SHIFT_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_uint64)
 
 
@@ -58,7 +61,7 @@ EXPORTS = [
     "sdrm_wire_read_header", "sdrm_wire_decode_rx_request",
     "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
-    "sdrm_probe_atan2", "sdrm_probe_boxcar_div", "sdrm_version", "sdrm_device_count",
+    "sdrm_probe_atan2", "sdrm_probe_quad", "sdrm_probe_boxcar_div", "sdrm_version", "sdrm_device_count",
     "sdrm_batch_k3_stamps", "sdrm_batch_timeline",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
     "interrupt_waiting_the_data", "destroy_queue",
@@ -146,6 +149,7 @@ def load():
     L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sdrm_probe_atan2.argtypes = [vp, vp, vp, C.c_size_t]
     L.sdrm_probe_boxcar_div.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+    L.sdrm_probe_quad.argtypes = [vp, C.c_size_t, C.c_float, vp, vp]
     L.fsk_demod_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_uint8, C.c_uint32, C.c_bool, C.c_uint32,
                                    C.POINTER(vp)]
     L.fsk_demod_process.argtypes = [vp, C.c_size_t, C.POINTER(i8p), C.POINTER(C.c_size_t), vp]
@@ -299,16 +303,21 @@ class Batch:
         return out
 
     def process_device(self, d_ptr, in_stride, lens, stream=None):
-        arr = (C.c_size_t * self.n)(*[int(x) for x in lens])
+        arr = lens if isinstance(lens, C.Array) else (C.c_size_t * self.n)(*[int(x) for x in lens])
         code = self.L.sdrm_batch_process_device(self.h, C.c_void_p(d_ptr), in_stride, arr, C.c_void_p(stream or 0))
         if code != 0:
             raise RuntimeError("sdrm_batch_process_device failed: %d" % code)
 
     def process_device_nco(self, d_ptr, in_stride, lens, segments, stream=None, n_segments=None):
         """device-resident call with Doppler pre-correction; segments: ctypes array of NcoSegment (n_segments of it, all
-        by default) or list of tuples"""
-        arr = (C.c_size_t * self.n)(*[int(x) for x in lens])
-        if not isinstance(segments, C.Array):
+        by default), an (n, 3) integer numpy array or a list of (channel, len, freq_hz) tuples"""
+        arr = lens if isinstance(lens, C.Array) else (C.c_size_t * self.n)(*[int(x) for x in lens])
+        if isinstance(segments, np.ndarray):  # (n, 3) integers: channel, len, freq_hz -- packed without a Python loop
+            n_segments = len(segments)
+            packed = np.zeros(max(n_segments, 1), dtype=NCO_DTYPE)
+            packed["channel"][:n_segments], packed["len"][:n_segments], packed["freq_hz"][:n_segments] = segments[:, 0], segments[:, 1], segments[:, 2]
+            segments = packed.ctypes.data_as(C.POINTER(NcoSegment))
+        elif not isinstance(segments, C.Array):
             n_segments = len(segments)
             segments = (NcoSegment * max(len(segments), 1))(*[NcoSegment(*t) for t in segments])
         code = self.L.sdrm_batch_process_device_nco(self.h, C.c_void_p(d_ptr), in_stride, arr, segments,

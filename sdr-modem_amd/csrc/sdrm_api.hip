@@ -448,6 +448,10 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.dc_lds = (uint32_t) pl.dc_lds_bytes();
     d.any_dc = any_dc;
     d.fast_fma = (flags & SDRM_FLAG_FAST_FMA) ? 1 : 0;
+    {
+        const char *q = getenv("SDRM_K1_QUAD");
+        d.quad_flat = (q != nullptr && strcmp(q, "flat") == 0) ? 1 : 0;
+    }
     b->in_stride = pl.in_stride;
     *out = b;
     return 0;
@@ -1578,6 +1582,38 @@ extern "C" int sdrm_probe_atan2(const float *y, const float *x, float *out, size
     (void) hipFree(dx);
     (void) hipFree(dt);
     (void) hipFree(dout);
+    return 0;
+}
+
+// the front-end's discriminator phase as the kernel runs it (short form with its per-wave fall-back): out[i] = gain *
+// fast_atan2f(y[i] conj(y[i-1])) for a stream of n complex samples y (y[-1] = 0); fast_waves (may be NULL) receives one
+// word per 960 samples: did that wave take the short form
+extern "C" int sdrm_probe_quad(const float *iq, size_t n, float gain, float *out, uint32_t *fast_waves) {
+    if (sdrm_device_count() <= 0) {
+        fprintf(stderr, "<3>sdrmodem_hip: no HIP device available\n");
+        return -ENODEV;
+    }
+    const size_t waves = (n + 64 * SDRM_K1_R - 1) / (64 * SDRM_K1_R) + 4;
+    sdrm_f2 *dy = nullptr;
+    float *dt = nullptr, *dout = nullptr;
+    uint32_t *df = nullptr;
+    HIP_TRY(hipMalloc((void **) &dy, n * 8 + 8));
+    HIP_TRY(hipMalloc((void **) &dout, n * 4 + 4));
+    HIP_TRY(hipMalloc((void **) &dt, 260 * 4));
+    HIP_TRY(hipMalloc((void **) &df, waves * 4));
+    HIP_TRY(hipMemset(df, 0, waves * 4));
+    HIP_TRY(hipMemcpy(dy, iq, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dt, sdrm_atan_tab, 257 * 4, hipMemcpyHostToDevice));
+    sdrm::launch_probe_quad(dy, n, gain, dt, dout, df, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    if (fast_waves != nullptr) {
+        HIP_TRY(hipMemcpy(fast_waves, df, ((n + 64 * SDRM_K1_R - 1) / (64 * SDRM_K1_R)) * 4, hipMemcpyDeviceToHost));
+    }
+    (void) hipFree(dy);
+    (void) hipFree(dt);
+    (void) hipFree(dout);
+    (void) hipFree(df);
     return 0;
 }
 

@@ -281,14 +281,60 @@ SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) {
 }
 #endif
 
+// one step of K taps of sdrm_fir_block_rp (below): window of N + K - 1 samples from xs + j0, as even- and odd-aligned pairs
+template <int N, int K, bool FUSED>
+SDRM_HD void sdrm_fir_step_rp(const float *xs, const float *xo, const float *taps, int j0, sdrm_v2 (&pa)[N / 2], float &tail) {
+    constexpr int P = N / 2;
+    constexpr int W = N + K - 1;  // window floats per step
+    sdrm_v2 we[(W + 1) / 2], wo[(W + 1) / 2];
+#pragma unroll
+    for (int k = 0; 2 * k + 1 < W; k++) {
+        we[k] = sdrm_v2_make(xs[j0 + 2 * k], xs[j0 + 2 * k + 1]);
+    }
+    if (W & 1) {
+        we[W / 2] = sdrm_v2_make(xs[j0 + W - 1], 0.0f);  // the window's last sample when it has no partner (only .x is used)
+    }
+#pragma unroll
+    for (int k = 0; 2 * k + 2 < W; k++) {
+        wo[k] = sdrm_v2_make(xo[j0 + 2 * k], xo[j0 + 2 * k + 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < K; u++) {
+        const float tp = taps[j0 + u];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const int i = 2 * p + u;
+            pa[p] = sdrm_v2_mac<FUSED>(pa[p], (i & 1) ? wo[i / 2] : we[i / 2], tp);
+        }
+        if (N & 1) {
+            const int i = N - 1 + u;
+            const float x = (i & 1) ? we[i / 2].y : we[i / 2].x;
+            tail = sdrm_mac<FUSED>(tail, x, tp);
+        }
+    }
+}
+
+// the `rest` < K taps left after the last whole step: one step of exactly that many (REST counts down to the match)
+template <int N, int REST, bool FUSED>
+SDRM_HD void sdrm_fir_rest_rp(const float *xs, const float *xo, const float *taps, int j0, int rest, sdrm_v2 (&pa)[N / 2], float &tail) {
+    if constexpr (REST > 0) {
+        if (rest == REST) {
+            sdrm_fir_step_rp<N, REST, FUSED>(xs, xo, taps, j0, pa, tail);
+        } else {
+            sdrm_fir_rest_rp<N, REST - 1, FUSED>(xs, xo, taps, j0, rest, pa, tail);
+        }
+    }
+}
+
 // The same real FIR block with neighbouring outputs paired: (acc[2p], acc[2p+1]) += (x[2p+u], x[2p+u+1]) * tap, one
 // packed multiply and one packed add per pair and tap (half the VALU instructions of sdrm_fir_block_r; per output the
 // operations and their order are unchanged).  The window is kept twice, as even-aligned pairs (x[2k], x[2k+1]) and as
 // odd-aligned pairs (x[2k+1], x[2k+2]), so that every pair operand is a register pair whatever the tap's parity.
+// The taps left over after the last whole step of K take one shorter step of the same form (round 2 ran them unpacked:
+// 3 of the 57 taps of the 9600-baud filter at two instructions per output instead of one).
 template <int N, int K, bool FUSED = false>
 SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, float (&acc)[N]) {
     constexpr int P = N / 2;
-    constexpr int W = N + K - 1;  // window floats per step
     sdrm_v2 pa[P];
 #pragma unroll
     for (int p = 0; p < P; p++) {
@@ -305,30 +351,9 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
     const float *xo = xs + one;
     int j0 = 0;
     for (; j0 + K <= ntaps; j0 += K) {
-        sdrm_v2 we[(W + 1) / 2], wo[(W + 1) / 2];
-#pragma unroll
-        for (int k = 0; 2 * k + 1 < W; k++) {
-            we[k] = sdrm_v2_make(xs[j0 + 2 * k], xs[j0 + 2 * k + 1]);
-        }
-#pragma unroll
-        for (int k = 0; 2 * k + 2 < W; k++) {
-            wo[k] = sdrm_v2_make(xo[j0 + 2 * k], xo[j0 + 2 * k + 1]);
-        }
-#pragma unroll
-        for (int u = 0; u < K; u++) {
-            const float tp = taps[j0 + u];
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                const int i = 2 * p + u;
-                pa[p] = sdrm_v2_mac<FUSED>(pa[p], (i & 1) ? wo[i / 2] : we[i / 2], tp);
-            }
-            if (N & 1) {
-                const int i = N - 1 + u;
-                const float x = (i & 1) ? we[i / 2].y : we[i / 2].x;
-                tail = sdrm_mac<FUSED>(tail, x, tp);
-            }
-        }
+        sdrm_fir_step_rp<N, K, FUSED>(xs, xo, taps, j0, pa, tail);
     }
+    sdrm_fir_rest_rp<N, K - 1, FUSED>(xs, xo, taps, j0, ntaps - j0, pa, tail);
 #pragma unroll
     for (int p = 0; p < P; p++) {
         acc[2 * p] = pa[p].x;
@@ -336,13 +361,6 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
     }
     if (N & 1) {
         acc[N - 1] = tail;
-    }
-    for (; j0 < ntaps; j0++) {
-        const float tp = taps[j0];
-#pragma unroll
-        for (int r = 0; r < N; r++) {
-            acc[r] = sdrm_mac<FUSED>(acc[r], xs[j0 + r], tp);
-        }
     }
 }
 
@@ -419,17 +437,129 @@ SDRM_HD void sdrm_k1_phase_lpf1(int tid, const sdrm_k1_tile &t, const sdrm_chan_
     bnd[tid] = regs.y[SDRM_K1_R - 1];
 }
 
+// ---- quadrature demod, the short form (device only).
+// sdrm_quad_sample_flat costs 41 vector instructions per sample, 11 of them one IEEE division.  The front-end is bound by
+// vector-instruction issue, so this phase is rewritten for the common case and keeps the flat form as the fall-back:
+//  * the division.  The compiler's expansion of a / b is v_div_scale x 2, v_rcp, SEVEN fused operations (one Newton step
+//    on the reciprocal, the quotient, two residual corrections), v_div_fmas, v_div_fixup.  Its first and last three
+//    instructions only act when an operand or the quotient is near the ends of the exponent range (v_div_scale leaves both
+//    operands as they are unless the denominator is denormal, 1/b or a/b is denormal, the exponents are 96 or more apart or
+//    the numerator is below 2^-103; v_div_fmas is then a plain FMA and v_div_fixup returns its first operand).  With
+//    2^-60 <= a <= b <= 2^60 -- checked for the thread's samples at once on the bit patterns, 0.5 instructions per
+//    sample and bound -- the seven fused operations on the unscaled operands ARE that division, and they pack: two
+//    samples per v_pk_fma_f32 / v_pk_mul_f32 (component-wise, each rounded as the scalar instruction rounds).
+//    a == 0 (a sample on an axis: real-valued test input, silence), tiny, huge, infinite and NaN operands fail the check;
+//    the whole wave then takes the flat form for this tile.  The host emulation always takes the flat form: both compute
+//    the correctly rounded quotient.
+//  * x[n] conj(x[n-1]) is three packed instructions (a c, b c | b d, a d | sum with the second imaginary term negated)
+//    instead of six: re = fl(fl(a c) + fl(b d)), im = fl(fl(b c) - fl(a d)) as in the reference (quadrature_demod.c:65).
+//  * the table entry and the difference to its successor come from a table of pairs {tab[i], fl(tab[i+1] - tab[i])}
+//    (the reference's subtraction, fast_atan2f.c:118, done once per workgroup instead of once per sample).
+//  * octant fix-up: every octant's result is offset + (+-base) (see sdrm_fast_atan2f_flat); here the offset is
+//    copysign(wide ? (x >= 0 ? 0 : pi) : pi/2, y >= 0 ? + : -).  That differs from the flat form's table in one entry, +0
+//    instead of -0 for x >= 0, y >= 0, |x| > |y|, where the other term is +base with base >= +0: (-0) + (+0) and
+//    (+0) + (+0) are both +0, and for base > 0 the zero's sign is irrelevant.  The `>= 0` tests stay float compares: the
+//    reference treats -0 as non-negative (fast_atan2f.c:131-155), and x[n] conj(x[n-1]) does produce -0 (real input).
+//  * the flat form's guard `ya > 0 || xa > 0` is true whenever the range check passes (b >= 2^-60).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDRM_QUAD_LO_BITS 0x21800000u  // 2^-60
+#define SDRM_QUAD_HI_BITS 0x5d800000u  // 2^60
+SDRM_HD sdrm_v2 sdrm_v2_fma(sdrm_v2 a, sdrm_v2 b, sdrm_v2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// x[n] conj(x[n-1]) = (a + ib)(c - id): (a c, b c), (b d, a d), then (a c + b d, b c - a d) -- three packed instructions
+SDRM_HD sdrm_v2 sdrm_cmul_conj_pk(sdrm_v2 cur, sdrm_v2 pv) {
+    sdrm_v2 p1, p2, ri;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p1) : "v"(cur), "v"(pv));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(p2) : "v"(cur), "v"(pv));
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(ri) : "v"(p1), "v"(p2));
+    return ri;
+}
+
+// q[r] for the thread's R samples; false when some operand is outside the range the short division covers
+typedef const __attribute__((address_space(3))) float *sdrm_lds_cf;
+template <int R>
+SDRM_HD bool sdrm_quad_block_fast(const sdrm_f2 (&y)[R], sdrm_f2 prev, float gain, sdrm_lds_cf tab2, float (&q)[R]) {
+    float re[R + 1], im[R + 1];
+    sdrm_v2 pv = sdrm_v2_make(prev.x, prev.y);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const sdrm_v2 cur = sdrm_v2_make(y[r].x, y[r].y);
+        const sdrm_v2 ri = sdrm_cmul_conj_pk(cur, pv);
+        re[r] = ri.x;
+        im[r] = ri.y;
+        pv = cur;
+    }
+    re[R] = re[R - 1];  // pad to whole pairs (R is odd)
+    im[R] = im[R - 1];
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int r = 0; r < R + 1; r += 2) {
+        float a[2], b[2];
+        bool wide[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const float xa = fabsf(re[r + k]), ya = fabsf(im[r + k]);
+            wide[k] = xa > ya;
+            a[k] = wide[k] ? ya : xa;
+            b[k] = wide[k] ? xa : ya;
+            lo = min(lo, sdrm_bits(a[k]));
+            hi = max(hi, sdrm_bits(b[k]));
+        }
+        const sdrm_v2 A = sdrm_v2_make(a[0], a[1]), B = sdrm_v2_make(b[0], b[1]);
+        const sdrm_v2 one = sdrm_v2_make(1.0f, 1.0f);
+        const sdrm_v2 y0 = sdrm_v2_make(__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1]));
+        const sdrm_v2 e = sdrm_v2_fma(-B, y0, one);
+        const sdrm_v2 y1 = sdrm_v2_fma(e, y0, y0);
+        const sdrm_v2 q0 = A * y1;
+        const sdrm_v2 r0 = sdrm_v2_fma(-B, q0, A);
+        const sdrm_v2 q1 = sdrm_v2_fma(r0, y1, q0);
+        const sdrm_v2 r1 = sdrm_v2_fma(-B, q1, A);
+        const sdrm_v2 z = sdrm_v2_fma(r1, y1, q1);
+        const sdrm_v2 al = z * sdrm_v2_make(255.0f, 255.0f);
+        float base[2], off[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const float zk = k ? z.y : z.x, alk = k ? al.y : al.x;
+            int idx;
+            asm("v_cvt_i32_f32 %0, %1" : "=v"(idx) : "v"(alk));
+            const float frac = __builtin_amdgcn_fractf(alk);
+            const float t0 = tab2[2 * idx], d = tab2[2 * idx + 1];
+            const float interp = t0 + d * frac;
+            base[k] = (zk < sdrm_from_bits(SDRM_TAN_MAP_RES_UP_BITS)) ? zk : interp;
+            const bool xp = re[r + k] >= 0.0f, yp = im[r + k] >= 0.0f;
+            const float pi_f = 3.14159265358979323846f, half_pi_f = 1.57079632679489661923f;
+            const float mag = wide[k] ? (xp ? 0.0f : pi_f) : half_pi_f;
+            off[k] = yp ? mag : -mag;
+            const bool flip = (xp != yp) != !wide[k];
+            base[k] = flip ? -base[k] : base[k];
+        }
+        const sdrm_v2 ang = sdrm_v2_make(off[0], off[1]) + sdrm_v2_make(base[0], base[1]);
+        const sdrm_v2 out = sdrm_v2_make(gain, gain) * ang;
+        q[r] = out.x;
+        if (r + 1 < R) {
+            q[r + 1] = out.y;
+        }
+    }
+    return lo >= SDRM_QUAD_LO_BITS && hi <= SDRM_QUAD_HI_BITS;
+}
+#endif
+
 // phase 2: quadrature demod (reference src/dsp/quadrature_demod.c:57-73) into LDS.  qs[-1] must be a valid slot: sample
 // k of the tile goes to qs[k], and the tile's first thread also writes its k = -1 (the predecessor-less sample nobody
 // reads); every thread stores all of its R samples -- positions past the tile's last needed sample (nq) hold finite
 // values nobody reads either, and NY - 2 < NY + QPAD -- so the stores are one base address plus constants and no
 // per-sample predicate (which also made the compiler sink half of the arctangent, with its constants re-made per sample,
 // into fifteen predicated blocks: 51 -> 40 vector instructions per sample).
-SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *tab,
+// tab2 (device only; nullptr on the host): the table of {entry, difference} pairs of the short form above.
+SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *tab, const float *tab2,
                                 const sdrm_f2 *bnd, const sdrm_k1_regs &regs, float *qs) {
     (void) t;
+    (void) tab2;
+    // the tile's first thread has no predecessor in the tile: its sample k = -1 is the one nobody reads, and its value
+    // does not matter -- (1, 0) rather than zero keeps it inside the short form's range (a zero product would send the
+    // wave, a quarter of all waves, to the general form)
     sdrm_f2 prev;
-    prev.x = 0.0f;
+    prev.x = 1.0f;
     prev.y = 0.0f;
     if (tid > 0) {
         prev = bnd[tid - 1];
@@ -439,9 +569,22 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
     asm volatile("" : "+s"(zero));  // keeps the table's LDS address one scalar (else: base + constant, an add per sample)
     tab += zero;
 #endif
+    float q[SDRM_K1_R];
+    float *dst = qs + tid * SDRM_K1_R - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // LDS-typed, opaque copy of the pair table's address: one scalar, reached with the index shifted in (v_lshl_add)
+    sdrm_lds_cf tab2_l = (sdrm_lds_cf) tab2;
+    asm volatile("" : "+s"(tab2_l));
+    if (tab2 != nullptr && __all(sdrm_quad_block_fast<SDRM_K1_R>(regs.y, prev, p.quad_gain, tab2_l, q))) {
+#pragma unroll
+        for (int r = 0; r < SDRM_K1_R; r++) {
+            dst[r] = q[r];
+        }
+        return;
+    }
+#endif
     // all of the thread's samples (threads past the tile's end hold zeros): fifteen independent chains the compiler can
     // interleave, so that the table reads and the reciprocals wait for each other's work
-    float q[SDRM_K1_R];
 #pragma unroll
     for (int r = 0; r < SDRM_K1_R; r++) {
         sdrm_f2 cur = regs.y[r];
@@ -456,7 +599,6 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
         q[r] = sdrm_quad_sample_flat(cur, prev, p.quad_gain, tab);
         prev = cur;
     }
-    float *dst = qs + tid * SDRM_K1_R - 1;
 #pragma unroll
     for (int r = 0; r < SDRM_K1_R; r++) {
         dst[r] = q[r];

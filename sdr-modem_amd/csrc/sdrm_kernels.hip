@@ -258,7 +258,7 @@ size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) {
     // the quadrature-demod tile (NY + pad floats) reuses the raw-IQ tile's space: LPF1 is done with it by then
     size_t xs = SDRM_K1_XS_BYTES(t1_max);
     size_t bnd = (size_t) SDRM_K1_THREADS * sizeof(sdrm_f2);
-    size_t tab = 260 * sizeof(float);
+    size_t tab = (260 + 512) * sizeof(float);  // the arctangent table, and the same as {entry, difference} pairs
     // both filters' taps, staged per workgroup: read from LDS next to the samples instead of waited for from global
     // memory inside the tap loop
     size_t taps = (size_t) (((t1_max + 3) & ~3u) + ((t2_max + 3) & ~3u) + 8) * sizeof(float);
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     // The taps go to LDS as well.  Their loads are issued BEFORE the tile's (short filters: up to three values per
     // thread held in registers), so that one wait covers both; long filters take the plain loop afterwards.
-    float *taps1 = tab + 260, *taps2 = taps1 + ((p.T1 + 3) & ~3u);  // 16-byte aligned (tab starts aligned, 260 % 4 == 0)
+    float *tab2 = tab + 260;  // {tab[i], tab[i+1] - tab[i]}, i < 256 (sdrm_quad_block_fast)
+    float *taps1 = tab2 + 512, *taps2 = taps1 + ((p.T1 + 3) & ~3u);  // 16-byte aligned (tab starts aligned, 260 % 4 == 0)
     const bool short_taps = p.T1 <= 2 * SDRM_K1_THREADS && p.T2 <= SDRM_K1_THREADS;
     float tv0 = 0.0f, tv1 = 0.0f, tv2 = 0.0f;
     if (short_taps) {
@@ -306,6 +307,11 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
         if ((uint32_t) tid < p.T2) tv2 = b.tap_pool[p.taps2_off + tid];
     }
     sdrm_k1_phase_load(tid, t, in, hist, (int) p.hist_len, b.atan_tab, xs, tab);
+    {
+        const float t0 = b.atan_tab[tid], t1 = b.atan_tab[tid + 1];  // 256 threads, 257 entries
+        tab2[2 * tid] = t0;
+        tab2[2 * tid + 1] = t1 - t0;  // the reference's subtraction (fast_atan2f.c:118), once per workgroup
+    }
     if (short_taps) {
         if ((uint32_t) tid < p.T1) taps1[tid] = tv0;
         if ((uint32_t) tid + SDRM_K1_THREADS < p.T1) taps1[tid + SDRM_K1_THREADS] = tv1;
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     sdrm_k1_phase_lpf1<FUSED>(tid, t, p, taps1, xs, bnd, regs);
     __syncthreads();
     unsigned long long t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    sdrm_k1_phase_quad(tid, t, p, tab, bnd, regs, qs);
+    sdrm_k1_phase_quad(tid, t, p, tab, b.quad_flat ? nullptr : tab2, bnd, regs, qs);
     __syncthreads();
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_lpf2<FUSED>(tid, t, p, taps2, qs, zs, b.nonfinite + c);
@@ -1730,6 +1736,65 @@ __global__ void probe_boxcar_div(const float *sums, float len_f, float inv_len, 
     if (i < n) {
         out[i] = v;
     }
+}
+
+// the front-end's discriminator phase on a stream of LPF1 outputs: thread t takes samples [15 t, 15 t + 15) with sample
+// 15 t - 1 as its predecessor (zero in front of the stream), the work of sdrm_k1_phase_quad; fast[wave] = the wave took
+// the short form (sdrm_quad_block_fast) rather than the flat fall-back
+__global__ __launch_bounds__(256) void probe_quad(const sdrm_f2 *y, size_t n, float gain, const float *atan_tab, float *out,
+                                                  uint32_t *fast) {
+    __shared__ __attribute__((aligned(16))) float tab[260];
+    __shared__ __attribute__((aligned(16))) float tab2[512];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 257; k += 256) {
+        tab[k] = atan_tab[k];
+    }
+    tab2[2 * tid] = atan_tab[tid];
+    tab2[2 * tid + 1] = atan_tab[tid + 1] - atan_tab[tid];
+    __syncthreads();
+    const size_t base = ((size_t) blockIdx.x * 256 + tid) * SDRM_K1_R;
+    sdrm_k1_regs regs;
+#pragma unroll
+    for (int r = 0; r < SDRM_K1_R; r++) {
+        regs.y[r].x = regs.y[r].y = 0.0f;
+        if (base + r < n) {
+            regs.y[r] = y[base + r];
+        }
+    }
+    sdrm_f2 prev;
+    prev.x = prev.y = 0.0f;
+    if (base > 0 && base - 1 < n) {
+        prev = y[base - 1];
+    }
+    float q[SDRM_K1_R];
+    bool ok = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sdrm_lds_cf tab2_l = (sdrm_lds_cf) tab2;
+    asm volatile("" : "+s"(tab2_l));
+    ok = __all(sdrm_quad_block_fast<SDRM_K1_R>(regs.y, prev, gain, tab2_l, q));
+#endif
+    if (!ok) {
+        sdrm_f2 pv = prev;
+#pragma unroll
+        for (int r = 0; r < SDRM_K1_R; r++) {
+            q[r] = sdrm_quad_sample_flat(regs.y[r], pv, gain, tab);
+            pv = regs.y[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < SDRM_K1_R; r++) {
+        if (base + r < n) {
+            out[base + r] = q[r];
+        }
+    }
+    if ((tid & 63) == 0) {
+        fast[blockIdx.x * 4 + (tid >> 6)] = ok ? 1u : 0u;
+    }
+}
+
+void launch_probe_quad(const sdrm_f2 *d_y, size_t n, float gain, const float *d_tab, float *d_out, uint32_t *d_fast, hipStream_t s) {
+    const unsigned blocks = (unsigned) ((n + 256 * SDRM_K1_R - 1) / (256 * SDRM_K1_R));
+    hipLaunchKernelGGL(probe_quad, dim3(blocks ? blocks : 1), dim3(256), 0, s, d_y, n, gain, d_tab, d_out, d_fast);
 }
 
 void launch_probe_boxcar_div(const float *d_sums, uint32_t length, float *d_out, size_t n, hipStream_t s) {

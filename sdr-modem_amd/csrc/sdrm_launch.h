@@ -48,6 +48,7 @@ struct DeviceBatch {
     uint32_t dc_group, dc_rpitch;    // channels per DC workgroup, floats between two of its delay rings in LDS
     uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
+    int quad_flat;                   // measurements (SDRM_K1_QUAD=flat): the discriminator always takes its general form
     int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching
 };
@@ -86,6 +87,7 @@ unsigned clock_workgroups(const DeviceBatch &b);
 
 // test probes
 void launch_probe_boxcar_div(const float *d_sums, uint32_t length, float *d_out, size_t n, hipStream_t s);
+void launch_probe_quad(const sdrm_f2 *d_y, size_t n, float gain, const float *d_tab, float *d_out, uint32_t *d_fast, hipStream_t s);
 void launch_probe_atan2(const float *d_y, const float *d_x, const float *d_tab, float *d_out, size_t n, hipStream_t s);
 
 }  // namespace sdrm

@@ -140,27 +140,48 @@ def fanout_configs(cfgs_rank0, total, device="cpu", balance="count"):
     return Shard(decode(table[lo:hi].cpu()), lo, hi, total, world, rank, balance)
 
 
-def fanout_nco_segments(segments_rank0, shard, device="cpu"):
+def fanout_nco_segments(segments_rank0, shard, device="cpu", as_array=False, capacity=None):
     """Doppler pre-correction at node scale: rank 0 runs the orbit model and the planner for every channel
-    of the node and holds the call's NCO batches as (global_channel, len, freq_hz), grouped by channel; one broadcast
-    (a count, then an int64 table -- RCCL on GPUs, KB-sized) gives every rank the batches of its own channels, with
-    the channel index rebased to the rank's shard.  `shard` is what fanout_configs returned on this rank (required: the
-    batches kept are those of exactly the channels the rank was given).  Returns [(local_channel, len, freq_hz)]."""
+    of the node and holds the call's NCO batches as (global_channel, len, freq_hz), grouped by channel -- a list of
+    tuples or an (n, 3) int64 array; a broadcast (RCCL on GPUs, KB-sized) gives every rank the batches of its own
+    channels, with the channel index rebased to the rank's shard.  `shard` is what fanout_configs returned on this rank
+    (required: the batches kept are those of exactly the channels the rank was given).  With `capacity` (rows, agreed
+    by all ranks at setup) the count travels in row 0 of ONE fixed-size table -- one collective per call; without it a
+    count is broadcast first.  Returns [(local_channel, len, freq_hz)], or with as_array the same as an (m, 3) int64
+    numpy array (what binding.Batch.process_device_nco takes without a Python loop: this runs before every call)."""
+    import numpy as np
     if not isinstance(shard, Shard):
         raise TypeError("fanout_nco_segments needs the Shard returned by fanout_configs")
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    count = torch.zeros(1, dtype=torch.int64, device=device)
+    rows0 = None
     if rank == 0:
-        count[0] = len(segments_rank0)
-    if world > 1:
-        dist.broadcast(count, src=0)
-    n = int(count.item())
-    table = torch.zeros((max(n, 1), 3), dtype=torch.int64, device=device)
-    if rank == 0 and n:
-        table[:n].copy_(torch.tensor([[int(c), int(ln), int(f)] for c, ln, f in segments_rank0], dtype=torch.int64))
-    if world > 1:
-        dist.broadcast(table, src=0)
-    lo, hi = shard.lo, shard.hi
-    rows = table[:n].cpu().tolist()
-    return [(int(c) - lo, int(ln), int(f)) for c, ln, f in rows if lo <= c < hi]
+        rows0 = np.ascontiguousarray(np.asarray(segments_rank0, dtype=np.int64).reshape(-1, 3))
+        if capacity is not None and len(rows0) > capacity:
+            raise ValueError("%d NCO batches exceed the agreed capacity of %d" % (len(rows0), capacity))
+    if capacity is not None:
+        table = torch.zeros((capacity + 1, 3), dtype=torch.int64, device=device)
+        if rank == 0:
+            table[0, 0] = len(rows0)
+            if len(rows0):
+                table[1:1 + len(rows0)].copy_(torch.from_numpy(rows0))
+        if world > 1:
+            dist.broadcast(table, src=0)
+        host = table.cpu().numpy()
+        rows = host[1:1 + int(host[0, 0])]
+    else:
+        count = torch.zeros(1, dtype=torch.int64, device=device)
+        if rank == 0:
+            count[0] = len(rows0)
+        if world > 1:
+            dist.broadcast(count, src=0)
+        n = int(count.item())
+        table = torch.zeros((max(n, 1), 3), dtype=torch.int64, device=device)
+        if rank == 0 and n:
+            table[:n].copy_(torch.from_numpy(rows0))
+        if world > 1:
+            dist.broadcast(table, src=0)
+        rows = table[:n].cpu().numpy()
+    mine = rows[(rows[:, 0] >= shard.lo) & (rows[:, 0] < shard.hi)].copy()
+    mine[:, 0] -= shard.lo
+    return mine if as_array else [(int(c), int(ln), int(f)) for c, ln, f in mine.tolist()]

@@ -108,7 +108,7 @@ static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
                 sdrm_k1_phase_lpf1(tid, t, p, pl.tap_pool.data() + p.taps1_off, xs.data(), bnd.data(), regs[tid]);
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
-                sdrm_k1_phase_quad(tid, t, p, tab.data(), bnd.data(), regs[tid], qs.data() + 1);
+                sdrm_k1_phase_quad(tid, t, p, tab.data(), nullptr, bnd.data(), regs[tid], qs.data() + 1);
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)
                 sdrm_k1_phase_lpf2(tid, t, p, pl.tap_pool.data() + p.taps2_off, qs.data() + 1, zs.data(), &b->nonfinite[c]);
             for (int tid = 0; tid < SDRM_K1_THREADS; tid++)

@@ -70,6 +70,53 @@ def test_probe_fast_atan2_bit_exact():
     assert np.array_equal(np.isnan(out), np.isnan(want))
 
 
+def test_probe_discriminator_short_form_and_its_fall_back():
+    """The front-end evaluates x[n] conj(x[n-1]) -> fast_atan2f -> gain (reference src/dsp/quadrature_demod.c:57-73) in a
+    short form -- the division as the seven fused operations of the IEEE expansion without its range scaling, packed two
+    samples per instruction -- whenever every operand of a wave lies in [2^-60, 2^60], and in the general form otherwise.
+    Streams over thirty decades of amplitude (both forms get whole waves), amplitudes at the range's two ends, real-valued
+    input (every sample on an axis: a zero numerator), zeros, signed zeros, denormals, Inf and NaN: the oracle's floats,
+    bit for bit, and both forms really taken."""
+    L = binding.load()
+    rng = np.random.default_rng(2026)
+    wave = 64 * 15
+    parts = []
+    for k in range(220):  # one amplitude per wave of 960 samples
+        amp = np.float32(10.0 ** rng.uniform(-16, 16))
+        parts.append(((rng.standard_normal(wave) + 1j * rng.standard_normal(wave)) * amp).astype(np.complex64))
+    for e in (-31, -30, -29, 29, 30, 31):  # products next to 2^-60 and 2^60
+        parts.append(((rng.standard_normal(wave) + 1j * rng.standard_normal(wave)) * np.float32(2.0 ** e)).astype(np.complex64))
+    ramp = np.zeros(wave, np.complex64)
+    ramp.real = (np.arange(wave) % 256).astype(np.float32) - 77.0   # the reference's perf input, shifted through zero
+    parts.append(ramp)
+    odd = (rng.standard_normal(wave) + 1j * rng.standard_normal(wave)).astype(np.complex64)
+    odd[5] = 0
+    odd[6] = complex(-0.0, 0.0)
+    odd[7] = complex(0.0, -0.0)
+    odd[100] = complex(np.nan, 1.0)
+    odd[200] = complex(1.0, np.inf)
+    odd[300] = complex(1e-41, -1e-42)
+    odd[301] = complex(-1e-39, 1e-45)
+    odd[400] = complex(3e38, -3e38)
+    parts.append(odd)
+    parts.append((rng.standard_normal(wave) + 1j * rng.standard_normal(wave)).astype(np.complex64))  # a clean wave behind it
+    y = np.concatenate(parts)
+    n = len(y)
+    gain = np.float32(1.5278874)
+    out = np.zeros(n, np.float32)
+    fast = np.zeros((n + wave - 1) // wave, np.uint32)
+    assert L.sdrm_probe_quad(y.view(np.float32).ctypes.data, n, gain, out.ctypes.data, fast.ctypes.data) == 0
+    with np.errstate(all="ignore"):
+        want = orc.Quad(float(gain), n).process(y.view(np.float32))
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(out), nan)
+    assert np.array_equal(out.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+    # amplitudes 1e-8 .. 1e8 have every |re|, |im| product inside the range (barring a sample on an axis): short form;
+    # the real-valued wave, the odd one and the extreme decades: general form
+    assert 60 < int(fast.sum()) < len(fast) - 20, (int(fast.sum()), len(fast))
+    assert fast[-1] == 1 and fast[-2] == 0 and fast[-3] == 0
+
+
 @pytest.mark.parametrize("length", [32, 80, 154, 160, 400, 1280, 3968])
 def test_probe_boxcar_quotient_is_the_ieee_division(length):
     """the DC blocker's `sum / L` (reference src/dsp/dc_blocker.c:63) as the kernel computes it: reciprocal multiply + two

@@ -67,6 +67,8 @@ def _worker(rank, world, port, ret):
     # the channels it was given (equal-count cuts would hand rank 1 the batches of channels rank 0 demodulates)
     segs_c = [(c, 4096, 100 * c) for c in range(24)] if rank == 0 else None
     mine_c = shard.fanout_nco_segments(segs_c, part_c)
+    one_shot = shard.fanout_nco_segments(np.array(segs_c) if rank == 0 else None, part_c, as_array=True, capacity=40)
+    ok = ok and one_shot.tolist() == [list(t) for t in mine_c]  # one fixed-size collective per call: the same batches
     ok = ok and [(ch + lo_c, f) for ch, _, f in mine_c] == [(c, 100 * c) for c in range(lo_c, hi_c)]
     try:
         shard.fanout_nco_segments(segs_c, 24)
