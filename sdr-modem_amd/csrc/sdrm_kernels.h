@@ -19,7 +19,9 @@
 
 #include "sdrm_core.h"
 
+#ifndef SDRM_K1_THREADS
 #define SDRM_K1_THREADS 256
+#endif
 #ifndef SDRM_K1_R
 #define SDRM_K1_R 15   // LPF1 outputs per thread (odd: lane stride 15*8 B is LDS-bank-conflict free)
 #endif
@@ -52,14 +54,20 @@
 // starting anywhere are elements s, s+2, s+4, s+6: two ds_read2_b64 instead of four ds_read2_b32 (an LDS instruction
 // costs a lone wave ~12 cycles of issue whatever its width, tools/ubench_chain.hip; a 16-byte read that is only 4-byte
 // aligned is served, but in 64 cycles: tools/ubench_lds_unaligned.hip).
-template <int LANES, int RING = 16384 / LANES>
+// PLAIN: the ring holds plain samples (4 bytes each) instead of pair elements: half the LDS, and a window that starts
+// anywhere is four 4-byte aligned ds_read2_b32 instead of two ds_read2_b64 (two more LDS instructions per symbol).
+template <int LANES, int RING = 16384 / LANES, bool PLAIN = false>
 struct sdrm_k3_geom {
     static constexpr int lanes = LANES;
     static constexpr int ring = RING;                    // per-channel sample ring in LDS (power of two): 4 staging blocks
     static constexpr int block = ring / 4;               // samples staged per channel per step
     static constexpr int segs = block / SDRM_K3_WAVE;    // 64-sample row segments per channel and step
+    static constexpr bool plain = PLAIN;
     static constexpr int rows = SDRM_K3_PRE + ring + SDRM_K3_POST;
-    static constexpr int cpitch = 2 * rows;              // floats between two channels' rings (22 mod 64 for every power-of-two ring: conflict-free b64 reads)
+    // floats between two channels' rings: pair elements 22 mod 64 for every power-of-two ring (conflict-free b64 reads),
+    // plain samples an odd number
+    static constexpr int cpitch = PLAIN ? rows : 2 * rows;
+    static_assert(segs >= 1, "a staging block is at least one 64-sample row segment");
 };
 #ifndef SDRM_K3_BANKPITCH
 #define SDRM_K3_BANKPITCH 12  // floats between two rows of the MMSE bank copy in LDS (48 B: rows start on 16 different bank offsets instead of 8)
@@ -74,18 +82,21 @@ struct sdrm_k3_geom {
 //   141 KB free): measured in round 2 as 8.45 ms for a 3.76 ms kernel.  A slim workgroup starts wherever one front-end
 //   workgroup has left, and costs the front-end one of its four slots on that CU instead of all of them.
 struct sdrm_k3_shape {
-    int lanes, ring;
+    int lanes, ring, plain;
 };
-SDRM_HD bool sdrm_k3_shape_ok(int lanes, int ring) {
+SDRM_HD bool sdrm_k3_shape_ok(int lanes, int ring, int plain) {
+    if (plain) {
+        return (lanes == 64 || lanes == 32) && ring == 256;
+    }
     return (lanes == 16 && (ring == 1024 || ring == 512 || ring == 256)) || (lanes == 32 && (ring == 512 || ring == 256)) ||
            (lanes == 64 && ring == 256);
 }
 // channels per workgroup for a batch of n channels (round 1, ms per step, 131072-sample chunks; lanes 64 / 32 / 16 / 8:
 // 256 channels 3.96 / 3.18 / 3.09 / 3.07, 1024: 4.67 / 4.37 / 3.88 / 4.46)
-static inline sdrm_k3_shape sdrm_k3_shape_for(int n_channels, int forced_lanes, int forced_ring) {
+static inline sdrm_k3_shape sdrm_k3_shape_for(int n_channels, int forced_lanes, int forced_ring, int forced_plain) {
     if (forced_lanes == 16 || forced_lanes == 32 || forced_lanes == 64) {
-        sdrm_k3_shape f = {forced_lanes, forced_ring ? forced_ring : 16384 / forced_lanes};
-        if (sdrm_k3_shape_ok(f.lanes, f.ring)) {
+        sdrm_k3_shape f = {forced_lanes, forced_ring ? forced_ring : 16384 / forced_lanes, forced_plain};
+        if (sdrm_k3_shape_ok(f.lanes, f.ring, f.plain)) {
             return f;
         }
     }
@@ -93,19 +104,27 @@ static inline sdrm_k3_shape sdrm_k3_shape_for(int n_channels, int forced_lanes, 
     // per workgroup, full shapes): 1280 channels 3.28 / 3.82 / 4.48, 1536: 4.02 / 3.81 / 4.62, 2048: 5.50 / 4.87 / 4.84,
     // 3072: 8.18 / 7.21 / 7.20, 4096: 10.8 / 9.56 / 9.17.  Few channels per workgroup = more waves on the latency chain
     // but more CUs whose LDS the front-end cannot use; the crossovers sit where the front-end becomes the longer stage.
-    sdrm_k3_shape s = {16, 1024};
+    // Round 3: beyond ~2500 channels the 64-channel workgroup takes the PLAIN ring (75 KB instead of 141 KB: two front-end
+    // workgroups fit beside it, and its workgroups are placed as soon as the previous call's leave instead of when the
+    // front-end's grid drains): 3072 channels 7.07 -> 6.95 ms per call, 4096: 9.22 -> 9.02 (profiles/r03_k3_shapes.txt);
+    // at 2048 the 32-channel pair shape is still ahead (4.96 against 5.33).
+    sdrm_k3_shape s = {16, 1024, 0};
     if (n_channels > 1280) {
-        s.lanes = n_channels <= 2048 ? 32 : 64;
+        s.lanes = n_channels <= 2560 ? 32 : 64;
         s.ring = 16384 / s.lanes;
+        s.plain = n_channels > 2560;
     }
     return s;
 }
-// "lanes" or "lanesxring" (SDRM_K3_LANES=16x256): tests and measurements force one workgroup shape
-static inline void sdrm_k3_parse_shape(const char *text, int *lanes, int *ring) {
+// "lanes", "lanesxring" or "lanesxringp" (SDRM_K3_LANES=64x256p: plain ring): tests and measurements force one shape
+static inline void sdrm_k3_parse_shape(const char *text, int *lanes, int *ring, int *plain) {
     *lanes = 0;
     *ring = 0;
+    *plain = 0;
     if (text != nullptr) {
-        sscanf(text, "%dx%d", lanes, ring);
+        char tail = 0;
+        sscanf(text, "%dx%d%c", lanes, ring, &tail);
+        *plain = tail == 'p';
     }
 }
 
@@ -880,29 +899,43 @@ struct sdrm_k3_lane {
     uint32_t cap;      // max symbols per call (= max_input_buffer_length, clock_recovery_mm.c:103)
 };
 
-// `col` = this channel's ring (ring + channel * CPITCH).  Element e = {x[e], x[e+1]} lives at col[2 * (slot + PRE)],
-// slot = e & (RING-1).  Slots < POST are mirrored above the ring and slots >= RING-PRE below it, so the elements
-// [slot-3, slot+7] around any slot are contiguous: a symbol's samples are one base address plus constant offsets.
-template <int RING>
+// `col` = this channel's ring (ring + channel * CPITCH).  Pair layout: element e = {x[e], x[e+1]} lives at
+// col[2 * (slot + PRE)], slot = e & (RING-1); plain layout: sample n lives at col[slot + PRE].  Slots < POST are
+// mirrored above the ring and slots >= RING-PRE below it, so the samples [slot-3, slot+7] around any slot are contiguous:
+// a symbol's samples are one base address plus constant offsets.
+template <typename G>
 SDRM_HD void sdrm_k3_elem_put(float *col, int slot, int half, float v) {
     col[2 * (slot + SDRM_K3_PRE) + half] = v;
     if (slot < SDRM_K3_POST) {
-        col[2 * (slot + RING + SDRM_K3_PRE) + half] = v;
+        col[2 * (slot + G::ring + SDRM_K3_PRE) + half] = v;
     }
-    if (slot >= RING - SDRM_K3_PRE) {
-        col[2 * (slot - RING + SDRM_K3_PRE) + half] = v;
+    if (slot >= G::ring - SDRM_K3_PRE) {
+        col[2 * (slot - G::ring + SDRM_K3_PRE) + half] = v;
     }
 }
 
-// sample n is the first half of its own element and the second half of its predecessor's
-template <int RING>
+// pair layout: sample n is the first half of its own element and the second half of its predecessor's
+template <typename G>
 SDRM_HD void sdrm_k3_ring_put(float *col, int n, float v) {
-    sdrm_k3_elem_put<RING>(col, n & (RING - 1), 0, v);
-    sdrm_k3_elem_put<RING>(col, (n - 1) & (RING - 1), 1, v);
+    if (G::plain) {
+        const int slot = n & (G::ring - 1);
+        col[slot + SDRM_K3_PRE] = v;
+        if (slot < SDRM_K3_POST) {
+            col[slot + G::ring + SDRM_K3_PRE] = v;
+        }
+        if (slot >= G::ring - SDRM_K3_PRE) {
+            col[slot - G::ring + SDRM_K3_PRE] = v;
+        }
+    } else {
+        sdrm_k3_elem_put<G>(col, n & (G::ring - 1), 0, v);
+        sdrm_k3_elem_put<G>(col, (n - 1) & (G::ring - 1), 1, v);
+    }
 }
 
-template <int RING>
-SDRM_HD float sdrm_k3_ring_get(const float *col, int n) { return col[2 * ((n & (RING - 1)) + SDRM_K3_PRE)]; }
+template <typename G>
+SDRM_HD float sdrm_k3_ring_get(const float *col, int n) {
+    return G::plain ? col[(n & (G::ring - 1)) + SDRM_K3_PRE] : col[2 * ((n & (G::ring - 1)) + SDRM_K3_PRE)];
+}
 
 // The loop condition `ii < working_len - 7` (clock_recovery_mm.c:103, ii compared as size_t: negative => stop) with
 // `avail` chunk samples staged, as ONE unsigned compare against a per-block limit: the window starts at chunk-relative
@@ -928,19 +961,32 @@ struct sdrm_k3_operands {
 
 // reference src/dsp/mmse_fir_interpolator.c:189: row = rint(mu * 128) (mu*128 in fp32, half-to-even)
 // (RingPtr / BankPtr: plain `const float *` on the host, LDS-address-space pointers in the kernel)
-template <bool FINITE, int RING, typename RingPtr, typename BankPtr>
+template <bool FINITE, typename G, typename RingPtr, typename BankPtr>
 SDRM_HD void sdrm_k3_fetch(const sdrm_k3_lane &L, RingPtr col, BankPtr bank_rev, sdrm_k3_operands &F) {
     const int n = L.st.ii - L.kept;
-    const RingPtr base = col + 2 * ((n & (RING - 1)) + SDRM_K3_PRE);
+    if (G::plain) {
+        const RingPtr base = col + ((n & (G::ring - 1)) + SDRM_K3_PRE);
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {  // elements s, s+2, s+4, s+6
-        F.w[j] = base[2 * j];
-        F.w[j + 1] = base[2 * j + 1];
-    }
-    if (!FINITE) {
-        F.lead[0] = base[-6];  // x[s-3], x[s-2] = element s-3; x[s-1] = first half of element s-1
-        F.lead[1] = base[-5];
-        F.lead[2] = base[-2];
+        for (int j = 0; j < 8; j++) {
+            F.w[j] = base[j];
+        }
+        if (!FINITE) {
+            F.lead[0] = base[-3];
+            F.lead[1] = base[-2];
+            F.lead[2] = base[-1];
+        }
+    } else {
+        const RingPtr base = col + 2 * ((n & (G::ring - 1)) + SDRM_K3_PRE);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {  // elements s, s+2, s+4, s+6
+            F.w[j] = base[2 * j];
+            F.w[j + 1] = base[2 * j + 1];
+        }
+        if (!FINITE) {
+            F.lead[0] = base[-6];  // x[s-3], x[s-2] = element s-3; x[s-1] = first half of element s-1
+            F.lead[1] = base[-5];
+            F.lead[2] = base[-2];
+        }
     }
     const float scaled = L.st.mu * (float) SDRM_MMSE_STEPS;
     int imu;

@@ -307,10 +307,10 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
         if ((uint32_t) tid < p.T2) tv2 = b.tap_pool[p.taps2_off + tid];
     }
     sdrm_k1_phase_load(tid, t, in, hist, (int) p.hist_len, b.atan_tab, xs, tab);
-    {
-        const float t0 = b.atan_tab[tid], t1 = b.atan_tab[tid + 1];  // 256 threads, 257 entries
-        tab2[2 * tid] = t0;
-        tab2[2 * tid + 1] = t1 - t0;  // the reference's subtraction (fast_atan2f.c:118), once per workgroup
+    for (int k = tid; k < 256; k += SDRM_K1_THREADS) {
+        const float t0 = b.atan_tab[k], t1 = b.atan_tab[k + 1];  // 257 entries
+        tab2[2 * k] = t0;
+        tab2[2 * k + 1] = t1 - t0;  // the reference's subtraction (fast_atan2f.c:118), once per workgroup
     }
     if (short_taps) {
         if ((uint32_t) tid < p.T1) taps1[tid] = tv0;
@@ -1149,8 +1149,8 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // conversion is k3_quantize's, behind this kernel).  Without NaN/Inf in the wave's channels the consumer runs the
 // hand-scheduled loop below (k3_drain_finite), otherwise the C++ form of the same arithmetic.  One barrier per step
 // hands block k to the consumer while block k+1 is written.
-size_t k3_lds_bytes(int lanes, int ring) {
-    const size_t rings = (size_t) lanes * 2 * (SDRM_K3_PRE + ring + SDRM_K3_POST);
+size_t k3_lds_bytes(int lanes, int ring, int plain) {
+    const size_t rings = (size_t) lanes * (plain ? 1 : 2) * (SDRM_K3_PRE + ring + SDRM_K3_POST);
     return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_WAVE) * sizeof(float);
 }
 
@@ -1173,8 +1173,26 @@ size_t k3_lds_bytes(int lanes, int ring) {
 // ACC / LAST: the register the symbol is accumulated in and the one that holds the previous symbol; consecutive symbols
 // swap them, which saves the copy.  CAPCMP / CAPAND: the `oo < output_len` half of the loop condition, empty in the
 // variant used while the output buffer cannot fill up within the call.
-#define K3_SYMBOL_ASM(ACC, LAST, CAPCMP, CAPAND) \
-    "s_waitcnt lgkmcnt(2)\n\t" \
+// WIN: how the window's eight samples are addressed and loaded.  Pair elements: slot * 8 bytes, two ds_read2_b64 (elements
+// s, s+2 | s+4, s+6; offsets in 8-byte units, PRE = 3 folded in); plain samples: slot * 4 bytes, four ds_read2_b32.
+#define K3_WIN_PAIR_ADDR "v_lshl_add_u32 v64, v64, 3, %[col]\n\t"
+#define K3_WIN_PAIR_LOADS \
+    "ds_read_b128 v[66:69], v65\n\t" \
+    "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t" \
+    "ds_read_b128 v[70:73], v65 offset:16\n\t" \
+    "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t"
+#define K3_WIN_PAIR_WAIT1 "s_waitcnt lgkmcnt(2)\n\t"
+#define K3_WIN_PLAIN_ADDR "v_lshl_add_u32 v64, v64, 2, %[col]\n\t"
+#define K3_WIN_PLAIN_LOADS \
+    "ds_read_b128 v[66:69], v65\n\t" \
+    "ds_read2_b32 v[74:75], v64 offset0:3 offset1:4\n\t" \
+    "ds_read2_b32 v[76:77], v64 offset0:5 offset1:6\n\t" \
+    "ds_read_b128 v[70:73], v65 offset:16\n\t" \
+    "ds_read2_b32 v[78:79], v64 offset0:7 offset1:8\n\t" \
+    "ds_read2_b32 v[80:81], v64 offset0:9 offset1:10\n\t"
+#define K3_WIN_PLAIN_WAIT1 "s_waitcnt lgkmcnt(3)\n\t"
+#define K3_SYMBOL_ASM(ACC, LAST, CAPCMP, CAPAND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
+    WIN_WAIT1 \
     "v_pk_mul_f32 v[66:67], v[66:67], v[74:75]\n\t" \
     "v_pk_mul_f32 v[68:69], v[68:69], v[76:77]\n\t" \
     "v_add_f32 " ACC ", 0, v66\n\t" \
@@ -1205,11 +1223,8 @@ size_t k3_lds_bytes(int lanes, int ring) {
     "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t" \
     "v_and_b32 v64, %[m255], %[pm]\n\t" \
     "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t" \
-    "v_lshl_add_u32 v64, v64, 3, %[col]\n\t" \
-    "ds_read_b128 v[66:69], v65\n\t" \
-    "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t" \
-    "ds_read_b128 v[70:73], v65 offset:16\n\t" \
-    "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
+    WIN_ADDR \
+    WIN_LOADS \
     "v_cmp_lt_f32 vcc, %[pm], %[limm]\n\t" \
     CAPCMP \
     "v_and_b32 v86, %[sgn], " ACC "\n\t" \
@@ -1235,7 +1250,7 @@ size_t k3_lds_bytes(int lanes, int ring) {
 #define K3_STR2(x) #x
 #define K3_STR(x) K3_STR2(x)
 #define K3_LOOP_SKEW ".rept " K3_STR(SDRM_K3_LOOP_SKEW) "\n\ts_nop 0\n\t.endr\n\t"
-template <bool CAP>
+template <bool CAP, bool PLAIN>
 __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, uint32_t col_addr, uint32_t bank_addr,
                                                 uint32_t &off, uint32_t off_end, const float *out_base, uint32_t ring_mask) {
     // row address = bank + rowbytes * rint(mu * 128): the low 24 bits of (mu * 128 + 1.5 * 2^23) are 0x400000 + row, so a
@@ -1255,19 +1270,16 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     // the symbol's dependent chain (two instructions less per symbol).
     float pm = SDRM_RINT_MAGIC + (float) (ii - L.kept);
     const float limm = SDRM_RINT_MAGIC + (float) ((int) lim - L.kept);
-#define K3_DRAIN_ASM(CMP, AND) \
+#define K3_DRAIN_ASM(CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
     asm volatile( \
         "s_mov_b64 %[sv], exec\n\t" \
         /* operands of the first symbol: MMSE row (2 x 16 bytes) and the window's four pair elements */ \
         "v_sub_u32 v64, %[ii], %[kept]\n\t" \
         "v_and_b32 v64, %[m255], v64\n\t" \
-        "v_lshl_add_u32 v64, v64, 3, %[col]\n\t" \
+        WIN_ADDR \
         "v_fma_f32 v65, %[mu], %[c128], %[magic]\n\t" \
         "v_mad_u32_u24 v65, v65, %[rowb], %[bias]\n\t" \
-        "ds_read_b128 v[66:69], v65\n\t" \
-        "ds_read2_b64 v[74:77], v64 offset0:3 offset1:5\n\t" \
-        "ds_read_b128 v[70:73], v65 offset:16\n\t" \
-        "ds_read2_b64 v[78:81], v64 offset0:7 offset1:9\n\t" \
+        WIN_LOADS \
         "v_mov_b32 v87, %[last]\n\t" \
         "v_and_b32 v86, %[sgn], %[last]\n\t" \
         "v_mov_b32 v88, %[off]\n" \
@@ -1277,21 +1289,21 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
         K3_LOOP_SKEW \
         "1:\n\t" \
         /* eight symbols per trip: the taken branch back costs a lone wave ~25 cycles */ \
-        K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
+        K3_SYMBOL_ASM("v82", "v87", CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
         "s_cbranch_execz 2f\n\t" \
-        K3_SYMBOL_ASM("v87", "v82", CMP, AND) \
+        K3_SYMBOL_ASM("v87", "v82", CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
         "s_cbranch_execz 2f\n\t" \
-        K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
+        K3_SYMBOL_ASM("v82", "v87", CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
         "s_cbranch_execz 2f\n\t" \
-        K3_SYMBOL_ASM("v87", "v82", CMP, AND) \
+        K3_SYMBOL_ASM("v87", "v82", CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
         "s_cbranch_execz 2f\n\t" \
-        K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
+        K3_SYMBOL_ASM("v82", "v87", CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
         "s_cbranch_execz 2f\n\t" \
-        K3_SYMBOL_ASM("v87", "v82", CMP, AND) \
+        K3_SYMBOL_ASM("v87", "v82", CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
         "s_cbranch_execz 2f\n\t" \
-        K3_SYMBOL_ASM("v82", "v87", CMP, AND) \
+        K3_SYMBOL_ASM("v82", "v87", CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
         "s_cbranch_execz 2f\n\t" \
-        K3_SYMBOL_ASM("v87", "v82", CMP, AND) \
+        K3_SYMBOL_ASM("v87", "v82", CMP, AND, WIN_ADDR, WIN_LOADS, WIN_WAIT1) \
         "s_cbranch_execnz 1b\n" \
         "2:\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t" \
@@ -1315,10 +1327,18 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
           [m255] "s"(ring_mask), [rowb] "n"(SDRM_K3_BANKPITCH * 4), [sgn] "s"(0x80000000u) \
         : "memory", "vcc", "s74", "s75", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", \
           "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88")
-    if (CAP) {
-        K3_DRAIN_ASM(K3_CAPCMP, K3_CAPAND);
+    if (PLAIN) {
+        if (CAP) {
+            K3_DRAIN_ASM(K3_CAPCMP, K3_CAPAND, K3_WIN_PLAIN_ADDR, K3_WIN_PLAIN_LOADS, K3_WIN_PLAIN_WAIT1);
+        } else {
+            K3_DRAIN_ASM("", "", K3_WIN_PLAIN_ADDR, K3_WIN_PLAIN_LOADS, K3_WIN_PLAIN_WAIT1);
+        }
     } else {
-        K3_DRAIN_ASM("", "");
+        if (CAP) {
+            K3_DRAIN_ASM(K3_CAPCMP, K3_CAPAND, K3_WIN_PAIR_ADDR, K3_WIN_PAIR_LOADS, K3_WIN_PAIR_WAIT1);
+        } else {
+            K3_DRAIN_ASM("", "", K3_WIN_PAIR_ADDR, K3_WIN_PAIR_LOADS, K3_WIN_PAIR_WAIT1);
+        }
     }
 #undef K3_DRAIN_ASM
     L.st.mu = mu;
@@ -1328,9 +1348,9 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     L.st.inc = inc;
 }
 
-template <int LANES, int RING>
+template <int LANES, int RING, bool PLAIN>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
-    typedef sdrm_k3_geom<LANES, RING> G;
+    typedef sdrm_k3_geom<LANES, RING, PLAIN> G;
     extern __shared__ __attribute__((aligned(16))) float k3_lds[];
     float *bank_rev = k3_lds;                       // [129*8] at LDS offset 0: a row is two aligned ds_read_b128
     float *ring = bank_rev + ((129 * SDRM_K3_BANKPITCH + 3) & ~3);  // [LANES][CPITCH]
@@ -1381,7 +1401,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             flagged = b.nonfinite[c];
             clean = (flagged == 0) & (cs->poison == 0);
             for (int j = 0; j < L.kept; j++) {
-                sdrm_k3_ring_put<G::ring>(my_col, j - L.kept, cs->hist[j]);
+                sdrm_k3_ring_put<G>(my_col, j - L.kept, cs->hist[j]);
             }
         }
         nz_sh[lane] = L.nz;
@@ -1439,6 +1459,26 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     {                                                                                                        \
         const int n_ = (k) * G::block + lane;                                                            \
         if (uniform && ((k) + 1) * G::block <= min_nz) {                                                 \
+            if (G::plain) {                                                                                   \
+                _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                         \
+                    float *dst_ = ring + (((n_ + h * SDRM_K3_WAVE) & (G::ring - 1)) + SDRM_K3_PRE);           \
+                    _Pragma("unroll") for (int r = 0; r < G::lanes; r++) {                                    \
+                        dst_[r * G::cpitch] = pre[r * G::segs + h];                                            \
+                    }                                                                                         \
+                }                                                                                             \
+                __builtin_amdgcn_wave_barrier();                                                              \
+                /* mirrors, one channel per lane: the first 8 samples above the ring, the last 3 below it */ \
+                if ((((k) * G::block) & (G::ring - 1)) == 0 && lane < G::lanes) {                             \
+                    _Pragma("unroll") for (int j = 0; j < SDRM_K3_POST; j++) {                                \
+                        my_col[j + G::ring + SDRM_K3_PRE] = my_col[j + SDRM_K3_PRE];                          \
+                    }                                                                                         \
+                }                                                                                             \
+                if (((((k) + 1) * G::block) & (G::ring - 1)) == 0 && lane < G::lanes) {                       \
+                    _Pragma("unroll") for (int j = 0; j < SDRM_K3_PRE; j++) {                                 \
+                        my_col[j] = my_col[j + G::ring];                                                      \
+                    }                                                                                         \
+                }                                                                                             \
+            } else {                                                                                          \
             /* sample n = first half of element n, second half of element n - 1 (of every channel r) */      \
             _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                        \
                 const int nh_ = n_ + h * SDRM_K3_WAVE;                                                        \
@@ -1463,12 +1503,13 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
                     my_col[j] = my_col[j + 2 * G::ring];                                                 \
                 }                                                                                            \
             }                                                                                                \
+            }                                                                                                \
         } else {                                                                                             \
             _Pragma("unroll") for (int r = 0; r < G::lanes; r++) {                                       \
                 const int nz_r = r < nrows ? __builtin_amdgcn_readlane(my_nz, r) : 0;                         \
                 _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                    \
                     if (n_ + h * SDRM_K3_WAVE < nz_r) {                                                       \
-                        sdrm_k3_ring_put<G::ring>(ring + r * G::cpitch, n_ + h * SDRM_K3_WAVE, pre[r * G::segs + h]); \
+                        sdrm_k3_ring_put<G>(ring + r * G::cpitch, n_ + h * SDRM_K3_WAVE, pre[r * G::segs + h]); \
                     }                                                                                        \
                 }                                                                                            \
             }                                                                                                \
@@ -1510,10 +1551,10 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 #define K3_DRAIN(FIN)                                                                                        \
     if (sdrm_k3_can_step(L, lim)) {                                                                          \
         sdrm_k3_operands F;                                                                                   \
-        sdrm_k3_fetch<FIN, G::ring>(L, col_l, bank_rev, F);                                                            \
+        sdrm_k3_fetch<FIN, G>(L, col_l, bank_rev, F);                                                            \
         do {                                                                                                 \
             const float soft = sdrm_k3_step<FIN>(L, F);                                                       \
-            sdrm_k3_fetch<FIN, G::ring>(L, col_l, bank_rev, F);                                                        \
+            sdrm_k3_fetch<FIN, G>(L, col_l, bank_rev, F);                                                        \
             *pf++ = soft;                                                                                     \
             /* `oo < output_len`: the output pointer stands in for the symbol count (low words suffice) */    \
         } while (((uint32_t) L.st.ii < lim) & ((uint32_t) (uintptr_t) pf != end_lo));                        \
@@ -1545,9 +1586,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
                 // than a ring of them staged: with that much room left in every lane's output the loop needs no output
                 // test (reference clock_recovery_mm.c:103 `oo < output_len`, true throughout)
                 if (__all(L.k.omega_mid - L.k.omega_lim >= 1.0f && off_end - off > 4u * ((uint32_t) G::ring + 8u))) {
-                    k3_drain_finite<false>(L, lim, col_addr, bank_addr, off, off_end, wg_out, (uint32_t) (G::ring - 1));
+                    k3_drain_finite<false, G::plain>(L, lim, col_addr, bank_addr, off, off_end, wg_out, (uint32_t) (G::ring - 1));
                 } else {
-                    k3_drain_finite<true>(L, lim, col_addr, bank_addr, off, off_end, wg_out, (uint32_t) (G::ring - 1));
+                    k3_drain_finite<true, G::plain>(L, lim, col_addr, bank_addr, off, off_end, wg_out, (uint32_t) (G::ring - 1));
                 }
                 L.oo = (off - off_base) / (uint32_t) sizeof(float);
             }
@@ -1582,7 +1623,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         int from_n, new_kept;
         sdrm_k3_finish(L, &from_n, &new_kept);
         for (int j = 0; j < new_kept; j++) {
-            cs->hist[j] = sdrm_k3_ring_get<G::ring>(my_col, from_n + j);
+            cs->hist[j] = sdrm_k3_ring_get<G>(my_col, from_n + j);
         }
         cs->kept = (uint32_t) new_kept;
         cs->mu = L.st.mu;
@@ -1627,33 +1668,35 @@ __global__ __launch_bounds__(256) void k3_quantize(DeviceBatch b) {
     }
 }
 
-template <int LANES, int RING>
+template <int LANES, int RING, bool PLAIN>
 static KernelLaunch describe_clock_as(const DeviceBatch &b) {
     KernelLaunch k;
     static lds_grant granted;
-    k.lds = k3_lds_bytes(LANES, RING);
-    allow_lds(k3_clock<LANES, RING>, k.lds, &granted);
-    k.func = reinterpret_cast<const void *>(k3_clock<LANES, RING>);
+    k.lds = k3_lds_bytes(LANES, RING, PLAIN);
+    allow_lds(k3_clock<LANES, RING, PLAIN>, k.lds, &granted);
+    k.func = reinterpret_cast<const void *>(k3_clock<LANES, RING, PLAIN>);
     k.grid = dim3((unsigned) ((b.n_channels + LANES - 1) / LANES));
     k.block = dim3(128);
     return k;
 }
 
 sdrm_k3_shape k3_shape(const DeviceBatch &b) {
-    int lanes = 0, ring = 0;
-    sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring);  // tests and measurements: force one workgroup shape (read per launch)
-    return sdrm_k3_shape_for(b.n_channels, lanes, ring);
+    int lanes = 0, ring = 0, plain = 0;
+    sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring, &plain);  // tests and measurements: force one workgroup shape (read per launch)
+    return sdrm_k3_shape_for(b.n_channels, lanes, ring, plain);
 }
 
 KernelLaunch describe_clock(const DeviceBatch &b) {
     const sdrm_k3_shape sh = k3_shape(b);
-    switch (sh.lanes * 10000 + sh.ring) {
-        case 16 * 10000 + 1024: return describe_clock_as<16, 1024>(b);
-        case 16 * 10000 + 512: return describe_clock_as<16, 512>(b);
-        case 16 * 10000 + 256: return describe_clock_as<16, 256>(b);
-        case 32 * 10000 + 512: return describe_clock_as<32, 512>(b);
-        case 32 * 10000 + 256: return describe_clock_as<32, 256>(b);
-        default: return describe_clock_as<64, 256>(b);
+    switch ((sh.lanes * 10000 + sh.ring) * (sh.plain ? -1 : 1)) {
+        case 16 * 10000 + 1024: return describe_clock_as<16, 1024, false>(b);
+        case 16 * 10000 + 512: return describe_clock_as<16, 512, false>(b);
+        case 16 * 10000 + 256: return describe_clock_as<16, 256, false>(b);
+        case 32 * 10000 + 512: return describe_clock_as<32, 512, false>(b);
+        case 32 * 10000 + 256: return describe_clock_as<32, 256, false>(b);
+        case -(64 * 10000 + 256): return describe_clock_as<64, 256, true>(b);
+        case -(32 * 10000 + 256): return describe_clock_as<32, 256, true>(b);
+        default: return describe_clock_as<64, 256, false>(b);
     }
 }
 

@@ -228,9 +228,9 @@ static void emu_dc(EmuBatch *b) {
     }
 }
 
-template <int LANES, int RING>
+template <int LANES, int RING, bool PLAIN>
 static void emu_clock_as(EmuBatch *b) {
-    typedef sdrm_k3_geom<LANES, RING> G;
+    typedef sdrm_k3_geom<LANES, RING, PLAIN> G;
     const BatchPlan &pl = b->plan;
     const int C = (int) pl.params.size();
     std::vector<float> ring(G::lanes * G::cpitch);
@@ -263,7 +263,7 @@ static void emu_clock_as(EmuBatch *b) {
             flagged[l] = b->nonfinite[c];
             clean[l] = flagged[l] == 0 && cs.poison == 0;
             float *col = ring.data() + l * G::cpitch;
-            for (int j = 0; j < L.kept; j++) sdrm_k3_ring_put<G::ring>(col, j - L.kept, cs.hist[j]);
+            for (int j = 0; j < L.kept; j++) sdrm_k3_ring_put<G>(col, j - L.kept, cs.hist[j]);
             max_nz = L.nz > max_nz ? L.nz : max_nz;
         }
         const int nblocks = (max_nz + G::block - 1) / G::block;
@@ -274,7 +274,7 @@ static void emu_clock_as(EmuBatch *b) {
                     const float *src = (pl.params[cr].dc_len ? b->dcout.data() : b->z.data()) + (size_t) cr * pl.z_stride;
                     float *col = ring.data() + r * G::cpitch;
                     for (int n = k * G::block; n < (k + 1) * G::block && n < lanes[r].nz; n++)
-                        sdrm_k3_ring_put<G::ring>(col, n, src[n]);
+                        sdrm_k3_ring_put<G>(col, n, src[n]);
                 }
             }
             for (int l = 0; l < nl; l++) {
@@ -290,10 +290,10 @@ static void emu_clock_as(EmuBatch *b) {
                     sdrm_k3_operands F;
                     float soft;
                     if (clean[l]) {
-                        sdrm_k3_fetch<true, G::ring>(L, col, bank_rev, F);
+                        sdrm_k3_fetch<true, G>(L, col, bank_rev, F);
                         soft = sdrm_k3_step<true>(L, F);
                     } else {
-                        sdrm_k3_fetch<false, G::ring>(L, col, bank_rev, F);
+                        sdrm_k3_fetch<false, G>(L, col, bank_rev, F);
                         soft = sdrm_k3_step<false>(L, F);
                     }
                     b->out8[(size_t) c * pl.out_stride + L.oo] = clean[l] ? sdrm_soft_to_i8_finite(soft) : sdrm_soft_to_i8(soft);
@@ -314,7 +314,7 @@ static void emu_clock_as(EmuBatch *b) {
             sdrm_k3_finish(L, &from_n, &new_kept);
             const float *col = ring.data() + l * G::cpitch;
             float tmp[SDRM_CLOCK_HCAP];
-            for (int j = 0; j < new_kept; j++) tmp[j] = sdrm_k3_ring_get<G::ring>(col, from_n + j);
+            for (int j = 0; j < new_kept; j++) tmp[j] = sdrm_k3_ring_get<G>(col, from_n + j);
             for (int j = 0; j < new_kept; j++) cs.hist[j] = tmp[j];
             cs.kept = (uint32_t) new_kept;
             cs.mu = L.st.mu;
@@ -330,16 +330,18 @@ static void emu_clock_as(EmuBatch *b) {
 
 // the workgroup shape the library would launch for this batch (same policy, same SDRM_K3_LANES override)
 static void emu_clock(EmuBatch *b) {
-    int lanes = 0, ring = 0;
-    sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring);
-    const sdrm_k3_shape sh = sdrm_k3_shape_for((int) b->plan.params.size(), lanes, ring);
-    switch (sh.lanes * 10000 + sh.ring) {
-        case 16 * 10000 + 1024: emu_clock_as<16, 1024>(b); break;
-        case 16 * 10000 + 512: emu_clock_as<16, 512>(b); break;
-        case 16 * 10000 + 256: emu_clock_as<16, 256>(b); break;
-        case 32 * 10000 + 512: emu_clock_as<32, 512>(b); break;
-        case 32 * 10000 + 256: emu_clock_as<32, 256>(b); break;
-        default: emu_clock_as<64, 256>(b); break;
+    int lanes = 0, ring = 0, plain = 0;
+    sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring, &plain);
+    const sdrm_k3_shape sh = sdrm_k3_shape_for((int) b->plan.params.size(), lanes, ring, plain);
+    switch ((sh.lanes * 10000 + sh.ring) * (sh.plain ? -1 : 1)) {
+        case 16 * 10000 + 1024: emu_clock_as<16, 1024, false>(b); break;
+        case 16 * 10000 + 512: emu_clock_as<16, 512, false>(b); break;
+        case 16 * 10000 + 256: emu_clock_as<16, 256, false>(b); break;
+        case 32 * 10000 + 512: emu_clock_as<32, 512, false>(b); break;
+        case 32 * 10000 + 256: emu_clock_as<32, 256, false>(b); break;
+        case -(64 * 10000 + 256): emu_clock_as<64, 256, true>(b); break;
+        case -(32 * 10000 + 256): emu_clock_as<32, 256, true>(b); break;
+        default: emu_clock_as<64, 256, false>(b); break;
     }
 }
 

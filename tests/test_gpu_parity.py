@@ -151,7 +151,7 @@ def test_design_parameters_match_oracle():
     g.close()
 
 
-@pytest.mark.parametrize("lanes", ["16", "32", "64", "16x512", "16x256", "32x256"])
+@pytest.mark.parametrize("lanes", ["16", "32", "64", "16x512", "16x256", "32x256", "64x256p", "32x256p"])
 def test_clock_stage_workgroup_shapes(lanes, monkeypatch):
     """The clock stage runs with 16 channels per workgroup (256-sample steps) up to 1024 channels and with 64 (64-sample
     steps) beyond; SDRM_K3_LANES forces a shape.  Both shapes, both builds (float soft bits kept / int8 only, i.e. the C++

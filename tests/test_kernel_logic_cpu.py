@@ -107,7 +107,7 @@ def test_ragged_chunks_cross_tiles_and_phases():
         assert run_both(cfg, iq, chunks, 12000) <= len(iq)
 
 
-@pytest.mark.parametrize("lanes", ["16", "32", "64", "16x512", "16x256", "32x256"])
+@pytest.mark.parametrize("lanes", ["16", "32", "64", "16x512", "16x256", "32x256", "64x256p", "32x256p"])
 def test_clock_stage_workgroup_shapes(lanes, monkeypatch):
     """the clock stage's two workgroup shapes (16 channels x 256-sample steps, 64 x 64; SDRM_K3_LANES forces one) stage
     and drain the same samples: ragged chunks around both step sizes"""
