@@ -764,7 +764,6 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     if (b->timing) {
         timing_end(b, 0, b->s_front, ev);
     }
-    sdrm::launch_hist_roll(d, d_in, in_stride, b->s_front);
     HIP_TRY(hipEventRecord(b->ev_front[slot], b->s_front));
 
     // ---- DC blocker: needs z of this call, and dcout[i&1] released by the clock stage of call i-2
@@ -1051,7 +1050,6 @@ static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h
     add_copy(b->d_in, b->h_in_stage, n * sizeof(sdrm_f2), hipMemcpyHostToDevice);
     add_copy(b->d_ctl + (size_t) SG_SLOT, h, sizeof(sdrm_chunk_ctl), hipMemcpyHostToDevice);
     add_kernel(sdrm::describe_front(d));
-    add_kernel(sdrm::describe_hist_roll(d));
     add_kernel(sdrm::describe_dc(d));
     add_kernel(sdrm::describe_clock(d));
     add_kernel(sdrm::describe_quantize(d));

@@ -274,6 +274,16 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
     const int c = blockIdx.y;
     const sdrm_chunk_ctl ctl = b.ctl[c];
+    const sdrm_chan_params p = b.params[c];
+    if (blockIdx.x == 0) {
+        // The channel's first workgroup also rolls the raw history for the next call (the last T1 + T2 - 1 samples of
+        // history ++ input, into the other of the two history buffers: the tiles of THIS call read the current one).
+        // Every channel gets this workgroup, also one without a tile this call (an empty or absent input still rolls).
+        const sdrm_f2 *cur = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
+        sdrm_f2 *next = b.raw_hist + ((size_t) c * 2 + (ctl.parity ^ 1u)) * b.hist_stride;
+        const sdrm_f2 *src = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
+        sdrm_hist_roll((int) threadIdx.x, SDRM_K1_THREADS, p, ctl, src, cur, next);
+    }
     if (blockIdx.x >= ctl.tiles) {
         return;
     }
@@ -281,7 +291,6 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
 #ifndef SDRM_K1_NOPRIO
     __builtin_amdgcn_s_setprio(1);  // ahead of the clock stage's companion waves (priority 0) wherever they share a SIMD
 #endif
-    const sdrm_chan_params p = b.params[c];
     sdrm_f2 *xs = reinterpret_cast<sdrm_f2 *>(k1_lds);
     float *qs = reinterpret_cast<float *>(xs) + 1;  // aliases the raw tile: written only after every LPF1 read (barrier); qs[-1] exists
     float *zs = qs + SDRM_K1_NY + SDRM_K1_QPAD - 1;  // LPF2 outputs of the tile, behind the demodulated samples
@@ -348,16 +357,6 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     }
 }
 
-__global__ __launch_bounds__(256) void k1_hist_roll(DeviceBatch b, const sdrm_f2 *__restrict__ d_in, size_t in_stride) {
-    const int c = blockIdx.x;
-    const sdrm_chunk_ctl ctl = b.ctl[c];
-    const sdrm_chan_params p = b.params[c];
-    const sdrm_f2 *cur = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
-    sdrm_f2 *next = b.raw_hist + ((size_t) c * 2 + (ctl.parity ^ 1u)) * b.hist_stride;
-    const sdrm_f2 *in = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
-    sdrm_hist_roll((int) threadIdx.x, (int) blockDim.x, p, ctl, in, cur, next);
-}
-
 // dynamic LDS above the 64 KiB default has to be requested per kernel (up to the CU's 160 KiB); the attribute belongs
 // to the kernel's code object on ONE device, so what has been granted is remembered per device (a process that drives
 // several GPUs gets it right for each)
@@ -388,9 +387,6 @@ static void launch_described(const KernelLaunch &k, void **args, hipStream_t s) 
 
 KernelLaunch describe_front(const DeviceBatch &b) {
     KernelLaunch k;
-    if (b.max_tiles == 0) {
-        return k;
-    }
     static lds_grant granted, granted_fused;
     k.lds = k1_lds_bytes(b.t1_max, b.t2_max);
     if (b.fast_fma) {
@@ -400,7 +396,7 @@ KernelLaunch describe_front(const DeviceBatch &b) {
         allow_lds(k1_front<false>, k.lds, &granted);
         k.func = reinterpret_cast<const void *>(k1_front<false>);
     }
-    k.grid = dim3(b.max_tiles, (unsigned) b.n_channels);
+    k.grid = dim3(b.max_tiles ? b.max_tiles : 1u, (unsigned) b.n_channels);  // tile 0 of every channel also rolls its history
     k.block = dim3(SDRM_K1_THREADS);
     return k;
 }
@@ -408,19 +404,6 @@ KernelLaunch describe_front(const DeviceBatch &b) {
 void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s) {
     void *args[] = {(void *) &b, (void *) &d_in, (void *) &in_stride};
     launch_described(describe_front(b), args, s);
-}
-
-KernelLaunch describe_hist_roll(const DeviceBatch &b) {
-    KernelLaunch k;
-    k.func = reinterpret_cast<const void *>(k1_hist_roll);
-    k.grid = dim3((unsigned) b.n_channels);
-    k.block = dim3(256);
-    return k;
-}
-
-void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s) {
-    void *args[] = {(void *) &b, (void *) &d_in, (void *) &in_stride};
-    launch_described(describe_hist_roll(b), args, s);
 }
 
 // ================================================================================================ K2
@@ -1151,7 +1134,7 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // hands block k to the consumer while block k+1 is written.
 size_t k3_lds_bytes(int lanes, int ring, int plain) {
     const size_t rings = (size_t) lanes * (plain ? 1 : 2) * (SDRM_K3_PRE + ring + SDRM_K3_POST);
-    return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 2 * SDRM_K3_WAVE) * sizeof(float);
+    return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 3 * SDRM_K3_WAVE) * sizeof(float);
 }
 
 // Order of work inside a symbol:
@@ -1247,6 +1230,8 @@ size_t k3_lds_bytes(int lanes, int ring, int plain) {
 #ifndef SDRM_K3_LOOP_SKEW
 #define SDRM_K3_LOOP_SKEW 0
 #endif
+#define K3_STORE_SLACK 32   // store instructions of the consumer that may still be in flight at a hand-over
+#define K3_FUSED_INT8(G) (G::block >= 256)  // the staging wave converts the soft bits to int8 (else: k3_quantize)
 #define K3_STR2(x) #x
 #define K3_STR(x) K3_STR2(x)
 #define K3_LOOP_SKEW ".rept " K3_STR(SDRM_K3_LOOP_SKEW) "\n\ts_nop 0\n\t.endr\n\t"
@@ -1356,6 +1341,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     float *ring = bank_rev + ((129 * SDRM_K3_BANKPITCH + 3) & ~3);  // [LANES][CPITCH]
     int *nz_sh = reinterpret_cast<int *>(ring + G::lanes * G::cpitch);  // [64] samples per channel
     int *dc_sh = nz_sh + SDRM_K3_WAVE;                                           // [64] reads dcout (1) or z (0)
+    int *safe_sh = dc_sh + SDRM_K3_WAVE;                                         // [64] float soft bits the staging wave may convert
     tl_mark(b, 2, 0);
     const int lane = threadIdx.x & 63;
     const bool producer = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) != 0;
@@ -1515,19 +1501,99 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             }                                                                                                \
         }                                                                                                    \
     }
+        // int8 soft bits (reference src/dsp/fsk_demod.c:106).  The recursion's wave pays for every instruction it issues, so
+        // it only stores the float soft bits; this wave, idle between two staging steps, converts them: whenever a channel
+        // has 64 finished ones (`safe`: published by the consumer at each hand-over, behind an s_waitcnt that lets only its
+        // newest stores be outstanding) one coalesced 256-byte read and one 64-byte write, the rest after the last step.
+        // Sixteen channels per step, and software-pipelined: a step converts and stores what the previous step read, so
+        // that no memory latency ever sits between this wave and the hand-over the consumer is waiting for.
+        // Only for staging steps of 256 samples (the shapes of up to 1280 channels): with 128- or 64-sample steps the
+        // consumer is back for the next block within 1-2 us, less than a memory round trip, and every load this wave has
+        // in flight delays the samples it must deliver (measured: 2048 channels 4.96 -> 6.0 ms per call, 4096: 9.0 -> 17);
+        // those shapes leave the conversion to the pointwise kernel k3_quantize behind the stage.
+        uint32_t done = 0;  // lane = channel: soft bits read for conversion so far (a multiple of 64 until the end)
+        float qv[16];
+        uint32_t q_at[16], q_cnt[16];
+        int q_r0 = -1;      // the group of sixteen channels whose values sit in qv (-1: none)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            qv[j] = 0.0f;
+            q_at[j] = q_cnt[j] = 0;
+        }
+        auto q_store = [&]() {
+            if (q_r0 >= 0) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if ((uint32_t) lane < q_cnt[j]) {
+                        b.out_i8[(size_t) (c0 + q_r0 + j) * b.out_stride + q_at[j] + lane] = sdrm_soft_to_i8(qv[j]);
+                    }
+                }
+            }
+            q_r0 = -1;
+        };
+        // read the next 64 (last: whatever is left) finished soft bits of the channels r0 .. r0 + 15; false: nothing to read
+        auto q_load = [&](int r0, bool last) {
+            const uint32_t safe = lane < G::lanes ? (uint32_t) safe_sh[lane] : 0u;
+            const uint32_t pend = safe - done;
+            const unsigned long long todo = __ballot(last ? pend > 0u : pend >= 64u);
+            if (((todo >> r0) & 0xffffull) == 0) {
+                return false;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int r = r0 + j;
+                q_at[j] = (uint32_t) __builtin_amdgcn_readlane((int) done, r);
+                const uint32_t left = (uint32_t) __builtin_amdgcn_readlane((int) safe, r) - q_at[j];
+                q_cnt[j] = ((todo >> r) & 1ull) ? (left < 64u ? left : 64u) : 0u;
+                if ((uint32_t) lane < q_cnt[j]) {
+                    // agent-scope load: from the L2 the consumer's stores went to, never a stale line of this CU's L1
+                    qv[j] = __hip_atomic_load(b.out_f32 + (size_t) (c0 + r) * b.out_stride + q_at[j] + lane, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+                }
+                done = lane == r ? q_at[j] + q_cnt[j] : done;
+            }
+            q_r0 = r0;
+            return true;
+        };
         if (nblocks > 0) {
             K3_ISSUE(0)
         }
         for (int k = 0; k < nblocks; k++) {
             K3_COMMIT(k)
+            if (K3_FUSED_INT8(G)) {
+                q_store();
+                q_load((k % (G::lanes / 16)) * 16, false);
+            }
             if (k + 1 < nblocks) {
                 K3_ISSUE(k + 1)
             }
-            __syncthreads();  // block k is in the ring; the consumer works on it while block k+1 is written
+            // block k is in the ring; the consumer works on it while block k+1 is written
+            if (K3_FUSED_INT8(G)) {
+                // LDS traffic only: the loads and stores above stay in flight across the hand-over
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                __syncthreads();
+            }
+        }
+        if (!K3_FUSED_INT8(G)) {
+            tl_mark(b, 2, 1);
+            return;  // short staging steps: k3_quantize converts behind the kernel
+        }
+        q_store();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the consumer has stored its last soft bit (and waited for the stores)
+        for (bool more = true; more;) {
+            more = false;
+            for (int r0 = 0; r0 < G::lanes; r0 += 16) {
+                if (q_load(r0, true)) {
+                    q_store();
+                    more = true;
+                }
+            }
         }
 #undef K3_ISSUE
 #undef K3_COMMIT
 #undef K3_ROW_SRC
+        tl_mark(b, 2, 1);
         return;
     }
 
@@ -1573,6 +1639,12 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         // k == nblocks: nothing new, only drains what the carried history alone allows (nz == 0 case)
         unsigned long long t0 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         if (k < nblocks) {
+            // float soft bits the staging wave may convert now: all but those of the newest stores (one store instruction
+            // per symbol of the wave's loop; stores complete in order, so behind this wait at most K3_STORE_SLACK are open)
+            if (K3_FUSED_INT8(G)) {
+                asm volatile("s_waitcnt vmcnt(" K3_STR(K3_STORE_SLACK) ")" ::: "memory");
+                safe_sh[lane] = L.oo > K3_STORE_SLACK ? (int) (L.oo - K3_STORE_SLACK) : 0;
+            }
             __syncthreads();  // block k staged
         }
         unsigned long long t1 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -1617,6 +1689,11 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
                                           ((unsigned long long) (hw_sh & 0xffffu) << 48);
     }
 #undef K3_DRAIN
+    if (K3_FUSED_INT8(G)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every float soft bit is in memory
+        safe_sh[lane] = (int) L.oo;
+        __syncthreads();  // the staging wave converts what is left
+    }
     if (absent) {
         b.out_len[c] = 0;
     } else if (active) {
@@ -1641,8 +1718,8 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     tl_mark(b, 2, 1);
 }
 
-// int8 soft bits from the float ones (reference src/dsp/fsk_demod.c:106), pointwise behind the clock stage: the
-// recursion's wave pays ~4.4 cycles for every instruction it issues, three of which were this conversion.
+// int8 soft bits from the float ones (reference src/dsp/fsk_demod.c:106), pointwise behind the clock stage, for the
+// workgroup shapes whose staging wave has no time for it (K3_FUSED_INT8).
 // grid (ceil(max_symbols / 1024), channels), 256 threads, four symbols per thread
 __global__ __launch_bounds__(256) void k3_quantize(DeviceBatch b) {
     const int c = blockIdx.y;
@@ -1702,7 +1779,8 @@ KernelLaunch describe_clock(const DeviceBatch &b) {
 
 KernelLaunch describe_quantize(const DeviceBatch &b) {
     KernelLaunch k;
-    if (b.max_symbols == 0) {
+    const sdrm_k3_shape sh = k3_shape(b);
+    if (b.max_symbols == 0 || sh.ring / 4 >= 256) {  // K3_FUSED_INT8: the clock stage's staging wave has done it
         return k;
     }
     k.func = reinterpret_cast<const void *>(k3_quantize);

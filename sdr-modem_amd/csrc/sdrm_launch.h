@@ -61,10 +61,9 @@ struct KernelLaunch {
     size_t lds = 0;
 };
 KernelLaunch describe_front(const DeviceBatch &b);      // args: DeviceBatch, const sdrm_f2 *d_in, size_t in_stride
-KernelLaunch describe_hist_roll(const DeviceBatch &b);  // args: the same three
 KernelLaunch describe_dc(const DeviceBatch &b);         // args: DeviceBatch
 KernelLaunch describe_clock(const DeviceBatch &b);      // args: DeviceBatch
-KernelLaunch describe_quantize(const DeviceBatch &b);   // args: DeviceBatch
+KernelLaunch describe_quantize(const DeviceBatch &b);   // args: DeviceBatch (nothing to launch for the shapes that convert inside the clock stage)
 
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 void launch_dc_hold(const DeviceBatch &b, hipStream_t s);
@@ -76,7 +75,6 @@ void launch_front_hold(hipStream_t s);
 void launch_nco_phase(const DeviceBatch &b, hipStream_t s);
 void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);
 void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
-void launch_hist_roll(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
 void launch_dc(const DeviceBatch &b, hipStream_t s);
 // diagnostics buffer layout: 4 words per clock-stage workgroup (room for the smallest shape, 16 channels each), then 8
 // words of the front-end, then 10 of the DC blocker
