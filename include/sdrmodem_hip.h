@@ -245,6 +245,10 @@ int sdrm_batcher_reset_channel(sdrm_batcher *batcher, size_t channel, const sdrm
 /* Doppler pre-correction for one channel: `planner` (borrowed, see sdrm_doppler_create) is asked for the segments of
  * every buffer of that channel when its round is launched; NULL switches it off */
 int sdrm_batcher_set_doppler(sdrm_batcher *batcher, size_t channel, sdrm_doppler *planner);
+/* 0 while the device answers; the code of the first failed device call afterwards (sticky).  A failed device ends every
+ * client of the batcher: sdrm_batcher_take returns NULL from then on (as after a poison pill -- this query tells the two
+ * apart), sdrm_batcher_put drops.  The streams' state lived on the device: the batcher has to be destroyed. */
+int sdrm_batcher_error(const sdrm_batcher *batcher);
 size_t sdrm_batcher_channels(const sdrm_batcher *batcher);
 uint64_t sdrm_batcher_rounds(const sdrm_batcher *batcher); /* batched calls launched so far */
 void sdrm_batcher_destroy(sdrm_batcher *batcher);
@@ -309,7 +313,9 @@ void dsp_worker_destroy(void *data);
 #define SDRM_WIRE_TYPE_RESPONSE 2
 #define SDRM_WIRE_STATUS_SUCCESS 0
 #define SDRM_WIRE_STATUS_FAILURE 1
+#define SDRM_WIRE_MAX_MESSAGE 65536u /* largest body sdrm_wire_read_header accepts (an RxRequest with two TLE lines is < 300 bytes) */
 int sdrm_wire_write_response(int socket, uint32_t status, uint32_t details);
+/* 0; -1 peer closed / read error; -2 unknown protocol version; -3 body longer than SDRM_WIRE_MAX_MESSAGE */
 int sdrm_wire_read_header(int socket, uint8_t *type, uint32_t *message_length);
 int sdrm_wire_decode_rx_request(const uint8_t *body, size_t len, sdrm_worker_config *config, int *has_doppler);
 

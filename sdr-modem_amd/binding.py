@@ -59,7 +59,7 @@ EXPORTS = [
     "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect", "sdrm_batch_reset_channel",
     "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt", "sdrm_batcher_abandon", "sdrm_fsk_demod_error", "sdrm_last_error", "sdrm_batch_wait_input", "sdrm_wire_write_response",
     "sdrm_wire_read_header", "sdrm_wire_decode_rx_request",
-    "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_destroy",
+    "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_error", "sdrm_batcher_destroy",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_quad", "sdrm_probe_boxcar_div", "sdrm_version", "sdrm_device_count",
     "sdrm_batch_k3_stamps", "sdrm_batch_timeline",
@@ -90,6 +90,8 @@ def bind_batcher(L):
     L.sdrm_batcher_channels.argtypes = [vp]
     L.sdrm_batcher_channels.restype = C.c_size_t
     L.sdrm_batcher_rounds.argtypes = [vp]
+    L.sdrm_batcher_error.argtypes = [vp]
+    L.sdrm_batcher_error.restype = C.c_int
     L.sdrm_batcher_rounds.restype = C.c_uint64
     L.sdrm_batcher_destroy.argtypes = [vp]
     L.sdrm_batcher_destroy.restype = None
@@ -411,6 +413,9 @@ class Batcher:
 
     def abandon(self, channel):
         self.L.sdrm_batcher_abandon(self.h, channel)
+
+    def error(self):
+        return int(self.L.sdrm_batcher_error(self.h))
 
     def rounds(self):
         return int(self.L.sdrm_batcher_rounds(self.h))

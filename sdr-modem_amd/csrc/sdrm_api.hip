@@ -1519,7 +1519,8 @@ extern "C" void fsk_demod_process(const sdrm_cf32 *input, size_t input_len, int8
         sdrm_batcher_put(demod->shared, demod->slot, input, input_len);
         sdrm_batcher_take(demod->shared, demod->slot, &soft, &n);
         if (soft == nullptr) {
-            demod_failed(demod, -EPIPE, "the shared batcher went away");
+            const int dev = sdrm_batcher_error(demod->shared);  // a failed device call ends every handle on the batcher
+            demod_failed(demod, dev != 0 ? dev : -EPIPE, dev != 0 ? "the shared batcher's device call failed" : "the shared batcher went away");
             return;
         }
         memcpy(demod->out, soft, n);

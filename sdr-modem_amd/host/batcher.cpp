@@ -83,7 +83,7 @@ void Batcher::put(size_t c, const sdrm_cf32 *buf, size_t len) {
     uint64_t r = 0;
     bool overwrite = false;
     for (;;) {
-        if (closed_[c] || stopping_) {
+        if (closed_[c] || stopping_ || error_.load(std::memory_order_relaxed) != 0) {
             return;
         }
         r = std::max(next_put_[c], fill_base_);
@@ -138,8 +138,8 @@ void Batcher::take(size_t c, int8_t **out, size_t *len) {
     }
     std::unique_lock<std::mutex> lk(m_);
     for (;;) {
-        if (abandoned_[c]) {
-            return;  // the channel was given up: nothing is delivered any more
+        if (abandoned_[c] || error_.load(std::memory_order_relaxed) != 0) {
+            return;  // the channel was given up, or the device failed (error()): nothing is delivered any more
         }
         if (!mine_[c].empty()) {
             Round &rd = round(mine_[c].front());
@@ -156,6 +156,23 @@ void Batcher::take(size_t c, int8_t **out, size_t *len) {
         }
         cv_result_.wait(lk);
     }
+}
+
+// the device failed: what the rounds in flight hold is lost and no later call can be trusted (the streams' state lives
+// on the device).  Every channel is closed and given up, every waiter woken; take() and put() return at once from now on.
+void Batcher::fail_locked(int code) {
+    int expected = 0;
+    error_.compare_exchange_strong(expected, code, std::memory_order_release);
+    for (size_t c = 0; c < n_; c++) {
+        if (!closed_[c]) {
+            closed_[c] = 1;
+            open_--;
+        }
+        abandoned_[c] = 1;
+    }
+    cv_work_.notify_all();
+    cv_space_.notify_all();
+    cv_result_.notify_all();
 }
 
 void Batcher::retire_locked() {
@@ -338,17 +355,15 @@ void Batcher::run() {
                 fprintf(stderr, "<3>batcher: device call failed: %d\n", code);
             }
             lk.lock();
-            if (code != 0) {  // deliver empty results so that consumers are not left waiting
+            if (code != 0) {  // no results will come: end every client instead of leaving it waiting (or fed empty buffers)
                 Round &bad = round(r);
                 std::fill(bad.out_len.begin(), bad.out_len.end(), 0);
                 bad.state = DONE;
                 inflight_.erase(std::find(inflight_.begin(), inflight_.end(), r));
-                cv_result_.notify_all();
+                fail_locked(code);
                 retire_locked();
                 for (size_t c = 0; c < n_; c++) {
-                    if (abandoned_[c]) {
-                        drop_done_locked(c);
-                    }
+                    drop_done_locked(c);
                 }
             }
             continue;
@@ -368,6 +383,10 @@ void Batcher::run() {
             lk.lock();
             done.state = DONE;
             inflight_.pop_front();
+            if (code != 0) {
+                fprintf(stderr, "<3>batcher: device results could not be collected: %d\n", code);
+                fail_locked(code);
+            }
             cv_result_.notify_all();
             retire_locked();
             for (size_t c = 0; c < n_; c++) {
@@ -430,6 +449,10 @@ extern "C" void sdrm_batcher_abandon(sdrm_batcher *b, size_t channel) {
     if (b != nullptr) {
         reinterpret_cast<sdrm::Batcher *>(b)->abandon(channel);
     }
+}
+
+extern "C" int sdrm_batcher_error(const sdrm_batcher *b) {
+    return b ? reinterpret_cast<const sdrm::Batcher *>(b)->error() : -1;
 }
 
 extern "C" size_t sdrm_batcher_channels(const sdrm_batcher *b) {

@@ -16,6 +16,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -60,6 +61,10 @@ public:
     // hand the channel to a new client: waits until everything put on it has been consumed, drains the device, resets
     // the channel (cfg may be NULL = same configuration) and reopens it after a poison pill
     int reset_channel(size_t channel, const sdrm_fsk_config *cfg);
+    // first device failure (submit or collect), 0 while the device answers.  Sticky: from then on nothing is delivered any
+    // more -- take() returns NULL like after a poison pill, put() drops -- and the owners of the channels read the code
+    // here (sdrm_batcher_error) to tell a dead device from a client that left.
+    int error() const { return error_.load(std::memory_order_acquire); }
     size_t channels() const { return n_; }
     uint64_t rounds_launched() const { return launched_; }
 
@@ -114,6 +119,8 @@ private:
     int reset_waiters_ = 0;       // resets waiting for their channel to run dry (complete() wakes them)
     size_t out_cap_ = 0;          // result bytes reserved per channel and round (the batch's largest buffer)
     bool stopping_ = false;
+    std::atomic<int> error_{0};
+    void fail_locked(int code);   // record the first device failure, close every channel, wake everybody
     uint64_t launched_ = 0;
     std::mutex m_;
     std::condition_variable cv_work_, cv_space_, cv_result_;

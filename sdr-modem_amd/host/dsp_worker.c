@@ -81,17 +81,25 @@ static int write_fully(const uint8_t *bytes, size_t n, int fd) {
 /* thread body when the worker sits on a shared batcher: the soft bits arrive already demodulated */
 static void *batched_main(void *arg) {
     dsp_worker *w = (dsp_worker *) arg;
+    int gave_up = 0;
     fprintf(stdout, "[%d] dsp_worker is starting\n", w->id);
     for (;;) {
         int8_t *soft = NULL;
         size_t soft_len = 0;
         sdrm_batcher_take(w->batcher, w->channel, &soft, &soft_len);
         if (soft == NULL) {
-            break; /* poison pill */
+            /* poison pill (everything put before it has been delivered) -- or the device behind the batcher failed, which
+             * ends every client at once: say so, as the private-handle path does through sdrm_fsk_demod_error */
+            const int dev = sdrm_batcher_error(w->batcher);
+            if (dev != 0) {
+                fprintf(stderr, "<3>[%d] the demodulator's device call failed (%d); the client is ended\n", w->id, dev);
+            }
+            break;
         }
         if (w->soft_dump != NULL && fwrite(soft, sizeof(int8_t), soft_len, w->soft_dump) < soft_len) {
             sdrm_batcher_complete(w->batcher, w->channel);
             fprintf(stderr, "<3>[%d] unable to write demod data\n", w->id);
+            gave_up = 1;
             break;
         }
         int code = 0;
@@ -100,12 +108,17 @@ static void *batched_main(void *arg) {
         }
         sdrm_batcher_complete(w->batcher, w->channel);
         if (code != 0) {
+            gave_up = 1;
             break;
         }
     }
-    /* whatever made the loop end, nobody takes this client's results any more: let the shared rounds go (the reference's
-     * worker leaves its own queue to fill up, src/dsp_worker.c:56-64,83-101; here the rounds belong to every client) */
-    sdrm_batcher_abandon(w->batcher, w->channel);
+    if (gave_up) {
+        /* nobody takes this client's results any more: let the shared rounds go (the reference's worker leaves its own
+         * queue to fill up, src/dsp_worker.c:56-64,83-101; here the rounds belong to every client).  Not after the
+         * poison pill: that path has drained the channel, and the slot may already have been handed to the next client
+         * (sdrm_batcher_reset_channel) by the time this thread is joined -- a late abandon would close ITS channel. */
+        sdrm_batcher_abandon(w->batcher, w->channel);
+    }
     printf("[%d] dsp_worker stopped\n", w->id);
     return NULL;
 }

@@ -86,8 +86,12 @@ int sdrm_wire_read_header(int socket, uint8_t *type, uint32_t *message_length) {
     }
     uint32_t len;
     memcpy(&len, h + 2, 4);
+    len = ntohl(len);
+    if (len > SDRM_WIRE_MAX_MESSAGE) {
+        return -3; /* no message of this protocol's RX side comes near it: do not let a peer size the caller's buffer */
+    }
     *type = h[1];
-    *message_length = ntohl(len);
+    *message_length = len;
     return 0;
 }
 
@@ -106,6 +110,18 @@ static int get_varint(struct cursor *c, uint64_t *v) {
         }
     }
     return -1;
+}
+
+/* a field key: (field number << 3) | wire type.  Field numbers are 1 .. 2^29 - 1 (protobuf encoding rules); a key with
+ * higher bits set must not alias onto a known field when truncated */
+static int get_key(struct cursor *c, unsigned *field, unsigned *wire_type) {
+    uint64_t key;
+    if (get_varint(c, &key) != 0 || key > 0xffffffffull || (key >> 3) == 0) {
+        return -1;
+    }
+    *field = (unsigned) (key >> 3);
+    *wire_type = (unsigned) (key & 7);
+    return 0;
 }
 
 static int skip_field(struct cursor *c, unsigned wire_type) {
@@ -133,9 +149,9 @@ static int skip_field(struct cursor *c, unsigned wire_type) {
 /* fsk_demodulation_settings (api.proto:21-25) */
 static int decode_fsk_settings(struct cursor c, sdrm_worker_config *cfg) {
     while (c.p < c.end) {
-        uint64_t key, v;
-        if (get_varint(&c, &key) != 0) return -1;
-        const unsigned field = (unsigned) (key >> 3), wt = (unsigned) (key & 7);
+        uint64_t v;
+        unsigned field, wt;
+        if (get_key(&c, &field, &wt) != 0) return -1;
         if (wt == 0 && field >= 1 && field <= 3) {
             if (get_varint(&c, &v) != 0) return -1;
             if (field == 1) cfg->demod_fsk_deviation = (int64_t) v; /* int64: two's complement varint */
@@ -156,9 +172,9 @@ int sdrm_wire_decode_rx_request(const uint8_t *body, size_t len, sdrm_worker_con
     unsigned seen = 0;
     int doppler = 0;
     while (c.p < c.end) {
-        uint64_t key, v;
-        if (get_varint(&c, &key) != 0) return -1;
-        const unsigned field = (unsigned) (key >> 3), wt = (unsigned) (key & 7);
+        uint64_t v;
+        unsigned field, wt;
+        if (get_key(&c, &field, &wt) != 0) return -1;
         if (wt == 0 && field >= 1 && field <= 8) {
             if (get_varint(&c, &v) != 0) return -1;
             seen |= 1u << field;
@@ -168,7 +184,10 @@ int sdrm_wire_decode_rx_request(const uint8_t *body, size_t len, sdrm_worker_con
                 case 5: if (v != 1) return -1; break; /* modem_type GMSK = 1 is all the reference has */
                 case 6: cfg->demod_baud_rate = (uint32_t) v; break;
                 case 7: cfg->demod_decimation = (uint32_t) v; break;
-                case 8: cfg->demod_destination = (int) v; break;
+                case 8:
+                    if (v > 2) return -1; /* demod_destination: FILE = 0, SOCKET = 1, BOTH = 2 (api.proto:29-33) */
+                    cfg->demod_destination = (int) v;
+                    break;
                 default: break; /* rx_center_freq, rx_offset: the device's business */
             }
         } else if (wt == 2 && (field == 9 || field == 10 || field == 11)) {

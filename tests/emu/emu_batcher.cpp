@@ -19,7 +19,18 @@ extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t
 extern "C" int emu_process_nco(EmuBatch *b, const float *const *inputs, const size_t *lens, const sdrm_nco_segment *segs,
                                size_t n_segs, const int8_t **out8, const float **outf, size_t *outlens);
 
+#include <atomic>
+
 namespace {
+
+// fault injection: the n-th submit / collect from now fails with -EIO (0: never)
+std::atomic<int> g_fail_submit_in{0}, g_fail_collect_in{0};
+bool countdown(std::atomic<int> &n) {
+    int v = n.load();
+    while (v > 0 && !n.compare_exchange_weak(v, v - 1)) {
+    }
+    return v == 1;
+}
 
 struct EmuBackend : sdrm::BatchBackend {
     EmuBatch *emu = nullptr;
@@ -45,6 +56,7 @@ struct EmuBackend : sdrm::BatchBackend {
     }
     int submit(size_t slot, const size_t *lens, const sdrm_nco_segment *segs, size_t n_segs) override {
         if (done.size() >= 3) return -11;
+        if (countdown(g_fail_submit_in)) return -5;
         const size_t C = maxlen.size();
         std::vector<const float *> ins(C);
         for (size_t c = 0; c < C; c++) ins[c] = arena_mem.data() + 2 * ((slot * C + c) * stride);
@@ -69,6 +81,10 @@ struct EmuBackend : sdrm::BatchBackend {
     int collect(int8_t **outs, size_t *lens) override {
         if (done.empty()) return -1;
         if (delay_us) usleep(delay_us);
+        if (countdown(g_fail_collect_in)) {
+            done.pop_front();
+            return -5;
+        }
         last = std::move(done.front().out);
         done.pop_front();
         for (size_t c = 0; c < last.size(); c++) {
@@ -80,6 +96,11 @@ struct EmuBackend : sdrm::BatchBackend {
 };
 
 }  // namespace
+
+extern "C" void emu_batcher_inject(int submit_in, int collect_in) {
+    g_fail_submit_in = submit_in;
+    g_fail_collect_in = collect_in;
+}
 
 extern "C" int emu_batcher_create(const sdrm_fsk_config *cfgs, size_t n, uint32_t slots, uint32_t max_wait_us, int blocking,
                                   unsigned device_delay_us, sdrm_batcher **out) {

@@ -180,6 +180,10 @@ def test_wire_response_bytes_and_header_round_trip():
     a.recv(300)
     b.sendall(bytes([9, 0, 0, 0, 0, 0]))                             # wrong protocol version
     assert L.sdrm_wire_read_header(a.fileno(), C.byref(t), C.byref(n)) == -2
+    b.sendall(bytes([0, 0, 0xff, 0xff, 0xff, 0xff]))                 # a peer announcing 4 GiB does not size our buffer
+    assert L.sdrm_wire_read_header(a.fileno(), C.byref(t), C.byref(n)) == -3
+    b.sendall(bytes([0, 0, 0, 1, 0, 0]))                             # 65536: the largest body accepted
+    assert L.sdrm_wire_read_header(a.fileno(), C.byref(t), C.byref(n)) == 0 and n.value == 65536
     b.close()
     assert L.sdrm_wire_read_header(a.fileno(), C.byref(t), C.byref(n)) == -1  # peer gone
     a.close()
@@ -206,3 +210,19 @@ def test_wire_rx_request_fields_reach_the_worker_configuration():
     bad = body[:len(body) - 3]                                        # truncated in the middle of a field
     buf = (C.c_uint8 * len(bad)).from_buffer_copy(bad)
     assert L.sdrm_wire_decode_rx_request(buf, len(bad), C.byref(cfg), C.byref(dop)) == -1
+    # demod_destination outside FILE / SOCKET / BOTH (api.proto:29-33) is refused, not turned into a worker that
+    # demodulates and discards
+    odd = body.replace(_field(8, 1), _field(8, 3))
+    buf = (C.c_uint8 * len(odd)).from_buffer_copy(odd)
+    assert L.sdrm_wire_decode_rx_request(buf, len(odd), C.byref(cfg), C.byref(dop)) == -1
+    # a key whose high bits would alias onto field 8 when truncated to 32 bits (field 2^29 + 8), and field number 0
+    for key in ((((1 << 29) + 8) << 3), 0):
+        v, enc = key, b""
+        while True:
+            enc += bytes([(v & 0x7f) | (0x80 if v >> 7 else 0)])
+            v >>= 7
+            if not v:
+                break
+        alias = short + enc + bytes([1])
+        buf = (C.c_uint8 * len(alias)).from_buffer_copy(alias)
+        assert L.sdrm_wire_decode_rx_request(buf, len(alias), C.byref(cfg), C.byref(dop)) == -1, key

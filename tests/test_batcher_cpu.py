@@ -260,3 +260,55 @@ def test_a_dead_consumer_does_not_stall_the_other_clients():
     bt.put(1, sig_b)
     assert np.array_equal(bt.take(1), oracle_stream(CFG_A, [sig_b])[0])
     bt.close()
+
+
+def _failing_device(fail_submit, fail_collect):
+    """three clients stream four buffers each; the device call of the third round fails"""
+    cfgs = [CFG_A, CFG_B, CFG_A]
+    sigs = [siggen.gmsk_channel(40 + i, 4 * 2000, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    bt = emu_api.emu_batcher(cfgs, slots=4, max_wait_us=200000, blocking=True)
+    emu_api.lib().emu_batcher_inject(3 if fail_submit else 0, 3 if fail_collect else 0)
+    got = [[] for _ in cfgs]
+    ended = [None] * len(cfgs)
+
+    def producer(c):
+        for k in range(4):
+            bt.put(c, sigs[c][k * 2000:(k + 1) * 2000])
+
+    def consumer(c):
+        while True:
+            r = bt.take(c)
+            if r is None:
+                ended[c] = bt.error()
+                return
+            got[c].append(r)
+
+    th = [threading.Thread(target=f, args=(c,)) for c in range(len(cfgs)) for f in (producer, consumer)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+        assert not t.is_alive(), "a client is still waiting on a dead device"
+    emu_api.lib().emu_batcher_inject(0, 0)
+    return bt, cfgs, sigs, got, ended
+
+
+def test_a_failed_device_call_ends_every_client_with_an_error_code(capfd):
+    """A batched call that fails must not look like "no symbols for ever after": take() returns NULL for every client,
+    the blocked producers return, and sdrm_batcher_error() holds the device's code (the worker mirror and the shared
+    fsk_demod handles turn that into their sticky error) -- for a failed submit and for a failed collect."""
+    for fail_submit, fail_collect in ((True, False), (False, True)):
+        bt, cfgs, sigs, got, ended = _failing_device(fail_submit, fail_collect)
+        assert ended == [-5, -5, -5], ended
+        assert bt.error() == -5
+        for c, cfg in enumerate(cfgs):
+            # what was delivered before the failure is the oracle's stream; never an empty stand-in for a lost buffer
+            assert len(got[c]) <= 2, (c, len(got[c]))
+            exp = oracle_stream(cfg, [sigs[c][k * 2000:(k + 1) * 2000] for k in range(len(got[c]))])
+            for k in range(len(got[c])):
+                assert np.array_equal(got[c][k], exp[k]), (c, k)
+        # later puts are dropped, later takes return at once
+        bt.put(0, sigs[0][:100])
+        assert bt.take(0) is None
+        bt.close()
+    assert "<3>batcher" in capfd.readouterr().err

@@ -4,9 +4,9 @@
 # mixed-rate Doppler workload.  Everything lands under gpurun_out/r02/; summaries are then copied into profiles/ by hand.
 set +e
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run this on the gpurun box (GRAFT_REPO_ROOT is the snapshot root)}
 OUT=$R/gpurun_out/r02
-rm -rf $OUT; mkdir -p $OUT
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 echo "== bench under rocprofv3 --kernel-trace --stats"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 $R/bench.py --no-cpu-baseline --no-extras --sweep "" > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err; echo "exit $?"

@@ -1,11 +1,11 @@
 #!/bin/bash
 # vector instructions per launch and duration of the front-end alone (stages serialised): tools/k1_valu.sh [channels]
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run this on the gpurun box (GRAFT_REPO_ROOT is the snapshot root)}
 CH=${1:-256}
 python $R/tools/stage_times.py $CH
 cd /tmp
-rm -rf $R/gpurun_out/pmc_k1v
+rm -rf "$R/gpurun_out/pmc_k1v"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_k1v -- python3 $R/tools/stage_times.py $CH > /dev/null 2>&1
 python3 - <<PY
 import csv,glob,collections
