@@ -587,9 +587,10 @@ def main():
                 out["roofline_fast"] = {"kernel": "k1_front<fused> (SDRM_FLAG_FAST_FMA, opt-in, not bit-exact)", "bound": "hbm",
                                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kf[0], 4), "steps": SWEEP_STEPS,
-                                        "parity": "int8 soft bits within the reference's +-2 LSB of its golden files on 3 of 4 "
-                                                  "fixtures, float soft bits 2e-4 .. 3.4e-3 RMS from the exact mode "
-                                                  "(tests/test_gpu_parity.py::test_fast_fma_mode..., profiles/r02_fast_mode.txt)"}
+                                        "parity": "NONE CLAIMED: float soft bits 2e-4 .. 3.4e-3 RMS from the exact mode (bar: 1e-4); int8 soft "
+                                                  "bits within the reference's +-2 LSB of its golden files on 3 of 4 fixtures, NOT on "
+                                                  "lucky7_nodc (up to 19 LSB) -- tests/test_gpu_parity.py::test_fast_fma_mode..., "
+                                                  "profiles/r02_fast_mode.txt"}
             except Exception as exc:
                 out["roofline_fast"] = {"error": str(exc)[:200]}
             for name, fn in (("end_to_end", lambda: end_to_end(binding, siggen, C, N)),

@@ -188,6 +188,10 @@ static void *worker_main(void *arg) {
 }
 
 int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *cfg, dsp_worker **result) {
+    return sdrm_dsp_worker_create(id, client_socket, cfg, result);
+}
+
+int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *cfg, dsp_worker **result) {
     dsp_worker *w = calloc(1, sizeof(*w));
     if (w == NULL) {
         return -ENOMEM;

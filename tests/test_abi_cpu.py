@@ -226,3 +226,126 @@ def test_wire_rx_request_fields_reach_the_worker_configuration():
         alias = short + enc + bytes([1])
         buf = (C.c_uint8 * len(alias)).from_buffer_copy(alias)
         assert L.sdrm_wire_decode_rx_request(buf, len(alias), C.byref(cfg), C.byref(dop)) == -1, key
+
+
+def _ref_adapter(tmp_path):
+    """integration/dsp_worker_ref.c (dsp_worker_create with the reference's own parameter list, src/dsp_worker.h:22)
+    built against integration/ref_fields.h -- the two reference types restated, api.pb-c.h:104-121, server_config.h:16-40 --
+    and linked against the library"""
+    import subprocess
+    so = os.path.join(str(tmp_path), "libref_adapter.so")
+    libdir = os.path.dirname(binding.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "integration"), os.path.join(ROOT, "integration", "dsp_worker_ref.c"),
+                           "-o", so, "-L", libdir, "-lsdrmodem_hip", "-Wl,-rpath," + libdir])
+    binding.load()  # the library first: the adapter's DT_NEEDED then resolves to the copy already mapped
+    return C.CDLL(so)
+
+
+class _PbBase(C.Structure):
+    _fields_ = [("descriptor", C.c_void_p), ("n_unknown_fields", C.c_uint), ("unknown_fields", C.c_void_p)]
+
+
+class _FskSettings(C.Structure):
+    _fields_ = [("base", _PbBase), ("demod_fsk_deviation", C.c_int64), ("demod_fsk_transition_width", C.c_uint32),
+                ("demod_fsk_use_dc_block", C.c_int)]
+
+
+class _RxRequest(C.Structure):
+    _fields_ = [("base", _PbBase), ("rx_center_freq", C.c_uint64), ("rx_sampling_freq", C.c_uint64), ("rx_dump_file", C.c_int),
+                ("rx_offset", C.c_int64), ("demod_type", C.c_int), ("demod_baud_rate", C.c_uint32), ("demod_decimation", C.c_uint32),
+                ("demod_destination", C.c_int), ("doppler", C.c_void_p), ("fsk_settings", C.POINTER(_FskSettings)),
+                ("file_settings", C.c_void_p)]
+
+
+class _ServerConfig(C.Structure):
+    _fields_ = [("bind_address", C.c_char_p), ("port", C.c_uint16), ("read_timeout_seconds", C.c_int), ("buffer_size", C.c_uint32),
+                ("queue_size", C.c_uint16), ("rx_sdr_type", C.c_uint8), ("rx_sdr_server_address", C.c_char_p),
+                ("rx_sdr_server_port", C.c_int), ("base_path", C.c_char_p), ("rx_file_base_path", C.c_char_p),
+                ("tx_file_base_path", C.c_char_p), ("tx_sdr_type", C.c_uint8), ("tx_plutosdr_gain", C.c_double),
+                ("rx_plutosdr_gain", C.c_double), ("tx_plutosdr_timeout_millis", C.c_uint), ("iio", C.c_void_p)]
+
+
+def _request(fs, baud, dev, decim, tw, dc, dump, dest):
+    fsk = _FskSettings(demod_fsk_deviation=dev, demod_fsk_transition_width=tw, demod_fsk_use_dc_block=1 if dc else 0)
+    req = _RxRequest(rx_center_freq=437525000, rx_sampling_freq=fs, rx_dump_file=1 if dump else 0, demod_type=1,
+                     demod_baud_rate=baud, demod_decimation=decim, demod_destination=dest, fsk_settings=C.pointer(fsk))
+    req._keep = fsk
+    return req
+
+
+def test_reference_signature_adapter_compiles_and_maps_the_request(tmp_path, capfd):
+    """the adapter a maintainer drops into sdr-modem in place of src/dsp_worker.c: compiled -Wall -Wextra -Werror, called
+    with the reference's parameter list.  Without a GPU the demodulator cannot be created, but the request is mapped and
+    judged first, as in the reference: its own unit test's bad request (test/test_dsp_worker.c:58-66, baud == sampling
+    rate => LPF cutoff above fs/2 => -1) fails with -1 and the reference's message, a good one with -ENODEV."""
+    A = _ref_adapter(tmp_path)
+    A.dsp_worker_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(_ServerConfig), C.POINTER(_RxRequest), C.POINTER(C.c_void_p)]
+    sc = _ServerConfig(buffer_size=4096, queue_size=4, rx_sdr_type=2, base_path=str(tmp_path).encode())
+    w = C.c_void_p()
+    bad = _request(48000, 48000, 5000, 1, 2000, True, False, 0)
+    assert A.dsp_worker_create(3, -1, C.byref(sc), C.byref(bad), C.byref(w)) == -1
+    assert "<3>[3] unable to create demodulator" in capfd.readouterr().err
+    if binding.load().sdrm_device_count() == 0:
+        good = _request(48000, 4800, 5000, 2, 2000, True, False, 0)
+        assert A.dsp_worker_create(4, -1, C.byref(sc), C.byref(good), C.byref(w)) == -errno.ENODEV
+    other = _request(48000, 4800, 5000, 2, 2000, True, False, 0)
+    other.demod_type = 7  # not GMSK: rejected instead of dereferencing a demodulator that was never made
+    assert A.dsp_worker_create(5, -1, C.byref(sc), C.byref(other), C.byref(w)) == -1
+
+
+def test_reference_signature_adapter_drives_workers_on_a_shared_batcher(tmp_path):
+    """the same adapter with a per-GPU batcher attached (here: the product's batcher code over the kernel emulation): three
+    RX clients created through dsp_worker_create(id, socket, server_config *, RxRequest *, &worker), fed through
+    dsp_worker_put like sdr_worker.c:25-29 does, shut down through dsp_worker_destroy; the files the reference's worker
+    writes (rx.demod2client.<id>.s8, rx.sdr2demod.<id>.cf32, src/dsp_worker.c:154,165) hold the oracle's bytes."""
+    import emu_api
+    import orc
+    from sdr_modem_amd import siggen
+    A = _ref_adapter(tmp_path)
+    A.dsp_worker_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(_ServerConfig), C.POINTER(_RxRequest), C.POINTER(C.c_void_p)]
+    NEXT = C.CFUNCTYPE(C.c_size_t, C.c_void_p)
+    A.sdrm_ref_attach_batcher.argtypes = [C.c_void_p, NEXT, C.c_void_p]
+    L = binding.load()
+    cfg = (48000, 4800, 5000, 2, 2000, True, 4096)
+    n_w = 3
+    bt = emu_api.emu_batcher([cfg] * n_w, slots=4, max_wait_us=20000, blocking=True)
+    counter = [0]
+
+    def next_channel(_user):
+        counter[0] += 1
+        return counter[0] - 1
+    cb = NEXT(next_channel)
+    A.sdrm_ref_attach_batcher(bt.h, cb, None)
+    sc = _ServerConfig(buffer_size=4096, queue_size=4, rx_sdr_type=2, base_path=str(tmp_path).encode())
+    sigs = [siggen.gmsk_channel(70 + i, 3 * 4096 + 100, fs=48000, baud=4800) for i in range(n_w)]
+    ws = []
+    for i in range(n_w):
+        req = _request(48000, 4800, 5000, 2, 2000, True, i == 1, 0)
+        w = C.c_void_p()
+        assert A.dsp_worker_create(30 + i, -1, C.byref(sc), C.byref(req), C.byref(w)) == 0
+        ws.append(w)
+    L.dsp_worker_put.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.dsp_worker_destroy.argtypes = [C.c_void_p]
+
+    def feed(i):
+        for off in range(0, len(sigs[i]), 4096):
+            part = np.ascontiguousarray(sigs[i][off:off + 4096]).view(np.float32)
+            L.dsp_worker_put(part.ctypes.data, len(part) // 2, ws[i])
+    import threading
+    th = [threading.Thread(target=feed, args=(i,)) for i in range(n_w)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+        assert not t.is_alive()
+    for w in ws:
+        L.dsp_worker_destroy(w)
+    for i in range(n_w):
+        got = np.fromfile(os.path.join(str(tmp_path), "rx.demod2client.%d.s8" % (30 + i)), dtype=np.int8)
+        want, _ = orc.demod_stream(cfg[:6], sigs[i], 4096)
+        assert np.array_equal(got, want), i
+    dump = np.fromfile(os.path.join(str(tmp_path), "rx.sdr2demod.31.cf32"), dtype=np.complex64)
+    assert np.array_equal(dump, sigs[1])
+    A.sdrm_ref_attach_batcher(None, NEXT(0), None)
+    bt.close()

@@ -226,12 +226,13 @@ def test_lucky7_float_soft_bits_all_configs():
         run_stream(cfg, iq, [4096] * 23 + [96000 - 23 * 4096], 4096)
 
 
-def test_fast_fma_mode_within_the_references_own_tolerance(capsys):
+def test_fast_fma_mode_is_measured_against_the_references_tolerance(capsys):
     """SDRM_FLAG_FAST_FMA (opt-in, never the default): fused multiply-adds in both filters.  Not the reference's bits --
     SURVEY.md finding 2: any change of the FIR rounding flips the 129-way MMSE filter choice on a few per cent of the
-    symbols -- so it is held to the reference's OWN test tolerance, +-2 LSB of the int8 soft bits against its golden files
-    (test/test_fsk_demod.c:14-19, 47), and what it costs against the exact mode is measured and printed: RMS, median,
-    fraction of float soft bits off by more than 1e-4, hard-bit (sign) errors."""
+    symbols -- so it is measured against the reference's OWN test tolerance, +-2 LSB of the int8 soft bits against its
+    golden files (test/test_fsk_demod.c:14-19, 47): three of the four fixtures hold it, lucky7_nodc does NOT (one burst of
+    ~30 symbols up to 19 LSB off, bounded below).  The mode therefore carries no parity claim; what it costs against the
+    exact mode is measured and printed: RMS, median, fraction of float soft bits off by more than 1e-4, hard-bit errors."""
     rows = []
     for name, cfg, inp, exp in E2E:
         iq = np.fromfile(os.path.join(GOLDEN, inp), dtype=np.complex64)
@@ -997,12 +998,8 @@ def test_batcher_many_clients_on_the_device_match_oracle():
         for k in range(K):
             x = chunks[c][k].view(np.float32)
             want = o.process(d.process(x) if d else chunks[c][k])[0]
-            if d is None:
-                assert np.array_equal(got[c][k], want), (c, k)
-            else:  # device cos/sin vs glibc: the reference's own 2-LSB tolerance (test_fsk_demod.c:47)
-                assert len(got[c][k]) == len(want)
-                if len(want):
-                    assert np.abs(got[c][k].astype(np.int32) - want.astype(np.int32)).max() <= 2
+            # the Doppler-corrected client too: the device's oscillator is the correctly rounded one
+            assert np.array_equal(got[c][k], want), (c, k)
     assert bt.rounds() <= K + 3  # batched: about one device call per buffer index, not 24 * K
     for c in range(len(cfgs)):
         bt.interrupt(c)
