@@ -24,8 +24,9 @@
 
 /* most samples the clock-recovery stage may carry across calls.  The reference sizes its buffer for 8
  * (clock_recovery_mm.c:58) and silently overruns it when samples-per-symbol >= 8 (carry < 1.01*sps + 6);
- * the oracle and the device path both provision 63 and truncate (keeping the newest) beyond that. */
-#define ORC_CLOCK_HCAP 63
+ * the oracle and the device path both provision 255 (samples-per-symbol up to 244) and truncate, keeping the newest,
+ * beyond that. */
+#define ORC_CLOCK_HCAP 255
 
 /* float -> int32 the way the reference's x86-64 build does it (cvttss2si): out of range / NaN -> INT_MIN.
  * In C that conversion is undefined; the reference relies on it at fast_atan2f.c:112 and

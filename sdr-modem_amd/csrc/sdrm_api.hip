@@ -447,6 +447,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.dc_rpitch = sdrm_k2_ring_pitch((pl.dc_l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK);
     d.dc_lds = (uint32_t) pl.dc_lds_bytes();
     d.any_dc = any_dc;
+    d.k3_carried_max = (int) pl.clock_carried_max;
     d.fast_fma = (flags & SDRM_FLAG_FAST_FMA) ? 1 : 0;
     {
         const char *q = getenv("SDRM_K1_QUAD");
@@ -522,6 +523,7 @@ extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_
         b->any_nodc = b->any_nodc || q.dc_len == 0;
     }
     b->last_lens[c] = 0;
+    b->dev.k3_carried_max = (int) pl.clock_carried_max;
     return 0;
 }
 
@@ -691,14 +693,14 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     d.max_tiles = max_tiles;
     {
         // no channel can produce more symbols than this in the call (grid of the int8 conversion): every symbol advances
-        // by at least floor(omega_mid - omega_lim) samples of what the call brings plus the <= 63 carried ones
+        // by at least floor(omega_mid - omega_lim) samples of what the call brings plus the carried ones (< SDRM_CLOCK_HCAP)
         uint32_t most = 0;
         for (size_t c = 0; c < C; c++) {
             const sdrm_chan_params &p = b->plan.params[c];
             const float adv = floorf(p.omega_mid - p.omega_lim);
             uint32_t bound = p.max_len;
             if (adv >= 1.0f) {
-                bound = std::min<uint32_t>(bound, (uint32_t) ((h[c].nz + 64u) / (uint32_t) adv) + 8u);
+                bound = std::min<uint32_t>(bound, (uint32_t) ((h[c].nz + (uint32_t) SDRM_CLOCK_HCAP) / (uint32_t) adv) + 8u);
             }
             most = std::max(most, bound);
         }
@@ -1000,7 +1002,7 @@ static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h
     uint32_t most = p.max_len;
     const float adv = floorf(p.omega_mid - p.omega_lim);
     if (adv >= 1.0f) {
-        most = std::min<uint32_t>(most, (uint32_t) ((nz_cap + 64u) / (uint32_t) adv) + 8u);
+        most = std::min<uint32_t>(most, (uint32_t) ((nz_cap + (uint32_t) SDRM_CLOCK_HCAP) / (uint32_t) adv) + 8u);
     }
     d.max_symbols = most;
     d.z = b->d_z;

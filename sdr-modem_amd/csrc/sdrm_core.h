@@ -22,7 +22,9 @@
 
 #define SDRM_MMSE_TAPS 8
 #define SDRM_MMSE_STEPS 128
-#define SDRM_CLOCK_HCAP 64   // max samples the clock stage carries between calls
+#define SDRM_CLOCK_HCAP 256  // max samples the clock stage carries between calls: < 1.01 samples/symbol + 8 (round 3: 64 -> 256,
+                             // which admits 240 kHz / 1200 baud without decimation: 200 samples per symbol)
+#define SDRM_DC_MAX_LEN 7712  // longest boxcar of the DC blocker (32 x 241 samples per symbol)
 #define SDRM_INT_MIN (-2147483647 - 1)
 
 struct sdrm_f2 {

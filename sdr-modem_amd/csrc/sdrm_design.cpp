@@ -84,15 +84,16 @@ int design_channel(const sdrm_fsk_config &cfg, ChannelDesign &out) {
     out.omega_lim = out.sps * 0.01f;  // clock_recovery_mm.c:43
     // limits of the device path (DESIGN.md "Supported range"):
     //  - the clock stage carries < 1.01*sps + 6 samples between calls; SDRM_CLOCK_HCAP are provisioned
-    //  - the DC blocker keeps its delay lines in LDS rings of at most 4096 + 8192 floats (delay + blocks in flight)
+    //  - the DC blocker keeps three delay lines of L + 64 floats per channel in LDS: one channel per workgroup still fits
+    //    at L = 7712 (159 KB); the three-instruction quotient is proven for every length up to there (tools/dc_div_sweep)
     //  - a decimating FIR needs decimation <= taps (the reference underflows otherwise, fir_filter.c:107)
     if (!(out.sps >= 1.0f) || out.sps * 1.01f + 8.0f > (float) SDRM_CLOCK_HCAP) {
         fprintf(stderr, "<3>samples per symbol %.3f outside the supported range [1, %d)\n", (double) out.sps,
                 (int) ((SDRM_CLOCK_HCAP - 8) / 1.01f));
         return -ENOTSUP;
     }
-    if (cfg.use_dc_block && (out.dc_length < 2 || out.dc_length > 3968)) {
-        fprintf(stderr, "<3>dc blocker length %u outside the supported range [2, 3968]\n", out.dc_length);
+    if (cfg.use_dc_block && (out.dc_length < 2 || out.dc_length > SDRM_DC_MAX_LEN)) {
+        fprintf(stderr, "<3>dc blocker length %u outside the supported range [2, %d]\n", out.dc_length, SDRM_DC_MAX_LEN);
         return -ENOTSUP;
     }
     if ((size_t) cfg.decimation > out.taps2.size()) {

@@ -93,12 +93,19 @@ SDRM_HD bool sdrm_k3_shape_ok(int lanes, int ring, int plain) {
 }
 // channels per workgroup for a batch of n channels (round 1, ms per step, 131072-sample chunks; lanes 64 / 32 / 16 / 8:
 // 256 channels 3.96 / 3.18 / 3.09 / 3.07, 1024: 4.67 / 4.37 / 3.88 / 4.46)
-static inline sdrm_k3_shape sdrm_k3_shape_for(int n_channels, int forced_lanes, int forced_ring, int forced_plain) {
+// carried_max: the most samples any channel of the batch can carry between calls (< 1.01 samples/symbol + 8).  They sit
+// in the ring in front of the call's first block while the staging wave already writes the second: the ring must hold
+// them plus two blocks, i.e. ring / 2 >= carried_max -- long symbols (more than ~120 samples) need the 1024-sample ring.
+static inline sdrm_k3_shape sdrm_k3_shape_for(int n_channels, int forced_lanes, int forced_ring, int forced_plain, int carried_max) {
     if (forced_lanes == 16 || forced_lanes == 32 || forced_lanes == 64) {
         sdrm_k3_shape f = {forced_lanes, forced_ring ? forced_ring : 16384 / forced_lanes, forced_plain};
-        if (sdrm_k3_shape_ok(f.lanes, f.ring, f.plain)) {
+        if (sdrm_k3_shape_ok(f.lanes, f.ring, f.plain) && f.ring / 2 >= carried_max) {
             return f;
         }
+    }
+    if (carried_max > 128) {
+        sdrm_k3_shape l = {16, 1024, 0};
+        return l;
     }
     // Measured per batch size (round 2, tools/k3_ab.py, ms per call of 131072 samples per channel; 16 / 32 / 64 channels
     // per workgroup, full shapes): 1280 channels 3.28 / 3.82 / 4.48, 1536: 4.02 / 3.81 / 4.62, 2048: 5.50 / 4.87 / 4.84,

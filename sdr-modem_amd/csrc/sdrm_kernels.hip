@@ -1760,7 +1760,7 @@ static KernelLaunch describe_clock_as(const DeviceBatch &b) {
 sdrm_k3_shape k3_shape(const DeviceBatch &b) {
     int lanes = 0, ring = 0, plain = 0;
     sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring, &plain);  // tests and measurements: force one workgroup shape (read per launch)
-    return sdrm_k3_shape_for(b.n_channels, lanes, ring, plain);
+    return sdrm_k3_shape_for(b.n_channels, lanes, ring, plain, b.k3_carried_max);
 }
 
 KernelLaunch describe_clock(const DeviceBatch &b) {

@@ -48,6 +48,7 @@ struct DeviceBatch {
     uint32_t dc_group, dc_rpitch;    // channels per DC workgroup, floats between two of its delay rings in LDS
     uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
+    int k3_carried_max;              // most samples a channel can carry between calls of the clock stage (sizes its ring)
     int quad_flat;                   // measurements (SDRM_K1_QUAD=flat): the discriminator always takes its general form
     int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching

@@ -100,6 +100,7 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
             plan.any_dc = 1;
             plan.dc_l_cap = std::max(plan.dc_l_cap, p.dc_len);
         }
+        plan.clock_carried_max = std::max(plan.clock_carried_max, (uint32_t) (d.sps * 1.01f + 8.0f));
         plan.t1_max = std::max(plan.t1_max, p.T1);
         plan.t2_max = std::max(plan.t2_max, p.T2);
         h_max = std::max(h_max, p.hist_len);
@@ -167,6 +168,7 @@ int replan_channel(BatchPlan &plan, size_t c, const sdrm_fsk_config &cfg, std::v
     std::copy(d.taps2.rbegin(), d.taps2.rend(), taps_slot.begin() + round_up_u32(plan.t1_max, 8));
     plan.design[c] = d;
     plan.params[c] = p;
+    plan.clock_carried_max = std::max(plan.clock_carried_max, (uint32_t) (d.sps * 1.01f + 8.0f));  // the clock stage follows with its ring
     plan.phase[c] = 0;
     plan.parity[c] = 0;
     plan.zbase[c] = 0;

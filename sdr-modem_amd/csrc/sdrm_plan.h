@@ -28,6 +28,7 @@ struct BatchPlan {
     int any_dc = 0;
     // streaming bookkeeping that depends on input lengths only (kept on the host)
     std::vector<uint32_t> phase, parity, zbase;
+    uint32_t clock_carried_max = 0;  // most samples a channel can carry between calls of the clock stage (< 1.01 sps + 8)
     size_t dc_lds_bytes() const;  // dynamic LDS of the DC kernel for this batch
 };
 

@@ -332,7 +332,7 @@ static void emu_clock_as(EmuBatch *b) {
 static void emu_clock(EmuBatch *b) {
     int lanes = 0, ring = 0, plain = 0;
     sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring, &plain);
-    const sdrm_k3_shape sh = sdrm_k3_shape_for((int) b->plan.params.size(), lanes, ring, plain);
+    const sdrm_k3_shape sh = sdrm_k3_shape_for((int) b->plan.params.size(), lanes, ring, plain, (int) b->plan.clock_carried_max);
     switch ((sh.lanes * 10000 + sh.ring) * (sh.plain ? -1 : 1)) {
         case 16 * 10000 + 1024: emu_clock_as<16, 1024, false>(b); break;
         case 16 * 10000 + 512: emu_clock_as<16, 512, false>(b); break;

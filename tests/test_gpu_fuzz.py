@@ -67,3 +67,38 @@ def test_random_configurations_streams_match_the_oracle(keep_soft):
             if keep_soft:
                 assert np.array_equal(g.last_soft(i).view(np.uint32), of.view(np.uint32)), (live_cfg[i], call)
     g.close()
+
+
+@pytest.mark.parametrize("keep_soft", [False, True])
+def test_long_symbols_up_to_two_hundred_samples(keep_soft):
+    """Round 3 lifted two limits of the device path: the clock stage carries up to 255 samples between calls (64 before:
+    samples/symbol < 55) and the DC blocker's boxcars reach 7712 samples (3968 before).  240 kHz / 1200 baud without
+    decimation -- 200 samples per symbol, L = 6400 -- and its neighbours, in ONE batch with a 5-samples/symbol channel (the
+    batch then takes the clock stage's 1024-sample ring for everybody), ragged calls: bit-exact, including the symbol
+    the reference re-emits at every chunk edge when a symbol spans 8 or more samples (clock_recovery_mm.c:127-133)."""
+    maxlen = 9000
+    cfgs = [(240000, 1200, 5000, 1, 2000, True), (192000, 1200, 5000, 1, 2000, True), (96000, 1200, 5000, 1, 2000, False),
+            (240000, 2400, 2400, 1, 1000, True), (48000, 9600, 5000, 1, 2000, True), (240000, 1200, 5000, 1, 2000, False),
+            (240000, 1000, 5000, 1, 2000, True)]  # 240 samples per symbol, L = 7680: the new ceiling
+    full = [c + (maxlen,) for c in cfgs]
+    oracles = [orc.Fsk(*c) for c in full]
+    assert all(o.code == 0 for o in oracles)
+    g = binding.Batch(full, keep_soft=keep_soft)
+    assert g.code == 0
+    assert max(g.info(i).dc_length for i in range(len(cfgs))) == 7680 and max(g.info(i).sps for i in range(len(cfgs))) == 240.0
+    sigs = [siggen.gmsk_channel(300 + i, 5 * maxlen, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    rng = np.random.default_rng(11)
+    pos = [0] * len(cfgs)
+    for call in range(6):
+        lens = [int(rng.choice([0, 1, 7, 250, 3000, 8191, maxlen])) for _ in cfgs]
+        parts = [s[p:p + n] for s, p, n in zip(sigs, pos, lens)]
+        pos = [p + n for p, n in zip(pos, lens)]
+        g8 = g.process(parts)
+        for i, o in enumerate(oracles):
+            o8, of = o.process(parts[i])
+            assert np.array_equal(g8[i], o8), (cfgs[i], call, lens[i])
+            if keep_soft:
+                assert np.array_equal(g.last_soft(i).view(np.uint32), of.view(np.uint32)), (cfgs[i], call)
+    g.close()
+    # beyond the ceiling the library still says so instead of misbehaving
+    assert binding.Batch([(240000, 900, 5000, 1, 2000, True, 4096)]).code == -95  # -ENOTSUP: 266 samples per symbol

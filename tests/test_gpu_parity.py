@@ -283,7 +283,8 @@ def test_mixed_rate_configs():
     for cfg, fs, baud in [((240000, 19200, 5000, 5, 2000, True), 240000, 19200),
                           ((48000, 1200, 5000, 8, 2000, True), 48000, 1200),
                           ((48000, 1200, 5000, 1, 2000, True), 48000, 1200),  # sps 40: tail quirk, chunk-faithful
-                          ((240000, 19200, 5000, 1, 2000, True), 240000, 19200)]:
+                          ((240000, 19200, 5000, 1, 2000, True), 240000, 19200),
+                          ((240000, 1200, 5000, 1, 2000, True), 240000, 1200)]:  # sps 200, DC length 6400, LPF1 of 1033 taps
         iq = siggen.gmsk_channel(3, 40000, fs=fs, baud=baud)
         run_stream(cfg, iq, [16384, 5, 16384, 7227], 16384)
 

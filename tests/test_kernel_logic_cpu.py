@@ -118,6 +118,16 @@ def test_clock_stage_workgroup_shapes(lanes, monkeypatch):
         assert run_both(cfg, iq, chunks, 12000) <= len(iq)
 
 
+def test_two_hundred_samples_per_symbol():
+    """240 kHz / 1200 baud without decimation (the reference's defaults for a 1200-baud satellite on a 240 kHz stream):
+    200 samples per symbol, a 1033-tap LPF1, a 6400-sample DC boxcar (one channel per DC workgroup), up to 210 samples
+    carried by the clock stage between calls -- which re-emits a symbol at chunk edges there (clock_recovery_mm.c:127-133),
+    so the chunking is the oracle's.  Refused (-ENOTSUP) until round 3."""
+    iq = siggen.gmsk_channel(5, 66000, fs=240000, baud=1200)
+    run_both((240000, 1200, 5000, 1, 2000, True), iq, [16384, 1000, 16384, 7, 20000, 12225], 20000)
+    run_both((240000, 1200, 5000, 1, 2000, False), iq[:30000], [9000, 300, 20700], 20700)
+
+
 def test_synthetic_gmsk_large_chunk():
     iq = siggen.gmsk_channel(0, 70000)
     run_both((48000, 9600, 5000, 1, 2000, True), iq, [65536, 4464], 65536)
