@@ -81,6 +81,9 @@ struct sdrm_batch_t {
     hipStream_t s_company = nullptr;
     hipEvent_t ev_company = nullptr;
     uint32_t *d_k3_done = nullptr;   // clock-stage workgroups finished, all launches
+    uint32_t *d_placed = nullptr;    // [2] DC / clock-stage workgroups started, all launches (what the stream holds wait for)
+    uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started
+    uint32_t k3_placed_after[SDRM_CTL_SLOTS] = {};        // ... once the clock stage of the call in that slot has
     uint32_t k3_done_target = 0;     // what the counter reads when the launch enqueued last has finished
     int company_blocks = 0;
     int company_rounds = 120;        // bound on the companion grid's life, in ~50 us looks at the counter
@@ -176,6 +179,7 @@ static void batch_free(sdrm_batch_t *b) {
         (void) hipEventDestroy(b->ev_company);
     }
     (void) hipFree(b->d_k3_done);
+    (void) hipFree(b->d_placed);
     for (hipStream_t st : streams) {
         if (st) {
             (void) hipStreamDestroy(st);
@@ -373,6 +377,8 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     } else {
         e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
         e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
+        e = e ? e : hipMalloc((void **) &b->d_placed, 64);
+        e = e ? e : hipMemset(b->d_placed, 0, 64);
         // company for the clock stage while the batch is too small to keep the chip busy by itself: the front-end of a
         // full-length call must be expected to take well under the clock stage's time (at 1024 channels of the bench
         // workload it does not, nor with the 397-tap filters of 240 kHz channels: BASELINE configs[4] in one GPU's share
@@ -393,6 +399,12 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
                 symbols = sym > symbols ? sym : symbols;
             }
             if (macs / 18.4e12 > 0.7 * symbols * 97e-9) {
+                blocks = 0;
+            }
+            // and the clock stage of a full call must run long enough to pay for the grid's launch and wind-down: with
+            // 4096-sample calls (0.08 ms of clock stage) the grid cost 14 % at 256 channels, with 32768-sample calls
+            // (0.64 ms) it gains 8 % (profiles/r03_heuristics.txt)
+            if (symbols * 97e-9 < 0.3e-3) {
                 blocks = 0;
             }
             // the grid lives as long as a full-length call's clock stage may take (half as long again), at least ~1 ms
@@ -736,14 +748,16 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
             HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[prev2], 0));  // channels without DC: K3 reads z
         }
     }
-    int dc_first_loops = 0;
-    if (!b->serial && i >= 1 && d.any_dc && sdrm::front_waits_for_dc_start((int) C, &dc_first_loops)) {
-        sdrm::launch_front_hold_for_dc(dc_first_loops, b->s_front);  // the previous call's DC stage places its workgroups first
+    d.placed = b->d_placed;
+    int dc_first_us = 0;
+    if (!b->serial && i >= 1 && d.any_dc && sdrm::front_waits_for_dc_start((int) C, &dc_first_us)) {
+        // the previous call's DC stage (released by the end of its front-end, i.e. now) places its workgroups first
+        sdrm::launch_hold_until(b->d_placed + 0, b->k2_placed_target, dc_first_us, b->s_front);
     }
     if (!b->serial && i >= 3 && sdrm::front_waits_for_clock_start((int) C)) {
         // let the clock stage of call i-2 (released by the end of call i-3's) take its CUs before this grid floods the chip
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[(i + SDRM_CTL_SLOTS - 3) % SDRM_CTL_SLOTS], 0));
-        sdrm::launch_front_hold(b->s_front);
+        sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_after[(i + SDRM_CTL_SLOTS - 2) % SDRM_CTL_SLOTS], 100, b->s_front);
     }
     if (nco_aside) {
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->ev_phase[slot], 0));
@@ -774,9 +788,11 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         if (have_prev2) {
             HIP_TRY(hipStreamWaitEvent(b->s_dc, b->slot_done[prev2], 0));
         }
-        if (!b->serial && have_prev2) {
-            sdrm::launch_dc_hold(d, b->s_dc);  // many channels: the clock stage released by the same event takes its CUs first
+        if (!b->serial && have_prev2 && sdrm::dc_waits_for_clock_start(d)) {
+            // many channels: the clock stage of call i-1, released by the same event (the end of call i-2's), takes its CUs first
+            sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_after[(i + SDRM_CTL_SLOTS - 1) % SDRM_CTL_SLOTS], 200, b->s_dc);
         }
+        b->k2_placed_target += sdrm::dc_workgroups(d);
         if (b->timing) {
             timing_begin(b, 1, b->s_dc, &ev);
         }
@@ -795,6 +811,8 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     if (b->out_busy[i & 1]) {
         HIP_TRY(hipStreamWaitEvent(b->s_clock, b->ev_out_free[i & 1], 0));  // that output set is still being copied back
     }
+    b->k3_placed_target += sdrm::clock_workgroups(d);
+    b->k3_placed_after[slot] = b->k3_placed_target;
     if (b->timing) {
         timing_begin(b, 2, b->s_clock, &ev);
     }
@@ -994,6 +1012,7 @@ static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h
     sdrm::DeviceBatch d = b->dev;
     d.k3_stamps = nullptr;
     d.timeline = nullptr;
+    d.placed = nullptr;
     d.nco_segs = nullptr;
     d.ctl = b->d_ctl + (size_t) SG_SLOT;
     d.nonfinite = b->d_flags + (size_t) SG_SLOT;

@@ -408,52 +408,64 @@ void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, h
 
 // ================================================================================================ K2
 
-// A clock-recovery workgroup needs a CU's LDS nearly to itself (141 KB); a DC workgroup of sixteen channels holds ~105 KB,
-// so the two never share a CU.  The clock stage of call k and the DC stage of call k+1 are released by the same event
-// (the clock stage of call k-1 finishing); with many channels the DC grid would cover every CU before the clock
-// stage's workgroups are placed, which then wait for DC workgroups to finish.  This one-wave kernel in front of the DC
-// kernel gives the clock stage ~100 us of head start (of the slack the DC stage has).
-__global__ void k2_hold(int loops) {
-    for (int i = 0; i < loops; i++) {
-        __builtin_amdgcn_s_sleep(127);
+// Which stage's workgroups get onto the compute units first matters, and the dispatcher reserves nothing:
+//  * A clock-recovery workgroup needs most of a CU's LDS (141 KB in the full shapes), a DC workgroup of sixteen channels
+//    ~117 KB: the two never share a CU.  The clock stage of call k and the DC stage of call k+1 are released by the same
+//    event (the clock stage of call k-1 finishing); with many channels the DC grid would cover every CU before the clock
+//    stage's workgroups are placed, which then wait for DC workgroups to finish.
+//  * The front-end of call k+2 is released by that event too; once its thousands of small workgroups are streaming through
+//    the chip no CU ever has 141 KB free and the clock stage starts only when that grid has drained (seen: every other call
+//    0.5-1.2 ms late at 512 channels).
+//  * With thousands of channels a DC workgroup cannot start on a CU that holds more than one front-end workgroup, and the
+//    front-end's grid of the NEXT call refills every CU as fast as it drains: the DC stage then starts only when that grid
+//    is nearly through (9.4 ms for 1.5 ms of work at 4096 channels).
+// So a stage that would swamp the chip waits, in front of its kernel, until the stage that must go first HAS ITS WORKGROUPS
+// PLACED: every DC / clock-stage workgroup bumps a counter when it starts (b.placed[0] / [1], cumulative over calls), and a
+// one-wave kernel on the waiting stream spins on that counter (s_sleep between looks) up to a bound.  Rounds 1-2 used
+// fixed sleeps (~50 / 120 / 240 us) tuned on 131072-sample calls; with 4096-sample calls those cost up to 16 %
+// (profiles/r03_heuristics.txt), and the counter takes what the placement really needs (tens of microseconds).
+__global__ void k_hold_until(const uint32_t *counter, uint32_t target, int max_looks) {
+    for (int i = 0; i < max_looks; i++) {
+        if ((int32_t) (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) {
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);  // ~1 us between two looks
     }
 }
-// The front-end of call k+2 and the clock stage of call k are both free to go when the clock stage of call k-1 ends.
-// Once the front-end's thousands of small workgroups are streaming through the chip no CU ever has 141 KB free, and the
-// clock stage starts only when the front-end's grid has drained (seen: every other call 0.5-1.2 ms late at 512 channels).
-// Half a hold in the front-end's stream lets the clock stage place its workgroups first.
+void launch_hold_until(const uint32_t *counter, uint32_t target, int max_us, hipStream_t s) {
+    hipLaunchKernelGGL(k_hold_until, dim3(1), dim3(64), 0, s, counter, target, max_us);
+}
+// The front-end waits for the clock stage's placement between these channel counts (below, the stages' phases miss each
+// other anyway; above, the front-end is what the step waits for).  SDRM_FRONT_HOLD="lo,hi" overrides.
 bool front_waits_for_clock_start(int n_channels) {
-    static const char *e = getenv("SDRM_FRONT_HOLD");  // measurements: "lo,hi" channel range (default 128..1024)
+    static const char *e = getenv("SDRM_FRONT_HOLD");
     int lo = 128, hi = 1024;
     if (e != nullptr) {
         sscanf(e, "%d,%d", &lo, &hi);
     }
     return n_channels >= lo && n_channels <= hi;
 }
-void launch_front_hold(hipStream_t s) { hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 12); }
-
-// With thousands of channels a DC workgroup (~110 KB of LDS, eleven waves) cannot start on a CU that holds more than one
-// front-end workgroup (35 KB, four waves, a quarter of the register file each), and the front-end's grid of the NEXT
-// call -- released at the same moment, when this call's front-end ends -- refills every CU as fast as it drains: the
-// DC stage then starts only when that grid is nearly through (9.4 ms for 1.5 ms of work at 4096 channels).  The next
-// front-end therefore waits until the DC grid (itself held back ~100 us for the clock stage, launch_dc_hold) has taken
-// its CUs; it fills what is left, one workgroup per CU while the DC blocker runs, four afterwards.
-// SDRM_DC_FIRST="channels,loops" overrides from where this applies and how long (0: never).
-bool front_waits_for_dc_start(int n_channels, int *loops) {
+// The next front-end can wait for the DC stage's placement.  Rounds 1-2 needed that from 1536 channels on (4096 channels:
+// 9.7 -> 8.9 ms per call); since the clock stage of large batches takes the plain ring (75 KB: its workgroups no longer
+// wait for whole CUs, and the DC grid finds room beside them) it changes nothing between 1536 and 4096 channels at 32768-
+// and 131072-sample calls (profiles/r03_dcfirst.txt) and costs up to 8 % when the DC stage is not yet released and the
+// wait runs into its bound.  Off by default; SDRM_DC_FIRST="channels,max_us" switches it on from that many channels.
+bool front_waits_for_dc_start(int n_channels, int *max_us) {
     static const char *e = getenv("SDRM_DC_FIRST");
-    int lo = 1536, n = 60;
+    int lo = 0, n = 100;
     if (e != nullptr) {
         sscanf(e, "%d,%d", &lo, &n);
     }
-    *loops = n;
+    *max_us = n;
     return lo > 0 && n_channels >= lo;
 }
-void launch_front_hold_for_dc(int loops, hipStream_t s) { hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, loops); }
-
-void launch_dc_hold(const DeviceBatch &b, hipStream_t s) {
-    if (b.any_dc && b.n_channels >= 2048) {
-        hipLaunchKernelGGL(k2_hold, dim3(1), dim3(64), 0, s, 30);
-    }
+// The DC stage can wait for the clock stage's placement (rounds 1-2: from 2048 channels on, so that the clock stage released
+// by the same event got its CUs first).  With the plain-ring clock stage it makes no measurable difference between 1536
+// and 4096 channels (profiles/r03_dchold.txt): off by default, SDRM_DC_HOLD=<channels> switches it on from there.
+bool dc_waits_for_clock_start(const DeviceBatch &b) {
+    static const char *e = getenv("SDRM_DC_HOLD");
+    const int lo = e != nullptr ? atoi(e) : 0;
+    return b.any_dc && lo > 0 && b.n_channels >= lo;
 }
 
 // DC blocker: design in sdrm_kernels.h (K2).  Workgroup = dc_group channels (16 unless long boxcars need the LDS), six
@@ -573,6 +585,9 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c0 = blockIdx.x * b.dc_group;
     tl_mark(b, 1, 0);
+    if (b.placed != nullptr && tid == 0) {
+        atomicAdd(b.placed + 0, 1u);  // this workgroup has its CU (k_hold_until)
+    }
 
     // ---- set-up: slot constants, zeroed term rows, delay rings from the channels' tails
     if (tid == 0) {
@@ -1343,6 +1358,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     int *dc_sh = nz_sh + SDRM_K3_WAVE;                                           // [64] reads dcout (1) or z (0)
     int *safe_sh = dc_sh + SDRM_K3_WAVE;                                         // [64] float soft bits the staging wave may convert
     tl_mark(b, 2, 0);
+    if (b.placed != nullptr && threadIdx.x == 0) {
+        atomicAdd(b.placed + 1, 1u);  // this workgroup has its CU (k_hold_until)
+    }
     const int lane = threadIdx.x & 63;
     const bool producer = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) != 0;
     const int c0 = blockIdx.x * G::lanes;
@@ -1824,6 +1842,7 @@ void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, int
 }
 
 unsigned clock_workgroups(const DeviceBatch &b) { return describe_clock(b).grid.x; }
+unsigned dc_workgroups(const DeviceBatch &b) { return b.any_dc ? describe_dc(b).grid.x : 0u; }
 
 void launch_clock(const DeviceBatch &b, hipStream_t s) {
     void *args[] = {(void *) &b};

@@ -51,6 +51,7 @@ struct DeviceBatch {
     int k3_carried_max;              // most samples a channel can carry between calls of the clock stage (sizes its ring)
     int quad_flat;                   // measurements (SDRM_K1_QUAD=flat): the discriminator always takes its general form
     int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
+    uint32_t *placed;                // [2] DC / clock-stage workgroups that have started, cumulative over calls (k_hold_until)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching
 };
 
@@ -67,11 +68,11 @@ KernelLaunch describe_clock(const DeviceBatch &b);      // args: DeviceBatch
 KernelLaunch describe_quantize(const DeviceBatch &b);   // args: DeviceBatch (nothing to launch for the shapes that convert inside the clock stage)
 
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
-void launch_dc_hold(const DeviceBatch &b, hipStream_t s);
 bool front_waits_for_clock_start(int n_channels);
-bool front_waits_for_dc_start(int n_channels, int *loops);
-void launch_front_hold_for_dc(int loops, hipStream_t s);
-void launch_front_hold(hipStream_t s);
+bool front_waits_for_dc_start(int n_channels, int *max_us);
+bool dc_waits_for_clock_start(const DeviceBatch &b);
+void launch_hold_until(const uint32_t *counter, uint32_t target, int max_us, hipStream_t s);
+unsigned dc_workgroups(const DeviceBatch &b);
 
 void launch_nco_phase(const DeviceBatch &b, hipStream_t s);
 void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);
