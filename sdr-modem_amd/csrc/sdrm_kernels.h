@@ -390,6 +390,51 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
     }
 }
 
+// Decimating real FIR (reference src/dsp/fir_filter.c:93-114 with decimation d > 1) on R outputs whose windows start at
+// xs[r * stride]: output r accumulates xs[r * stride + j] * taps[j], j ascending, one separately rounded multiply and add
+// each -- the reference's order.  Outputs are paired into packed operands like sdrm_fir_block_rp's (two outputs meet the
+// same tap on samples `stride` apart); every operand is its own LDS read.  The kernel hands a thread the outputs tid,
+// tid + 256, ...: consecutive lanes then read addresses d floats apart (conflict-free for odd d) and all four waves share
+// the work -- round 2 gave each of the first few threads fifteen consecutive outputs and left three waves idle.
+template <int R, int K, bool FUSED = false>
+SDRM_HD void sdrm_fir_block_rd(const float *xs, int stride, int valid, const float *taps, int ntaps, float (&acc)[R]) {
+    static_assert(R % 2 == 0, "outputs are processed in pairs");
+    constexpr int P = R / 2;
+    sdrm_v2 pa[P];
+    const float *p[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        p[r] = xs + (r < valid ? r : 0) * stride;  // outputs past the last one re-read the first window (their sums are dropped)
+    }
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        pa[q] = sdrm_v2_make(acc[2 * q], acc[2 * q + 1]);
+    }
+    int j0 = 0;
+    for (; j0 + K <= ntaps; j0 += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const float tp = taps[j0 + u];
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                pa[q] = sdrm_v2_mac<FUSED>(pa[q], sdrm_v2_make(p[2 * q][j0 + u], p[2 * q + 1][j0 + u]), tp);
+            }
+        }
+    }
+    for (; j0 < ntaps; j0++) {
+        const float tp = taps[j0];
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            pa[q] = sdrm_v2_mac<FUSED>(pa[q], sdrm_v2_make(p[2 * q][j0], p[2 * q + 1][j0]), tp);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        acc[2 * q] = pa[q].x;
+        acc[2 * q + 1] = pa[q].y;
+    }
+}
+
 // values a K1 thread keeps in registers between phases
 struct sdrm_k1_regs {
     sdrm_f2 y[SDRM_K1_R];
@@ -631,41 +676,58 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
     }
 }
 
-// phase 3: LPF2 with decimation (reference src/dsp/fir_filter.c:93-114), results to global z
-template <bool FUSED = false>
-SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps2_rev,
-                                const float *qs, float *zs, uint32_t *nonfinite_flag) {
-    const int base = tid * SDRM_K1_RZ;
-    if (base >= t.m) {
-        return;
-    }
-    float acc[SDRM_K1_RZ];
+// phase 3: LPF2 with decimation (reference src/dsp/fir_filter.c:93-114), results to the tile's staging area
+template <int R, bool FUSED>
+SDRM_HD bool sdrm_k1_lpf2_decimated(int tid, const sdrm_k1_tile &t, int d, int ntaps, const float *taps2_rev, const float *qs, float *zs) {
+    bool odd = false;
+    // thread tid takes the outputs tid + k * THREADS (k = 0, 1, ...), R of them per pass
+    for (int o0 = tid; o0 < t.m; o0 += R * SDRM_K1_THREADS) {
+        float acc[R];
 #pragma unroll
-    for (int r = 0; r < SDRM_K1_RZ; r++) {
-        acc[r] = 0.0f;
-    }
-    if (p.decim == 1) {
-        sdrm_fir_block_rp<SDRM_K1_RZ, SDRM_K1_U, FUSED>(qs + base, taps2_rev, (int) p.T2, acc);
-    } else {
-        const int d = (int) p.decim;
-        for (int j = 0; j < (int) p.T2; j++) {
-            const float tp = taps2_rev[j];
+        for (int r = 0; r < R; r++) {
+            acc[r] = 0.0f;
+        }
+        const int valid = (t.m - o0 + SDRM_K1_THREADS - 1) / SDRM_K1_THREADS;  // outputs o0 + r * THREADS below m
+        sdrm_fir_block_rd<R, SDRM_K1_U, FUSED>(qs + o0 * d, SDRM_K1_THREADS * d, valid, taps2_rev, ntaps, acc);
 #pragma unroll
-            for (int r = 0; r < SDRM_K1_RZ; r++) {
-                int ol = base + r;
-                float v = (ol < t.m) ? qs[ol * d + j] : 0.0f;
-                acc[r] = sdrm_mac<FUSED>(acc[r], v, tp);
+        for (int r = 0; r < R; r++) {
+            const int o = o0 + r * SDRM_K1_THREADS;
+            if (o < t.m) {
+                zs[o] = acc[r];
+                odd |= !(fabsf(acc[r]) < INFINITY);
             }
         }
     }
-    // results go to the tile's staging area (lane stride 15 floats: conflict-free) and leave in sdrm_k1_phase_store
+    return odd;
+}
+
+template <bool FUSED = false>
+SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps2_rev,
+                                const float *qs, float *zs, uint32_t *nonfinite_flag) {
     bool odd = false;
-#pragma unroll
-    for (int r = 0; r < SDRM_K1_RZ; r++) {
-        if (base + r < t.m) {
-            zs[base + r] = acc[r];
-            odd |= !(fabsf(acc[r]) < INFINITY);
+    if (p.decim == 1) {
+        const int base = tid * SDRM_K1_RZ;
+        if (base >= t.m) {
+            return;
         }
+        float acc[SDRM_K1_RZ];
+#pragma unroll
+        for (int r = 0; r < SDRM_K1_RZ; r++) {
+            acc[r] = 0.0f;
+        }
+        sdrm_fir_block_rp<SDRM_K1_RZ, SDRM_K1_U, FUSED>(qs + base, taps2_rev, (int) p.T2, acc);
+        // results go to the tile's staging area (lane stride 15 floats: conflict-free) and leave in sdrm_k1_phase_store
+#pragma unroll
+        for (int r = 0; r < SDRM_K1_RZ; r++) {
+            if (base + r < t.m) {
+                zs[base + r] = acc[r];
+                odd |= !(fabsf(acc[r]) < INFINITY);
+            }
+        }
+    } else if (t.m <= 2 * SDRM_K1_THREADS) {
+        odd = sdrm_k1_lpf2_decimated<2, FUSED>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs);
+    } else {
+        odd = sdrm_k1_lpf2_decimated<4, FUSED>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs);
     }
     if (odd) {
         *nonfinite_flag = 1u;  // tells the clock stage to take its general (NaN-aware) path for this channel

@@ -304,16 +304,17 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
 
     const bool stamp = b.k3_stamps != nullptr;  // diagnostics: per-phase cycles, summed over workgroups
     unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    // The taps go to LDS as well.  Their loads are issued BEFORE the tile's (short filters: up to three values per
-    // thread held in registers), so that one wait covers both; long filters take the plain loop afterwards.
+    // The taps go to LDS as well.  Their loads are issued BEFORE the tile's (filters of up to 512 taps: up to four values per
+    // thread held in registers), so that one wait covers both; filters beyond 512 taps are staged afterwards.
     float *tab2 = tab + 260;  // {tab[i], tab[i+1] - tab[i]}, i < 256 (sdrm_quad_block_fast)
     float *taps1 = tab2 + 512, *taps2 = taps1 + ((p.T1 + 3) & ~3u);  // 16-byte aligned (tab starts aligned, 260 % 4 == 0)
-    const bool short_taps = p.T1 <= 2 * SDRM_K1_THREADS && p.T2 <= SDRM_K1_THREADS;
-    float tv0 = 0.0f, tv1 = 0.0f, tv2 = 0.0f;
+    const bool short_taps = p.T1 <= 2 * SDRM_K1_THREADS && p.T2 <= 2 * SDRM_K1_THREADS;
+    float tv0 = 0.0f, tv1 = 0.0f, tv2 = 0.0f, tv3 = 0.0f;
     if (short_taps) {
         if ((uint32_t) tid < p.T1) tv0 = b.tap_pool[p.taps1_off + tid];
         if ((uint32_t) tid + SDRM_K1_THREADS < p.T1) tv1 = b.tap_pool[p.taps1_off + tid + SDRM_K1_THREADS];
         if ((uint32_t) tid < p.T2) tv2 = b.tap_pool[p.taps2_off + tid];
+        if ((uint32_t) tid + SDRM_K1_THREADS < p.T2) tv3 = b.tap_pool[p.taps2_off + tid + SDRM_K1_THREADS];
     }
     sdrm_k1_phase_load(tid, t, in, hist, (int) p.hist_len, b.atan_tab, xs, tab);
     for (int k = tid; k < 256; k += SDRM_K1_THREADS) {
@@ -325,12 +326,36 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
         if ((uint32_t) tid < p.T1) taps1[tid] = tv0;
         if ((uint32_t) tid + SDRM_K1_THREADS < p.T1) taps1[tid + SDRM_K1_THREADS] = tv1;
         if ((uint32_t) tid < p.T2) taps2[tid] = tv2;
+        if ((uint32_t) tid + SDRM_K1_THREADS < p.T2) taps2[tid + SDRM_K1_THREADS] = tv3;
     } else {
-        for (uint32_t k = tid; k < p.T1; k += SDRM_K1_THREADS) {
-            taps1[k] = b.tap_pool[p.taps1_off + k];
+        // longer filters (more than 512 taps: 200 samples per symbol at 240 kHz): every thread's tap loads are issued before
+        // the first is stored, so that they are in flight together like the tile's
+        constexpr int TAPS_DEPTH = 6;  // 1536 taps per pass
+        for (uint32_t k0 = 0; k0 < p.T1; k0 += TAPS_DEPTH * SDRM_K1_THREADS) {
+            float v[TAPS_DEPTH];
+#pragma unroll
+            for (int i = 0; i < TAPS_DEPTH; i++) {
+                const uint32_t k = k0 + tid + i * SDRM_K1_THREADS;
+                v[i] = k < p.T1 ? b.tap_pool[p.taps1_off + k] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < TAPS_DEPTH; i++) {
+                const uint32_t k = k0 + tid + i * SDRM_K1_THREADS;
+                if (k < p.T1) taps1[k] = v[i];
+            }
         }
-        for (uint32_t k = tid; k < p.T2; k += SDRM_K1_THREADS) {
-            taps2[k] = b.tap_pool[p.taps2_off + k];
+        for (uint32_t k0 = 0; k0 < p.T2; k0 += TAPS_DEPTH * SDRM_K1_THREADS) {
+            float v[TAPS_DEPTH];
+#pragma unroll
+            for (int i = 0; i < TAPS_DEPTH; i++) {
+                const uint32_t k = k0 + tid + i * SDRM_K1_THREADS;
+                v[i] = k < p.T2 ? b.tap_pool[p.taps2_off + k] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < TAPS_DEPTH; i++) {
+                const uint32_t k = k0 + tid + i * SDRM_K1_THREADS;
+                if (k < p.T2) taps2[k] = v[i];
+            }
         }
     }
     __syncthreads();
