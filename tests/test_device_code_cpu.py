@@ -1,0 +1,38 @@
+"""The hot kernels must not spill: a register spill turns a VALU-bound kernel into a scratch-memory-bound one (an LPF1 loop
+variant that kept two sample windows in flight compiled to 128 VGPRs + 288 bytes of scratch and ran 4x slower -- with
+bit-identical results, so no parity test notices).  The device code is compiled here (hipcc cross-compiles gfx950 without
+a GPU) and the code object's metadata is read: no private segment for the pipeline's kernels in the shapes the library
+picks by itself, and the front-end inside the register budget its four-workgroups-per-CU occupancy needs."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sdr-modem_amd", "csrc")
+
+
+def _metadata(tmp_path):
+    out = os.path.join(str(tmp_path), "kernels.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "sdrm_kernels.hip")], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
+        meta[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    return meta
+
+
+def test_pipeline_kernels_do_not_spill(tmp_path):
+    meta = _metadata(tmp_path)
+
+    def find(*parts):
+        hits = [k for k in meta if all(p in k for p in parts)]
+        assert len(hits) == 1, (parts, hits)
+        return meta[hits[0]]
+    for parts in (("k1_front", "ILb0E"), ("k1_front", "ILb1E"), ("k2_dc",), ("k0_nco_phase",), ("k0_nco_mix",),
+                  ("k3_clock", "ILi16ELi1024ELb0E"), ("k3_clock", "ILi32ELi512ELb0E"), ("k3_clock", "ILi64ELi256ELb1E"),
+                  ("k3_clock", "ILi64ELi256ELb0E")):
+        scratch, vgprs = find(*parts)
+        assert scratch == 0, (parts, "spills %d bytes per lane" % scratch)
+    for parts in (("k1_front", "ILb0E"), ("k1_front", "ILb1E")):
+        assert find(*parts)[1] <= 128, parts  # 4 workgroups x 4 waves per CU = 4 waves per SIMD of 512 registers
