@@ -563,7 +563,10 @@ def main():
                     sweep[str(c2)] = {"value": round(c2 * N * SWEEP_STEPS / dt / 1e6, 1), "unit": "Msamples/s",
                                       "ms_per_step": round(dt / SWEEP_STEPS * 1e3, 3), "steps": SWEEP_STEPS,
                                       "kernel_ms": [round(m, 3) for m in km],
-                                      "front_hbm_frac": round(c2 * N * 8.0 / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                      "front_hbm_frac": round(c2 * N * 8.0 / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      # the front-end's share of its exact-mode arithmetic ceiling (nominal 2.4 GHz) at this size
+                                      "front_frac_of_ceiling": round(c2 * N * 8.0 / (km[0] * 1e-3) / 1e9 /
+                                                                     (VALU_EXACT_MACS / (2 * T1 + T2) * 8.0 / 1e9), 4)}
                     r2.close()
                 except Exception as exc:  # the sweep is informative only
                     sweep[str(c2)] = {"error": str(exc)[:200]}

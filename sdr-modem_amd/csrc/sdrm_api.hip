@@ -464,6 +464,8 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     {
         const char *q = getenv("SDRM_K1_QUAD");
         d.quad_flat = (q != nullptr && strcmp(q, "flat") == 0) ? 1 : 0;
+        const char *cp = getenv("SDRM_CHAIN_PRIO");
+        d.chain_prio = cp != nullptr ? atoi(cp) : 3;
     }
     b->in_stride = pl.in_stride;
     *out = b;

@@ -679,7 +679,16 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         if (s.chan >= 0) {
             acc = sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4];
         }
-        __builtin_amdgcn_s_setprio(3);  // one dependent chain: issue ahead of whatever shares the SIMD
+        // one dependent chain: issue ahead of whatever shares the SIMD
+        if (b.chain_prio >= 3) {
+            __builtin_amdgcn_s_setprio(3);
+        } else if (b.chain_prio == 2) {
+            __builtin_amdgcn_s_setprio(2);
+        } else if (b.chain_prio == 1) {
+            __builtin_amdgcn_s_setprio(1);
+        } else {
+            __builtin_amdgcn_s_setprio(0);
+        }
     } else {
         __builtin_amdgcn_s_setprio(1);  // the helpers: ahead of the clock stage's companion waves (priority 0)
     }
@@ -1589,9 +1598,12 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
                 const uint32_t left = (uint32_t) __builtin_amdgcn_readlane((int) safe, r) - q_at[j];
                 q_cnt[j] = ((todo >> r) & 1ull) ? (left < 64u ? left : 64u) : 0u;
                 if ((uint32_t) lane < q_cnt[j]) {
-                    // agent-scope load: from the L2 the consumer's stores went to, never a stale line of this CU's L1
+                    // Workgroup-scope load: the consumer wave of this workgroup stored these floats (write-through, complete:
+                    // its s_waitcnt) and nobody on this CU has read the two cache lines of this 256-byte chunk before, so the
+                    // read misses the L1 and hits the L2 the stores went through.  (An agent-scope load bypasses the L2 on
+                    // this part -- one L2 per XCD -- and fetched the 27 MB per 256 channels from memory again.)
                     qv[j] = __hip_atomic_load(b.out_f32 + (size_t) (c0 + r) * b.out_stride + q_at[j] + lane, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 done = lane == r ? q_at[j] + q_cnt[j] : done;
             }
@@ -1642,7 +1654,15 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 
     // ------------------------------------------------------------------ consumer wave
     // a long dependent chain on one wave: let it win issue arbitration against the throughput kernels sharing the SIMD
-    __builtin_amdgcn_s_setprio(3);
+    if (b.chain_prio >= 3) {
+        __builtin_amdgcn_s_setprio(3);
+    } else if (b.chain_prio == 2) {
+        __builtin_amdgcn_s_setprio(2);
+    } else if (b.chain_prio == 1) {
+        __builtin_amdgcn_s_setprio(1);
+    } else {
+        __builtin_amdgcn_s_setprio(0);
+    }
     // the stage writes the float soft bits; k3_quantize turns them into the int8 output behind it
     float *of = b.out_f32 + (size_t) (active ? c : 0) * b.out_stride;
     const bool wave_clean = __all(clean);
