@@ -122,6 +122,9 @@ SDRM_HD float sdrm_fast_atan2f(float y, float x, const float *tab) {
 //    the same fp32 operation; the offset of the first octant is MINUS zero, which leaves both base = +0 and -base = -0
 //    as they are (+0 would turn -0 into +0);
 //  * the sign is flipped when (x >= 0) != (y >= 0) in the |x| > |y| half and when they are equal in the other.
+// STRIDE: floats between two table entries (1: the plain 257-entry table; 2: the front-end's table of {entry, difference}
+// pairs, of which this form reads the entries only)
+template <int STRIDE = 1>
 SDRM_HD float sdrm_fast_atan2f_flat(float y, float x, const float *tab) {
     const float ya = fabsf(y), xa = fabsf(x);
     const bool wide = xa > ya;
@@ -137,8 +140,8 @@ SDRM_HD float sdrm_fast_atan2f_flat(float y, float x, const float *tab) {
     const int idx = sdrm_cvt_i32(a) & 0xff;
     const float frac = a - (float) idx;
 #endif
-    const float t0 = tab[idx];
-    const float t1 = tab[idx + 1];
+    const float t0 = tab[idx * STRIDE];
+    const float t1 = tab[(idx + 1) * STRIDE];
     const float interp = t0 + (t1 - t0) * frac;
     const float base = (z < sdrm_from_bits(SDRM_TAN_MAP_RES_UP_BITS)) ? z : interp;
     const bool xp = x >= 0.0f, yp = y >= 0.0f;
@@ -153,10 +156,11 @@ SDRM_HD float sdrm_fast_atan2f_flat(float y, float x, const float *tab) {
 }
 
 // reference src/dsp/quadrature_demod.c:65-67 through the branch-free arctangent (what the front-end kernel runs)
+template <int STRIDE = 1>
 SDRM_HD float sdrm_quad_sample_flat(sdrm_f2 cur, sdrm_f2 prev, float gain, const float *tab) {
     const float re = cur.x * prev.x + cur.y * prev.y;
     const float im = cur.y * prev.x - cur.x * prev.y;
-    return gain * sdrm_fast_atan2f_flat(im, re, tab);
+    return gain * sdrm_fast_atan2f_flat<STRIDE>(im, re, tab);
 }
 
 // one boxcar stage of the DC blocker, pointwise parts (reference src/dsp/dc_blocker.c:61-63).
