@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds the host-side code (queue.c, batcher.cpp, the planner and the kernel emulation the CPU tests drive) with the
 # sanitizers and runs (1) the threaded stress driver, (2) the CPU test-suite's emulation / batcher tests with the
-# sanitized emulation library preloaded.  CPU build only.  Logs -> profiles/r02_sanitizers.txt when $1 = "record".
+# sanitized emulation library preloaded.  CPU build only.  Logs -> profiles/r03_sanitizers.txt when $1 = "record".
 set -u
 cd "$(dirname "$0")/../.."
 ROOT=$PWD
@@ -36,6 +36,6 @@ echo "pytest exit $rc" | tee -a $LOG
 [ $rc -ne 0 ] && status=1
 grep -cE "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer" $LOG | sed 's/^/sanitizer reports: /' | tee -a $LOG
 if [ "${1:-}" = "record" ]; then
-  { echo "tests/san/run.sh  ($(date -u +%Y-%m-%d), gcc $(gcc -dumpversion), CPU build)"; grep -E "^==|exit|host_stress:|passed|failed|sanitizer reports|ERROR|WARNING: Thread|runtime error" $LOG; } > profiles/r02_sanitizers.txt
+  { echo "tests/san/run.sh  ($(date -u +%Y-%m-%d), gcc $(gcc -dumpversion), CPU build)"; grep -E "^==|exit|host_stress:|passed|failed|sanitizer reports|ERROR|WARNING: Thread|runtime error" $LOG; } > profiles/r03_sanitizers.txt
 fi
 exit $status

@@ -354,12 +354,11 @@ def test_batch_256_channels_bit_exact_and_independent():
     g.close()
 
 
-@pytest.mark.parametrize("channels", [512, 1100, 2100])
+@pytest.mark.parametrize("channels", [512, 1100, 2100, 2700])
 def test_many_channel_batches_bit_exact(channels):
     """BASELINE configs[3] gives every GPU 512 channels; 1100 is not a multiple of any workgroup size, with a second
-    configuration mixed in (different filters, decimation and DC length inside one DC workgroup); 2100 takes the shapes
-    and stream holds of the largest batches (64 channels per clock-stage workgroup, the front-end held back until the DC
-    stage has started, the DC stage held back for the clock stage).  Three calls (full,
+    configuration mixed in (different filters, decimation and DC length inside one DC workgroup); 2100 takes the 32-channel
+    clock-stage workgroups (k3_quantize behind them), 2700 the 64-channel ones with the plain ring.  Three calls (full,
     short, ragged) so that every stage's state crosses call boundaries; 24 spot channels against the oracle, float
     and int8 soft bits bit for bit; every other channel against its twin (same waveform: same bits)."""
     N = 8192

@@ -42,6 +42,9 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed)
     maxlen = int(rng.choice([6000, 20000]))
     cfgs = [c + (maxlen,) for c in _cases(seed, int(rng.integers(3, 40)))]
+    if seed % 7 == 2:  # round 3: long symbols (up to 240 samples each, DC boxcars up to 7680) inside an ordinary batch
+        cfgs += [c + (maxlen,) for c in [(240000, 1200, 5000, 1, 2000, True), (192000, 1200, 2400, 1, 4000, bool(rng.integers(0, 2))),
+                                         (240000, 1000, 5000, 1, 2000, True), (96000, 1200, 7500, 1, 1000, False)]]
     oracles = [orc.Fsk(*c) for c in cfgs]
     keep = [o.code == 0 for o in oracles]
     cfgs = [c for c, k in zip(cfgs, keep) if k]; oracles = [o for o, k in zip(oracles, keep) if k]
@@ -134,7 +137,7 @@ while time.time() < t_end:
         g.close()
         del bufs
     if seed % 25 == 0:  # many channels: the 64-channel clock-stage workgroups, the DC / front-end placement holds
-        n_big = int(rng.choice([400, 1100, 2100]))
+        n_big = int(rng.choice([400, 1100, 2100, 2700]))
         pool = cfgs[:6]
         big = [pool[i % len(pool)] for i in range(n_big)]
         g = binding.Batch(big)
