@@ -148,9 +148,9 @@ int sdrm_batch_process_device_nco(sdrm_batch *batch, const void *d_input, size_t
                                   const sdrm_nco_segment *segments, size_t n_segments, void *stream);
 /* A channel of a batch can be handed to a new stream (a client disconnects, another connects): its streaming state is
  * cleared and, with config != NULL, its configuration replaced -- what fsk_demod_destroy + fsk_demod_create do for a
- * single handle.  The batch keeps the geometry it was created with: the new configuration's filters, DC length and
- * buffer size must not exceed the largest the batch was created for (-ENOTSUP), and a DC blocker needs a batch created
- * with at least one DC-blocked channel.  Waits for all enqueued calls first. */
+ * single handle.  Longer filters, a longer DC boxcar or the batch's first DC blocker make the batch grow (the other
+ * channels keep their streams); only the buffer length is fixed for the batch's life: max_input_buffer_length must not
+ * exceed the largest the batch was created with (-ENOTSUP).  Waits for all enqueued calls first. */
 int sdrm_batch_reset_channel(sdrm_batch *batch, size_t channel, const sdrm_fsk_config *config);
 
 /* Pipelined host-buffer path.  The reference's boundary hands over HOST buffers (src/dsp/fsk_demod.h:13, filled by

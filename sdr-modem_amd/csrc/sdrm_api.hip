@@ -492,9 +492,101 @@ extern "C" int sdrm_batch_info(const sdrm_batch *b, size_t c, sdrm_fsk_info *inf
     return 0;
 }
 
+// The batch grows: longer filters, a longer raw history or a longer (or the first) DC boxcar than any channel had when the
+// batch was created.  Nothing is in flight (the caller has synchronised).  The other channels keep their streams: their raw
+// histories move to the new stride, their DC states to the new region layout (carried samples, three tails, four sums), the
+// taps of channels in private slots to the new slot size.  Rare (a client with a lower baud rate than anybody before), so
+// done the simple way, through the host.
+static int grow_geometry(sdrm_batch_t *b, const sdrm::GeometryGrowth &g) {
+    sdrm::BatchPlan &pl = b->plan;
+    const size_t C = pl.design.size();
+    const uint32_t old_hist = pl.hist_stride, old_hx = pl.dc_hx_cap, old_l = pl.dc_l_cap;
+    const size_t old_region = pl.dc_region_floats;
+    const bool had_dc = pl.any_dc != 0;
+    std::vector<sdrm_f2> hist(C * 2 * (size_t) old_hist);
+    HIP_TRY(hipMemcpy(hist.data(), b->d_hist, sizeof(sdrm_f2) * hist.size(), hipMemcpyDeviceToHost));
+    std::vector<float> dc(had_dc ? C * old_region : 0);
+    if (had_dc) {
+        HIP_TRY(hipMemcpy(dc.data(), b->d_dcstate, sizeof(float) * dc.size(), hipMemcpyDeviceToHost));
+    }
+    std::vector<size_t> moved;
+    sdrm::apply_growth(pl, g, moved);
+    // raw histories: [C][2][stride], a row holds the channel's hist_len samples from its start: copied as they are
+    std::vector<sdrm_f2> hist2(C * 2 * (size_t) pl.hist_stride);
+    memset(hist2.data(), 0, sizeof(sdrm_f2) * hist2.size());
+    for (size_t r = 0; r < C * 2; r++) {
+        memcpy(hist2.data() + r * pl.hist_stride, hist.data() + r * old_hist, sizeof(sdrm_f2) * old_hist);
+    }
+    std::vector<float> dc2(pl.any_dc ? C * pl.dc_region_floats : 0, 0.0f);
+    if (had_dc) {
+        for (size_t ch = 0; ch < C; ch++) {
+            const float *src = dc.data() + ch * old_region;
+            float *dst = dc2.data() + ch * pl.dc_region_floats;
+            memcpy(dst, src, sizeof(float) * old_hx);  // carried samples of x: at the front of the array
+            for (int ring = 0; ring < 3; ring++) {
+                memcpy(dst + pl.dc_hx_cap + (size_t) ring * pl.dc_l_cap, src + old_hx + (size_t) ring * old_l, sizeof(float) * old_l);
+            }
+            memcpy(dst + pl.dc_hx_cap + 3 * (size_t) pl.dc_l_cap, src + old_hx + 3 * (size_t) old_l, sizeof(float) * 8);
+        }
+    }
+    // device buffers of the new sizes
+    sdrm_f2 *n_hist = nullptr;
+    float *n_dc = nullptr, *n_taps = nullptr, *n_dcout = b->d_dcout, *n_dcout2 = b->d_dcout2;
+    int code = dev_alloc_zero(&n_hist, hist2.size());
+    code = code ? code : dev_alloc_zero(&n_taps, pl.private_taps_base + C * pl.private_taps_slot + 16);
+    if (pl.any_dc) {
+        code = code ? code : dev_alloc_zero(&n_dc, dc2.size());
+        if (!had_dc) {
+            code = code ? code : dev_alloc_zero(&n_dcout, C * (size_t) pl.z_stride);
+            code = code ? code : dev_alloc_zero(&n_dcout2, C * (size_t) pl.z_stride);
+        }
+    }
+    if (code != 0) {
+        return code;
+    }
+    HIP_TRY(hipMemcpy(n_hist, hist2.data(), sizeof(sdrm_f2) * hist2.size(), hipMemcpyHostToDevice));
+    if (pl.any_dc) {
+        HIP_TRY(hipMemcpy(n_dc, dc2.data(), sizeof(float) * dc2.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(n_taps, pl.tap_pool.data(), sizeof(float) * pl.tap_pool.size(), hipMemcpyHostToDevice));
+    for (size_t ch : moved) {  // private slots: taps from the channel's design, reversed, at the new offsets
+        const sdrm::ChannelDesign &d = pl.design[ch];
+        std::vector<float> t1(d.taps1.rbegin(), d.taps1.rend()), t2(d.taps2.rbegin(), d.taps2.rend());
+        HIP_TRY(hipMemcpy(n_taps + pl.params[ch].taps1_off, t1.data(), sizeof(float) * t1.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(n_taps + pl.params[ch].taps2_off, t2.data(), sizeof(float) * t2.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(b->d_params, pl.params.data(), sizeof(sdrm_chan_params) * C, hipMemcpyHostToDevice));
+    (void) hipFree(b->d_hist);
+    (void) hipFree(b->d_taps);
+    if (b->d_dcstate != nullptr) {
+        (void) hipFree(b->d_dcstate);
+    }
+    b->d_hist = n_hist;
+    b->d_taps = n_taps;
+    b->d_dcstate = n_dc;
+    b->d_dcout = n_dcout;
+    b->d_dcout2 = n_dcout2;
+    sdrm::DeviceBatch &d = b->dev;
+    d.tap_pool = b->d_taps;
+    d.raw_hist = b->d_hist;
+    d.hist_stride = pl.hist_stride;
+    d.dc_state = b->d_dcstate;
+    d.dcout = b->d_dcout;
+    d.t1_max = pl.t1_max;
+    d.t2_max = pl.t2_max;
+    d.dc_hx_cap = pl.dc_hx_cap;
+    d.dc_l_cap = pl.dc_l_cap;
+    d.dc_group = pl.dc_group;
+    d.dc_rpitch = sdrm_k2_ring_pitch((pl.dc_l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK);
+    d.dc_lds = (uint32_t) pl.dc_lds_bytes();
+    d.any_dc = pl.any_dc;
+    return 0;
+}
+
 // Hand channel `c` to a new stream: zero its streaming state (filter histories, DC blocker, timing loop, NCO phase)
-// and, with `cfg` != NULL, give it a new configuration.  The batch's geometry stays what it was created with, so the
-// new filters, DC length and buffer size must not exceed the batch's largest (-ENOTSUP).  Waits for enqueued calls.
+// and, with `cfg` != NULL, give it a new configuration.  Filters, raw history and DC boxcar longer than anything the
+// batch has held so far make the batch grow (round 3; the other channels keep their streams); only the buffer length
+// is fixed for the batch's life (-ENOTSUP beyond it).  Waits for enqueued calls.
 extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_config *cfg) {
     if (b == nullptr || c >= b->plan.design.size()) {
         return -1;
@@ -503,8 +595,19 @@ extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_
     HIP_TRY(hipDeviceSynchronize());
     sdrm::BatchPlan &pl = b->plan;
     const sdrm_fsk_config use = cfg ? *cfg : pl.design[c].cfg;
+    sdrm::GeometryGrowth growth;
+    int code = sdrm::plan_growth(pl, use, growth);
+    if (code != 0) {
+        return code;
+    }
+    if (growth.needed) {
+        code = grow_geometry(b, growth);
+        if (code != 0) {
+            return code;
+        }
+    }
     std::vector<float> slot;
-    int code = sdrm::replan_channel(pl, c, use, slot);
+    code = sdrm::replan_channel(pl, c, use, slot);
     if (code != 0) {
         return code;
     }

@@ -20,6 +20,20 @@ static size_t dc_lds_bytes_for(uint32_t l_cap, uint32_t group) {
             (size_t) SDRM_K2_SLOTS * 2 * SDRM_K2_BLK + 3 * (size_t) group * sdrm_k2_ring_pitch(rcap)) * sizeof(float) + SDRM_K2_SLOTS * sizeof(sdrm_k2_slot) + 64;
 }
 
+static uint32_t dc_group_for(uint32_t l_cap) {
+    uint32_t group = SDRM_K2_SLOTS;
+    if (const char *e = getenv("SDRM_DC_GROUP")) {  // measurements: channels per DC workgroup (a power of two <= 16)
+        const int g = atoi(e);
+        if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) {
+            group = (uint32_t) g;
+        }
+    }
+    while (group > 1 && dc_lds_bytes_for(l_cap, group) > 150 * 1024) {
+        group /= 2;
+    }
+    return group;
+}
+
 size_t BatchPlan::dc_lds_bytes() const { return dc_lds_bytes_for(dc_l_cap, dc_group); }
 
 // everything of a channel's device parameters that follows from its design alone (no offsets into shared storage)
@@ -111,16 +125,7 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
     plan.dc_hx_cap = plan.any_dc ? 2 * (plan.dc_l_cap - 1) : 0;
     plan.dc_region_floats = plan.any_dc ? sdrm_k2_state_floats(plan.dc_hx_cap, plan.dc_l_cap) : 0;
     // sixteen channels per DC workgroup while their delay rings fit beside the term rows (150 KB of the CU's 160)
-    plan.dc_group = SDRM_K2_SLOTS;
-    if (const char *e = getenv("SDRM_DC_GROUP")) {  // measurements: channels per DC workgroup (a power of two <= 16)
-        const int g = atoi(e);
-        if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) {
-            plan.dc_group = (uint32_t) g;
-        }
-    }
-    while (plan.dc_group > 1 && dc_lds_bytes_for(plan.dc_l_cap, plan.dc_group) > 150 * 1024) {
-        plan.dc_group /= 2;
-    }
+    plan.dc_group = dc_group_for(plan.dc_l_cap);
     if (plan.any_dc && dc_lds_bytes_for(plan.dc_l_cap, plan.dc_group) > 160 * 1024) {
         fprintf(stderr, "<3>DC blocker of %u samples does not fit the device\n", plan.dc_l_cap);
         return -ENOTSUP;
@@ -137,6 +142,62 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
     plan.out_stride = round_up_u32(maxlen_max + 64, 64);
     plan.in_stride = round_up_u32(std::max<uint32_t>(maxlen_max, 1), 64);
     return 0;
+}
+
+int plan_growth(const BatchPlan &plan, const sdrm_fsk_config &cfg, GeometryGrowth &g) {
+    ChannelDesign d;
+    int code = design_channel(cfg, d);
+    if (code != 0) {
+        return code;
+    }
+    sdrm_chan_params p;
+    code = params_from_design(d, p);
+    if (code != 0) {
+        return code;
+    }
+    if (p.max_len > plan.in_stride || p.max_len + 64 > plan.z_stride) {
+        fprintf(stderr, "<3>configuration does not fit the batch it is assigned to (buffer of %u samples, the batch holds %u)\n",
+                p.max_len, plan.in_stride);
+        return -ENOTSUP;
+    }
+    g.t1_max = std::max(plan.t1_max, p.T1);
+    g.t2_max = std::max(plan.t2_max, p.T2);
+    g.hist_stride = std::max(plan.hist_stride, round_up_u32(p.hist_len, 8));
+    g.dc_l_cap = std::max(plan.dc_l_cap, p.dc_len);
+    g.any_dc = plan.any_dc || p.dc_len != 0;
+    g.needed = g.t1_max != plan.t1_max || g.t2_max != plan.t2_max || g.hist_stride != plan.hist_stride ||
+               g.dc_l_cap != plan.dc_l_cap || g.any_dc != plan.any_dc;
+    if (g.any_dc && dc_lds_bytes_for(g.dc_l_cap, dc_group_for(g.dc_l_cap)) > 160 * 1024) {
+        fprintf(stderr, "<3>DC blocker of %u samples does not fit the device\n", g.dc_l_cap);
+        return -ENOTSUP;
+    }
+    return 0;
+}
+
+void apply_growth(BatchPlan &plan, const GeometryGrowth &g, std::vector<size_t> &moved) {
+    const size_t n = plan.params.size();
+    plan.t1_max = g.t1_max;
+    plan.t2_max = g.t2_max;
+    plan.hist_stride = g.hist_stride;
+    plan.any_dc = g.any_dc;
+    plan.dc_l_cap = g.dc_l_cap;
+    plan.dc_hx_cap = plan.any_dc ? 2 * (plan.dc_l_cap - 1) : 0;
+    plan.dc_region_floats = plan.any_dc ? sdrm_k2_state_floats(plan.dc_hx_cap, plan.dc_l_cap) : 0;
+    plan.dc_group = dc_group_for(plan.dc_l_cap);
+    plan.dc_state_floats = n * plan.dc_region_floats;
+    plan.private_taps_slot = (size_t) round_up_u32(plan.t1_max, 8) + round_up_u32(plan.t2_max, 8);
+    moved.clear();
+    for (size_t c = 0; c < n; c++) {
+        sdrm_chan_params &p = plan.params[c];
+        p.dc_state_off = (uint32_t) (c * plan.dc_region_floats);
+        if (p.taps1_off >= plan.private_taps_base) {
+            // every channel that lives in a private slot is listed, also when the slot size stays: the caller builds a new
+            // tap buffer and must fill all of them again
+            p.taps1_off = (uint32_t) (plan.private_taps_base + c * plan.private_taps_slot);
+            p.taps2_off = p.taps1_off + round_up_u32(plan.t1_max, 8);
+            moved.push_back(c);
+        }
+    }
 }
 
 int replan_channel(BatchPlan &plan, size_t c, const sdrm_fsk_config &cfg, std::vector<float> &taps_slot) {

@@ -40,6 +40,20 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan);
 // tap_pool offset params[c].taps1_off) and resets the channel's streaming bookkeeping.  0, a design error, or -ENOTSUP.
 int replan_channel(BatchPlan &plan, size_t c, const sdrm_fsk_config &cfg, std::vector<float> &taps_slot);
 
+// The geometry a batch needs once channel c takes `cfg`: what of {longest filters, history, DC boxcar} would have to grow.
+// The buffer length never grows (the input / output buffers and the pinned arena were handed out at that size).
+struct GeometryGrowth {
+    bool needed = false;
+    uint32_t t1_max = 0, t2_max = 0, hist_stride = 0, dc_l_cap = 0;
+    int any_dc = 0;
+};
+// 0 and `g` filled (g.needed false: the configuration fits as it is), a design error, or -ENOTSUP (buffer too long, or the
+// grown DC blocker would not fit the device)
+int plan_growth(const BatchPlan &plan, const sdrm_fsk_config &cfg, GeometryGrowth &g);
+// Apply a growth: new maxima, strides, per-channel DC regions and private tap slots (every channel that lives in a private
+// slot gets new tap offsets; `moved` lists them).  Device buffers are the caller's to re-lay-out.
+void apply_growth(BatchPlan &plan, const GeometryGrowth &g, std::vector<size_t> &moved);
+
 // Fill ctl[C] for one call and advance the bookkeeping.  lens[c] > max_len prints the reference's message
 // (src/dsp/fir_filter.c:147-152) and is treated as an empty input.  Returns the largest tile count.
 uint32_t plan_call(BatchPlan &plan, const size_t *lens, sdrm_chunk_ctl *ctl);

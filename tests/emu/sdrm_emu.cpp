@@ -69,8 +69,40 @@ extern "C" int emu_reset_channel(EmuBatch *b, size_t c, const sdrm_fsk_config *c
     BatchPlan &pl = b->plan;
     if (c >= pl.params.size()) return -1;
     const sdrm_fsk_config use = cfg ? *cfg : pl.design[c].cfg;
+    GeometryGrowth growth;
+    int code = plan_growth(pl, use, growth);
+    if (code != 0) return code;
+    if (growth.needed) {
+        // the emulation's counterpart of grow_geometry (sdrm_api.hip): the same planning calls, vectors instead of device memory
+        const size_t n = pl.params.size();
+        const uint32_t old_hist = pl.hist_stride, old_hx = pl.dc_hx_cap, old_l = pl.dc_l_cap;
+        const size_t old_region = pl.dc_region_floats;
+        const bool had_dc = pl.any_dc != 0;
+        std::vector<size_t> moved;
+        apply_growth(pl, growth, moved);
+        std::vector<sdrm_f2> hist2(n * 2 * (size_t) pl.hist_stride, sdrm_f2{0.0f, 0.0f});
+        for (size_t r = 0; r < n * 2; r++) std::copy(b->hist.begin() + r * old_hist, b->hist.begin() + (r + 1) * old_hist, hist2.begin() + r * pl.hist_stride);
+        b->hist.swap(hist2);
+        std::vector<float> dc2(pl.dc_state_floats + 8, 0.0f);
+        if (had_dc) {
+            for (size_t ch = 0; ch < n; ch++) {
+                const float *src = b->dcstate.data() + ch * old_region;
+                float *dst = dc2.data() + ch * pl.dc_region_floats;
+                std::copy(src, src + old_hx, dst);
+                for (int ring = 0; ring < 3; ring++) std::copy(src + old_hx + (size_t) ring * old_l, src + old_hx + (size_t) (ring + 1) * old_l, dst + pl.dc_hx_cap + (size_t) ring * pl.dc_l_cap);
+                std::copy(src + old_hx + 3 * (size_t) old_l, src + old_hx + 3 * (size_t) old_l + 8, dst + pl.dc_hx_cap + 3 * (size_t) pl.dc_l_cap);
+            }
+        }
+        b->dcstate.swap(dc2);
+        pl.tap_pool.resize(pl.private_taps_base + n * pl.private_taps_slot + 16, 0.0f);
+        for (size_t ch : moved) {
+            const ChannelDesign &d = pl.design[ch];
+            std::copy(d.taps1.rbegin(), d.taps1.rend(), pl.tap_pool.begin() + pl.params[ch].taps1_off);
+            std::copy(d.taps2.rbegin(), d.taps2.rend(), pl.tap_pool.begin() + pl.params[ch].taps2_off);
+        }
+    }
     std::vector<float> slot;
-    int code = replan_channel(pl, c, use, slot);
+    code = replan_channel(pl, c, use, slot);
     if (code != 0) return code;
     std::copy(slot.begin(), slot.end(), pl.tap_pool.begin() + pl.params[c].taps1_off);
     std::fill(b->hist.begin() + c * 2 * pl.hist_stride, b->hist.begin() + (c + 1) * 2 * pl.hist_stride, sdrm_f2{0.0f, 0.0f});

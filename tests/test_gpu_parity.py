@@ -153,9 +153,10 @@ def test_design_parameters_match_oracle():
 
 @pytest.mark.parametrize("lanes", ["16", "32", "64", "16x512", "16x256", "32x256", "64x256p", "32x256p"])
 def test_clock_stage_workgroup_shapes(lanes, monkeypatch):
-    """The clock stage runs with 16 channels per workgroup (256-sample steps) up to 1024 channels and with 64 (64-sample
-    steps) beyond; SDRM_K3_LANES forces a shape.  Both shapes, both builds (float soft bits kept / int8 only, i.e. the C++
-    loop and the hand-scheduled one), ragged chunks of one stream and a ragged 69-channel mixed batch with NaN input."""
+    """The clock stage's workgroup shape is channels x ring length, with pair-element or plain ("p") rings: 16 x 1024 up to
+    1280 channels (int8 conversion in the staging wave), 32 x 512 up to 2560, 64 x 256 plain beyond; SDRM_K3_LANES forces
+    one.  Every shape, both builds (float soft bits kept / int8 only), ragged chunks of one stream and a ragged 69-channel
+    mixed batch with NaN input."""
     monkeypatch.setenv("SDRM_K3_LANES", lanes)
     iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
     chunks = [0, 1, 7, 100, 255, 256, 257, 3839, 5000, 9000, 1, 8191, 12000, 64, 63, 65, 1]
@@ -1102,7 +1103,7 @@ def test_file_source_harness_reproduces_the_reference_fixture_files(workers):
 def test_batch_channel_reassignment_on_the_device():
     """sdrm_batch_reset_channel: after streaming, channels are given other configurations (other rates, decimation, DC
     blocker off) or just a new stream; they then match freshly created oracles, their neighbours are undisturbed, a
-    configuration beyond the batch's geometry is refused and leaves the channel alone."""
+    configuration with a longer buffer than the batch's is refused and leaves the channel alone."""
     big = (48000, 4800, 5000, 2, 2000, True, 8192)
     cfgs = [big, (48000, 9600, 5000, 1, 2000, True, 8192), big, (240000, 19200, 5000, 5, 2000, True, 8192)]
     g = binding.Batch(cfgs, keep_soft=True)
@@ -1115,7 +1116,7 @@ def test_batch_channel_reassignment_on_the_device():
     new1 = (48000, 9600, 5000, 1, 2000, False, 8192)
     new3 = (48000, 2400, 2400, 4, 1000, True, 4096)
     assert g.reset_channel(1, new1) == 0 and g.reset_channel(2) == 0 and g.reset_channel(3, new3) == 0
-    assert g.reset_channel(0, (48000, 1200, 5000, 1, 2000, True, 8192)) != 0
+    assert g.reset_channel(0, (48000, 4800, 5000, 2, 2000, True, 16384)) != 0  # the buffer length is the batch's for life
     orcs[1], orcs[2], orcs[3] = orc.Fsk(*new1), orc.Fsk(*big), orc.Fsk(*new3)
     sigs[1] = siggen.gmsk_channel(311, 3 * 8192, fs=48000, baud=9600)
     sigs[3] = siggen.gmsk_channel(313, 3 * 8192, fs=48000, baud=2400)
@@ -1126,6 +1127,53 @@ def test_batch_channel_reassignment_on_the_device():
         for i in range(4):
             o8, of = orcs[i].process(parts[i])
             assert_same(of, g.last_soft(i), o8, g8[i], where="channel %d call %d" % (i, k))
+    g.close()
+
+
+def test_batch_grows_when_a_client_needs_longer_filters_or_a_longer_dc_boxcar():
+    """Round 3: the batch's geometry is no longer frozen when it is created.  A batch of five 9600-baud channels WITHOUT DC
+    blocker streams; then one slot gets the batch's first DC blocker, another a 240 kHz / 19200 baud client (LPF1 of 397
+    taps instead of 117, LPF2 of 289 instead of 57, a 400-sample boxcar), later a third a 1200-baud client (1280-sample
+    boxcar, 40 samples per symbol): every time the batch grows -- raw histories to a new stride, DC states to a new layout,
+    private tap slots to a new size -- and the channels that keep their clients continue their streams bit for bit."""
+    n = 6000
+    base = (48000, 9600, 5000, 1, 2000, False, n)
+    cfgs = [base] * 5
+    g = binding.Batch(cfgs, keep_soft=True)
+    assert g.code == 0
+    sigs = [siggen.gmsk_channel(500 + i, 8 * n, fs=48000, baud=9600) for i in range(5)]
+    orcs = [orc.Fsk(*c) for c in cfgs]
+    pos = [0] * 5
+
+    def calls(k):
+        for _ in range(k):
+            lens = [n, n - 17, n, 1000, n]
+            parts = [s[p:p + ln] for s, p, ln in zip(sigs, pos, lens)]
+            for i, ln in enumerate(lens):
+                pos[i] += ln
+            g8 = g.process(parts)
+            for i in range(5):
+                o8, of = orcs[i].process(parts[i])
+                assert_same(of, g.last_soft(i), o8, g8[i], where="channel %d at %d" % (i, pos[i]))
+
+    def hand_over(ch, cfg, seed):
+        assert g.reset_channel(ch, cfg) == 0, cfg
+        orcs[ch] = orc.Fsk(*cfg)
+        sigs[ch] = siggen.gmsk_channel(seed, 8 * n, fs=cfg[0], baud=cfg[1])
+        pos[ch] = 0
+
+    calls(2)
+    hand_over(1, (48000, 9600, 5000, 1, 2000, True, n), 601)      # the batch's first DC blocker
+    calls(1)
+    hand_over(3, (240000, 19200, 5000, 1, 2000, True, n), 603)    # longer filters, longer history, longer boxcar
+    calls(2)
+    hand_over(0, (48000, 1200, 5000, 1, 2000, True, n), 600)      # 1280-sample boxcar
+    hand_over(3, base, 613)                                        # and back to a small configuration in a grown batch
+    calls(2)
+    info = g.info(0)
+    assert (info.dc_length, g.info(1).dc_length, g.info(3).dc_length) == (1280, 160, 0)
+    assert g.reset_channel(2, (48000, 9600, 5000, 1, 2000, True, 2 * n)) != 0  # only the buffer length cannot grow
+    calls(1)
     g.close()
 
 

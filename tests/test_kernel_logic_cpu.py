@@ -109,8 +109,8 @@ def test_ragged_chunks_cross_tiles_and_phases():
 
 @pytest.mark.parametrize("lanes", ["16", "32", "64", "16x512", "16x256", "32x256", "64x256p", "32x256p"])
 def test_clock_stage_workgroup_shapes(lanes, monkeypatch):
-    """the clock stage's two workgroup shapes (16 channels x 256-sample steps, 64 x 64; SDRM_K3_LANES forces one) stage
-    and drain the same samples: ragged chunks around both step sizes"""
+    """the clock stage's workgroup shapes (channels x ring length, pair-element or plain rings; SDRM_K3_LANES forces one)
+    stage and drain the same samples: ragged chunks around every step size"""
     monkeypatch.setenv("SDRM_K3_LANES", lanes)
     iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
     chunks = [0, 1, 7, 100, 255, 256, 257, 1023, 1024, 1025, 3839, 5000, 9000, 1, 8191, 12000, 64, 63, 65, 1]
@@ -396,3 +396,45 @@ def test_streaming_front_end_equals_the_tiled_one(tiles, monkeypatch):
         run_both(cfg, sig, [10000, 5, 19995], 20000)
     nan = np.fromfile(os.path.join(GOLDEN, "inputnan.cf32"), dtype=np.complex64)
     run_both((240000, 9600, 5000, 1, 2000, True), nan, [4096], 4096)
+
+
+def test_batch_geometry_grows_with_a_new_clients_configuration():
+    """plan_growth / apply_growth (shared with the device path's grow_geometry): a batch of small no-DC channels takes, slot
+    by slot, the first DC blocker, a 240 kHz client with 397 / 289-tap filters and a 400-sample boxcar, a 1200-baud client
+    with a 1280-sample boxcar; the channels that keep their clients continue bit for bit through every re-layout of the raw
+    histories, the DC states and the private tap slots; a longer buffer than the batch's is refused."""
+    n = 3000
+    base = (48000, 9600, 5000, 1, 2000, False, n)
+    e = emu_api.EmuBatch([base] * 4)
+    assert e.code == 0
+    sigs = [siggen.gmsk_channel(700 + i, 10 * n, fs=48000, baud=9600) for i in range(4)]
+    orcs = [orc.Fsk(*base) for _ in range(4)]
+    pos = [0] * 4
+
+    def calls(k):
+        for _ in range(k):
+            lens = [n, n - 17, 1000, n]
+            parts = [s[p:p + ln] for s, p, ln in zip(sigs, pos, lens)]
+            for i, ln in enumerate(lens):
+                pos[i] += ln
+            e8, ef = e.process(parts)
+            for i in range(4):
+                o8, of = orcs[i].process(parts[i])
+                assert np.array_equal(o8, e8[i]) and np.array_equal(of.view(np.uint32), ef[i].view(np.uint32)), (i, pos[i])
+
+    def hand_over(ch, cfg, seed):
+        assert e.reset_channel(ch, cfg) == 0, cfg
+        orcs[ch] = orc.Fsk(*cfg)
+        sigs[ch] = siggen.gmsk_channel(seed, 10 * n, fs=cfg[0], baud=cfg[1])
+        pos[ch] = 0
+
+    calls(2)
+    hand_over(1, (48000, 9600, 5000, 1, 2000, True, n), 801)
+    calls(1)
+    hand_over(3, (240000, 19200, 5000, 1, 2000, True, n), 803)
+    calls(2)
+    hand_over(0, (48000, 1200, 5000, 1, 2000, True, n), 800)
+    hand_over(3, base, 813)
+    calls(2)
+    assert e.reset_channel(2, (48000, 9600, 5000, 1, 2000, True, 2 * n)) != 0
+    calls(1)

@@ -26,7 +26,7 @@ if os.environ.get("LOAD"):  # keep the rest of the chip busy (fp32 GEMMs on a si
         for _ in range(int(os.environ["LOAD"])):
             a = (a @ a) * 1e-4
 torch.cuda.synchronize()
-lanes = int(os.environ.get('SDRM_K3_LANES', '16' if Cn <= 1024 else '64'))
+lanes = int(os.environ.get('SDRM_K3_LANES', '16' if Cn <= 1280 else ('32' if Cn <= 2560 else '64')).split('x')[0])
 slots = (Cn + 15) // 16  # record slots (sized for the smallest workgroup shape)
 waves = (Cn + lanes - 1) // lanes
 out = np.zeros(slots * 4 + 24, dtype=np.uint64)
