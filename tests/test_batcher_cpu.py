@@ -218,7 +218,23 @@ def test_channel_changes_hands_while_the_others_keep_streaming():
     bt.put(1, sb[4096:])
     assert np.array_equal(bt.take(0), o0.process(s0[8192:12288])[0])
     assert np.array_equal(bt.take(1), ob.process(sb[4096:])[0])
-    assert bt.reset_channel(1, (48000, 1200, 5000, 1, 2000, True, 4096)) != 0  # 207-tap filter: larger than the batch's
+    # a third client whose configuration needs longer filters and a DC boxcar longer than anything in the batch (207 taps,
+    # 1280 samples): the batch grows under the running channel 0 (round 3; refused with -ENOTSUP before)
+    bt.interrupt(1)
+    assert bt.take(1) is None
+    cfg_c = (48000, 1200, 5000, 1, 2000, True, 4096)
+    assert bt.reset_channel(1, cfg_c) == 0
+    oc = orc.Fsk(*cfg_c)
+    sc = siggen.gmsk_channel(77, 4096, fs=48000, baud=1200)
+    s0b = siggen.gmsk_channel(78, 4096)
+    bt.put(0, s0b)
+    bt.put(1, sc)
+    assert np.array_equal(bt.take(0), o0.process(s0b)[0])
+    assert np.array_equal(bt.take(1), oc.process(sc)[0])
+    # the one thing that cannot grow: the buffer length
+    bt.interrupt(1)
+    assert bt.take(1) is None
+    assert bt.reset_channel(1, (48000, 9600, 5000, 1, 2000, True, 8192)) != 0
     bt.close()
 
 

@@ -264,7 +264,7 @@ def test_channel_reassignment_matches_a_fresh_demodulator():
     new_cfg = (48000, 9600, 5000, 1, 2000, False, 4096)
     assert e.reset_channel(1, new_cfg) == 0
     assert e.reset_channel(2) == 0                        # same configuration, new stream
-    assert e.reset_channel(0, (48000, 1200, 5000, 1, 2000, True, 4096)) != 0  # 207 taps: does not fit, channel 0 untouched
+    assert e.reset_channel(0, (48000, 4800, 5000, 2, 2000, True, 8192)) != 0  # a longer buffer than the batch's: refused, channel 0 untouched
     fresh = {1: orc.Fsk(*new_cfg), 2: orc.Fsk(*big)}
     new_sig = {1: siggen.gmsk_channel(77, 2 * 4096, fs=48000, baud=9600), 2: siggen.gmsk_channel(78, 2 * 4096, fs=48000, baud=4800)}
     for k in range(2):
