@@ -498,17 +498,20 @@ extern "C" int sdrm_batch_info(const sdrm_batch *b, size_t c, sdrm_fsk_info *inf
 // taps of channels in private slots to the new slot size.  Rare (a client with a lower baud rate than anybody before), so
 // done the simple way, through the host.
 static int grow_geometry(sdrm_batch_t *b, const sdrm::GeometryGrowth &g) {
-    sdrm::BatchPlan &pl = b->plan;
-    const size_t C = pl.design.size();
-    const uint32_t old_hist = pl.hist_stride, old_hx = pl.dc_hx_cap, old_l = pl.dc_l_cap;
-    const size_t old_region = pl.dc_region_floats;
-    const bool had_dc = pl.any_dc != 0;
+    const sdrm::BatchPlan &old = b->plan;
+    const size_t C = old.design.size();
+    const uint32_t old_hist = old.hist_stride, old_hx = old.dc_hx_cap, old_l = old.dc_l_cap;
+    const size_t old_region = old.dc_region_floats;
+    const bool had_dc = old.any_dc != 0;
     std::vector<sdrm_f2> hist(C * 2 * (size_t) old_hist);
     HIP_TRY(hipMemcpy(hist.data(), b->d_hist, sizeof(sdrm_f2) * hist.size(), hipMemcpyDeviceToHost));
     std::vector<float> dc(had_dc ? C * old_region : 0);
     if (had_dc) {
         HIP_TRY(hipMemcpy(dc.data(), b->d_dcstate, sizeof(float) * dc.size(), hipMemcpyDeviceToHost));
     }
+    // the new plan is worked out on a copy and the new buffers are filled before anything of the batch changes: a failed
+    // allocation leaves the batch exactly as it was
+    sdrm::BatchPlan pl = old;
     std::vector<size_t> moved;
     sdrm::apply_growth(pl, g, moved);
     // raw histories: [C][2][stride], a row holds the channel's hist_len samples from its start: copied as they are
@@ -529,11 +532,12 @@ static int grow_geometry(sdrm_batch_t *b, const sdrm::GeometryGrowth &g) {
             memcpy(dst + pl.dc_hx_cap + 3 * (size_t) pl.dc_l_cap, src + old_hx + 3 * (size_t) old_l, sizeof(float) * 8);
         }
     }
-    // device buffers of the new sizes
     sdrm_f2 *n_hist = nullptr;
-    float *n_dc = nullptr, *n_taps = nullptr, *n_dcout = b->d_dcout, *n_dcout2 = b->d_dcout2;
+    float *n_dc = nullptr, *n_taps = nullptr, *n_dcout = nullptr, *n_dcout2 = nullptr;
+    sdrm_chan_params *n_params = nullptr;
     int code = dev_alloc_zero(&n_hist, hist2.size());
     code = code ? code : dev_alloc_zero(&n_taps, pl.private_taps_base + C * pl.private_taps_slot + 16);
+    code = code ? code : dev_alloc_zero(&n_params, C);
     if (pl.any_dc) {
         code = code ? code : dev_alloc_zero(&n_dc, dc2.size());
         if (!had_dc) {
@@ -541,45 +545,65 @@ static int grow_geometry(sdrm_batch_t *b, const sdrm::GeometryGrowth &g) {
             code = code ? code : dev_alloc_zero(&n_dcout2, C * (size_t) pl.z_stride);
         }
     }
-    if (code != 0) {
-        return code;
+    hipError_t e = hipSuccess;
+    if (code == 0) {
+        e = e ? e : hipMemcpy(n_hist, hist2.data(), sizeof(sdrm_f2) * hist2.size(), hipMemcpyHostToDevice);
+        if (pl.any_dc) {
+            e = e ? e : hipMemcpy(n_dc, dc2.data(), sizeof(float) * dc2.size(), hipMemcpyHostToDevice);
+        }
+        e = e ? e : hipMemcpy(n_taps, pl.tap_pool.data(), sizeof(float) * pl.tap_pool.size(), hipMemcpyHostToDevice);
+        for (size_t ch : moved) {  // private slots: taps from the channel's design, reversed, at the new offsets
+            const sdrm::ChannelDesign &d = pl.design[ch];
+            std::vector<float> t1(d.taps1.rbegin(), d.taps1.rend()), t2(d.taps2.rbegin(), d.taps2.rend());
+            e = e ? e : hipMemcpy(n_taps + pl.params[ch].taps1_off, t1.data(), sizeof(float) * t1.size(), hipMemcpyHostToDevice);
+            e = e ? e : hipMemcpy(n_taps + pl.params[ch].taps2_off, t2.data(), sizeof(float) * t2.size(), hipMemcpyHostToDevice);
+        }
+        e = e ? e : hipMemcpy(n_params, pl.params.data(), sizeof(sdrm_chan_params) * C, hipMemcpyHostToDevice);
     }
-    HIP_TRY(hipMemcpy(n_hist, hist2.data(), sizeof(sdrm_f2) * hist2.size(), hipMemcpyHostToDevice));
-    if (pl.any_dc) {
-        HIP_TRY(hipMemcpy(n_dc, dc2.data(), sizeof(float) * dc2.size(), hipMemcpyHostToDevice));
+    if (code != 0 || e != hipSuccess) {
+        void *fresh[] = {n_hist, n_taps, n_params, n_dc, n_dcout, n_dcout2};
+        for (void *q : fresh) {
+            if (q) {
+                (void) hipFree(q);
+            }
+        }
+        if (code == 0) {
+            fprintf(stderr, "<3>sdrmodem_hip: growing the batch failed: %s\n", hipGetErrorString(e));
+        }
+        return code ? code : -EIO;
     }
-    HIP_TRY(hipMemcpy(n_taps, pl.tap_pool.data(), sizeof(float) * pl.tap_pool.size(), hipMemcpyHostToDevice));
-    for (size_t ch : moved) {  // private slots: taps from the channel's design, reversed, at the new offsets
-        const sdrm::ChannelDesign &d = pl.design[ch];
-        std::vector<float> t1(d.taps1.rbegin(), d.taps1.rend()), t2(d.taps2.rbegin(), d.taps2.rend());
-        HIP_TRY(hipMemcpy(n_taps + pl.params[ch].taps1_off, t1.data(), sizeof(float) * t1.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(n_taps + pl.params[ch].taps2_off, t2.data(), sizeof(float) * t2.size(), hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipMemcpy(b->d_params, pl.params.data(), sizeof(sdrm_chan_params) * C, hipMemcpyHostToDevice));
+    // commit
     (void) hipFree(b->d_hist);
     (void) hipFree(b->d_taps);
+    (void) hipFree(b->d_params);
     if (b->d_dcstate != nullptr) {
         (void) hipFree(b->d_dcstate);
     }
+    b->plan = std::move(pl);
     b->d_hist = n_hist;
     b->d_taps = n_taps;
+    b->d_params = n_params;
     b->d_dcstate = n_dc;
-    b->d_dcout = n_dcout;
-    b->d_dcout2 = n_dcout2;
+    if (!had_dc && b->plan.any_dc) {
+        b->d_dcout = n_dcout;
+        b->d_dcout2 = n_dcout2;
+    }
     sdrm::DeviceBatch &d = b->dev;
+    const sdrm::BatchPlan &np = b->plan;
+    d.params = b->d_params;
     d.tap_pool = b->d_taps;
     d.raw_hist = b->d_hist;
-    d.hist_stride = pl.hist_stride;
+    d.hist_stride = np.hist_stride;
     d.dc_state = b->d_dcstate;
     d.dcout = b->d_dcout;
-    d.t1_max = pl.t1_max;
-    d.t2_max = pl.t2_max;
-    d.dc_hx_cap = pl.dc_hx_cap;
-    d.dc_l_cap = pl.dc_l_cap;
-    d.dc_group = pl.dc_group;
-    d.dc_rpitch = sdrm_k2_ring_pitch((pl.dc_l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK);
-    d.dc_lds = (uint32_t) pl.dc_lds_bytes();
-    d.any_dc = pl.any_dc;
+    d.t1_max = np.t1_max;
+    d.t2_max = np.t2_max;
+    d.dc_hx_cap = np.dc_hx_cap;
+    d.dc_l_cap = np.dc_l_cap;
+    d.dc_group = np.dc_group;
+    d.dc_rpitch = sdrm_k2_ring_pitch((np.dc_l_cap + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK + SDRM_K2_BLK);
+    d.dc_lds = (uint32_t) np.dc_lds_bytes();
+    d.any_dc = np.any_dc;
     return 0;
 }
 
