@@ -360,14 +360,25 @@ SDRM_HD float sdrm_nco_advance(float phase, float step) {
     return phase;
 }
 
-// The same step without branches, for |phase| <= 2 pi and |step| <= 2 pi (what the accumulator's own wrap maintains):
-// the sum can only leave the interval on the side the step points to, so one magnitude test and one subtraction of
-// w = copysign(2 pi, step) do the work of the two tests above (x + 2 pi and x - (-2 pi) are the same operation).
-SDRM_HD float sdrm_nco_advance_signed(float phase, float step, float w) {
-    const float two_pi = 6.28318530717958647692f;
+// The same step without branches or compares, for |phase| <= 2 pi and |step| <= 2 pi (what the accumulator's own wrap
+// maintains).  The sum q = phase + step can only leave the interval on the side the step points to, so with
+// s = -1 for step < 0 and +1 otherwise (a zero step never wraps) the two tests above are the single test s q > 2 pi.
+//   ind = clamp01(fma(q, s 2^24, -2 pi 2^24)): scaling by a power of two is exact, so this is 2^24 (s q - 2 pi) rounded
+//         once.  s q > 2 pi means at least one ulp of 2 pi beyond it (2^-21), times 2^24 is >= 8: ind = 1; otherwise the
+//         value is <= 0: ind = 0.  Never anything in between.
+//   r   = fma(ind, -s 2 pi, q): with ind = 1 the one rounding of q - s 2 pi, the reference's subtraction (addition for
+//         a negative step: x + 2 pi and x - (-2 pi) are the same operation); with ind = 0 it is q + (-s 0) = q, sign of
+//         zero included (q = -0 needs phase = step = -0, which takes s = +1 and adds -0).
+// tests/test_kernel_logic_cpu.py compares the two forms around every boundary.
+#define SDRM_NCO_WRAP_BIG 16777216.0f
+#define SDRM_NCO_WRAP_C (-6.28318530717958647692f * 16777216.0f)
+SDRM_HD float sdrm_nco_wrap_bigs(float step) { return step < 0.0f ? -SDRM_NCO_WRAP_BIG : SDRM_NCO_WRAP_BIG; }
+SDRM_HD float sdrm_nco_wrap_negw(float step) { return step < 0.0f ? 6.28318530717958647692f : -6.28318530717958647692f; }
+SDRM_HD float sdrm_nco_advance_nomask(float phase, float step, float bigs, float negw) {
     const float q = phase + step;
-    const float t = q - w;
-    return (fabsf(q) > two_pi) ? t : q;
+    float ind = fmaf(q, bigs, SDRM_NCO_WRAP_C);
+    ind = ind > 1.0f ? 1.0f : (ind > 0.0f ? ind : 0.0f);  // v_fma_f32 ... clamp
+    return fmaf(ind, negw, q);
 }
 
 // input sample times oscillator sample: C complex multiply as VOLK generic volk_32fc_x2_multiply_32fc (sig_source.c:71)

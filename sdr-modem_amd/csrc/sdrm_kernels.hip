@@ -25,8 +25,8 @@ __device__ __forceinline__ void tl_mark(const DeviceBatch &b, int kernel, int en
 // ================================================================================================ K0 (NCO, row f-1)
 
 // Phase accumulator (reference src/dsp/sig_source.c:43-58): the fp32 recursion phase += step with its wrap is sequential
-// per channel, five issue slots per sample at best, so a chunk costs its length times ~30 cycles whatever the channel
-// count.  One workgroup serves K0_CH = 64 channels with two waves: the generator wave runs the recursion, lane per
+// per channel, three issue slots per sample (k0_advance4) plus the hand-over, so a chunk costs its length times ~20
+// cycles whatever the channel count.  One workgroup serves K0_CH = 64 channels with two waves: the generator wave runs the recursion, lane per
 // channel, and drops 128-sample blocks into an LDS ring (rows of 128 + 4 floats: conflict-free b128 writes); the store
 // wave reads them back time-major and writes 512-byte runs per channel (a lane-per-channel store touches one cache line
 // per lane).  One barrier per block hands a ring half over.  (Unlike the clock stage, this chain gains nothing from a
@@ -46,22 +46,20 @@ __device__ __forceinline__ bool k0_block_is_plain(uint32_t left, float step, flo
     return __all(left >= K0_BLK && fabsf(step) <= two_pi && fabsf(phase) <= two_pi);
 }
 
-// Four steps of sdrm_nco_advance_signed in the order that costs a lone wave five issue slots per sample: the compare's
-// result may be read two slots after it is written and the subtraction fills one of them (the compiler puts the
-// subtraction first and pads with s_nop 1: 24 cycles per sample instead of 20, tools/ubench_nco.hip).
-// v = the phases of the four samples, phase = the phase after them.
+// Four steps of sdrm_nco_advance_nomask (sdrm_core.h: why it returns the bits of the reference's two-test wrap): three
+// dependent VALU instructions per sample and no compare -- a lone wave issues one instruction every four cycles, so the
+// chain costs 12.1 cycles per sample where add / compare / subtract / wait / select cost 20.2 (a compare's mask may be
+// read two issue slots after it is written; tools/ubench_nco.hip, modes 1 and 13).
+// v = the phases of the four samples, phase = the phase after them.  bigs = +-2^24 and negw = -+2 pi by the step's sign.
 #define K0_STEP(in, out) \
-    "v_add_f32 " out ", " in ", %5\n\t"          \
-    "v_cmp_gt_f32_e64 vcc, |" out "|, %6\n\t"    \
-    "v_sub_f32 %4, " out ", %7\n\t"              \
-    "s_nop 0\n\t"                                \
-    "v_cndmask_b32 " out ", " out ", %4, vcc\n\t"
-__device__ __forceinline__ void k0_advance4(float4 &v, float &phase, float step, float w) {
+    "v_add_f32 " out ", " in ", %5\n\t"             \
+    "v_fma_f32 %4, " out ", %6, %7 clamp\n\t"       \
+    "v_fma_f32 " out ", %4, %8, " out "\n\t"
+__device__ __forceinline__ void k0_advance4(float4 &v, float &phase, float step, float bigs, float negw) {
     float y, z, u, next, t;
-    asm volatile(K0_STEP("%8", "%0") K0_STEP("%0", "%1") K0_STEP("%1", "%2") K0_STEP("%2", "%3")
+    asm volatile(K0_STEP("%9", "%0") K0_STEP("%0", "%1") K0_STEP("%1", "%2") K0_STEP("%2", "%3")
                  : "=&v"(y), "=&v"(z), "=&v"(u), "=&v"(next), "=&v"(t)
-                 : "v"(step), "s"(6.28318530717958647692f), "v"(w), "v"(phase)
-                 : "vcc");
+                 : "v"(step), "v"(bigs), "s"(SDRM_NCO_WRAP_C), "v"(negw), "v"(phase));
     v.x = phase;
     v.y = y;
     v.z = z;
@@ -133,13 +131,16 @@ __global__ __launch_bounds__(128) void k0_nco_phase(DeviceBatch b) {
                     left = 0xffffffffu;
                 }
                 if (k0_block_is_plain(left, step, phase)) {
-                    const float w = copysignf(6.28318530717958647692f, step);
+                    const float bigs = sdrm_nco_wrap_bigs(step), negw = sdrm_nco_wrap_negw(step);
                     for (int g0 = 0; g0 < K0_BLK / 4; g0 += 16) {
 #pragma unroll
-                        for (int g = 0; g < 16; g++) {
-                            float4 v;
-                            k0_advance4(v, phase, step, w);
-                            *reinterpret_cast<float4 *>(dst + 4 * (g0 + g)) = v;
+                        for (int g = 0; g < 16; g += 2) {
+                            // two writes back to back cost less than two apart (ubench_nco.hip, modes 14 and 16)
+                            float4 v0, v1;
+                            k0_advance4(v0, phase, step, bigs, negw);
+                            k0_advance4(v1, phase, step, bigs, negw);
+                            *reinterpret_cast<float4 *>(dst + 4 * (g0 + g)) = v0;
+                            *reinterpret_cast<float4 *>(dst + 4 * (g0 + g + 1)) = v1;
                         }
                     }
                     left -= K0_BLK;

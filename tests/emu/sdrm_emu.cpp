@@ -597,6 +597,29 @@ extern "C" uint64_t emu_check_boxcar_div(uint32_t length, uint32_t bexp, uint64_
     return bad;
 }
 
+// sdrm_nco_advance_nomask (what the phase kernel's hand-written loop computes) against the reference's two-test wrap
+// sdrm_nco_advance: `n` pairs (phase, step), both within +-2 pi.  Returns how many results differ in their bits.
+extern "C" uint64_t emu_check_nco_advance(const float *phase, const float *step, size_t n) {
+    uint64_t bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        const float want = sdrm_nco_advance(phase[i], step[i]);
+        const float got = sdrm_nco_advance_nomask(phase[i], step[i], sdrm_nco_wrap_bigs(step[i]), sdrm_nco_wrap_negw(step[i]));
+        if (sdrm_bits(got) != sdrm_bits(want)) bad++;
+    }
+    return bad;
+}
+// the same along the recursion itself: `len` steps from `phase0`; returns the first sample where the two forms part (len: never)
+extern "C" size_t emu_check_nco_run(float phase0, float step, size_t len) {
+    float a = phase0, b = phase0;
+    const float bigs = sdrm_nco_wrap_bigs(step), negw = sdrm_nco_wrap_negw(step);
+    for (size_t i = 0; i < len; i++) {
+        a = sdrm_nco_advance(a, step);
+        b = sdrm_nco_advance_nomask(b, step, bigs, negw);
+        if (sdrm_bits(a) != sdrm_bits(b)) return i;
+    }
+    return len;
+}
+
 // NCO sample helpers for the CPU suite: the double-double sin/cos, and a sweep that counts, over `n` consecutive fp32
 // phases starting at `first_bits`, how often the fragile path was taken and how often the result differs from the host
 // libm's (float) cos / (float) sin

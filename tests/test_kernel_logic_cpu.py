@@ -339,6 +339,45 @@ def test_boxcar_quotient_short_form_is_the_ieee_division():
         assert uns.value == 2 * (1 << 23)
 
 
+def test_nco_wrap_without_a_compare_returns_the_reference_bits():
+    """sdrm_nco_advance_nomask (csrc/sdrm_core.h: add, fma-with-clamp, fma -- the phase kernel's three instructions per
+    sample) against the reference's two-test wrap (src/dsp/sig_source.c:47-53) for |phase|, |step| <= 2 pi: random pairs,
+    every float within 64 ulp of the boundaries +-2 pi reached from both sides, zeros of both signs, denormals, and the
+    recursion itself over long runs at Doppler-sized and at extreme steps."""
+    import ctypes as C
+    lib = emu_api.lib()
+    lib.emu_check_nco_advance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.emu_check_nco_advance.restype = C.c_uint64
+    lib.emu_check_nco_run.argtypes = [C.c_float, C.c_float, C.c_size_t]
+    lib.emu_check_nco_run.restype = C.c_size_t
+    two_pi = np.float32(6.28318530717958647692)
+    rng = np.random.default_rng(11)
+    ph = [rng.uniform(-two_pi, two_pi, 1 << 20).astype(np.float32)]
+    st = [rng.uniform(-two_pi, two_pi, 1 << 20).astype(np.float32)]
+    # sums that land within a few ulp of +-2 pi: phase = +-2 pi - step + k ulp
+    steps = np.concatenate([rng.uniform(-two_pi, two_pi, 4096), 10.0 ** rng.uniform(-8, 0.79, 4096) * rng.choice([-1, 1], 4096)]).astype(np.float32)
+    for sign in (-1.0, 1.0):
+        edge = np.float32(sign) * two_pi
+        for k in range(-64, 65):
+            target = (edge.view(np.int32) + np.int32(k)).view(np.float32)   # k ulp beyond / inside the boundary
+            p = (target - steps).astype(np.float32)
+            keep = np.abs(p) <= two_pi
+            ph.append(p[keep])
+            st.append(steps[keep])
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-38, two_pi, -two_pi, np.nextafter(two_pi, np.float32(0)),
+                        -np.nextafter(two_pi, np.float32(0)), 3.1415927, -3.1415927], dtype=np.float32)
+    gp, gs = np.meshgrid(special, special)
+    ph.append(gp.ravel())
+    st.append(gs.ravel())
+    p = np.ascontiguousarray(np.concatenate(ph))
+    s_ = np.ascontiguousarray(np.concatenate(st))
+    assert p.size == s_.size and p.size > 2_000_000
+    assert lib.emu_check_nco_advance(p.ctypes.data, s_.ctypes.data, p.size) == 0
+    for phase0, step in ((0.0, 2e-4), (1.0, -0.13089969), (-6.2831855, 6.2831855), (6.2831855, -6.2831855), (0.5, 3.1415927),
+                         (0.0, -1e-7), (-0.0, -0.0), (2.0, 0.0), (6.2831855, 4.7e-7), (-6.2831855, -4.7e-7)):
+        assert lib.emu_check_nco_run(phase0, step, 3_000_000) == 3_000_000, (phase0, step)
+
+
 def test_nco_sample_is_the_correctly_rounded_float_of_the_exact_cosine():
     """sdrm_nco_sample (csrc/sdrm_core.h; reference src/dsp/sig_source.c:46): where (float) cos((double) phase) hangs on the
     last bits of the double, the sample is re-evaluated in double-double and rounded once.  Here on the host: the
