@@ -39,6 +39,11 @@ struct TimingLane {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
     double total_ms = 0.0;
     uint64_t launches = 0;
+    // a stage whose consecutive launches overlap (the clock stage resident early): a launch's time counts from the end of
+    // the launch before it, if that came later than its own start
+    bool overlapped = false;
+    bool has_prev = false;
+    std::pair<hipEvent_t, hipEvent_t> prev;
 };
 
 struct sdrm_batch_t {
@@ -77,6 +82,14 @@ struct sdrm_batch_t {
     // The three stages of consecutive calls overlap: each stage has its own stream, the stage-to-stage buffers
     // (z, dcout) are double buffered, and events order producer -> consumer and buffer reuse.
     hipStream_t s_front = nullptr, s_dc = nullptr, s_clock = nullptr;
+    // Small and medium batches: the clock stage of call i+1 is launched on a second stream as soon as ITS inputs are ready
+    // and takes its CUs while call i's is still running; its workgroups wait inside the kernel for the finished-workgroups
+    // counter (DeviceBatch::k3_wait_for).  The hand-over from one call's clock stage to the next then costs a counter
+    // look instead of a kernel boundary plus the hunt for CUs with 141 KB of free LDS among the front-end's workgroups.
+    hipStream_t s_clock_alt = nullptr;
+    bool clock_early = false;
+    bool clock_prev_alt = false;       // the previous call's clock stage went to s_clock_alt
+    bool clock_prev_converts = false;  // ... and had k3_quantize behind it
     // Small batches: a grid of idle-spinning waves beside every clock-stage launch (sdrm_kernels.hip, k3_company)
     hipStream_t s_company = nullptr;
     hipEvent_t ev_company = nullptr;
@@ -164,6 +177,10 @@ static void batch_free(sdrm_batch_t *b) {
             (void) hipEventDestroy(pr.first);
             (void) hipEventDestroy(pr.second);
         }
+        if (lane.has_prev) {
+            (void) hipEventDestroy(lane.prev.first);
+            (void) hipEventDestroy(lane.prev.second);
+        }
     }
     for (int i = 0; i < SDRM_CTL_SLOTS; i++) {
         hipEvent_t evs[5] = {b->slot_done[i], b->ev_in[i], b->ev_front[i], b->ev_dc[i], b->ev_phase[i]};
@@ -173,8 +190,8 @@ static void batch_free(sdrm_batch_t *b) {
             }
         }
     }
-    hipStream_t streams[5] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock,
-                              b->s_nco != b->s_front ? b->s_nco : nullptr, b->s_company};
+    hipStream_t streams[6] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock,
+                              b->s_nco != b->s_front ? b->s_nco : nullptr, b->s_company, b->s_clock_alt};
     if (b->ev_company) {
         (void) hipEventDestroy(b->ev_company);
     }
@@ -415,6 +432,22 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
             b->company_blocks = blocks;
             e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
             e = e ? e : hipEventCreateWithFlags(&b->ev_company, hipEventDisableTiming);
+        }
+        // the next call's clock stage resident early: where the clock stage bounds the step and the front-end is short
+        // beside it -- the companion grid's condition.  Elsewhere the workgroups that only wait cost the front-end their
+        // CUs' LDS and gain nothing: the bench workload ran 2 % faster with them at 256 and 512 channels, 2 % slower at
+        // 1024, and BASELINE configs[4]'s mix (front-end as long as the clock stage) 12 % slower
+        // (profiles/r03_clock_early.txt).  SDRM_K3_EARLY=<channels>: instead, up to that many channels (0: never)
+        bool early = b->company_blocks > 0;
+        if (const char *env = getenv("SDRM_K3_EARLY")) {
+            early = (int) n_channels <= atoi(env);
+        }
+        if (early) {
+            b->clock_early = true;
+            e = e ? e : hipStreamCreateWithPriority(&b->s_clock_alt, hipStreamNonBlocking, prio_high);
+            b->lanes[2].overlapped = true;
+        }
+        if (b->company_blocks > 0 || b->clock_early) {
             e = e ? e : hipMalloc((void **) &b->d_k3_done, 64);
             e = e ? e : hipMemset(b->d_k3_done, 0, 64);
         }
@@ -706,10 +739,23 @@ static void timing_collect(sdrm_batch_t *b) {
             (void) hipEventSynchronize(pr.second);
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                float waited = 0.0f;  // from this launch's start to the end of the one before it
+                if (lane.overlapped && lane.has_prev && hipEventElapsedTime(&waited, pr.first, lane.prev.second) == hipSuccess &&
+                    waited > 0.0f) {
+                    ms -= waited < ms ? waited : ms;
+                }
                 lane.total_ms += ms;
                 lane.launches++;
             }
-            lane.free_list.push_back(pr);
+            if (lane.overlapped) {
+                if (lane.has_prev) {
+                    lane.free_list.push_back(lane.prev);
+                }
+                lane.prev = pr;
+                lane.has_prev = true;
+            } else {
+                lane.free_list.push_back(pr);
+            }
         }
         lane.pending.clear();
     }
@@ -948,32 +994,48 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     }
 
     // ---- clock recovery + int8
-    HIP_TRY(hipStreamWaitEvent(b->s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
+    // consecutive calls' clock stages alternate between two streams when the next one is to be resident early: the order
+    // between them is then kept inside the kernel (k3_wait_for), the order two calls apart by the stream
+    // (a call whose int8 conversion is a kernel of its own behind the clock stage reads the float soft bits there: the
+    // next call's clock stage, which writes them, stays behind it on the same stream)
+    hipStream_t s_clock = b->s_clock;
+    if (b->clock_early) {
+        hipStream_t prev = b->clock_prev_alt ? b->s_clock_alt : b->s_clock;
+        hipStream_t other = b->clock_prev_alt ? b->s_clock : b->s_clock_alt;
+        s_clock = (i == 0 || b->clock_prev_converts) ? prev : other;
+        b->clock_prev_alt = s_clock == b->s_clock_alt;
+        b->clock_prev_converts = sdrm::describe_quantize(d).func != nullptr;
+    }
+    HIP_TRY(hipStreamWaitEvent(s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
     if (d.any_dc && b->any_nodc) {
-        HIP_TRY(hipStreamWaitEvent(b->s_clock, b->ev_front[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_front[slot], 0));
     }
     if (b->out_busy[i & 1]) {
-        HIP_TRY(hipStreamWaitEvent(b->s_clock, b->ev_out_free[i & 1], 0));  // that output set is still being copied back
+        HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_out_free[i & 1], 0));  // that output set is still being copied back
     }
     b->k3_placed_target += sdrm::clock_workgroups(d);
     b->k3_placed_after[slot] = b->k3_placed_target;
     if (b->timing) {
-        timing_begin(b, 2, b->s_clock, &ev);
+        timing_begin(b, 2, s_clock, &ev);
+    }
+    if (b->d_k3_done != nullptr) {
+        d.k3_done = b->d_k3_done;
+        d.k3_wait = b->clock_early ? 1 : 0;
+        d.k3_wait_for = b->k3_done_target;  // every workgroup of the launches before this one has finished
+        b->k3_done_target += sdrm::clock_workgroups(d);
     }
     if (b->company_blocks > 0) {
         // starts when the clock stage may start, leaves when the clock stage's last workgroup has
-        d.k3_done = b->d_k3_done;
-        b->k3_done_target += sdrm::clock_workgroups(d);
-        HIP_TRY(hipEventRecord(b->ev_company, b->s_clock));
+        HIP_TRY(hipEventRecord(b->ev_company, s_clock));
         HIP_TRY(hipStreamWaitEvent(b->s_company, b->ev_company, 0));
         sdrm::launch_clock_company(d, b->k3_done_target, b->company_blocks, b->company_rounds, b->s_company);
     }
-    sdrm::launch_clock(d, b->s_clock);
+    sdrm::launch_clock(d, s_clock);
     if (b->timing) {
-        timing_end(b, 2, b->s_clock, ev);
+        timing_end(b, 2, s_clock, ev);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->slot_done[slot], b->s_clock));
+    HIP_TRY(hipEventRecord(b->slot_done[slot], s_clock));
     b->slot_used[slot] = true;
     b->last_slot = slot;
     b->calls++;
@@ -1006,15 +1068,26 @@ extern "C" int sdrm_batch_wait_input(sdrm_batch *b, void *stream) {
     return 0;
 }
 
+// the host waits until every enqueued call has finished.  Consecutive calls' clock stages may sit on two streams
+// (clock_early): the later one cannot do its work before the earlier one has done all of its, but the earlier KERNEL may
+// still be retiring when the later one's event fires, so both events are waited for.
+static int wait_for_all_calls(sdrm_batch_t *b) {
+    if (b->last_slot >= 0) {
+        HIP_TRY(hipEventSynchronize(b->slot_done[b->last_slot]));
+        const int before = (b->last_slot + SDRM_CTL_SLOTS - 1) % SDRM_CTL_SLOTS;
+        if (b->clock_early && b->slot_used[before]) {
+            HIP_TRY(hipEventSynchronize(b->slot_done[before]));
+        }
+    }
+    return 0;
+}
+
 // block the host until every enqueued call has finished
 extern "C" int sdrm_batch_sync(sdrm_batch *b) {
     if (b == nullptr) {
         return -1;
     }
-    if (b->last_slot >= 0) {
-        HIP_TRY(hipEventSynchronize(b->slot_done[b->last_slot]));
-    }
-    return 0;
+    return wait_for_all_calls(b);
 }
 
 extern "C" int sdrm_batch_process_device(sdrm_batch *b, const void *d_input, size_t in_stride, const size_t *input_lens,
@@ -1247,8 +1320,11 @@ static int serial_graph_call(sdrm_batch_t *b, const sdrm_cf32 *input, size_t n, 
         b->sg_broken = true;
         return 0;
     }
-    if (b->last_slot >= 0) {
-        HIP_TRY(hipEventSynchronize(b->slot_done[b->last_slot]));  // an asynchronous device-resident call may still run
+    {
+        const int code = wait_for_all_calls(b);  // an asynchronous device-resident call may still run
+        if (code != 0) {
+            return code;
+        }
     }
     sdrm_chunk_ctl *h = b->h_ctl + (size_t) SG_SLOT;
     if (b->sg_exec == nullptr || b->sg_len != n) {

@@ -1506,7 +1506,6 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     int *nz_sh = reinterpret_cast<int *>(ring + G::lanes * G::cpitch);  // [64] samples per channel
     int *dc_sh = nz_sh + SDRM_K3_WAVE;                                           // [64] reads dcout (1) or z (0)
     int *safe_sh = dc_sh + SDRM_K3_WAVE;                                         // [64] float soft bits the staging wave may convert
-    tl_mark(b, 2, 0);
     if (b.placed != nullptr && threadIdx.x == 0) {
         atomicAdd(b.placed + 1, 1u);  // this workgroup has its CU (k_hold_until)
     }
@@ -1519,6 +1518,26 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     for (int k = threadIdx.x; k < 129 * 8; k += 128) {
         bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];  // rows reversed once: tap j meets window sample j
     }
+    if (b.k3_wait) {
+        // Launched while the previous call's clock stage was still running (sdrm_api.hip, clock_early): this workgroup
+        // has its CU, and from here on it needs what that call leaves behind -- the channels' loop state and carried
+        // samples.  Every workgroup of every earlier launch bumps k3_done behind a release fence when its state is
+        // written; an acquire look that finds them all makes those writes visible here, whichever XCD wrote them.
+        // The look is bounded (~4 s): a launch that never finishes would otherwise hang the device instead of failing a test.
+        if (threadIdx.x == 0) {
+            // relaxed looks (an acquire load invalidates this XCD's L2 every time, under the other stages' feet), one
+            // acquire fence when the count is there
+            for (int looks = 0; looks < (1 << 22); looks++) {
+                if ((int32_t) (__hip_atomic_load(b.k3_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - b.k3_wait_for) >= 0) {
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        __syncthreads();
+    }
+    tl_mark(b, 2, 0);
     sdrm_k3_lane L;
     L.kept = 0;
     L.nz = 0;
@@ -1890,8 +1909,14 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
         b.out_len[c] = L.oo;
     }
-    if (b.k3_done != nullptr && lane == 0) {
-        atomicAdd(b.k3_done, 1u);  // the companion grid (k3_company) leaves when every workgroup of this launch has
+    if (b.k3_done != nullptr) {
+        // this wave's writes of the channels' state are out (and written back past this XCD's L2) before the count says so:
+        // the next call's clock stage may be waiting for it on another XCD; the companion grid (k3_company) leaves when
+        // every workgroup of this launch has counted
+        __threadfence();
+        if (lane == 0) {
+            __hip_atomic_fetch_add(b.k3_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     tl_mark(b, 2, 1);
 }

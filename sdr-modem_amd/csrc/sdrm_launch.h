@@ -56,6 +56,8 @@ struct DeviceBatch {
     int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
     uint32_t *placed;                // [2] DC / clock-stage workgroups that have started, cumulative over calls (k_hold_until)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching
+    int k3_wait;                     // the clock stage's workgroups wait for k3_done to reach k3_wait_for before they touch any
+    uint32_t k3_wait_for;            //   state of the previous call (they were launched while that call's clock stage still ran)
 };
 
 // one kernel launch, described: what launch_* puts on a stream and what the explicitly built graph of the one-channel

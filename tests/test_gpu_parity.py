@@ -748,6 +748,60 @@ def test_pipelined_host_path_calls_in_flight_match_oracle():
     g.close()
 
 
+@pytest.mark.parametrize("channels,lanes", [(48, "16"), (4, "16"), (150, "32"), (130, "64x256p")])
+def test_next_calls_clock_stage_resident_early_matches_oracle(channels, lanes, monkeypatch):
+    """With the clock stage bounding the step, call i+1's clock stage is launched on a second stream while call i's still
+    runs and waits inside the kernel for the finished-workgroups counter before it reads the channels' loop state
+    (csrc/sdrm_api.hip clock_early, sdrm_kernels.hip k3_wait).  The library switches this on with the companion grid
+    (long calls of 32..768 channels); SDRM_K3_EARLY forces it here for short calls, three kept in flight through the
+    pinned-arena path so that consecutive clock stages really are resident together: 14 calls (full, ragged, empty, one
+    channel poisoned by a NaN), EVERY channel's stream against the oracle's."""
+    monkeypatch.setenv("SDRM_K3_EARLY", "100000")
+    monkeypatch.setenv("SDRM_K3_LANES", lanes)
+    N = 8192
+    kinds = [(48000, 9600, 5000, 1, 2000, True, N), (48000, 4800, 5000, 2, 2000, False, N), (240000, 19200, 5000, 5, 2000, True, N)]
+    cfgs = [kinds[c % 3] for c in range(channels)]
+    distinct = min(channels, 12)
+    base = [siggen.gmsk_channel(300 + i, 15 * N, fs=cfgs[i][0], baud=cfgs[i][1]) for i in range(distinct)]
+    base[min(5, distinct - 1)][3 * N + 100] = np.nan
+    g = binding.Batch(cfgs)
+    assert g.code == 0
+    arena = g.arena(4)
+    plan = [[N] * channels] * 3 + [[(N - 7 * (c % 5)) for c in range(channels)], [0 if c % 4 == 0 else 3000 + c for c in range(channels)],
+                                   [N] * channels, [1] * channels, [N] * channels, [0] * channels, [N - 1] * channels] + [[N] * channels] * 4
+    pos = [0] * channels
+    got = [[] for _ in range(channels)]
+    pending = 0
+    for k, lens in enumerate(plan):
+        slot = k % 4
+        for c in range(channels):
+            part = base[c % distinct][pos[c]:pos[c] + lens[c]].view(np.float32)
+            arena[slot, c, :len(part)] = part
+            pos[c] += lens[c]
+        if g.submit(slot, lens) != 0:  # three already in flight
+            for c, o in enumerate(g.collect()):
+                got[c].append(o)
+            pending -= 1
+            assert g.submit(slot, lens) == 0
+        pending += 1
+    while pending:
+        for c, o in enumerate(g.collect()):
+            got[c].append(o)
+        pending -= 1
+    want = {}
+    for c in range(channels):
+        key = (c % distinct, tuple(l[c] for l in plan))
+        if key not in want:
+            o = orc.Fsk(*cfgs[c])
+            exp, p0 = [], 0
+            for lens in plan:
+                exp.append(o.process(base[c % distinct][p0:p0 + lens[c]])[0])
+                p0 += lens[c]
+            want[key] = np.concatenate(exp)
+        assert np.array_equal(np.concatenate(got[c]), want[key]), (channels, lanes, c)
+    g.close()
+
+
 def test_dsp_worker_file_sink_matches_oracle():
     """dsp_worker push/pull surface (src/dsp_worker.c:44-106): put IQ buffers, get rx.demod2client.<id>.s8."""
     L = binding.load()
