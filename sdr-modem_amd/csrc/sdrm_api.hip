@@ -89,6 +89,7 @@ struct sdrm_batch_t {
     hipStream_t s_clock_alt = nullptr;
     bool clock_early = false;
     bool clock_prev_alt = false;       // the previous call's clock stage went to s_clock_alt
+    bool clock_same_stream = false;    // this call's goes to the same stream as the previous call's
     bool clock_prev_converts = false;  // ... and had k3_quantize behind it
     // Small batches: a grid of idle-spinning waves beside every clock-stage launch (sdrm_kernels.hip, k3_company)
     hipStream_t s_company = nullptr;
@@ -433,12 +434,14 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
             e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
             e = e ? e : hipEventCreateWithFlags(&b->ev_company, hipEventDisableTiming);
         }
-        // the next call's clock stage resident early: where the clock stage bounds the step and the front-end is short
-        // beside it -- the companion grid's condition.  Elsewhere the workgroups that only wait cost the front-end their
-        // CUs' LDS and gain nothing: the bench workload ran 2 % faster with them at 256 and 512 channels, 2 % slower at
-        // 1024, and BASELINE configs[4]'s mix (front-end as long as the clock stage) 12 % slower
-        // (profiles/r03_clock_early.txt).  SDRM_K3_EARLY=<channels>: instead, up to that many channels (0: never)
-        bool early = b->company_blocks > 0;
+        // The next call's clock stage resident early -- OPT-IN: SDRM_K3_EARLY=<channels> switches it on for batches of up
+        // to that many channels.  Where the clock stage bounds the step and the front-end is short beside it (the companion
+        // grid's condition) the step gains 2-3 % (256 channels: 2.59 -> 2.52 ms per call, clock stages 1 us apart instead
+        // of 85), but the front-end then never meets a quiet chip: it takes 0.49 instead of 0.47 ms by the device's clock and
+        // 0.53 between its HIP events (more queues for the command processor to serve) -- and the front-end's time is what the
+        // roofline figure of this path is made of.  Elsewhere it loses outright: 1024 channels -2 %, BASELINE configs[4]'s mix
+        // (front-end as long as the clock stage) -12 % (profiles/r03_clock_early.txt).
+        bool early = false;
         if (const char *env = getenv("SDRM_K3_EARLY")) {
             early = (int) n_channels <= atoi(env);
         }
@@ -1003,6 +1006,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         hipStream_t prev = b->clock_prev_alt ? b->s_clock_alt : b->s_clock;
         hipStream_t other = b->clock_prev_alt ? b->s_clock : b->s_clock_alt;
         s_clock = (i == 0 || b->clock_prev_converts) ? prev : other;
+        b->clock_same_stream = s_clock == prev;
         b->clock_prev_alt = s_clock == b->s_clock_alt;
         b->clock_prev_converts = sdrm::describe_quantize(d).func != nullptr;
     }
@@ -1022,6 +1026,12 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         d.k3_done = b->d_k3_done;
         d.k3_wait = b->clock_early ? 1 : 0;
         d.k3_wait_for = b->k3_done_target;  // every workgroup of the launches before this one has finished
+        if (b->clock_early && i > 0 && !b->clock_same_stream) {
+            // ... and it is let onto the chip only when they are all nearly done (k3_done[1]): workgroups that wait through
+            // most of the previous call's clock stage keep the front-end off their CUs for nothing (256 channels: the
+            // front-end took 0.54 instead of 0.47 ms beside two resident clock stages)
+            sdrm::launch_hold_until(b->d_k3_done + 1, b->k3_done_target, 50000, s_clock);
+        }
         b->k3_done_target += sdrm::clock_workgroups(d);
     }
     if (b->company_blocks > 0) {

@@ -1395,6 +1395,7 @@ size_t k3_lds_bytes(int lanes, int ring, int plain) {
 #define SDRM_K3_LOOP_SKEW 0
 #endif
 #define K3_STORE_SLACK 32   // store instructions of the consumer that may still be in flight at a hand-over
+#define K3_NEAR_BLOCKS 32   // staging steps before its end at which a workgroup reports "nearly done" (~150 us at 5 samples per symbol)
 #define K3_FUSED_INT8(G) (G::block >= 256)  // the staging wave converts the soft bits to int8 (else: k3_quantize)
 #define K3_STR2(x) #x
 #define K3_STR(x) K3_STR2(x)
@@ -1832,8 +1833,14 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     const uint32_t bank_addr = (uint32_t) (uintptr_t) (lds_cf) bank_rev;
     unsigned long long t_wait = 0, t_drain = 0, n_iter = 0;
     const unsigned long long real0 = b.k3_stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz reference clock
+    // the next call's clock stage is let onto the chip when every workgroup of this one is within K3_NEAR_BLOCKS staging
+    // steps of its end (sdrm_api.hip, clock_early): k3_done[1] counts the workgroups that are
+    const int near_at = nblocks > K3_NEAR_BLOCKS ? nblocks - K3_NEAR_BLOCKS : 0;
     for (int k = 0; k <= nblocks; k++) {
         // k == nblocks: nothing new, only drains what the carried history alone allows (nz == 0 case)
+        if (k == near_at && b.k3_done != nullptr && lane == 0) {
+            __hip_atomic_fetch_add(b.k3_done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         unsigned long long t0 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         if (k < nblocks) {
             // float soft bits the staging wave may convert now: all but those of the newest stores (one store instruction
