@@ -575,11 +575,14 @@ __global__ void k_hold_until(const uint32_t *counter, uint32_t target, int max_l
 void launch_hold_until(const uint32_t *counter, uint32_t target, int max_us, hipStream_t s) {
     hipLaunchKernelGGL(k_hold_until, dim3(1), dim3(64), 0, s, counter, target, max_us);
 }
-// The front-end waits for the clock stage's placement between these channel counts (below, the stages' phases miss each
-// other anyway; above, the front-end is what the step waits for).  SDRM_FRONT_HOLD="lo,hi" overrides.
+// The front-end waits for the clock stage's placement between these channel counts (below, the front-end is short enough
+// to be through before the next clock stage looks for its CUs; above, the front-end is what the step waits for).  The lower
+// bound was 128 until the end of round 3: with the placement counters and the int8 conversion inside the clock stage the
+// wait costs 2-3 % from 128 to 768 channels and still gains 2-5 % from 896 to 1024 (131072- and 32768-sample calls,
+// profiles/r03_front_hold_bounds.txt).  SDRM_FRONT_HOLD="lo,hi" overrides.
 bool front_waits_for_clock_start(int n_channels) {
     static const char *e = getenv("SDRM_FRONT_HOLD");
-    int lo = 128, hi = 1024;
+    int lo = 832, hi = 1024;
     if (e != nullptr) {
         sscanf(e, "%d,%d", &lo, &hi);
     }
