@@ -10,7 +10,7 @@ O=gpurun_out/r03_soak_b.log
 : > $O
 git_rev=$(cat .git_rev 2>/dev/null)
 echo "round-3 soak session B, commit ${git_rev:-unknown}" >> $O
-run() { echo "\$ $*" >> $O; timeout $1 "${@:2}" 2>&1 | grep -v "amdgpu.ids\|dsp_worker" | tail -3 >> $O; echo "exit ${PIPESTATUS[0]}" >> $O; }
+run() { echo "\$ $*" >> $O; timeout $1 "${@:2}" 2>&1 | tr "\r" "\n" | grep -a -o "[a-z ]*soak ok:.*\|MISMATCH.*\|Traceback.*\|Error.*" | tail -3 >> $O; echo "exit ${PIPESTATUS[0]}" >> $O; }
 run 600 python tools/soak_fuzz.py 500 91000
 echo "-- SDRM_K3_EARLY=100000 (forced)" >> $O
 export SDRM_K3_EARLY=100000
