@@ -485,9 +485,9 @@ def main():
         if config5s is not None:
             out["config5_sharded"] = config5s
         if world == 1 and not args.no_extras:
-            # BASELINE configs[4]'s mix first among the side blocks: a batch created and closed earlier in the process costs
-            # this one ~12 % (its clock-stage workgroups then wait longer for CUs between calls; not understood,
-            # profiles/r03_clock_early.txt) -- the blocks below create and close several
+            # BASELINE configs[4]'s mix, first among the side blocks (the ones below create and close several batches).
+            # Alone in a process (tools/config5.py) it runs ~12 % faster than here beside the headline's live batch: its
+            # clock-stage workgroups then find their CUs sooner between calls (profiles/r03_clock_early.txt, last paragraph)
             try:
                 out["config5"] = config5_single(torch, binding, siggen, dev, C, N)
             except Exception as exc:  # informative sub-blocks: never cost the headline its line
