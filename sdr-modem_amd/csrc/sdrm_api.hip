@@ -82,10 +82,10 @@ struct sdrm_batch_t {
     // The three stages of consecutive calls overlap: each stage has its own stream, the stage-to-stage buffers
     // (z, dcout) are double buffered, and events order producer -> consumer and buffer reuse.
     hipStream_t s_front = nullptr, s_dc = nullptr, s_clock = nullptr;
-    // Small and medium batches: the clock stage of call i+1 is launched on a second stream as soon as ITS inputs are ready
-    // and takes its CUs while call i's is still running; its workgroups wait inside the kernel for the finished-workgroups
-    // counter (DeviceBatch::k3_wait_for).  The hand-over from one call's clock stage to the next then costs a counter
-    // look instead of a kernel boundary plus the hunt for CUs with 141 KB of free LDS among the front-end's workgroups.
+    // Opt-in (SDRM_K3_EARLY, see sdrm_batch_create): the clock stage of call i+1 is launched on a second stream as soon as
+    // ITS inputs are ready and takes its CUs while call i's is still running; its workgroups wait inside the kernel for the
+    // finished-workgroups counter (DeviceBatch::k3_wait_for).  The hand-over from one call's clock stage to the next then
+    // costs a counter look instead of a kernel boundary plus the hunt for CUs with 141 KB of free LDS.
     hipStream_t s_clock_alt = nullptr;
     bool clock_early = false;
     bool clock_prev_alt = false;       // the previous call's clock stage went to s_clock_alt
