@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--chunks-resident", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0)
-    ap.add_argument("--verify", action="store_true", help="also check 2 channels of the last step against the oracle")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the spot check against the oracle that follows every timed region (headline, sweep, config5)")
+    ap.add_argument("--verify", action="store_true", help="(default since round 4; kept so older command lines still parse)")
     ap.add_argument("--sweep", type=str, default="512,1024,4096",
                     help="extra channel counts measured briefly at N=1 (reported under 'channel_sweep'); '' to skip")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / config5 / perf_fsk_modem_style / config3")
@@ -157,10 +159,17 @@ class Rig:
         self.stream = torch.cuda.current_stream().cuda_stream
         self.lens = [chunk] * self.C
         self.n_total = n_total
+        self.cfgs = list(cfgs)
+        self.fed = []  # resident-chunk index of every call made so far, in order (what the spot check replays)
 
     def step(self, i):
         off = (i % self.R) * self.N * 8  # bytes into each channel row
         self.batch.process_device(self.x.data_ptr() + off, self.n_total, self.lens, self.stream)
+        self.fed.append(i % self.R)
+
+    def row(self, c):
+        """channel c's resident waveform as the device holds it (complex64, R chunks)"""
+        return np.roll(self.base[c % self.k][:self.n_total], 977 * (c // self.k))
 
     def kernel_ms(self):
         out = []
@@ -174,6 +183,64 @@ class Rig:
         self.batch = None
         del self.x
         self.torch.cuda.empty_cache()
+
+
+class SpotChecker:
+    """The oracle beside a device-resident run, for a few spot channels: replays exactly the calls the run made (same
+    chunks in the same order, same Doppler batches) through the CPU restatement of the reference (tests/orc.py) and
+    compares the LAST call's int8 and float soft bits bit for bit.  Never inside a timed region; the oracle objects keep
+    their stream state, so check() may be called at several points of one run (each time after a synchronisation)."""
+
+    def __init__(self, cfgs, rows, chunk, spots, segments_of=None):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc  # the checker -- test infrastructure, used only outside the timed regions
+        self.orc, self.cfgs, self.chunk, self.spots = orc, cfgs, chunk, sorted(set(int(c) for c in spots))
+        self.rows = {c: np.ascontiguousarray(rows(c)) for c in self.spots}
+        self.fsk = {c: orc.Fsk(*cfgs[c][:6], chunk) for c in self.spots}
+        self.segments_of = segments_of  # channel -> [(len, freq_hz)] applied to every call, or None
+        self.nco = {c: orc.Nco(1.0, cfgs[c][0], chunk) for c in self.spots} if segments_of else {}
+        self.done = 0
+        self.last = {}
+
+    def _advance(self, c, fed):
+        o, row, n = self.fsk[c], self.rows[c], self.chunk
+        last = None
+        for j in fed:
+            x = row[j * n:(j + 1) * n].view(np.float32)
+            if self.segments_of is not None:
+                pos, parts = 0, []
+                for ln, freq in self.segments_of(c):
+                    parts.append(self.nco[c].multiply(int(freq), x[2 * pos:2 * (pos + ln)]))
+                    pos += ln
+                x = np.concatenate(parts)
+            last = o.process(x)
+        return last
+
+    def check(self, batch, fed, soft=True):
+        """fed: the run's whole call history so far.  Returns (ok, detail)."""
+        from concurrent.futures import ThreadPoolExecutor
+        new = fed[self.done:]
+        self.done = len(fed)
+        if new:
+            with ThreadPoolExecutor(max_workers=max(1, min(len(self.spots), usable_cores()))) as ex:  # ctypes releases the GIL
+                for c, res in zip(self.spots, ex.map(lambda c: self._advance(c, new), self.spots)):
+                    self.last[c] = res
+        batch.sync()
+        most = max(int(self.chunk * cf[1] / cf[0] * 1.05) + 64 for cf in self.cfgs)  # symbols per call: chunk x baud / fs
+        data, olen = batch.fetch(min(self.chunk, most))
+        bad = []
+        for c in self.spots:
+            o8, of = self.last[c]
+            if olen[c] != len(o8) or not np.array_equal(data[c, :olen[c]], o8):
+                bad.append((c, "int8"))
+            elif soft and not np.array_equal(batch.last_soft(c).view(np.uint32), of.view(np.uint32)):
+                bad.append((c, "f32"))
+        return not bad, {"channels": self.spots, "calls": self.done, "mismatches": bad}
+
+
+def spot_channels(channels):
+    """first, the two sides of a 16-channel clock-stage workgroup boundary, a middle one, the last (partial workgroups)"""
+    return sorted(set(c for c in (0, 15, 16, channels // 2 + 1, channels - 1) if 0 <= c < channels))
 
 
 def end_to_end(binding, siggen, channels, chunk, calls=24, slots=4):
@@ -236,31 +303,58 @@ def config5(torch, binding, siggen, dev, cfgs, chunk, steps=24, plan_step=None, 
 
     lens_c = (binding.C.c_size_t * channels)(*lens)
 
+    fed = []  # resident-chunk index of every call, in order (what the spot check replays)
+
     def step(i):
         b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens_c, plan_step(), st)
+        fed.append(i % 2)
     for i in range(4):
         step(i)
     torch.cuda.synchronize()
     b.timing_enable(True)
+    step.fed = fed
+    step.row = lambda c: a if cfgs[c][0] == 240000 else b_
     return b, x, step
 
 
-def config5_single(torch, binding, siggen, dev, channels, chunk, steps=24):
-    """configs[4] in one GPU's share (N = 1): the two kinds of channel interleaved, batches planned locally"""
+def config5_single(torch, binding, siggen, dev, channels, chunk, steps=24, verify=True, check_at=()):
+    """configs[4] in one GPU's share (N = 1): the two kinds of channel interleaved, batches planned locally.  After the
+    timed loop (and at the step counts in `check_at`, for the tests) spot channels are compared with the oracle:
+    orc.Nco on the channel's three batches per call, then orc.Fsk."""
     cfgs = [(240000, 19200, 5000, 5, 2000, True, chunk) if c % 2 == 0 else (48000, 1200, 5000, 8, 2000, True, chunk)
             for c in range(channels)]
     mine = config5_segments(range(channels), chunk)
     b, x, step = config5(torch, binding, siggen, dev, cfgs, chunk, steps, plan_step=lambda: mine)
+    checker, ok, bad = None, None, []
+    if verify:
+        per_channel = {}
+        for c, ln, f in mine:
+            per_channel.setdefault(int(c), []).append((int(ln), int(f)))
+        spots = sorted(set(c for c in (0, 1, 16, 17, channels - 2, channels - 1) if 0 <= c < channels))
+        checker = SpotChecker(cfgs, step.row, chunk, spots, segments_of=lambda c: per_channel[c])
     t0 = time.perf_counter()
+    dt = 0.0
     for i in range(steps):
         step(i)
+        if checker is not None and (i + 1) in check_at:
+            torch.cuda.synchronize()
+            dt += time.perf_counter() - t0
+            good, detail = checker.check(b, step.fed)
+            ok = good if ok is None else (ok and good)
+            bad += detail["mismatches"]
+            t0 = time.perf_counter()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = (dt + time.perf_counter() - t0) / steps
     km = [b.timing_read(w) for w in range(3)]
+    if checker is not None:
+        good, detail = checker.check(b, step.fed)
+        ok = good if ok is None else (ok and good)
+        bad += detail["mismatches"]
     b.close()
     del x
     torch.cuda.empty_cache()
     return {"value": round(channels * chunk / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+            "verified_vs_oracle": ok, "verify_mismatches": bad,
             "channels": channels, "steps": steps, "kernel_ms": [round(m / max(n, 1), 3) for m, n in km],
             "workload": "half (240000,19200,5000,5,2000,dc) + half (48000,1200,5000,8,2000,dc), per-channel Doppler NCO "
                         "(3 batches per channel and call), inputs in HBM"}
@@ -352,20 +446,12 @@ def main():
     samples_per_step = C * N * world
     msps = samples_per_step * args.steps / elapsed / 1e6
 
-    verify = None
-    if args.verify and rank == 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import orc
-        data, olen = batch.fetch(N)
-        verify = True
-        for c in (0, C - 1):
-            o = orc.Fsk(FS, BAUD, DEV, DECIM, TW, DC, N)
-            row = rig.x[c].cpu().numpy().view(np.complex64)
-            last = None
-            for i in range(args.warmup + args.steps):
-                j = i % R
-                last, _ = o.process(row[j * N:(j + 1) * N])
-            verify = verify and bool(np.array_equal(last, data[c, :olen[c]]))
+    # AFTER the timed region: the last call's soft bits (int8 and float) of a few spot channels against the CPU
+    # restatement of the reference, fed the same chunks in the same order as the device was
+    verify = verify_detail = None
+    if not args.no_verify and rank == 0:
+        checker = SpotChecker(cfgs, rig.row, N, spot_channels(C))
+        verify, verify_detail = checker.check(batch, rig.fed)
 
     row0 = rig.x[0].cpu().numpy().view(np.complex64)[:2 * N] if rank == 0 else None
     base = rig.base
@@ -444,7 +530,7 @@ def main():
                     "are circular shifts), resident in HBM" % min(C, DISTINCT),
             "config": {"workload": "BASELINE configs[2]: %d concurrent 48 kHz / 9600 baud GMSK channels per GPU, "
                                    "fsk_demod(48000,9600,5000,1,2000,dc), %d-sample chunks" % (C, N),
-                       "channels_per_gpu": C, "chunk_samples": N, "mode": "exact (bit-identical to CPU reference)",
+                       "channels_per_gpu": C, "chunk_samples": N, "mode": "exact (bit-identical to the CPU restatement of the reference)",
                        "stages": "serial" if os.environ.get("SDRM_SERIAL_STAGES") else "pipelined across calls",
                        "parallelism": "channel-sharded x%d, no data-path collective" % world},
             "channels_at_realtime": int(msps * 1e6 / FS),
@@ -480,6 +566,8 @@ def main():
         }
         if verify is not None:
             out["verified_vs_oracle"] = verify
+            out["verify"] = dict(verify_detail, what="int8 and float soft bits of the last timed call, spot channels, bit for bit "
+                                                     "against the CPU restatement of the reference fed the same calls")
         if config3 is not None:
             out["config3_sharded"] = config3
         if config5s is not None:
@@ -489,7 +577,7 @@ def main():
             # Alone in a process (tools/config5.py) it runs ~12 % faster than here beside the headline's live batch: its
             # clock-stage workgroups then find their CUs sooner between calls (profiles/r03_clock_early.txt, last paragraph)
             try:
-                out["config5"] = config5_single(torch, binding, siggen, dev, C, N)
+                out["config5"] = config5_single(torch, binding, siggen, dev, C, N, verify=not args.no_verify)
             except Exception as exc:  # informative sub-blocks: never cost the headline its line
                 out["config5"] = {"error": str(exc)[:200]}
         if world == 1 and not args.no_cpu_baseline:
@@ -568,7 +656,10 @@ def main():
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
                     km = r2.kernel_ms()
-                    sweep[str(c2)] = {"value": round(c2 * N * SWEEP_STEPS / dt / 1e6, 1), "unit": "Msamples/s",
+                    ok2 = None
+                    if not args.no_verify:
+                        ok2, _ = SpotChecker(r2.cfgs, r2.row, N, spot_channels(c2)).check(r2.batch, r2.fed)
+                    sweep[str(c2)] = {"verified_vs_oracle": ok2, "value": round(c2 * N * SWEEP_STEPS / dt / 1e6, 1), "unit": "Msamples/s",
                                       "ms_per_step": round(dt / SWEEP_STEPS * 1e3, 3), "steps": SWEEP_STEPS,
                                       "kernel_ms": [round(m, 3) for m in km],
                                       "front_hbm_frac": round(c2 * N * 8.0 / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

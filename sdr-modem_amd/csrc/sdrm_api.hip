@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <initializer_list>
 #include <vector>
 
 #include "../../include/sdrmodem_hip.h"
@@ -99,6 +100,7 @@ struct sdrm_batch_t {
     uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started
     uint32_t k3_placed_after[SDRM_CTL_SLOTS] = {};        // ... once the clock stage of the call in that slot has
     uint32_t k3_done_target = 0;     // what the counter reads when the launch enqueued last has finished
+    int device_error = 0;            // sticky: a kernel reported through d_k3_done[2] that it gave up a bounded wait
     int company_blocks = 0;
     int company_rounds = 120;        // bound on the companion grid's life, in ~50 us looks at the counter
     float *d_z2 = nullptr, *d_dcout2 = nullptr;
@@ -421,7 +423,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
             }
             // and the clock stage of a full call must run long enough to pay for the grid's launch and wind-down: with
             // 4096-sample calls (0.08 ms of clock stage) the grid cost 14 % at 256 channels, with 32768-sample calls
-            // (0.64 ms) it gains 8 % (profiles/r03_heuristics.txt)
+            // (0.64 ms) it gains 8 % (profiles/r03_heuristics_before.txt / _after.txt)
             if (symbols * 97e-9 < 0.3e-3) {
                 blocks = 0;
             }
@@ -1081,13 +1083,32 @@ extern "C" int sdrm_batch_wait_input(sdrm_batch *b, void *stream) {
 // the host waits until every enqueued call has finished.  Consecutive calls' clock stages may sit on two streams
 // (clock_early): the later one cannot do its work before the earlier one has done all of its, but the earlier KERNEL may
 // still be retiring when the later one's event fires, so both events are waited for.
+// A clock stage that was resident early and gave up waiting for its predecessor (k3_clock, bounded look) raises the word
+// at d_k3_done[2]: its results cannot be trusted, and neither can any later call's -- the batch is in error for good.
+static int check_device_error(sdrm_batch_t *b) {
+    if (b->device_error == 0 && b->clock_early && b->d_k3_done != nullptr) {
+        uint32_t word = 0;
+        HIP_TRY(hipMemcpy(&word, b->d_k3_done + 2, sizeof(word), hipMemcpyDeviceToHost));
+        if (word != 0) {
+            b->device_error = -ETIMEDOUT;
+            fprintf(stderr, "<3>sdrmodem_hip: a clock stage launched early timed out waiting for the previous call's; "
+                            "the batch is unusable\n");
+        }
+    }
+    return b->device_error;
+}
+
 static int wait_for_all_calls(sdrm_batch_t *b) {
+    if (b->device_error != 0) {
+        return b->device_error;
+    }
     if (b->last_slot >= 0) {
         HIP_TRY(hipEventSynchronize(b->slot_done[b->last_slot]));
         const int before = (b->last_slot + SDRM_CTL_SLOTS - 1) % SDRM_CTL_SLOTS;
         if (b->clock_early && b->slot_used[before]) {
             HIP_TRY(hipEventSynchronize(b->slot_done[before]));
         }
+        return check_device_error(b);
     }
     return 0;
 }
@@ -1573,6 +1594,9 @@ extern "C" int sdrm_batch_collect(sdrm_batch *b, int8_t **outputs, size_t *outpu
         }
     }
     HIP_TRY(hipEventSynchronize(b->ev_res[set]));
+    if (int code = check_device_error(b)) {
+        return code;
+    }
     for (size_t c = 0; c < C; c++) {
         const uint32_t n = b->h_reslen[set][c];
         int8_t *dst = b->h_res8[set] + c * (size_t) b->dev.out_stride;
@@ -1598,6 +1622,9 @@ extern "C" int sdrm_batch_fetch(sdrm_batch *b, int8_t *data, size_t stride, size
     HIP_TRY(hipSetDevice(b->device));
     const size_t C = b->plan.design.size();
     HIP_TRY(hipDeviceSynchronize());
+    if (int code = wait_for_all_calls(b)) {
+        return code;  // sticky device error (a bounded in-kernel wait expired)
+    }
     const uint64_t last = b->calls ? b->calls - 1 : 0;
     HIP_TRY(hipMemcpy(b->h_outlen, outlen_of(b, last), sizeof(uint32_t) * C, hipMemcpyDeviceToHost));
     for (size_t c = 0; c < C; c++) {
@@ -1618,6 +1645,9 @@ extern "C" int sdrm_batch_last_soft(sdrm_batch *b, size_t c, float *dst, size_t 
     }
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (int code = wait_for_all_calls(b)) {
+        return code;  // sticky device error (a bounded in-kernel wait expired)
+    }
     uint32_t n = 0;
     HIP_TRY(hipMemcpy(&n, outlen_of(b, b->calls ? b->calls - 1 : 0) + c, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (len) {
@@ -1813,27 +1843,40 @@ extern "C" void fsk_demod_destroy(fsk_demod *demod) {
 
 // ================================================================================================ probes
 
+// every probe: one exit path (all device buffers freed whatever failed), and a failed launch is an error, not a vector of
+// uninitialised results
+static int probe_finish(hipError_t e, const char *what, std::initializer_list<void *> buffers) {
+    for (void *p : buffers) {
+        (void) hipFree(p);
+    }
+    if (e != hipSuccess) {
+        fprintf(stderr, "<3>sdrmodem_hip: %s failed: %s\n", what, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? -ENOMEM : -EIO;
+    }
+    return 0;
+}
+
 extern "C" int sdrm_probe_atan2(const float *y, const float *x, float *out, size_t n) {
     if (sdrm_device_count() <= 0) {
         fprintf(stderr, "<3>sdrmodem_hip: no HIP device available\n");
         return -ENODEV;
     }
     float *dy = nullptr, *dx = nullptr, *dt = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void **) &dy, n * 4 + 4));
-    HIP_TRY(hipMalloc((void **) &dx, n * 4 + 4));
-    HIP_TRY(hipMalloc((void **) &dout, n * 4 + 4));
-    HIP_TRY(hipMalloc((void **) &dt, 260 * 4));
-    HIP_TRY(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dt, sdrm_atan_tab, 257 * 4, hipMemcpyHostToDevice));
-    sdrm::launch_probe_atan2(dy, dx, dt, dout, n, nullptr);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-    (void) hipFree(dy);
-    (void) hipFree(dx);
-    (void) hipFree(dt);
-    (void) hipFree(dout);
-    return 0;
+    hipError_t e = hipSuccess;
+    e = e ? e : hipMalloc((void **) &dy, n * 4 + 4);
+    e = e ? e : hipMalloc((void **) &dx, n * 4 + 4);
+    e = e ? e : hipMalloc((void **) &dout, n * 4 + 4);
+    e = e ? e : hipMalloc((void **) &dt, 260 * 4);
+    e = e ? e : hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice);
+    e = e ? e : hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice);
+    e = e ? e : hipMemcpy(dt, sdrm_atan_tab, 257 * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        sdrm::launch_probe_atan2(dy, dx, dt, dout, n, nullptr);
+        e = hipGetLastError();
+    }
+    e = e ? e : hipDeviceSynchronize();
+    e = e ? e : hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    return probe_finish(e, "sdrm_probe_atan2", {dy, dx, dt, dout});
 }
 
 // the front-end's discriminator phase as the kernel runs it (short form with its per-wave fall-back): out[i] = gain *
@@ -1848,24 +1891,24 @@ extern "C" int sdrm_probe_quad(const float *iq, size_t n, float gain, float *out
     sdrm_f2 *dy = nullptr;
     float *dt = nullptr, *dout = nullptr;
     uint32_t *df = nullptr;
-    HIP_TRY(hipMalloc((void **) &dy, n * 8 + 8));
-    HIP_TRY(hipMalloc((void **) &dout, n * 4 + 4));
-    HIP_TRY(hipMalloc((void **) &dt, 260 * 4));
-    HIP_TRY(hipMalloc((void **) &df, waves * 4));
-    HIP_TRY(hipMemset(df, 0, waves * 4));
-    HIP_TRY(hipMemcpy(dy, iq, n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dt, sdrm_atan_tab, 257 * 4, hipMemcpyHostToDevice));
-    sdrm::launch_probe_quad(dy, n, gain, dt, dout, df, nullptr);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-    if (fast_waves != nullptr) {
-        HIP_TRY(hipMemcpy(fast_waves, df, ((n + 64 * SDRM_K1_R - 1) / (64 * SDRM_K1_R)) * 4, hipMemcpyDeviceToHost));
+    hipError_t e = hipSuccess;
+    e = e ? e : hipMalloc((void **) &dy, n * 8 + 8);
+    e = e ? e : hipMalloc((void **) &dout, n * 4 + 4);
+    e = e ? e : hipMalloc((void **) &dt, 260 * 4);
+    e = e ? e : hipMalloc((void **) &df, waves * 4);
+    e = e ? e : hipMemset(df, 0, waves * 4);
+    e = e ? e : hipMemcpy(dy, iq, n * 8, hipMemcpyHostToDevice);
+    e = e ? e : hipMemcpy(dt, sdrm_atan_tab, 257 * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        sdrm::launch_probe_quad(dy, n, gain, dt, dout, df, nullptr);
+        e = hipGetLastError();
     }
-    (void) hipFree(dy);
-    (void) hipFree(dt);
-    (void) hipFree(dout);
-    (void) hipFree(df);
-    return 0;
+    e = e ? e : hipDeviceSynchronize();
+    e = e ? e : hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    if (fast_waves != nullptr) {
+        e = e ? e : hipMemcpy(fast_waves, df, ((n + 64 * SDRM_K1_R - 1) / (64 * SDRM_K1_R)) * 4, hipMemcpyDeviceToHost);
+    }
+    return probe_finish(e, "sdrm_probe_quad", {dy, dt, dout, df});
 }
 
 // quotients of the DC blocker's boxcars: the three-instruction form with its fall-back, as the DC kernel runs it
@@ -1875,15 +1918,17 @@ extern "C" int sdrm_probe_boxcar_div(const float *sums, uint32_t length, float *
         return -ENODEV;
     }
     float *dt = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void **) &dt, n * 4 + 4));
-    HIP_TRY(hipMalloc((void **) &dout, n * 4 + 4));
-    HIP_TRY(hipMemcpy(dt, sums, n * 4, hipMemcpyHostToDevice));
-    sdrm::launch_probe_boxcar_div(dt, length, dout, n, nullptr);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-    (void) hipFree(dt);
-    (void) hipFree(dout);
-    return 0;
+    hipError_t e = hipSuccess;
+    e = e ? e : hipMalloc((void **) &dt, n * 4 + 4);
+    e = e ? e : hipMalloc((void **) &dout, n * 4 + 4);
+    e = e ? e : hipMemcpy(dt, sums, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        sdrm::launch_probe_boxcar_div(dt, length, dout, n, nullptr);
+        e = hipGetLastError();
+    }
+    e = e ? e : hipDeviceSynchronize();
+    e = e ? e : hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    return probe_finish(e, "sdrm_probe_boxcar_div", {dt, dout});
 }
 
 // diagnostics: allocate (once) and return the device buffer K3 writes its per-wave cycle stamps into; enable != 0

@@ -563,7 +563,7 @@ void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, h
 // PLACED: every DC / clock-stage workgroup bumps a counter when it starts (b.placed[0] / [1], cumulative over calls), and a
 // one-wave kernel on the waiting stream spins on that counter (s_sleep between looks) up to a bound.  Rounds 1-2 used
 // fixed sleeps (~50 / 120 / 240 us) tuned on 131072-sample calls; with 4096-sample calls those cost up to 16 %
-// (profiles/r03_heuristics.txt), and the counter takes what the placement really needs (tens of microseconds).
+// (profiles/r03_heuristics_before.txt), and the counter takes what the placement really needs (tens of microseconds).
 __global__ void k_hold_until(const uint32_t *counter, uint32_t target, int max_looks) {
     for (int i = 0; i < max_looks; i++) {
         if ((int32_t) (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) {
@@ -1527,15 +1527,22 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         // has its CU, and from here on it needs what that call leaves behind -- the channels' loop state and carried
         // samples.  Every workgroup of every earlier launch bumps k3_done behind a release fence when its state is
         // written; an acquire look that finds them all makes those writes visible here, whichever XCD wrote them.
-        // The look is bounded (~4 s): a launch that never finishes would otherwise hang the device instead of failing a test.
+        // The look is bounded (~4 s): a launch that never finishes would otherwise hang the device instead of failing a test;
+        // an expired bound raises the batch's device error word.
         if (threadIdx.x == 0) {
             // relaxed looks (an acquire load invalidates this XCD's L2 every time, under the other stages' feet), one
             // acquire fence when the count is there
-            for (int looks = 0; looks < (1 << 22); looks++) {
-                if ((int32_t) (__hip_atomic_load(b.k3_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - b.k3_wait_for) >= 0) {
-                    break;
+            bool there = false;
+            for (int looks = 0; looks < (1 << 22) && !there; looks++) {
+                there = (int32_t) (__hip_atomic_load(b.k3_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - b.k3_wait_for) >= 0;
+                if (!there) {
+                    __builtin_amdgcn_s_sleep(32);
                 }
-                __builtin_amdgcn_s_sleep(32);
+            }
+            if (!there) {
+                // the bound expired: what follows reads state the previous call may not have written.  Never silent: the
+                // batch's device error word (k3_done[2]) makes every later sync / collect / fetch of the batch fail
+                atomicOr(b.k3_done + 2, 1u);
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }

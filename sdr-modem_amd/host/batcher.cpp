@@ -275,19 +275,29 @@ int Batcher::reset_channel(size_t c, const sdrm_fsk_config *cfg) {
     req.done = false;
     req.code = 0;
     std::unique_lock<std::mutex> lk(m_);
+    // a batcher whose device has failed hands out no slots: the streams' state lived on that device (sdrm_batcher_error)
+    if (error_ != 0) {
+        return error_;
+    }
     // what was put for the previous client is still delivered to (and has to be consumed by) its consumer
     reset_waiters_++;
-    while (!mine_[c].empty() && !stopping_) {
+    while (!mine_[c].empty() && !stopping_ && error_ == 0) {
         cv_result_.wait(lk);
     }
     reset_waiters_--;
     if (stopping_) {
         return -1;
     }
+    if (error_ != 0) {
+        return error_;
+    }
     resets_.push_back(&req);
     cv_work_.notify_all();
     while (!req.done && !stopping_) {
         cv_result_.wait(lk);
+    }
+    if (req.done && req.code == 0 && error_ != 0) {
+        return error_;  // the device failed while the reset was queued: run() did not reopen the channel
     }
     return req.done ? req.code : -1;
 }
@@ -323,7 +333,7 @@ void Batcher::run() {
             lk.unlock();
             const int code = be_->reset_channel(req->channel, req->has_cfg ? &req->cfg : nullptr);
             lk.lock();
-            if (code == 0 && closed_[req->channel]) {
+            if (code == 0 && error_ == 0 && closed_[req->channel]) {
                 closed_[req->channel] = 0;  // the slot serves a new client
                 abandoned_[req->channel] = 0;
                 open_++;

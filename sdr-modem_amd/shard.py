@@ -157,17 +157,22 @@ def fanout_nco_segments(segments_rank0, shard, device="cpu", as_array=False, cap
     rows0 = None
     if rank == 0:
         rows0 = np.ascontiguousarray(np.asarray(segments_rank0, dtype=np.int64).reshape(-1, 3))
-        if capacity is not None and len(rows0) > capacity:
-            raise ValueError("%d NCO batches exceed the agreed capacity of %d" % (len(rows0), capacity))
     if capacity is not None:
         table = torch.zeros((capacity + 1, 3), dtype=torch.int64, device=device)
         if rank == 0:
-            table[0, 0] = len(rows0)
-            if len(rows0):
+            # too many batches for the agreed table: the failure travels THROUGH the collective (count -1 in row 0, the real
+            # count beside it) so that every rank raises after the broadcast -- raising on rank 0 alone would leave the others
+            # blocked in it until the backend's timeout
+            fits = len(rows0) <= capacity
+            table[0, 0] = len(rows0) if fits else -1
+            table[0, 1] = len(rows0)
+            if fits and len(rows0):
                 table[1:1 + len(rows0)].copy_(torch.from_numpy(rows0))
         if world > 1:
             dist.broadcast(table, src=0)
         host = table.cpu().numpy()
+        if int(host[0, 0]) < 0:
+            raise ValueError("%d NCO batches exceed the agreed capacity of %d" % (int(host[0, 1]), capacity))
         rows = host[1:1 + int(host[0, 0])]
     else:
         count = torch.zeros(1, dtype=torch.int64, device=device)

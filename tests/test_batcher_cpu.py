@@ -326,5 +326,11 @@ def test_a_failed_device_call_ends_every_client_with_an_error_code(capfd):
         # later puts are dropped, later takes return at once
         bt.put(0, sigs[0][:100])
         assert bt.take(0) is None
+        # and the dead batcher hands no slot to a new client: reset_channel answers with the device's code, with the same
+        # configuration or a new one, and the channel stays closed (put dropped, take returns at once)
+        assert bt.reset_channel(0) == -5
+        assert bt.reset_channel(1, cfgs[0]) == -5
+        bt.put(0, sigs[0][:100])
+        assert bt.take(0) is None
         bt.close()
     assert "<3>batcher" in capfd.readouterr().err

@@ -1,0 +1,95 @@
+"""`-m gpu`: the shapes bench.py REPORTS, checked against the oracle at the sizes it reports them at.
+
+The other parity tests feed 8 192- or 16 384-sample calls; the library picks its schedule from the call length and the
+channel count (clock-stage workgroup shape, companion grid, placement holds, int8 conversion in the staging wave or in
+k3_quantize), so the 131 072-sample calls of the bench line are a different schedule.  These tests drive exactly the
+bench path -- bench.Rig: device-resident input, sdrm_batch_process_device with rolling chunk offsets, no host
+synchronisation between steps -- and compare spot channels with the CPU restatement of the reference, int8 and float
+soft bits bit for bit, after the last step and at two points in between (reference behaviour:
+src/dsp/fsk_demod.c:80-110 on buffer_size 131072, src/resources/config.conf:11)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import sdrm_pkg  # noqa: E402
+
+sdrm_pkg.load()
+from sdr_modem_amd import binding, siggen  # noqa: E402
+
+import bench  # noqa: E402  (repo root: the Rig / SpotChecker the bench line itself uses)
+
+pytestmark = pytest.mark.gpu
+N = 131072
+CFG = (bench.FS, bench.BAUD, bench.DEV, bench.DECIM, bench.TW, bench.DC, N)
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert binding.load().sdrm_device_count() > 0, "these tests need an MI355X; the library has no CPU path"
+    torch.cuda.set_device(0)
+    return torch, torch.device("cuda", 0)
+
+
+def _run(torch, dev, channels, steps, check_at, spots, resident=2):
+    rig = bench.Rig(torch, binding, siggen, dev, 0, [CFG] * channels, 0, N, resident)
+    checker = bench.SpotChecker(rig.cfgs, rig.row, N, spots)
+    checks = 0
+    try:
+        for i in range(steps):
+            rig.step(i)  # no synchronisation between steps: stages of consecutive calls overlap as in the bench
+            if (i + 1) in check_at or i + 1 == steps:
+                ok, detail = checker.check(rig.batch, rig.fed)
+                assert ok, ("%d channels x %d samples, after step %d" % (channels, N, i + 1), detail)
+                checks += 1
+        # size-independent property at this size: every channel produced ~N * baud / fs symbols in the last call
+        _, olen = rig.batch.fetch(1)
+        assert np.all(np.abs(np.asarray(olen) - N * bench.BAUD / bench.FS) < 40)
+    finally:
+        rig.close()
+    return checks
+
+
+def test_headline_shape_256_channels_pipelined_twelve_steps(torch_dev):
+    """BASELINE configs[2] as benchmarked: 256 x 131072, 12 pipelined steps -- the companion grid live, the clock stage
+    in its 16-channel x 1024-sample shape with the int8 conversion in the staging wave.  8 spot channels incl. both sides
+    of a clock-stage workgroup boundary and the last channel; checked after steps 4, 8 and 12."""
+    torch, dev = torch_dev
+    assert _run(torch, dev, 256, 12, (4, 8), [0, 15, 16, 17, 100, 129, 240, 255], resident=4) == 3
+
+
+@pytest.mark.parametrize("channels", [1024, 4096])
+def test_sweep_shapes_at_full_call_length(torch_dev, channels):
+    """bench.py's channel_sweep points: 1024 channels (front-end placement hold; 16 x 1024 clock stage) and 4096 (64
+    channels x 256-sample plain ring + k3_quantize), 131072-sample calls, 3 pipelined steps; 8 spot channels each incl.
+    the last workgroup of every stage."""
+    torch, dev = torch_dev
+    spots = [0, 15, 16, 63, 64, channels // 2 + 3, channels - 2, channels - 1]
+    assert _run(torch, dev, channels, 3, (1, 2), spots) == 3
+
+
+def test_config5_workload_as_benchmarked(torch_dev):
+    """bench.py's `config5` block: 256 channels, 240 kHz / 19200 baud / decimation 5 interleaved with 48 kHz / 1200 baud /
+    decimation 8, 131072-sample calls, three NCO batches per channel and call; 4 warm-up + 3 timed steps; 6 spot channels
+    against orc.Nco + orc.Fsk after every timed step."""
+    torch, dev = torch_dev
+    res = bench.config5_single(torch, binding, siggen, dev, 256, N, steps=3, verify=True, check_at=(1, 2))
+    assert res["verified_vs_oracle"] is True, res["verify_mismatches"]
+
+
+def test_bench_line_carries_the_spot_check(torch_dev, capsys):
+    """`python bench.py` (short) prints verified_vs_oracle: true on the headline, the sweep and config5"""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--sweep", "1024",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["verified_vs_oracle"] is True, line.get("verify")
+    assert line["channel_sweep"]["1024"]["verified_vs_oracle"] is True
+    assert line["config5"]["verified_vs_oracle"] is True, line["config5"]

@@ -75,6 +75,15 @@ def _worker(rank, world, port, ret):
         ok = False  # a bare channel count is no partition
     except TypeError:
         pass
+    # more batches than the agreed table holds: EVERY rank raises after the collective (rank 0 raising alone would leave
+    # the others blocked in the broadcast until the backend's timeout), and the next collective still lines up
+    try:
+        shard.fanout_nco_segments(segs_c, part_c, as_array=True, capacity=10)
+        ok = False
+    except ValueError as exc:
+        ok = ok and "24 NCO batches exceed the agreed capacity of 10" in str(exc)
+    again = shard.fanout_nco_segments(np.array(segs_c) if rank == 0 else None, part_c, as_array=True, capacity=24)
+    ok = ok and again.tolist() == one_shot.tolist()
     spans = [None] * world
     dist.all_gather_object(spans, (lo_c, hi_c, sum(shard.channel_cost(c) for c in cfgs_c)))
     ok = ok and spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 24
