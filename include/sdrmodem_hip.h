@@ -10,6 +10,7 @@
  *   2. fsk_demod_*       the reference operator, same names/signature/semantics (a batch of one);
  *   3. sdrm_batcher_*    the queue + worker surface of many clients in front of ONE batch (one device call per round);
  *   4. create_queue/...  and dsp_worker_*: the reference's queue + dsp_worker surface, feeding (2) or (3);
+ *   5. sdrm_node_*       one process, many GPUs: a batcher per device and cost-based placement of each new client;
  *      sdrm_doppler_*    the reference's Doppler batching (per-second shifts from the caller's orbit model) for the
  *                        device-side NCO in front of the demodulator.
  *
@@ -255,6 +256,58 @@ size_t sdrm_batcher_channels(const sdrm_batcher *batcher);
 uint64_t sdrm_batcher_rounds(const sdrm_batcher *batcher); /* batched calls launched so far */
 void sdrm_batcher_destroy(sdrm_batcher *batcher);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Node front door: ONE process, every GPU of the node.  sdr-modem is one process with one DSP thread per RX client
+ * (src/tcp_server.c:659 creates the client's dsp_worker, src/sdr_worker.c:25-55 feeds the workers of a source from that
+ * source's thread, src/dsp_worker.c:188 starts the thread); nothing in it knows about devices.  A node owns one batcher per
+ * device (or several) and PLACES every new client:
+ *   - a client costs fs x (4 T1 + 2 T2 / decimation) -- the front-end's multiply-adds per second of signal, the stage that
+ *     bounds a full GPU; sdrm_channel_cost returns it (the function sdr-modem_amd/shard.py cuts a known table with);
+ *   - the least-loaded healthy device with a free slot takes the client; a client whose source (source_id != 0: the SDR /
+ *     centre frequency it listens to) already has clients on a device joins them while that device is within 8 % of the
+ *     least-loaded one (a source's channels together);
+ *   - sdrm_node_detach frees the slot for the next client, whichever device that turns out to serve;
+ *   - a device whose batcher has failed (sdrm_batcher_error, sticky) takes no new clients; its own clients end through the
+ *     batcher's error path, the other devices' clients are not touched.
+ * sdrm_node_attach only RESERVES the slot (closed, so that it holds up nobody's rounds): the client's worker -- created with
+ * sdrm_worker_config.batcher / .batcher_channel from the slot, or simply with sdrm_worker_config.node, which does the
+ * attach and the detach by itself -- gives the slot the client's parameters and a clean state and opens it
+ * (sdrm_batcher_reset_channel).  No collective is involved: one process, so each device gets its tables by its own
+ * host-to-device copies.  Returns: 0; -ENODEV without a HIP device; -EBUSY when every slot of every healthy device is
+ * taken; the devices' error code when all of them have failed.
+ * --------------------------------------------------------------------------------------------------- */
+typedef struct sdrm_node_t sdrm_node;
+typedef struct {
+    const int *devices;         /* HIP device of each batcher; NULL = device i % visible devices for batcher i */
+    size_t n_batchers;          /* 0 = one per visible device */
+    size_t slots_per_batcher;   /* client slots of each batcher */
+    sdrm_fsk_config geometry;   /* what every slot is created with; a client's own parameters replace it when its worker
+                                 * takes the slot (longer filters make that device's batch grow).  max_input_buffer_length
+                                 * = the server's buffer_size, fixed for the node's life */
+    sdrm_batcher_config batcher; /* slots 0 = {4, 2000, true} */
+} sdrm_node_config;
+typedef struct {
+    sdrm_batcher *batcher;      /* borrowed: owned by the node */
+    size_t channel;
+    int device;
+    size_t batcher_index;
+} sdrm_node_slot;
+typedef struct {
+    int device;
+    sdrm_batcher *batcher;
+    size_t slots, clients;
+    double load;                /* sum of sdrm_channel_cost over the device's clients */
+    uint64_t attached;          /* clients placed on this batcher since the node was created */
+    int error;                  /* sdrm_batcher_error of the device's batcher */
+} sdrm_node_stat;
+int sdrm_node_create(const sdrm_node_config *config, sdrm_node **node);
+int sdrm_node_attach(sdrm_node *node, const sdrm_fsk_config *client, uint64_t source_id, sdrm_node_slot *slot);
+int sdrm_node_detach(sdrm_node *node, const sdrm_node_slot *slot);
+size_t sdrm_node_batchers(const sdrm_node *node);
+int sdrm_node_stat_read(const sdrm_node *node, size_t index, sdrm_node_stat *stat);
+double sdrm_channel_cost(const sdrm_fsk_config *config);
+void sdrm_node_destroy(sdrm_node *node); /* after the clients' workers have been destroyed */
+
 /* ------------------------------------------------------------------------------------------------
  * (3) Queue + worker surface (host side, C, pthreads).
  * Queue: same names/semantics as src/queue.h:10-18 (blocking put for file sources, overwrite-newest for
@@ -295,6 +348,16 @@ typedef struct {
      * batcher (its slots / blocking). */
     sdrm_batcher *batcher;
     size_t batcher_channel;
+    /* optional (batcher == NULL): let a node place this client -- the worker attaches itself (sdrm_node_attach with
+     * source_id), serves the slot it is given and detaches when it is destroyed.  A device that fails between the placement
+     * and the slot's reset is skipped and the placement repeated. */
+    sdrm_node *node;
+    uint64_t source_id;
+    /* optional: the file source's frequency offset (RxRequest.rx_offset applied by src/sdr/file_source.c:120-128 with a
+     * sig_source of its own, upstream of dsp_worker_put): every buffer is mixed with ONE oscillator at this integer
+     * frequency on the device, phase carried across buffers, in front of the demodulator.  Not together with
+     * doppler_shift (the reference then runs two oscillators in series; -ENOTSUP here). */
+    int64_t rx_offset_hz;
 } sdrm_worker_config;
 
 typedef struct dsp_worker_t dsp_worker;

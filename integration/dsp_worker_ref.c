@@ -34,6 +34,15 @@ void sdrm_ref_attach_batcher(sdrm_batcher *batcher, size_t (*next_channel)(void 
     g_next_channel_user = user;
 }
 
+/* Optional: the server has several GPUs -- one node handle (sdrm_node_create: a batcher per device) places every new client on
+ * the least-loaded healthy device; the worker gives its slot back when linked_list's destructor calls dsp_worker_destroy.
+ * Clients that share an SDR source in the reference (same centre frequency and offset, sdr_worker.c:83-95) carry the same
+ * source id, so the node keeps them on one device while that balances.  INTEGRATION.md section 3b. */
+static sdrm_node *g_node = NULL;
+void sdrm_ref_attach_node(sdrm_node *node) {
+    g_node = node;
+}
+
 /* Optional: Doppler pre-correction.  The reference builds its SGP4 predictor from req->doppler (TLE + ground station,
  * src/dsp_worker.c:120-136, src/dsp/doppler.c:31-42); that orbit model stays on the host side of the boundary, so the
  * integrator supplies a factory that turns the request into "shift in Hz for second k of the pass". */
@@ -83,6 +92,15 @@ int dsp_worker_create(uint32_t id, int client_socket, struct server_config *serv
     if (g_batcher != NULL) {
         c.batcher = g_batcher;
         c.batcher_channel = g_next_channel != NULL ? g_next_channel(g_next_channel_user) : 0;
+    } else if (g_node != NULL) {
+        c.node = g_node;
+        /* one id per SDR source as sdr_worker_find_closest tells them apart (sdr_worker.c:88-91); never 0 ("no source").
+         * rx_offset itself is NOT applied here: the reference's sources apply it upstream of dsp_worker_put
+         * (tcp_server.c:438-458, file_source.c:120-128) */
+        c.source_id = (req->rx_center_freq * 0x9E3779B97F4A7C15ull) ^ ((uint64_t) req->rx_offset * 0xC2B2AE3D27D4EB4Full) ^ 1ull;
+        if (c.source_id == 0) {
+            c.source_id = 1;
+        }
     }
     return sdrm_dsp_worker_create(id, client_socket, &c, worker);
 }

@@ -46,7 +46,8 @@ class WorkerConfig(C.Structure):
                 ("demod_fsk_use_dc_block", C.c_bool), ("rx_dump_file", C.c_bool), ("demod_destination", C.c_int),
                 ("buffer_size", C.c_uint32), ("queue_size", C.c_uint16), ("rx_file_source", C.c_bool),
                 ("base_path", C.c_char_p), ("doppler_shift", C.c_void_p), ("doppler_user", C.c_void_p),
-                ("batcher", C.c_void_p), ("batcher_channel", C.c_size_t)]
+                ("batcher", C.c_void_p), ("batcher_channel", C.c_size_t),
+                ("node", C.c_void_p), ("source_id", C.c_uint64), ("rx_offset_hz", C.c_int64)]
 
 
 # every symbol include/sdrmodem_hip.h declares
@@ -60,6 +61,8 @@ EXPORTS = [
     "sdrm_dsp_worker_create", "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt", "sdrm_batcher_abandon", "sdrm_fsk_demod_error", "sdrm_last_error", "sdrm_batch_wait_input", "sdrm_wire_write_response",
     "sdrm_wire_read_header", "sdrm_wire_decode_rx_request",
     "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_error", "sdrm_batcher_destroy",
+    "sdrm_node_create", "sdrm_node_attach", "sdrm_node_detach", "sdrm_node_batchers", "sdrm_node_stat_read",
+    "sdrm_node_destroy", "sdrm_channel_cost",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_quad", "sdrm_probe_boxcar_div", "sdrm_version", "sdrm_device_count",
     "sdrm_batch_k3_stamps", "sdrm_batch_timeline",
@@ -71,6 +74,32 @@ EXPORTS = [
 
 class BatcherConfig(C.Structure):
     _fields_ = [("slots", C.c_uint32), ("max_wait_us", C.c_uint32), ("blocking", C.c_bool)]
+
+
+class NodeConfig(C.Structure):
+    _fields_ = [("devices", C.POINTER(C.c_int)), ("n_batchers", C.c_size_t), ("slots_per_batcher", C.c_size_t),
+                ("geometry", FskConfig), ("batcher", BatcherConfig)]
+
+
+class NodeSlot(C.Structure):
+    _fields_ = [("batcher", C.c_void_p), ("channel", C.c_size_t), ("device", C.c_int), ("batcher_index", C.c_size_t)]
+
+
+class NodeStat(C.Structure):
+    _fields_ = [("device", C.c_int), ("batcher", C.c_void_p), ("slots", C.c_size_t), ("clients", C.c_size_t),
+                ("load", C.c_double), ("attached", C.c_uint64), ("error", C.c_int)]
+
+
+def bind_node(L):
+    """argtypes of the node front door's calls (also used on the test suite's emulation-backed build)"""
+    vp = C.c_void_p
+    L.sdrm_node_attach.argtypes = [vp, C.POINTER(FskConfig), C.c_uint64, C.POINTER(NodeSlot)]
+    L.sdrm_node_detach.argtypes = [vp, C.POINTER(NodeSlot)]
+    L.sdrm_node_batchers.argtypes = [vp]
+    L.sdrm_node_batchers.restype = C.c_size_t
+    L.sdrm_node_stat_read.argtypes = [vp, C.c_size_t, C.POINTER(NodeStat)]
+    L.sdrm_node_destroy.argtypes = [vp]
+    L.sdrm_node_destroy.restype = None
 
 
 def bind_batcher(L):
@@ -136,6 +165,10 @@ def load():
     L.sdrm_batch_process_device_nco.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(NcoSegment), C.c_size_t, vp]
     L.sdrm_batch_last_mixed.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     bind_batcher(L)
+    bind_node(L)
+    L.sdrm_node_create.argtypes = [C.POINTER(NodeConfig), C.POINTER(vp)]
+    L.sdrm_channel_cost.argtypes = [C.POINTER(FskConfig)]
+    L.sdrm_channel_cost.restype = C.c_double
     L.sdrm_batcher_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.c_int, C.POINTER(BatcherConfig), C.POINTER(vp)]
     L.sdrm_batcher_set_doppler.argtypes = [vp, C.c_size_t, vp]
     L.sdrm_batch_reset_channel.argtypes = [vp, C.c_size_t, C.POINTER(FskConfig)]
@@ -437,6 +470,65 @@ class Batcher:
             self.close()
         except Exception:
             pass
+
+
+class Node:
+    """sdrm_node_*: one process, a batcher per device, cost-based placement of every new client (include/sdrmodem_hip.h).
+    `lib`/`handle` let the CPU test-suite wrap its emulation-backed build (virtual devices) of the same host code."""
+
+    def __init__(self, geometry, slots_per_batcher, n_batchers=0, devices=None, batcher=(4, 2000, True), lib=None, handle=None):
+        if lib is not None:
+            self.L, self.h, self.code = lib, handle, 0
+            return
+        self.L = load()
+        self.h = C.c_void_p()
+        self._dev = (C.c_int * len(devices))(*devices) if devices else None
+        cfg = node_config(geometry, slots_per_batcher, n_batchers, self._dev, batcher)
+        self.code = self.L.sdrm_node_create(C.byref(cfg), C.byref(self.h))
+        if self.code != 0:
+            self.h = C.c_void_p()
+
+    def attach(self, cfg, source_id=0):
+        """-> (code, NodeSlot)"""
+        slot = NodeSlot()
+        arr = make_configs([cfg])
+        return self.L.sdrm_node_attach(self.h, arr, source_id, C.byref(slot)), slot
+
+    def detach(self, slot):
+        return self.L.sdrm_node_detach(self.h, C.byref(slot))
+
+    def batchers(self):
+        return int(self.L.sdrm_node_batchers(self.h))
+
+    def stat(self, i):
+        st = NodeStat()
+        assert self.L.sdrm_node_stat_read(self.h, i, C.byref(st)) == 0
+        return st
+
+    def close(self):
+        if self.h:
+            self.L.sdrm_node_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def node_config(geometry, slots_per_batcher, n_batchers=0, devices=None, batcher=(4, 2000, True)):
+    cfg = NodeConfig()
+    cfg.devices = devices if devices is not None else None
+    cfg.n_batchers = n_batchers
+    cfg.slots_per_batcher = slots_per_batcher
+    cfg.geometry = FskConfig(*geometry)
+    cfg.batcher = BatcherConfig(*batcher)
+    return cfg
+
+
+def channel_cost(cfg):
+    return float(load().sdrm_channel_cost(make_configs([cfg])))
 
 
 ABSENT = object()            # in a list of inputs: the channel takes no part in the call (its state stays as it is)

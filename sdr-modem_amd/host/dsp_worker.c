@@ -29,6 +29,9 @@ struct dsp_worker_t {
     sdrm_doppler *doppler;
     sdrm_batcher *batcher; /* shared per-GPU batcher (borrowed) used instead of demod/corrected + inbox */
     size_t channel;
+    sdrm_node *node;       /* the node that placed this client on `batcher` (borrowed), NULL otherwise */
+    sdrm_node_slot slot;   /* ... and the slot to give back */
+    int64_t rx_offset_hz;  /* the file source's frequency offset, what the built-in shift callback returns */
     queue *inbox;
     pthread_t thread;
     bool thread_started;
@@ -191,6 +194,14 @@ int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *
     return sdrm_dsp_worker_create(id, client_socket, cfg, result);
 }
 
+/* the file source's offset as a "Doppler" that never changes: the planner (doppler.c:128-180) interpolates between equal
+ * per-second values and truncates to the same integer, and batches of equal frequency are one oscillator run
+ * (sig_source.c:43-75 keeps its phase across calls) -- file_source.c:120-128's sig_source_multiply(freq_offset, ...) */
+static double constant_offset(void *user, uint64_t second) {
+    (void) second;
+    return (double) *(const int64_t *) user;
+}
+
 int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *cfg, dsp_worker **result) {
     dsp_worker *w = calloc(1, sizeof(*w));
     if (w == NULL) {
@@ -198,36 +209,71 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
     }
     w->id = id;
     w->client_socket = client_socket;
+    w->rx_offset_hz = cfg->rx_offset_hz;
     int code = 0;
-    if (cfg->batcher != NULL) {
-        if (cfg->batcher_channel >= sdrm_batcher_channels(cfg->batcher)) {
-            fprintf(stderr, "<3>[%d] batcher has no channel %zu\n", w->id, cfg->batcher_channel);
+    sdrm_doppler_shift_fn shift_fn = cfg->doppler_shift;
+    void *shift_user = cfg->doppler_user;
+    if (cfg->rx_offset_hz != 0) {
+        if (cfg->doppler_shift != NULL) {
+            /* the reference runs the file source's oscillator and the Doppler one in series (two roundings per sample) */
+            fprintf(stderr, "<3>[%d] rx offset and doppler correction together are not supported\n", w->id);
             free(w);
-            return -1;
+            return -ENOTSUP;
         }
-        w->batcher = cfg->batcher;
-        w->channel = cfg->batcher_channel;
-        /* the slot starts a new stream with this client's parameters (fsk_demod_create's part, src/dsp_worker.c:138-144) */
-        sdrm_fsk_config fc = {cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
-                              (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
-                              cfg->demod_fsk_use_dc_block, cfg->buffer_size};
-        code = sdrm_batcher_reset_channel(w->batcher, w->channel, &fc);
+        shift_fn = constant_offset;
+        shift_user = &w->rx_offset_hz;
+    }
+    sdrm_fsk_config fc = {cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
+                          (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
+                          cfg->demod_fsk_use_dc_block, cfg->buffer_size};
+    if (cfg->batcher != NULL || cfg->node != NULL) {
+        if (cfg->batcher != NULL) {
+            if (cfg->batcher_channel >= sdrm_batcher_channels(cfg->batcher)) {
+                fprintf(stderr, "<3>[%d] batcher has no channel %zu\n", w->id, cfg->batcher_channel);
+                free(w);
+                return -1;
+            }
+            w->batcher = cfg->batcher;
+            w->channel = cfg->batcher_channel;
+            /* the slot starts a new stream with this client's parameters (fsk_demod_create's part, src/dsp_worker.c:138-144) */
+            code = sdrm_batcher_reset_channel(w->batcher, w->channel, &fc);
+        } else {
+            /* the node places the client (least-loaded healthy device); a device that fails between the placement and the
+             * slot's reset is skipped next time round, so at most one attempt per batcher */
+            const size_t attempts = sdrm_node_batchers(cfg->node) + 1;
+            code = -EBUSY;
+            for (size_t k = 0; k < attempts; k++) {
+                code = sdrm_node_attach(cfg->node, &fc, cfg->source_id, &w->slot);
+                if (code != 0) {
+                    break;
+                }
+                code = sdrm_batcher_reset_channel(w->slot.batcher, w->slot.channel, &fc);
+                if (code == 0) {
+                    w->node = cfg->node;
+                    w->batcher = w->slot.batcher;
+                    w->channel = w->slot.channel;
+                    break;
+                }
+                const int dead = sdrm_batcher_error(w->slot.batcher);
+                sdrm_node_detach(cfg->node, &w->slot);
+                if (dead == 0) {
+                    break; /* the client's own parameters were refused (-1, -ENOTSUP): another device would refuse them too */
+                }
+            }
+        }
         if (code != 0) {
             fprintf(stderr, "<3>[%d] unable to create demodulator\n", w->id);
             free(w);
             return code;
         }
-        if (cfg->doppler_shift != NULL) {
-            code = sdrm_doppler_create(cfg->rx_sampling_freq, cfg->doppler_shift, cfg->doppler_user, &w->doppler);
+        if (shift_fn != NULL) {
+            code = sdrm_doppler_create(cfg->rx_sampling_freq, shift_fn, shift_user, &w->doppler);
             if (code == 0) {
                 code = sdrm_batcher_set_doppler(w->batcher, w->channel, w->doppler);
             }
         }
-    } else if (cfg->doppler_shift != NULL) {
-        sdrm_fsk_config fc = {cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
-                              (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
-                              cfg->demod_fsk_use_dc_block, cfg->buffer_size};
-        code = sdrm_doppler_create(cfg->rx_sampling_freq, cfg->doppler_shift, cfg->doppler_user, &w->doppler);
+    } else if (shift_fn != NULL) {
+        code = sdrm_doppler_create(cfg->rx_sampling_freq, shift_fn, shift_user, &w->doppler);
         if (code != 0) {
             fprintf(stderr, "<3>[%d] unable to create doppler correction block\n", w->id);
             dsp_worker_destroy(w);
@@ -316,6 +362,9 @@ void dsp_worker_destroy(void *data) {
     }
     if (w->doppler != NULL) {
         sdrm_doppler_destroy(w->doppler);
+    }
+    if (w->node != NULL) {
+        sdrm_node_detach(w->node, &w->slot); /* the slot serves the node's next client, on whichever device that is */
     }
     free(w);
 }

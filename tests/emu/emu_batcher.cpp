@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../sdr-modem_amd/host/batcher.h"
+#include "../../sdr-modem_amd/host/node.h"
 
 struct EmuBatch;
 extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out);
@@ -32,8 +33,12 @@ bool countdown(std::atomic<int> &n) {
     return v == 1;
 }
 
+// per virtual device (emu_node_create): the n-th submit from now on that device fails with -EIO (0: never)
+std::atomic<int> g_device_fail_in[16];
+
 struct EmuBackend : sdrm::BatchBackend {
     EmuBatch *emu = nullptr;
+    int virtual_device = -1;
     std::vector<uint32_t> maxlen;
     std::vector<float> arena_mem;
     size_t stride = 0, slots = 0;
@@ -57,6 +62,7 @@ struct EmuBackend : sdrm::BatchBackend {
     int submit(size_t slot, const size_t *lens, const sdrm_nco_segment *segs, size_t n_segs) override {
         if (done.size() >= 3) return -11;
         if (countdown(g_fail_submit_in)) return -5;
+        if (virtual_device >= 0 && virtual_device < 16 && countdown(g_device_fail_in[virtual_device])) return -5;
         const size_t C = maxlen.size();
         std::vector<const float *> ins(C);
         for (size_t c = 0; c < C; c++) ins[c] = arena_mem.data() + 2 * ((slot * C + c) * stride);
@@ -102,13 +108,14 @@ extern "C" void emu_batcher_inject(int submit_in, int collect_in) {
     g_fail_collect_in = collect_in;
 }
 
-extern "C" int emu_batcher_create(const sdrm_fsk_config *cfgs, size_t n, uint32_t slots, uint32_t max_wait_us, int blocking,
-                                  unsigned device_delay_us, sdrm_batcher **out) {
+static int emu_batcher_make(const sdrm_fsk_config *cfgs, size_t n, uint32_t slots, uint32_t max_wait_us, int blocking,
+                            unsigned device_delay_us, int virtual_device, sdrm_batcher **out) {
     std::unique_ptr<EmuBackend> be(new EmuBackend());
     int code = emu_create(cfgs, n, &be->emu);
     if (code != 0) return code;
     for (size_t c = 0; c < n; c++) be->maxlen.push_back(cfgs[c].max_input_buffer_length);
     be->delay_us = device_delay_us;
+    be->virtual_device = virtual_device;
     sdrm::Batcher *b = new sdrm::Batcher(std::move(be), slots, max_wait_us, blocking != 0);
     code = b->init();
     if (code != 0) {
@@ -117,4 +124,32 @@ extern "C" int emu_batcher_create(const sdrm_fsk_config *cfgs, size_t n, uint32_
     }
     *out = reinterpret_cast<sdrm_batcher *>(b);
     return 0;
+}
+
+extern "C" int emu_batcher_create(const sdrm_fsk_config *cfgs, size_t n, uint32_t slots, uint32_t max_wait_us, int blocking,
+                                  unsigned device_delay_us, sdrm_batcher **out) {
+    return emu_batcher_make(cfgs, n, slots, max_wait_us, blocking, device_delay_us, -1, out);
+}
+
+// ---- the product's node front door (sdr-modem_amd/host/node.cpp) over VIRTUAL devices: every "device" is an emulation-backed
+// batcher of its own; emu_node_fail_device makes one of them fail its n-th submit from now
+static int emu_node_factory(void *, int device, const sdrm_fsk_config *cfgs, size_t n, const sdrm_batcher_config *cfg,
+                            sdrm_batcher **out) {
+    return emu_batcher_make(cfgs, n, cfg->slots, cfg->max_wait_us, cfg->blocking ? 1 : 0, 0, device, out);
+}
+
+extern "C" int emu_node_create(const sdrm_node_config *config, int virtual_devices, sdrm_node **node) {
+    for (auto &f : g_device_fail_in) f = 0;
+    sdrm::Node *n = new sdrm::Node(emu_node_factory, sdrm_batcher_destroy, nullptr);
+    const int code = n->init(*config, virtual_devices);
+    if (code != 0) {
+        delete n;
+        return code;
+    }
+    *node = reinterpret_cast<sdrm_node *>(n);
+    return 0;
+}
+
+extern "C" void emu_node_fail_device(int virtual_device, int submit_in) {
+    if (virtual_device >= 0 && virtual_device < 16) g_device_fail_in[virtual_device] = submit_in;
 }

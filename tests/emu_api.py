@@ -45,8 +45,23 @@ def lib():
         bind_batcher(L)
         L.emu_batcher_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, C.c_uint,
                                          C.POINTER(C.c_void_p)]
+        from sdr_modem_amd.binding import bind_node, NodeConfig
+        bind_node(L)
+        L.emu_node_create.argtypes = [C.POINTER(NodeConfig), C.c_int, C.POINTER(C.c_void_p)]
+        L.emu_node_fail_device.argtypes = [C.c_int, C.c_int]
+        L.emu_node_fail_device.restype = None
         _LIB = L
     return _LIB
+
+
+def emu_node(geometry, slots_per_batcher, virtual_devices, batcher=(4, 2000, True)):
+    """the product's node front door (sdr-modem_amd/host/node.cpp) over `virtual_devices` emulation-backed batchers"""
+    from sdr_modem_amd.binding import Node, node_config
+    cfg = node_config(geometry, slots_per_batcher, 0, None, batcher)
+    h = C.c_void_p()
+    code = lib().emu_node_create(C.byref(cfg), virtual_devices, C.byref(h))
+    assert code == 0, code
+    return Node(None, 0, lib=lib(), handle=h)
 
 
 def emu_batcher(cfgs, slots=4, max_wait_us=2000, blocking=True, device_delay_us=0):

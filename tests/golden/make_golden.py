@@ -128,6 +128,14 @@ def main():
     unit["test_sig_source.c:success"] = {
         "source": "test/test_sig_source.c:8-18", "call": "sig_source_create(1.0, 4, 4); process(freq=1, n=4)",
         "values": [1, 0, 0, 1, -1, 0, 0, -1], "tolerance": 1e-2}
+    # the file source's frequency offset (src/sdr/file_source.c:120-128): "tx.cf32" is what test_success wrote before
+    # (`buffer`, five complex samples), read back through a source created with an offset of 1000 Hz at 48 kHz
+    fs_arrays = c_float_arrays(os.path.join(REF, "test/test_file_source.c"))
+    unit["test_file_source.c:rx_offset"] = {
+        "source": "test/test_file_source.c:47-61 (expected, line %d; input `buffer`, line %d)" % (fs_arrays["expected"][0], fs_arrays["buffer"][0]),
+        "call": "file_source_create(1, 'tx.cf32', NULL, 48000, 1000, 2000); sdr_process_rx -> sig_source_multiply(1000, input)",
+        "offset_hz": 1000, "sampling_freq": 48000, "input": fs_arrays["buffer"][1], "values": fs_arrays["expected"][1],
+        "tolerance": 1e-4}
     unit["perf_fsk_modem.c:config"] = {
         "source": "test/perf_fsk_modem.c:70-98",
         "call": "fsk_demod_create(48000,4800,5000,2,2000,true,2016000); input re=(uint8)i, im=0, 4096 samples; 10x100 calls"}

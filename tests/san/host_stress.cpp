@@ -17,6 +17,9 @@
 extern "C" int emu_batcher_create(const sdrm_fsk_config *cfgs, size_t n, uint32_t slots, uint32_t max_wait_us, int blocking,
                                   unsigned device_delay_us, sdrm_batcher **out);
 
+extern "C" int emu_node_create(const sdrm_node_config *config, int virtual_devices, sdrm_node **node);
+extern "C" void emu_node_fail_device(int virtual_device, int submit_in);
+
 static int failures = 0;
 #define CHECK(c)                                                       \
     do {                                                               \
@@ -142,6 +145,93 @@ static void batcher_round(bool blocking) {
     sdrm_batcher_destroy(bt);
 }
 
+// ---- node front door (host/node.cpp) over three virtual devices: client threads attach, open their slot, stream, leave,
+// come back; one device fails in the middle; placement, slot recycling and the error path run concurrently
+static void node_round() {
+    sdrm_node_config nc;
+    memset(&nc, 0, sizeof(nc));
+    nc.slots_per_batcher = 4;
+    nc.geometry.sampling_freq = 48000;
+    nc.geometry.baud_rate = 9600;
+    nc.geometry.deviation = 5000;
+    nc.geometry.decimation = 1;
+    nc.geometry.transition_width = 2000;
+    nc.geometry.use_dc_block = true;
+    nc.geometry.max_input_buffer_length = 1024;
+    nc.batcher.slots = 4;
+    nc.batcher.max_wait_us = 300;
+    nc.batcher.blocking = true;
+    sdrm_node *node = nullptr;
+    CHECK(emu_node_create(&nc, 3, &node) == 0);
+    CHECK(sdrm_node_batchers(node) == 3);
+    std::atomic<int> served{0}, refused{0}, ended_by_device{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < 10; t++) {
+        th.emplace_back([&, t] {
+            std::vector<sdrm_cf32> buf(1024);
+            for (size_t i = 0; i < buf.size(); i++) {
+                buf[i].re = (float) ((i * 3 + t) % 9) - 4.0f;
+                buf[i].im = (float) ((i * 5 + t) % 7) - 3.0f;
+            }
+            for (int life = 0; life < 6; life++) {
+                sdrm_fsk_config mine = nc.geometry;
+                mine.baud_rate = (t + life) & 1 ? 4800 : 9600;
+                mine.decimation = (t + life) & 1 ? 2 : 1;
+                sdrm_node_slot slot;
+                const int code = sdrm_node_attach(node, &mine, (uint64_t) (1 + t % 3), &slot);
+                if (code != 0) {
+                    refused++;  // -EBUSY: twelve slots (eight once a device is gone), ten clients: rare but legal
+                    usleep(200);
+                    continue;
+                }
+                if (sdrm_batcher_reset_channel(slot.batcher, slot.channel, &mine) != 0) {
+                    CHECK(sdrm_batcher_error(slot.batcher) != 0);  // only a dead device refuses a slot it handed out
+                    sdrm_node_detach(node, &slot);
+                    continue;
+                }
+                bool alive = true;
+                for (int k = 0; k < 5 && alive; k++) {
+                    sdrm_batcher_put(slot.batcher, slot.channel, buf.data(), 200 + (size_t) ((k * 131 + t * 17) % 800));
+                    int8_t *soft = nullptr;
+                    size_t n = 0;
+                    sdrm_batcher_take(slot.batcher, slot.channel, &soft, &n);
+                    if (soft == nullptr) {
+                        CHECK(sdrm_batcher_error(slot.batcher) != 0);
+                        ended_by_device++;
+                        alive = false;
+                        break;
+                    }
+                    long s = 0;
+                    for (size_t i = 0; i < n; i++) s += soft[i];
+                    (void) s;
+                    sdrm_batcher_complete(slot.batcher, slot.channel);
+                }
+                if (alive) {
+                    sdrm_batcher_interrupt(slot.batcher, slot.channel);
+                    served++;
+                }
+                CHECK(sdrm_node_detach(node, &slot) == 0);
+                if (t == 0 && life == 2) {
+                    emu_node_fail_device(1, 2);  // virtual device 1 fails its second call from now
+                }
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    CHECK(served > 20);
+    size_t clients = 0;
+    int dead = 0;
+    for (size_t i = 0; i < 3; i++) {
+        sdrm_node_stat st;
+        CHECK(sdrm_node_stat_read(node, i, &st) == 0);
+        clients += st.clients;
+        dead += st.error != 0;
+    }
+    CHECK(clients == 0);
+    CHECK(dead <= 1);
+    sdrm_node_destroy(node);
+}
+
 int main() {
     for (int rep = 0; rep < 3; rep++) {
         queue_round(true, 400, 4);
@@ -149,6 +239,7 @@ int main() {
         queue_round(true, 50, 1);
         batcher_round(true);
         batcher_round(false);
+        node_round();
     }
     printf("host_stress: %s\n", failures ? "FAILED" : "ok");
     return failures ? 1 : 0;

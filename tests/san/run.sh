@@ -1,14 +1,14 @@
 #!/bin/bash
-# Builds the host-side code (queue.c, batcher.cpp, the planner and the kernel emulation the CPU tests drive) with the
+# Builds the host-side code (queue.c, batcher.cpp, node.cpp, the planner and the kernel emulation the CPU tests drive) with the
 # sanitizers and runs (1) the threaded stress driver, (2) the CPU test-suite's emulation / batcher tests with the
-# sanitized emulation library preloaded.  CPU build only.  Logs -> profiles/r03_sanitizers.txt when $1 = "record".
+# sanitized emulation library preloaded.  CPU build only.  Logs -> profiles/r04_sanitizers.txt when $1 = "record".
 set -u
 cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=build/san
 mkdir -p $OUT
-SRC="tests/san/host_stress.cpp tests/emu/sdrm_emu.cpp tests/emu/emu_batcher.cpp sdr-modem_amd/host/batcher.cpp sdr-modem_amd/csrc/sdrm_plan.cpp sdr-modem_amd/csrc/sdrm_design.cpp"
-LIBSRC="tests/emu/sdrm_emu.cpp tests/emu/emu_batcher.cpp sdr-modem_amd/host/batcher.cpp sdr-modem_amd/csrc/sdrm_plan.cpp sdr-modem_amd/csrc/sdrm_design.cpp"
+SRC="tests/san/host_stress.cpp tests/emu/sdrm_emu.cpp tests/emu/emu_batcher.cpp sdr-modem_amd/host/batcher.cpp sdr-modem_amd/host/node.cpp sdr-modem_amd/csrc/sdrm_plan.cpp sdr-modem_amd/csrc/sdrm_design.cpp"
+LIBSRC="tests/emu/sdrm_emu.cpp tests/emu/emu_batcher.cpp sdr-modem_amd/host/batcher.cpp sdr-modem_amd/host/node.cpp sdr-modem_amd/csrc/sdrm_plan.cpp sdr-modem_amd/csrc/sdrm_design.cpp"
 FLAGS="-O1 -g -mfma -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-omit-frame-pointer -pthread -Wno-unknown-pragmas"
 LOG=$OUT/log.txt
 : > $LOG
@@ -31,11 +31,11 @@ done
 g++ $FLAGS -fsanitize=address,undefined -shared $LIBSRC -o $OUT/libsdrm_emu_asan.so -lm || status=1
 echo "== pytest (emulation + batcher tests) on the ASan/UBSan build" | tee -a $LOG
 SDRM_EMU_LIB=$ROOT/$OUT/libsdrm_emu_asan.so LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS="detect_leaks=0" \
-  UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1" timeout 900 python -m pytest tests/test_batcher_cpu.py tests/test_kernel_logic_cpu.py -q -x -p no:cacheprovider >> $LOG 2>&1; rc=$?
+  UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1" timeout 900 python -m pytest tests/test_batcher_cpu.py tests/test_node_cpu.py tests/test_kernel_logic_cpu.py -q -x -p no:cacheprovider >> $LOG 2>&1; rc=$?
 echo "pytest exit $rc" | tee -a $LOG
 [ $rc -ne 0 ] && status=1
 grep -cE "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer" $LOG | sed 's/^/sanitizer reports: /' | tee -a $LOG
 if [ "${1:-}" = "record" ]; then
-  { echo "tests/san/run.sh  ($(date -u +%Y-%m-%d), gcc $(gcc -dumpversion), CPU build)"; grep -E "^==|exit|host_stress:|passed|failed|sanitizer reports|ERROR|WARNING: Thread|runtime error" $LOG; } > profiles/r03_sanitizers.txt
+  { echo "tests/san/run.sh  ($(date -u +%Y-%m-%d), gcc $(gcc -dumpversion), CPU build)"; grep -E "^==|exit|host_stress:|passed|failed|sanitizer reports|ERROR|WARNING: Thread|runtime error" $LOG; } > profiles/r04_sanitizers.txt
 fi
 exit $status

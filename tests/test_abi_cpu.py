@@ -351,3 +351,53 @@ def test_reference_signature_adapter_drives_workers_on_a_shared_batcher(tmp_path
     assert np.array_equal(dump, sigs[1])
     A.sdrm_ref_attach_batcher(None, NEXT(0), None)
     bt.close()
+
+
+def test_reference_signature_adapter_places_workers_through_a_node(tmp_path):
+    """the adapter with a NODE attached (sdrm_ref_attach_node; here the product's node code over two virtual devices of the
+    kernel emulation): four RX clients created with the reference's parameter list are placed two per device -- clients of one
+    SDR source (same centre frequency, sdr_worker.c:83-95) together --, demodulate to the oracle's bytes, and give their slots
+    back in dsp_worker_destroy."""
+    import emu_api
+    import orc
+    from sdr_modem_amd import siggen
+    A = _ref_adapter(tmp_path)
+    A.dsp_worker_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(_ServerConfig), C.POINTER(_RxRequest), C.POINTER(C.c_void_p)]
+    A.sdrm_ref_attach_node.argtypes = [C.c_void_p]
+    L = binding.load()
+    cfg = (48000, 4800, 5000, 2, 2000, True, 4096)
+    node = emu_api.emu_node(cfg, 4, 2, batcher=(4, 20000, True))
+    A.sdrm_ref_attach_node(node.h)
+    sc = _ServerConfig(buffer_size=4096, queue_size=4, rx_sdr_type=2, base_path=str(tmp_path).encode())
+    sigs = [siggen.gmsk_channel(90 + i, 2 * 4096 + 50, fs=48000, baud=4800) for i in range(4)]
+    ws = []
+    for i in range(4):
+        req = _request(48000, 4800, 5000, 2, 2000, True, False, 0)
+        req.rx_center_freq = 437525000 if i % 2 == 0 else 145800000  # two SDR sources
+        w = C.c_void_p()
+        assert A.dsp_worker_create(60 + i, -1, C.byref(sc), C.byref(req), C.byref(w)) == 0
+        ws.append(w)
+    assert [node.stat(d).clients for d in range(2)] == [2, 2]
+    L.dsp_worker_put.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.dsp_worker_destroy.argtypes = [C.c_void_p]
+    import threading
+
+    def feed(i):
+        for off in range(0, len(sigs[i]), 4096):
+            part = np.ascontiguousarray(sigs[i][off:off + 4096]).view(np.float32)
+            L.dsp_worker_put(part.ctypes.data, len(part) // 2, ws[i])
+    th = [threading.Thread(target=feed, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+        assert not t.is_alive()
+    for w in ws:
+        L.dsp_worker_destroy(w)
+    assert [node.stat(d).clients for d in range(2)] == [0, 0]
+    for i in range(4):
+        got = np.fromfile(os.path.join(str(tmp_path), "rx.demod2client.%d.s8" % (60 + i)), dtype=np.int8)
+        want, _ = orc.demod_stream(cfg[:6], sigs[i], 4096)
+        assert np.array_equal(got, want), i
+    A.sdrm_ref_attach_node(None)
+    node.close()

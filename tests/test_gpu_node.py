@@ -1,0 +1,144 @@
+"""`-m gpu`: the in-process node front door (sdrm_node_*, sdr-modem_amd/host/node.cpp) on the device.  The pool's boxes have
+one GPU, so the node is given TWO batchers on device 0 -- the same code path as two devices (placement, one batcher thread
+and one device batch per batcher, per-batcher error), with the two batches sharing the chip.  Reference process model:
+src/tcp_server.c:659, src/sdr_worker.c:25-55, src/dsp_worker.c:188."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+import threading
+
+import numpy as np
+import pytest
+
+import orc
+import sdrm_pkg
+
+sdrm_pkg.load()
+from sdr_modem_amd import binding, siggen  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert binding.load().sdrm_device_count() > 0, "these tests need an MI355X; the library has no CPU path"
+
+
+def test_twenty_four_clients_behind_one_node_handle_on_two_batchers():
+    """a node of two batchers x 14 slots on device 0: 24 RX clients of three kinds (one kind over ten times as costly) created
+    with sdrm_worker_config.node, fed from per-client threads, files against the oracle; twice the slots of one batcher run
+    through one handle, and the placement balances cost, not count."""
+    L = binding.load()
+    geom = (48000, 9600, 5000, 1, 2000, True, 8192)
+    node = binding.Node(geom, 14, n_batchers=2, devices=[0, 0], batcher=(4, 50000, True))
+    assert node.code == 0 and node.batchers() == 2
+    kinds = [(48000, 9600, 5000, 1, 2000, True, 8192), (48000, 4800, 5000, 2, 2000, False, 8192),
+             (240000, 19200, 5000, 5, 2000, True, 8192)]
+    n_w, sizes = 24, [8192, 3000, 8192, 17, 8000]
+    cfgs = [kinds[(i * 7) % 3] for i in range(n_w)]
+    sigs = [siggen.gmsk_channel(500 + i, sum(sizes), fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    with tempfile.TemporaryDirectory() as tmp:
+        ws = []
+        for i in range(n_w):
+            c = cfgs[i]
+            wc = binding.WorkerConfig(c[0], c[1], c[2], c[3], c[4], c[5], False, 0, c[6], 8, True, tmp.encode(),
+                                      None, None, None, 0, node.h, 1 + i % 4, 0)
+            w = C.c_void_p()
+            assert L.dsp_worker_create(700 + i, -1, C.byref(wc), C.byref(w)) == 0
+            ws.append(w)
+        st = [node.stat(0), node.stat(1)]
+        assert st[0].clients + st[1].clients == n_w and st[0].device == 0 and st[1].device == 0
+        assert max(st[0].load, st[1].load) - min(st[0].load, st[1].load) <= binding.channel_cost(kinds[2]) * (1 + 1e-9)
+        # every slot of both batchers can be used through the one handle; with all 28 taken the next client is refused, not queued
+        wc = binding.WorkerConfig(48000, 9600, 5000, 1, 2000, True, False, 0, 8192, 8, True, tmp.encode(),
+                                  None, None, None, 0, node.h, 0, 0)
+        idle = []
+        for k in range(4):
+            w = C.c_void_p()
+            assert L.dsp_worker_create(900 + k, -1, C.byref(wc), C.byref(w)) == 0
+            idle.append(w)
+        w = C.c_void_p()
+        assert L.dsp_worker_create(999, -1, C.byref(wc), C.byref(w)) == -16  # -EBUSY
+        assert node.stat(0).clients == 14 and node.stat(1).clients == 14
+        for w in idle:
+            L.dsp_worker_destroy(w)  # four clients that never sent a buffer leave: their slots are free again
+
+        def feed(i):
+            pos = 0
+            for n in sizes:
+                part = np.ascontiguousarray(sigs[i][pos:pos + n]).view(np.float32)
+                L.dsp_worker_put(part.ctypes.data, n, ws[i])
+                pos += n
+        th = [threading.Thread(target=feed, args=(i,)) for i in range(n_w)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(180)
+            assert not t.is_alive()
+        for w in ws:
+            L.dsp_worker_destroy(w)
+        assert node.stat(0).clients == 0 and node.stat(1).clients == 0 and node.stat(0).error == 0 and node.stat(1).error == 0
+        for i in range(n_w):
+            got = np.fromfile(os.path.join(tmp, "rx.demod2client.%d.s8" % (700 + i)), dtype=np.int8)
+            o = orc.Fsk(*cfgs[i])
+            pos, want = 0, []
+            for n in sizes:
+                want.append(o.process(sigs[i][pos:pos + n])[0])
+                pos += n
+            assert np.array_equal(got, np.concatenate(want)), i
+    node.close()
+
+
+def _file_demod():
+    exe = os.path.join(ROOT, "tools", "file_demod")
+    src = os.path.join(ROOT, "tools", "file_demod.c")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-pthread", src, "-I" + os.path.join(ROOT, "include"),
+                               "-L" + os.path.join(ROOT, "sdr-modem_amd", "csrc"), "-lsdrmodem_hip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "sdr-modem_amd", "csrc"), "-o", exe])
+    return exe
+
+
+def test_file_source_harness_through_a_node_of_two_batchers():
+    """tools/file_demod -g 2 -n 5: a plain C program, one node handle, five workers placed over two batchers; every
+    worker's rx.demod2client.<id>.s8 is the oracle's stream, within the reference's 2 LSB of its golden file"""
+    src = os.path.join(GOLDEN, "lucky7.expected.cf32")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = subprocess.run([_file_demod(), "-n", "5", "-g", "2", src, tmp, "48000", "4800", "5000", "2", "2000", "1"],
+                             timeout=180, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-1500:]
+        served = sorted(int(ln.split("served")[1].split()[0]) for ln in out.stderr.splitlines() if "served" in ln)
+        assert served == [2, 3], out.stderr[-600:]
+        iq = np.fromfile(src, dtype=np.complex64)
+        want, _ = orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq, 4096)
+        golden = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.s8"), dtype=np.int8)
+        for i in range(5):
+            got = np.fromfile(os.path.join(tmp, "rx.demod2client.%d.s8" % i), dtype=np.int8)
+            assert np.array_equal(got, want), i
+            assert len(got) == len(golden) and np.abs(got.astype(np.int32) - golden.astype(np.int32)).max() <= 2
+
+
+@pytest.mark.parametrize("layout", [["-n", "1"], ["-n", "3"], ["-n", "3", "-g", "2"]], ids=["private", "batcher", "node"])
+def test_file_source_frequency_offset_on_the_device(layout):
+    """RxRequest.rx_offset as src/sdr/file_source.c:120-128 applies it -- sig_source_multiply(offset) on every buffer read,
+    phase carried -- done by the device's NCO in front of the demodulator (tools/file_demod -o): a recording moved up by
+    1200 Hz and read with -o -1200 gives, bit for bit, orc.Nco(-1200) + orc.Fsk on the same buffers."""
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
+    n = np.arange(len(iq))
+    moved = (iq * np.exp(2j * np.pi * 1200.0 * n / 48000.0)).astype(np.complex64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "moved.cf32")
+        moved.tofile(path)
+        subprocess.check_call([_file_demod(), "-o", "-1200"] + layout + [path, tmp, "48000", "4800", "5000", "2", "2000", "1"], timeout=180)
+        osc = orc.Nco(1.0, 48000, 4096)
+        o = orc.Fsk(48000, 4800, 5000, 2, 2000, True, 4096)
+        want = np.concatenate([o.process(osc.multiply(-1200, moved[k:k + 4096].view(np.float32)))[0] for k in range(0, len(moved), 4096)])
+        for i in range(int(layout[1])):
+            got = np.fromfile(os.path.join(tmp, "rx.demod2client.%d.s8" % i), dtype=np.int8)
+            assert np.array_equal(got, want), i
+        # and the recording is demodulated: same symbols as the un-moved file up to the oscillator's rounding (hard bits)
+        plain, _ = orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq, 4096)
+        assert len(plain) == len(want) and np.mean((plain >= 0) == (want >= 0)) > 0.995
