@@ -28,12 +28,12 @@ def _need_gpu():
 
 
 def test_twenty_four_clients_behind_one_node_handle_on_two_batchers():
-    """a node of two batchers x 14 slots on device 0: 24 RX clients of three kinds (one kind over ten times as costly) created
+    """a node of two batchers x 20 slots on device 0: 24 RX clients of three kinds (one kind over ten times as costly) created
     with sdrm_worker_config.node, fed from per-client threads, files against the oracle; twice the slots of one batcher run
     through one handle, and the placement balances cost, not count."""
     L = binding.load()
     geom = (48000, 9600, 5000, 1, 2000, True, 8192)
-    node = binding.Node(geom, 14, n_batchers=2, devices=[0, 0], batcher=(4, 50000, True))
+    node = binding.Node(geom, 20, n_batchers=2, devices=[0, 0], batcher=(4, 50000, True))
     assert node.code == 0 and node.batchers() == 2
     kinds = [(48000, 9600, 5000, 1, 2000, True, 8192), (48000, 4800, 5000, 2, 2000, False, 8192),
              (240000, 19200, 5000, 5, 2000, True, 8192)]
@@ -52,19 +52,19 @@ def test_twenty_four_clients_behind_one_node_handle_on_two_batchers():
         st = [node.stat(0), node.stat(1)]
         assert st[0].clients + st[1].clients == n_w and st[0].device == 0 and st[1].device == 0
         assert max(st[0].load, st[1].load) - min(st[0].load, st[1].load) <= binding.channel_cost(kinds[2]) * (1 + 1e-9)
-        # every slot of both batchers can be used through the one handle; with all 28 taken the next client is refused, not queued
+        # every slot of both batchers can be used through the one handle; with all 40 taken the next client is refused, not queued
         wc = binding.WorkerConfig(48000, 9600, 5000, 1, 2000, True, False, 0, 8192, 8, True, tmp.encode(),
                                   None, None, None, 0, node.h, 0, 0)
         idle = []
-        for k in range(4):
+        for k in range(16):
             w = C.c_void_p()
             assert L.dsp_worker_create(900 + k, -1, C.byref(wc), C.byref(w)) == 0
             idle.append(w)
         w = C.c_void_p()
         assert L.dsp_worker_create(999, -1, C.byref(wc), C.byref(w)) == -16  # -EBUSY
-        assert node.stat(0).clients == 14 and node.stat(1).clients == 14
+        assert node.stat(0).clients == 20 and node.stat(1).clients == 20
         for w in idle:
-            L.dsp_worker_destroy(w)  # four clients that never sent a buffer leave: their slots are free again
+            L.dsp_worker_destroy(w)  # sixteen clients that never sent a buffer leave: their slots are free again
 
         def feed(i):
             pos = 0
