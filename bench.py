@@ -78,6 +78,16 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one per GPU, RCCL rendezvous on
     127.0.0.1) BEFORE this process imports torch or touches the GPU, relay rank 0's JSON line, fail if any rank fails.
@@ -417,6 +427,7 @@ def main():
 
     rig = Rig(torch, binding, siggen, dev, local_rank, cfgs, rank * C, N, R)
     batch = rig.batch
+    schedule = batch.schedule()  # what the batch measured at creation to be its fastest schedule (outside every timed region)
 
     def barrier():
         torch.cuda.synchronize()
@@ -532,6 +543,7 @@ def main():
                                    "fsk_demod(48000,9600,5000,1,2000,dc), %d-sample chunks" % (C, N),
                        "channels_per_gpu": C, "chunk_samples": N, "mode": "exact (bit-identical to the CPU restatement of the reference)",
                        "stages": "serial" if os.environ.get("SDRM_SERIAL_STAGES") else "pipelined across calls",
+                       "schedule": schedule,
                        "parallelism": "channel-sharded x%d, no data-path collective" % world},
             "channels_at_realtime": int(msps * 1e6 / FS),
             "kernel_ms": {"front_lpf1_quad_lpf2": round(k_ms[0], 4), "dc_blocker": round(k_ms[1], 4),
@@ -588,7 +600,7 @@ def main():
             one, _, _ = orc.bench_fsk(row0, N, cfg6, 1, min(2.0, args.cpu_seconds))
             allc, secs, smp = orc.bench_fsk(row0, N, cfg6, cores, args.cpu_seconds)
             out["cpu_baseline"] = {
-                "value": round(allc, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "value": round(allc, 3), "unit": "Msamples/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
                 "single_thread_value": round(one, 3),
                 "sample": "oracle (plain-C restatement of the reference path, gcc -O2 -ffp-contract=off), one "
                           "independent channel per thread on %d threads, %d-sample chunks of channel 0 looped for "
@@ -659,7 +671,7 @@ def main():
                     ok2 = None
                     if not args.no_verify:
                         ok2, _ = SpotChecker(r2.cfgs, r2.row, N, spot_channels(c2)).check(r2.batch, r2.fed)
-                    sweep[str(c2)] = {"verified_vs_oracle": ok2, "value": round(c2 * N * SWEEP_STEPS / dt / 1e6, 1), "unit": "Msamples/s",
+                    sweep[str(c2)] = {"verified_vs_oracle": ok2, "schedule": r2.batch.schedule(), "value": round(c2 * N * SWEEP_STEPS / dt / 1e6, 1), "unit": "Msamples/s",
                                       "ms_per_step": round(dt / SWEEP_STEPS * 1e3, 3), "steps": SWEEP_STEPS,
                                       "kernel_ms": [round(m, 3) for m in km],
                                       "front_hbm_frac": round(c2 * N * 8.0 / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -209,6 +209,20 @@ int sdrm_probe_boxcar_div(const float *sums, uint32_t length, float *out, size_t
 int sdrm_batch_k3_stamps(sdrm_batch *batch, int enable, unsigned long long *out, size_t max_waves);
 int sdrm_batch_timeline(sdrm_batch *batch, int enable, unsigned long long *out, size_t max_rows);
 
+/* The schedule a batch runs with.  A batch of 32 channels or more calibrates itself when it is created: it times full-length
+ * calls of its own pipeline on a synthetic row (a few calls per candidate: clock-stage workgroup shape, the front-end's hold
+ * for the clock stage's placement, the companion grid beside the clock stage), keeps what is fastest by more than 3 %, and
+ * puts every stream back to its initial state.  SDRM_AUTOTUNE=0 keeps the built-in starting point (channel-count rules). */
+typedef struct {
+    int k3_lanes, k3_ring, k3_plain; /* clock stage: channels per workgroup, ring length in samples, plain ring */
+    int front_hold;                  /* 1: the front-end waits for the clock stage two calls back to have its workgroups placed */
+    int company_blocks;              /* workgroups of the companion grid beside each clock stage (0: none) */
+    int calibrated;                  /* 1: measured at creation; 0: the starting point (small batch, switched off, forced) */
+    float ms_before, ms_after;       /* ms per full-length call with the starting point / with what was kept */
+    float ms_spent;                  /* what the calibration took */
+} sdrm_batch_schedule_info;
+int sdrm_batch_schedule(const sdrm_batch *batch, sdrm_batch_schedule_info *info);
+
 const char *sdrm_version(void);
 int sdrm_device_count(void);
 

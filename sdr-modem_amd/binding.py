@@ -65,7 +65,7 @@ EXPORTS = [
     "sdrm_node_destroy", "sdrm_channel_cost",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",
     "sdrm_probe_atan2", "sdrm_probe_quad", "sdrm_probe_boxcar_div", "sdrm_version", "sdrm_device_count",
-    "sdrm_batch_k3_stamps", "sdrm_batch_timeline",
+    "sdrm_batch_k3_stamps", "sdrm_batch_timeline", "sdrm_batch_schedule",
     "create_queue", "queue_put", "take_buffer_for_processing", "complete_buffer_processing",
     "interrupt_waiting_the_data", "destroy_queue",
     "dsp_worker_create", "dsp_worker_put", "dsp_worker_shutdown", "dsp_worker_find_by_id", "dsp_worker_destroy",
@@ -74,6 +74,12 @@ EXPORTS = [
 
 class BatcherConfig(C.Structure):
     _fields_ = [("slots", C.c_uint32), ("max_wait_us", C.c_uint32), ("blocking", C.c_bool)]
+
+
+class ScheduleInfo(C.Structure):
+    _fields_ = [("k3_lanes", C.c_int), ("k3_ring", C.c_int), ("k3_plain", C.c_int), ("front_hold", C.c_int),
+                ("company_blocks", C.c_int), ("calibrated", C.c_int), ("ms_before", C.c_float), ("ms_after", C.c_float),
+                ("ms_spent", C.c_float)]
 
 
 class NodeConfig(C.Structure):
@@ -165,10 +171,11 @@ def load():
     L.sdrm_batch_process_device_nco.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(NcoSegment), C.c_size_t, vp]
     L.sdrm_batch_last_mixed.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     bind_batcher(L)
-    bind_node(L)
-    L.sdrm_node_create.argtypes = [C.POINTER(NodeConfig), C.POINTER(vp)]
-    L.sdrm_channel_cost.argtypes = [C.POINTER(FskConfig)]
-    L.sdrm_channel_cost.restype = C.c_double
+    if hasattr(L, "sdrm_node_create"):  # absent only from older builds loaded through SDRM_LIB_PATH for A/B measurements
+        bind_node(L)
+        L.sdrm_node_create.argtypes = [C.POINTER(NodeConfig), C.POINTER(vp)]
+        L.sdrm_channel_cost.argtypes = [C.POINTER(FskConfig)]
+        L.sdrm_channel_cost.restype = C.c_double
     L.sdrm_batcher_create.argtypes = [C.POINTER(FskConfig), C.c_size_t, C.c_int, C.POINTER(BatcherConfig), C.POINTER(vp)]
     L.sdrm_batcher_set_doppler.argtypes = [vp, C.c_size_t, vp]
     L.sdrm_batch_reset_channel.argtypes = [vp, C.c_size_t, C.POINTER(FskConfig)]
@@ -180,6 +187,8 @@ def load():
     L.sdrm_doppler_plan.restype = C.c_size_t
     L.sdrm_doppler_destroy.argtypes = [vp]
     L.sdrm_doppler_destroy.restype = None
+    if hasattr(L, "sdrm_batch_schedule"):
+        L.sdrm_batch_schedule.argtypes = [vp, C.POINTER(ScheduleInfo)]
     L.sdrm_batch_timing_enable.argtypes = [vp, C.c_int]
     L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sdrm_probe_atan2.argtypes = [vp, vp, vp, C.c_size_t]
@@ -381,6 +390,18 @@ class Batch:
         if code != 0:
             raise RuntimeError("sdrm_batch_fetch failed: %d" % code)
         return data, np.array(list(lens), dtype=np.int64)
+
+    def schedule(self):
+        """the schedule the batch runs with (measured at creation for batches of 32 channels or more): dict"""
+        if not hasattr(self.L, "sdrm_batch_schedule"):
+            return None
+        inf = ScheduleInfo()
+        if self.L.sdrm_batch_schedule(self.h, C.byref(inf)) != 0:
+            return None
+        return {"clock_stage": "%dx%d%s" % (inf.k3_lanes, inf.k3_ring, "p" if inf.k3_plain else ""), "front_hold": bool(inf.front_hold),
+                "company_blocks": inf.company_blocks, "calibrated": bool(inf.calibrated),
+                "ms_per_call_before": round(inf.ms_before, 3), "ms_per_call_after": round(inf.ms_after, 3),
+                "calibration_ms": round(inf.ms_spent, 1)}
 
     def timing_enable(self, on=True):
         self.L.sdrm_batch_timing_enable(self.h, 1 if on else 0)

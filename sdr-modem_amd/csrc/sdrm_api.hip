@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <initializer_list>
 #include <vector>
@@ -103,6 +104,12 @@ struct sdrm_batch_t {
     int device_error = 0;            // sticky: a kernel reported through d_k3_done[2] that it gave up a bounded wait
     int company_blocks = 0;
     int company_rounds = 120;        // bound on the companion grid's life, in ~50 us looks at the counter
+    int company_nops = 1;            // s_nop 7 between two vector instructions of a companion wave (1 / 4 / 16 / 64)
+    int company_grid = 4096;         // the grid the companion stage takes when it is on
+    bool hold_front = false;         // the front-end waits for the clock stage of call i-2 to have its workgroups placed
+    // what the batch's self-calibration decided (sdrm_batch_create -> calibrate), for inspection: sdrm_batch_schedule
+    bool calibrated = false;
+    float calib_ms[3] = {0.0f, 0.0f, 0.0f};  // ms per full-length call: before, after, and what the calibration itself took
     float *d_z2 = nullptr, *d_dcout2 = nullptr;
     bool any_nodc = false;
     bool serial = false;
@@ -293,6 +300,179 @@ static int dev_alloc_zero(T **ptr, size_t count) {
     return e == hipSuccess ? 0 : -EIO;
 }
 
+// ---- self-calibration of the schedule ------------------------------------------------------------------------------
+// Which clock-stage shape, whether the front-end holds back for the clock stage's placement and whether the clock stage gets
+// a companion grid used to be decided by constants fitted on one box at one power state (channel-count thresholds, 18.4e12
+// multiply-adds per second, 97 ns per symbol).  Those constants now only give the STARTING point: a batch of at least 32
+// channels times its own pipeline at creation -- full-length calls on a synthetic row that every channel reads (input
+// stride 0: no buffer of the batch's size is needed), a few calls per candidate setting, one dimension after the other --
+// keeps what was fastest by more than the noise, and then puts every stream back to its initial state.  Costs a few dozen
+// calls (tens of milliseconds for 256 channels, a few hundred for 4096) once per batch.
+// SDRM_AUTOTUNE=0 switches it off; SDRM_K3_LANES / SDRM_FRONT_HOLD / SDRM_K3_COMPANY pin their dimension as before.
+static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
+                        const sdrm_nco_segment *segs, size_t n_segs);
+static int wait_for_all_calls(sdrm_batch_t *b);
+
+static int reset_all_streams(sdrm_batch_t *b) {
+    const sdrm::BatchPlan &pl = b->plan;
+    const size_t C = pl.design.size();
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(b->d_hist, 0, sizeof(sdrm_f2) * C * 2 * (size_t) pl.hist_stride));
+    if (b->d_dcstate != nullptr) {
+        HIP_TRY(hipMemset(b->d_dcstate, 0, sizeof(float) * pl.dc_state_floats));
+    }
+    std::vector<sdrm_clock_state> cs(C);
+    for (size_t c = 0; c < C; c++) {
+        memset(&cs[c], 0, sizeof(cs[c]));
+        cs[c].mu = 0.5f;
+        cs[c].omega = pl.design[c].sps;
+    }
+    HIP_TRY(hipMemcpy(b->d_clock, cs.data(), sizeof(sdrm_clock_state) * C, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(b->d_flags, 0, sizeof(uint32_t) * C * SDRM_CTL_SLOTS));
+    HIP_TRY(hipMemset(b->d_outlen, 0, sizeof(uint32_t) * C));
+    HIP_TRY(hipDeviceSynchronize());
+    std::fill(b->plan.phase.begin(), b->plan.phase.end(), 0u);
+    std::fill(b->plan.parity.begin(), b->plan.parity.end(), 0u);
+    std::fill(b->plan.zbase.begin(), b->plan.zbase.end(), 0u);
+    std::fill(b->last_lens.begin(), b->last_lens.end(), 0u);
+    for (int i = 0; i < SDRM_CTL_SLOTS; i++) {
+        b->slot_used[i] = false;
+    }
+    b->calls = 0;
+    b->last_slot = -1;
+    return 0;
+}
+
+static int calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
+    const size_t C = b->plan.design.size();
+    const char *env = getenv("SDRM_AUTOTUNE");
+    if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->clock_early) {
+        return 0;
+    }
+    uint32_t longest = 0;
+    std::vector<size_t> lens(C);
+    for (size_t c = 0; c < C; c++) {
+        lens[c] = cfgs[c].max_input_buffer_length;
+        longest = std::max(longest, cfgs[c].max_input_buffer_length);
+    }
+    if (longest < 1024) {
+        return 0;  // calls this short are launch-bound whatever the schedule
+    }
+    // one row of plausible IQ: unit-amplitude FM of a slow square wave plus a little deterministic noise (finite, no zeros:
+    // the discriminator stays on its short form, the clock loop on its finite one, as with real signals)
+    std::vector<sdrm_f2> row(longest);
+    uint32_t lcg = 12345u;
+    double ph = 0.0;
+    for (uint32_t i = 0; i < longest; i++) {
+        ph += ((i / 5) % 7 < 3 ? 0.16 : -0.16);
+        lcg = lcg * 1664525u + 1013904223u;
+        const float n1 = (float) ((lcg >> 8) & 0xffff) / 65536.0f - 0.5f;
+        lcg = lcg * 1664525u + 1013904223u;
+        const float n2 = (float) ((lcg >> 8) & 0xffff) / 65536.0f - 0.5f;
+        row[i].x = (float) cos(ph) + 0.1f * n1;
+        row[i].y = (float) sin(ph) + 0.1f * n2;
+    }
+    sdrm_f2 *d_row = nullptr;
+    if (hipMalloc((void **) &d_row, sizeof(sdrm_f2) * longest) != hipSuccess) {
+        return 0;  // no room for the row: keep the starting point
+    }
+    int code = 0;
+    auto t_start = std::chrono::steady_clock::now();
+    if (hipMemcpy(d_row, row.data(), sizeof(sdrm_f2) * longest, hipMemcpyHostToDevice) != hipSuccess) {
+        code = -EIO;
+    }
+    // ms per call of the batch as it is set up now: `warm` calls to fill the pipeline, then `timed` calls between two waits
+    auto measure = [&](double *ms) -> int {
+        const int warm = 3, timed = 5;
+        for (int k = 0; k < warm; k++) {
+            int c2 = enqueue_call(b, d_row, 0, lens.data(), b->stream, nullptr, 0);
+            if (c2 != 0) return c2;
+        }
+        int c2 = wait_for_all_calls(b);
+        if (c2 != 0) return c2;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < timed; k++) {
+            c2 = enqueue_call(b, d_row, 0, lens.data(), b->stream, nullptr, 0);
+            if (c2 != 0) return c2;
+        }
+        c2 = wait_for_all_calls(b);
+        *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+        return c2;
+    };
+    double best = 0.0;
+    code = code ? code : measure(&best);  // first pass: also pays the kernels' first-launch costs
+    code = code ? code : measure(&best);
+    const double before = best;
+    const double margin = 0.97;  // a candidate replaces the incumbent only when it is more than 3 % faster
+    // (1) the clock stage's workgroup shape
+    if (code == 0 && !sdrm::k3_shape_is_forced() && b->plan.clock_carried_max <= 128 && C >= 512) {
+        const int shapes[3][3] = {{16, 1024, 0}, {32, 512, 0}, {64, 256, 1}};
+        const sdrm_k3_shape cur = sdrm_k3_shape_for((int) C, 0, 0, 0, (int) b->plan.clock_carried_max);
+        int keep[3] = {cur.lanes, cur.ring, cur.plain};
+        for (const auto &sh : shapes) {
+            if (sh[0] == cur.lanes && sh[1] == cur.ring && sh[2] == cur.plain) {
+                continue;
+            }
+            b->dev.k3_lanes = sh[0];
+            b->dev.k3_ring = sh[1];
+            b->dev.k3_plain = sh[2];
+            double ms = 0.0;
+            code = measure(&ms);
+            if (code != 0) {
+                break;
+            }
+            if (ms < best * margin) {
+                best = ms;
+                keep[0] = sh[0];
+                keep[1] = sh[1];
+                keep[2] = sh[2];
+            }
+        }
+        b->dev.k3_lanes = keep[0];
+        b->dev.k3_ring = keep[1];
+        b->dev.k3_plain = keep[2];
+    }
+    // (2) the front-end's hold for the clock stage's placement
+    if (code == 0 && !sdrm::front_hold_is_forced() && C >= 256) {
+        const bool was = b->hold_front;
+        b->hold_front = !was;
+        double ms = 0.0;
+        code = measure(&ms);
+        if (code == 0 && ms < best * margin) {
+            best = ms;
+        } else {
+            b->hold_front = was;
+        }
+    }
+    // (3) the companion grid beside the clock stage
+    if (code == 0 && getenv("SDRM_K3_COMPANY") == nullptr && C <= 2048) {
+        const int was = b->company_blocks;
+        b->company_blocks = was > 0 ? 0 : b->company_grid;
+        double ms = 0.0;
+        code = measure(&ms);
+        if (code == 0 && ms < best * margin) {
+            best = ms;
+        } else {
+            b->company_blocks = was;
+        }
+    }
+    if (code == 0) {
+        code = reset_all_streams(b);
+    }
+    (void) hipFree(d_row);
+    b->calibrated = code == 0;
+    b->calib_ms[0] = (float) before;
+    b->calib_ms[1] = (float) best;
+    b->calib_ms[2] = (float) std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    if (getenv("SDRM_AUTOTUNE_LOG") != nullptr) {
+        const sdrm_k3_shape sh = sdrm_k3_shape_for((int) C, b->dev.k3_lanes, b->dev.k3_ring, b->dev.k3_plain, (int) b->plan.clock_carried_max);
+        fprintf(stderr, "sdrmodem_hip: calibrated %zu channels in %.0f ms: %.3f -> %.3f ms per call; clock stage %dx%d%s, front hold %s, "
+                        "companion grid %d\n", C, b->calib_ms[2], before, best, sh.lanes, sh.ring, sh.plain ? "p" : "",
+                b->hold_front ? "on" : "off", b->company_blocks);
+    }
+    return code;
+}
+
 extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels, int device, uint32_t flags,
                                  sdrm_batch **out) {
     if (cfgs == nullptr || n_channels == 0 || out == nullptr) {
@@ -408,7 +588,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         // SDRM_K3_COMPANY="blocks,first,last" overrides grid and channel range (blocks 0: none)
         int blocks = 4096, lo = 32, hi = 768;
         if (const char *env = getenv("SDRM_K3_COMPANY")) {
-            sscanf(env, "%d,%d,%d", &blocks, &lo, &hi);
+            sscanf(env, "%d,%d,%d,%d", &blocks, &lo, &hi, &b->company_nops);
         } else {
             double macs = 0.0, symbols = 0.0;
             for (size_t c = 0; c < C; c++) {
@@ -433,9 +613,12 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         }
         if (blocks > 0 && (int) n_channels >= lo && (int) n_channels <= hi) {
             b->company_blocks = blocks;
-            e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
-            e = e ? e : hipEventCreateWithFlags(&b->ev_company, hipEventDisableTiming);
+            b->company_grid = blocks;
         }
+        // the side stream and its event exist whether the grid starts switched on or not: the calibration may switch it
+        e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
+        e = e ? e : hipEventCreateWithFlags(&b->ev_company, hipEventDisableTiming);
+        b->hold_front = sdrm::front_waits_for_clock_start((int) n_channels);
         // The next call's clock stage resident early -- OPT-IN: SDRM_K3_EARLY=<channels> switches it on for batches of up
         // to that many channels.  Where the clock stage bounds the step and the front-end is short beside it (the companion
         // grid's condition) the step gains 2-3 % (256 channels: 2.59 -> 2.52 ms per call, clock stages 1 us apart instead
@@ -452,10 +635,8 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
             e = e ? e : hipStreamCreateWithPriority(&b->s_clock_alt, hipStreamNonBlocking, prio_high);
             b->lanes[2].overlapped = true;
         }
-        if (b->company_blocks > 0 || b->clock_early) {
-            e = e ? e : hipMalloc((void **) &b->d_k3_done, 64);
-            e = e ? e : hipMemset(b->d_k3_done, 0, 64);
-        }
+        e = e ? e : hipMalloc((void **) &b->d_k3_done, 64);
+        e = e ? e : hipMemset(b->d_k3_done, 0, 64);
     }
     for (int i = 0; i < SDRM_CTL_SLOTS && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
@@ -506,11 +687,33 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         d.chain_prio = cp != nullptr ? atoi(cp) : 3;
     }
     b->in_stride = pl.in_stride;
+    code = calibrate(b, cfgs);
+    if (code != 0) {
+        batch_free(b);
+        return code;
+    }
     *out = b;
     return 0;
 }
 
 extern "C" void sdrm_batch_destroy(sdrm_batch *b) { batch_free(b); }
+
+extern "C" int sdrm_batch_schedule(const sdrm_batch *b, sdrm_batch_schedule_info *info) {
+    if (b == nullptr || info == nullptr) {
+        return -1;
+    }
+    const sdrm_k3_shape sh = sdrm::describe_shape(b->dev);
+    info->k3_lanes = sh.lanes;
+    info->k3_ring = sh.ring;
+    info->k3_plain = sh.plain;
+    info->front_hold = (!b->serial && b->hold_front) ? 1 : 0;
+    info->company_blocks = b->company_blocks;
+    info->calibrated = b->calibrated ? 1 : 0;
+    info->ms_before = b->calib_ms[0];
+    info->ms_after = b->calib_ms[1];
+    info->ms_spent = b->calib_ms[2];
+    return 0;
+}
 
 extern "C" size_t sdrm_batch_channels(const sdrm_batch *b) { return b ? b->plan.design.size() : 0; }
 
@@ -834,7 +1037,7 @@ static int ensure_nco(sdrm_batch_t *b) {
 }
 
 static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
-                        const sdrm_nco_segment *segs = nullptr, size_t n_segs = 0) {
+                        const sdrm_nco_segment *segs, size_t n_segs) {
     const size_t C = b->plan.design.size();
     const uint64_t i = b->calls;
     const int slot = (int) (i % SDRM_CTL_SLOTS);
@@ -949,7 +1152,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         // the previous call's DC stage (released by the end of its front-end, i.e. now) places its workgroups first
         sdrm::launch_hold_until(b->d_placed + 0, b->k2_placed_target, dc_first_us, b->s_front);
     }
-    if (!b->serial && i >= 3 && sdrm::front_waits_for_clock_start((int) C)) {
+    if (!b->serial && i >= 3 && b->hold_front) {
         // let the clock stage of call i-2 (released by the end of call i-3's) take its CUs before this grid floods the chip
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[(i + SDRM_CTL_SLOTS - 3) % SDRM_CTL_SLOTS], 0));
         sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_after[(i + SDRM_CTL_SLOTS - 2) % SDRM_CTL_SLOTS], 100, b->s_front);
@@ -1040,7 +1243,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         // starts when the clock stage may start, leaves when the clock stage's last workgroup has
         HIP_TRY(hipEventRecord(b->ev_company, s_clock));
         HIP_TRY(hipStreamWaitEvent(b->s_company, b->ev_company, 0));
-        sdrm::launch_clock_company(d, b->k3_done_target, b->company_blocks, b->company_rounds, b->s_company);
+        sdrm::launch_clock_company(d, b->k3_done_target, b->company_blocks, b->company_rounds, b->company_nops, b->s_company);
     }
     sdrm::launch_clock(d, s_clock);
     if (b->timing) {
@@ -1128,7 +1331,7 @@ extern "C" int sdrm_batch_process_device(sdrm_batch *b, const void *d_input, siz
     }
     HIP_TRY(hipSetDevice(b->device));
     // the K1 LDS request can exceed the 64 KiB default for long filters
-    return enqueue_call(b, (const sdrm_f2 *) d_input, in_stride, input_lens, (hipStream_t) stream);
+    return enqueue_call(b, (const sdrm_f2 *) d_input, in_stride, input_lens, (hipStream_t) stream, nullptr, 0);
 }
 
 extern "C" int sdrm_batch_process_device_nco(sdrm_batch *b, const void *d_input, size_t in_stride, const size_t *input_lens,

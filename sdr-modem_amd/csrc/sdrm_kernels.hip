@@ -580,6 +580,8 @@ void launch_hold_until(const uint32_t *counter, uint32_t target, int max_us, hip
 // bound was 128 until the end of round 3: with the placement counters and the int8 conversion inside the clock stage the
 // wait costs 2-3 % from 128 to 768 channels and still gains 2-5 % from 896 to 1024 (131072- and 32768-sample calls,
 // profiles/r03_front_hold_bounds.txt).  SDRM_FRONT_HOLD="lo,hi" overrides.
+bool front_hold_is_forced() { return getenv("SDRM_FRONT_HOLD") != nullptr; }
+bool k3_shape_is_forced() { return getenv("SDRM_K3_LANES") != nullptr; }
 bool front_waits_for_clock_start(int n_channels) {
     static const char *e = getenv("SDRM_FRONT_HOLD");
     int lo = 832, hi = 1024;
@@ -1399,7 +1401,13 @@ size_t k3_lds_bytes(int lanes, int ring, int plain) {
 #endif
 #define K3_STORE_SLACK 32   // store instructions of the consumer that may still be in flight at a hand-over
 #define K3_NEAR_BLOCKS 32   // staging steps before its end at which a workgroup reports "nearly done" (~150 us at 5 samples per symbol)
+#ifdef SDRM_K3_NO_FUSED_INT8  // A/B builds only (profiles/r04_1024_ab.txt): every shape leaves the conversion to k3_quantize
+#define K3_FUSED_INT8(G) false
+#define K3_FUSED_INT8_RING(ring) false
+#else
 #define K3_FUSED_INT8(G) (G::block >= 256)  // the staging wave converts the soft bits to int8 (else: k3_quantize)
+#define K3_FUSED_INT8_RING(ring) ((ring) / 4 >= 256)
+#endif
 #define K3_STR2(x) #x
 #define K3_STR(x) K3_STR2(x)
 #define K3_LOOP_SKEW ".rept " K3_STR(SDRM_K3_LOOP_SKEW) "\n\ts_nop 0\n\t.endr\n\t"
@@ -1980,8 +1988,15 @@ static KernelLaunch describe_clock_as(const DeviceBatch &b) {
 sdrm_k3_shape k3_shape(const DeviceBatch &b) {
     int lanes = 0, ring = 0, plain = 0;
     sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring, &plain);  // tests and measurements: force one workgroup shape (read per launch)
+    if (lanes == 0 && b.k3_lanes != 0) {  // the shape the batch measured to be its fastest (sdrm_api.hip, calibrate)
+        lanes = b.k3_lanes;
+        ring = b.k3_ring;
+        plain = b.k3_plain;
+    }
     return sdrm_k3_shape_for(b.n_channels, lanes, ring, plain, b.k3_carried_max);
 }
+
+sdrm_k3_shape describe_shape(const DeviceBatch &b) { return k3_shape(b); }
 
 KernelLaunch describe_clock(const DeviceBatch &b) {
     const sdrm_k3_shape sh = k3_shape(b);
@@ -2000,7 +2015,7 @@ KernelLaunch describe_clock(const DeviceBatch &b) {
 KernelLaunch describe_quantize(const DeviceBatch &b) {
     KernelLaunch k;
     const sdrm_k3_shape sh = k3_shape(b);
-    if (b.max_symbols == 0 || sh.ring / 4 >= 256) {  // K3_FUSED_INT8: the clock stage's staging wave has done it
+    if (b.max_symbols == 0 || K3_FUSED_INT8_RING(sh.ring)) {  // the clock stage's staging wave has done it
         return k;
     }
     k.func = reinterpret_cast<const void *>(k3_quantize);
@@ -2022,15 +2037,21 @@ KernelLaunch describe_quantize(const DeviceBatch &b) {
 // busy workgroup per channel on every CU, was that company without anybody knowing; the lane-dense one is not.
 // So small batches get a companion grid on a side stream beside each clock-stage launch: no LDS, no memory traffic but a
 // look at the counter the clock stage's workgroups bump when they finish, every ~50 us, and a bound on its life.
-#ifndef SDRM_K3_COMPANY_NOPS
-#define SDRM_K3_COMPANY_NOPS 1   // s_nop 7 between two vector instructions of a companion wave
-#endif
-#define SDRM_K3_COMPANY_REPS (64 / SDRM_K3_COMPANY_NOPS)
+// NOPS: s_nop 7 between two vector instructions of a companion wave (1 / 4 / 16 / 64): how sparse the company is.  The look
+// at the counter comes every 48 x 64 s_nop 7 whatever NOPS is (~50 us: thousands of waves looking, keep it rare).
+template <int NOPS>
 __global__ __launch_bounds__(64) void k3_company(const uint32_t *done, uint32_t target, int max_rounds) {
     float a = threadIdx.x;
     for (int i = 0; i < max_rounds; i++) {
-        for (int j = 0; j < 48; j++) {  // ~50 us between two looks at the counter (4096 waves looking: keep it rare)
-            asm volatile(".rept " K3_STR(SDRM_K3_COMPANY_REPS) "\n\tv_mov_b32 %0, %0\n\t.rept " K3_STR(SDRM_K3_COMPANY_NOPS) "\n\ts_nop 7\n\t.endr\n\t.endr" : "+v"(a));
+        for (int j = 0; j < 48; j++) {
+#pragma unroll
+            for (int r = 0; r < 64 / NOPS; r++) {  // unrolled: the instruction stream of rounds 2-3 (an assembler .rept) for NOPS = 1
+                asm volatile("v_mov_b32 %0, %0" : "+v"(a));
+#pragma unroll
+                for (int n = 0; n < NOPS; n++) {
+                    asm volatile("s_nop 7");
+                }
+            }
         }
         if ((int32_t) (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) {
             break;
@@ -2038,9 +2059,17 @@ __global__ __launch_bounds__(64) void k3_company(const uint32_t *done, uint32_t 
     }
 }
 
-void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, int max_rounds, hipStream_t s) {
+void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, int max_rounds, int nops, hipStream_t s) {
     // max_rounds x ~50 us bounds the grid's life whatever happens to the counter
-    hipLaunchKernelGGL(k3_company, dim3((unsigned) blocks), dim3(64), 0, s, b.k3_done, target, max_rounds);
+    if (nops >= 64) {
+        hipLaunchKernelGGL(k3_company<64>, dim3((unsigned) blocks), dim3(64), 0, s, b.k3_done, target, max_rounds);
+    } else if (nops >= 16) {
+        hipLaunchKernelGGL(k3_company<16>, dim3((unsigned) blocks), dim3(64), 0, s, b.k3_done, target, max_rounds);
+    } else if (nops >= 4) {
+        hipLaunchKernelGGL(k3_company<4>, dim3((unsigned) blocks), dim3(64), 0, s, b.k3_done, target, max_rounds);
+    } else {
+        hipLaunchKernelGGL(k3_company<1>, dim3((unsigned) blocks), dim3(64), 0, s, b.k3_done, target, max_rounds);
+    }
 }
 
 unsigned clock_workgroups(const DeviceBatch &b) { return describe_clock(b).grid.x; }

@@ -56,6 +56,7 @@ struct DeviceBatch {
     int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
     uint32_t *placed;                // [2] DC / clock-stage workgroups that have started, cumulative over calls (k_hold_until)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching
+    int k3_lanes, k3_ring, k3_plain; // clock-stage workgroup shape chosen for this batch (0: by channel count; SDRM_K3_LANES overrides both)
     int k3_wait;                     // the clock stage's workgroups wait for k3_done to reach k3_wait_for before they touch any
     uint32_t k3_wait_for;            //   state of the previous call (they were launched while that call's clock stage still ran)
 };
@@ -76,6 +77,9 @@ size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 size_t k1s_lds_bytes(uint32_t t1_max, uint32_t t2_max);
 bool front_streams(uint32_t t1_max, uint32_t t2_max, int n_channels);
 bool front_waits_for_clock_start(int n_channels);
+sdrm_k3_shape describe_shape(const DeviceBatch &b);  // the clock-stage shape the next launch takes
+bool front_hold_is_forced();      // SDRM_FRONT_HOLD is set: measurements, not to be re-decided by the batch's calibration
+bool k3_shape_is_forced();        // SDRM_K3_LANES likewise
 bool front_waits_for_dc_start(int n_channels, int *max_us);
 bool dc_waits_for_clock_start(const DeviceBatch &b);
 void launch_hold_until(const uint32_t *counter, uint32_t target, int max_us, hipStream_t s);
@@ -89,7 +93,7 @@ void launch_dc(const DeviceBatch &b, hipStream_t s);
 // words of the front-end, then 10 of the DC blocker
 #define SDRM_STAMP_K3_WAVES(n_channels) (((n_channels) + 15) / 16)
 void launch_clock(const DeviceBatch &b, hipStream_t s);
-void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, int max_rounds, hipStream_t s);
+void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, int max_rounds, int nops, hipStream_t s);
 unsigned clock_workgroups(const DeviceBatch &b);
 
 // test probes

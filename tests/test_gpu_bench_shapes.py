@@ -93,3 +93,43 @@ def test_bench_line_carries_the_spot_check(torch_dev, capsys):
     assert line["verified_vs_oracle"] is True, line.get("verify")
     assert line["channel_sweep"]["1024"]["verified_vs_oracle"] is True
     assert line["config5"]["verified_vs_oracle"] is True, line["config5"]
+
+
+def test_self_calibration_leaves_every_stream_as_new(torch_dev, monkeypatch):
+    """A batch of 32 channels or more times its own pipeline when it is created (sdrm_batch_schedule) and then puts every
+    stream back to its initial state: the first real calls give the oracle's bits, with the calibration and without it
+    (SDRM_AUTOTUNE=0), and the schedule says which of the two happened.  Small batches and forced settings are left alone."""
+    import orc
+    cfg = (48000, 9600, 5000, 1, 2000, True, 32768)
+    C_ = 96
+    sig = siggen.gmsk_batch(8, 2 * 32768, first_channel=40)
+    outs = {}
+    for mode in ("on", "off"):
+        if mode == "off":
+            monkeypatch.setenv("SDRM_AUTOTUNE", "0")
+        g = binding.Batch([cfg] * C_, keep_soft=True)
+        assert g.code == 0
+        sch = g.schedule()
+        assert sch["calibrated"] is (mode == "on"), sch
+        if mode == "on":
+            assert sch["ms_per_call_after"] <= sch["ms_per_call_before"] * 1.0001 and sch["calibration_ms"] > 0
+        res = []
+        for k in range(2):
+            res.append(g.process([sig[c % 8, k * 32768:(k + 1) * 32768] for c in range(C_)]))
+        for c in (0, 7, 95):
+            o8, of = orc.demod_stream(cfg[:6], sig[c % 8], 32768)
+            assert np.array_equal(np.concatenate([res[0][c], res[1][c]]), o8), (mode, c)
+        assert np.array_equal(g.last_soft(95).view(np.uint32), orc.demod_stream(cfg[:6], sig[95 % 8], 32768)[1][-len(g.last_soft(95)):].view(np.uint32))
+        outs[mode] = res
+        g.close()
+    for k in range(2):
+        for c in range(C_):
+            assert np.array_equal(outs["on"][k][c], outs["off"][k][c])
+    monkeypatch.delenv("SDRM_AUTOTUNE")
+    small = binding.Batch([cfg] * 8)
+    assert small.schedule()["calibrated"] is False
+    small.close()
+    monkeypatch.setenv("SDRM_K3_LANES", "32")
+    forced = binding.Batch([cfg] * 600)
+    assert forced.schedule()["clock_stage"] == "32x512"
+    forced.close()
