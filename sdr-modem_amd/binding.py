@@ -125,8 +125,9 @@ def bind_batcher(L):
     L.sdrm_batcher_channels.argtypes = [vp]
     L.sdrm_batcher_channels.restype = C.c_size_t
     L.sdrm_batcher_rounds.argtypes = [vp]
-    L.sdrm_batcher_error.argtypes = [vp]
-    L.sdrm_batcher_error.restype = C.c_int
+    if hasattr(L, "sdrm_batcher_error"):  # absent only from older builds loaded through SDRM_LIB_PATH for A/B measurements
+        L.sdrm_batcher_error.argtypes = [vp]
+        L.sdrm_batcher_error.restype = C.c_int
     L.sdrm_batcher_rounds.restype = C.c_uint64
     L.sdrm_batcher_destroy.argtypes = [vp]
     L.sdrm_batcher_destroy.restype = None

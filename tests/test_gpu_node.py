@@ -72,7 +72,7 @@ def test_twenty_four_clients_behind_one_node_handle_on_two_batchers():
                 part = np.ascontiguousarray(sigs[i][pos:pos + n]).view(np.float32)
                 L.dsp_worker_put(part.ctypes.data, n, ws[i])
                 pos += n
-        th = [threading.Thread(target=feed, args=(i,)) for i in range(n_w)]
+        th = [threading.Thread(target=feed, args=(i,), daemon=True) for i in range(n_w)]
         for t in th:
             t.start()
         for t in th:

@@ -9,6 +9,7 @@ echo "== ubench_mfma_fir"
 timeout 300 tools/ubench_mfma_fir > gpurun_out/r04_ubench_mfma_fir.txt 2>&1; echo "exit $?"; cat gpurun_out/r04_ubench_mfma_fir.txt
 O=gpurun_out/r04_1024_ab.txt
 : > $O
+export SDRM_AUTOTUNE=0   # the A/B legs compare fixed schedules; the self-calibration gets its own lines at the end
 echo "tools/sweep_cell.py <channels> 131072: ms per step, Msamples/s, kernel ms front / dc / clock" >> $O
 for rep in 1 2 3 4; do
   for lib in r02 head nofuse; do
@@ -28,4 +29,9 @@ for ch in 256 512 768 1280 2048 4096; do
   done
 done
 unset SDRM_LIB_PATH
+unset SDRM_AUTOTUNE
+echo "--- HEAD with the self-calibration on (what a batch decides for itself)" >> $O
+for ch in 256 512 768 1024 1280 2048 4096; do
+  echo "head calibrated $ch: $(SDRM_AUTOTUNE_LOG=1 timeout 200 python tools/sweep_cell.py $ch 131072 2>&1 | grep -E "calibrated|^[0-9]" | tr '\n' ' ')" >> $O
+done
 cat $O
