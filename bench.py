@@ -14,7 +14,8 @@ GPU at every N); the only collective is the RCCL broadcast of the channel config
 the contract's fields, `roofline` (front-end kernel), `cpu_baseline`, and -- informative sub-blocks, outside the timed
 region -- `config3_sharded` (BASELINE configs[3]: 512 channels per GPU, N > 1 only), and at N = 1 `channel_sweep`,
 `end_to_end` (host buffers in, soft bits out: PCIe-inclusive), `config5` (mixed rates with per-channel Doppler) and
-`perf_fsk_modem_style`.
+`perf_fsk_modem_style`.  Every timed region is followed by a spot check of its last call against the CPU restatement of the
+reference (`verified_vs_oracle`).
 """
 import argparse
 import glob
@@ -683,30 +684,6 @@ def main():
                     sweep[str(c2)] = {"error": str(exc)[:200]}
             out["channel_sweep"] = sweep
         if world == 1 and not args.no_extras:
-            # the opt-in fast mode (SDRM_FLAG_FAST_FMA: fused multiply-adds in both filters, NOT the reference's bits, held to
-            # its +-2 LSB test tolerance instead): the front-end alone, so that the HBM-roofline figure of the LPF stage has
-            # a measured counterpart without the exactness constraint.  Never the headline.
-            try:
-                rf = Rig(torch, binding, siggen, dev, local_rank, [(FS, BAUD, DEV, DECIM, TW, DC, N)] * C, 0, N, 2, base=base, fast_fma=True)
-                for i in range(4):
-                    rf.step(i)
-                torch.cuda.synchronize()
-                rf.batch.timing_enable(True)
-                for i in range(SWEEP_STEPS):
-                    rf.step(i)
-                torch.cuda.synchronize()
-                kf = rf.kernel_ms()
-                rf.close()
-                ach = (C * N * 8.0) / (kf[0] * 1e-3) / 1e9
-                out["roofline_fast"] = {"kernel": "k1_front<fused> (SDRM_FLAG_FAST_FMA, opt-in, not bit-exact)", "bound": "hbm",
-                                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kf[0], 4), "steps": SWEEP_STEPS,
-                                        "parity": "NONE CLAIMED: float soft bits 2e-4 .. 3.4e-3 RMS from the exact mode (bar: 1e-4); int8 soft "
-                                                  "bits within the reference's +-2 LSB of its golden files on 3 of 4 fixtures, NOT on "
-                                                  "lucky7_nodc (up to 19 LSB) -- tests/test_gpu_parity.py::test_fast_fma_mode..., "
-                                                  "profiles/r02_fast_mode.txt"}
-            except Exception as exc:
-                out["roofline_fast"] = {"error": str(exc)[:200]}
             try:
                 out["end_to_end"] = end_to_end(binding, siggen, C, N)
             except Exception as exc:

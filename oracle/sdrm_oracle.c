@@ -520,6 +520,9 @@ struct orc_clock {
     size_t cap;
     float *work; /* 16-byte aligned; kept tail followed by this call's input */
     size_t kept;
+    size_t hcap; /* most samples carried between calls: what a symbol can span (< 1.01 omega + 8), never less than
+                  * ORC_CLOCK_HCAP.  The reference provisions 8 and writes past its buffer beyond that; the oracle states
+                  * what the reference's arithmetic yields with the buffer long enough (round 4: any samples/symbol) */
     float *out;
 };
 
@@ -537,9 +540,13 @@ int orc_clock_create(float omega, float gain_omega, float mu, float gain_mu, flo
     c->gain_mu = gain_mu;
     c->last = 0.0f;
     c->cap = max_input_len;
+    c->hcap = ORC_CLOCK_HCAP;
+    if (omega * 1.01f + 24.0f > (float) c->hcap && omega < 1.0e6f) {
+        c->hcap = (size_t) (omega * 1.01f) + 24;
+    }
     c->out = malloc(sizeof(float) * (max_input_len + 1));
     void *w = NULL;
-    if (posix_memalign(&w, 64, sizeof(float) * (max_input_len + ORC_CLOCK_HCAP + 8)) != 0) {
+    if (posix_memalign(&w, 64, sizeof(float) * (max_input_len + c->hcap + 8)) != 0) {
         w = NULL;
     }
     c->work = w;
@@ -547,7 +554,7 @@ int orc_clock_create(float omega, float gain_omega, float mu, float gain_mu, flo
         orc_clock_destroy(c);
         return -ENOMEM;
     }
-    memset(c->work, 0, sizeof(float) * (max_input_len + ORC_CLOCK_HCAP + 8));
+    memset(c->work, 0, sizeof(float) * (max_input_len + c->hcap + 8));
     *out = c;
     return 0;
 }
@@ -599,9 +606,9 @@ void orc_clock_process(orc_clock *c, const float *input, size_t n, float **outpu
      * from the position of the last produced symbol (this re-emits a symbol when sps >= 8). */
     size_t from = ((size_t) (int64_t) ii > len) ? (size_t) prev : (size_t) ii;
     size_t keep = len - from;
-    if (keep > ORC_CLOCK_HCAP) { /* bounded where the reference would overrun its buffer */
-        from = len - ORC_CLOCK_HCAP;
-        keep = ORC_CLOCK_HCAP;
+    if (keep > c->hcap) { /* bounded where the reference would overrun its buffer; not reachable: a symbol spans < hcap */
+        from = len - c->hcap;
+        keep = c->hcap;
     }
     memmove(c->work, c->work + from, keep * sizeof(float));
     c->kept = keep;

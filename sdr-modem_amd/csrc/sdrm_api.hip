@@ -63,6 +63,11 @@ struct sdrm_batch_t {
     float *d_outf = nullptr;
     uint32_t *d_outlen = nullptr;
     uint32_t *d_flags = nullptr;  // [SLOTS][C] non-finite flags, one set per control slot
+    // generic channels (sdrm_kernels.h): per-channel state in global memory, the list of such channels and the pointer table
+    std::vector<float *> gen_ptr;  // [C] device allocations (null for the others)
+    float **d_gen_state = nullptr;
+    int *d_gen_list = nullptr;
+    int n_gen = 0;
     // NCO pre-mix (allocated on first use)
     sdrm_nco_seg *d_nco_segs = nullptr, *h_nco_segs = nullptr;  // [SLOTS][nco_seg_cap]
     size_t nco_seg_cap = 0;
@@ -178,6 +183,13 @@ static void batch_free(sdrm_batch_t *b) {
         (void) hipStreamSynchronize(b->stream);
     }
     (void) hipDeviceSynchronize();
+    for (float *g : b->gen_ptr) {
+        if (g != nullptr) {
+            (void) hipFree(g);
+        }
+    }
+    if (b->d_gen_state) (void) hipFree(b->d_gen_state);
+    if (b->d_gen_list) (void) hipFree(b->d_gen_list);
     for (auto &lane : b->lanes) {
         for (auto &pr : lane.pending) {
             (void) hipEventDestroy(pr.first);
@@ -300,6 +312,62 @@ static int dev_alloc_zero(T **ptr, size_t count) {
     return e == hipSuccess ? 0 : -EIO;
 }
 
+// the most samples a channel's clock stage carries from one call into the next (what bounds a call's symbol count from above)
+static uint32_t carried_cap(const sdrm_chan_params &p) {
+    return p.generic ? sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim).hcap : (uint32_t) SDRM_CLOCK_HCAP;
+}
+
+// ---- generic channels: one device allocation per such channel (its DC rings and clock working buffer), zeroed -------------
+static int sync_generic(sdrm_batch_t *b, long only_channel) {
+    const sdrm::BatchPlan &pl = b->plan;
+    const size_t C = pl.design.size();
+    if (b->gen_ptr.size() != C) {
+        b->gen_ptr.assign(C, nullptr);
+    }
+    bool any = false;
+    for (size_t c = 0; c < C; c++) {
+        const sdrm_chan_params &p = pl.params[c];
+        const bool touch = only_channel < 0 || (size_t) only_channel == c;
+        if (touch && b->gen_ptr[c] != nullptr) {
+            (void) hipFree(b->gen_ptr[c]);
+            b->gen_ptr[c] = nullptr;
+        }
+        if (touch && p.generic) {
+            const sdrm_gen_layout g = sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim);
+            if (hipMalloc((void **) &b->gen_ptr[c], sizeof(float) * g.total) != hipSuccess) {
+                b->gen_ptr[c] = nullptr;
+                return -ENOMEM;
+            }
+            HIP_TRY(hipMemset(b->gen_ptr[c], 0, sizeof(float) * g.total));
+        }
+        any = any || p.generic;
+    }
+    if (!any && b->d_gen_state == nullptr) {
+        b->n_gen = 0;
+        b->dev.n_gen = 0;
+        return 0;
+    }
+    if (b->d_gen_state == nullptr) {
+        HIP_TRY(hipMalloc((void **) &b->d_gen_state, sizeof(float *) * C));
+        HIP_TRY(hipMalloc((void **) &b->d_gen_list, sizeof(int) * C));
+    }
+    std::vector<int> list;
+    for (size_t c = 0; c < C; c++) {
+        if (pl.params[c].generic) {
+            list.push_back((int) c);
+        }
+    }
+    HIP_TRY(hipMemcpy(b->d_gen_state, b->gen_ptr.data(), sizeof(float *) * C, hipMemcpyHostToDevice));
+    if (!list.empty()) {
+        HIP_TRY(hipMemcpy(b->d_gen_list, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+    }
+    b->n_gen = (int) list.size();
+    b->dev.n_gen = b->n_gen;
+    b->dev.gen_list = b->d_gen_list;
+    b->dev.gen_state = b->d_gen_state;
+    return 0;
+}
+
 // ---- self-calibration of the schedule ------------------------------------------------------------------------------
 // Which clock-stage shape, whether the front-end holds back for the clock stage's placement and whether the clock stage gets
 // a companion grid used to be decided by constants fitted on one box at one power state (channel-count thresholds, 18.4e12
@@ -346,7 +414,7 @@ static int reset_all_streams(sdrm_batch_t *b) {
 static int calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
     const size_t C = b->plan.design.size();
     const char *env = getenv("SDRM_AUTOTUNE");
-    if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->clock_early) {
+    if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->clock_early || b->n_gen > 0) {
         return 0;
     }
     uint32_t longest = 0;
@@ -687,6 +755,11 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         d.chain_prio = cp != nullptr ? atoi(cp) : 3;
     }
     b->in_stride = pl.in_stride;
+    code = sync_generic(b, -1);
+    if (code != 0) {
+        batch_free(b);
+        return code;
+    }
     code = calibrate(b, cfgs);
     if (code != 0) {
         batch_free(b);
@@ -906,7 +979,7 @@ extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_
     }
     b->last_lens[c] = 0;
     b->dev.k3_carried_max = (int) pl.clock_carried_max;
-    return 0;
+    return sync_generic(b, (long) c);  // the channel's generic state goes, comes or starts afresh with its configuration
 }
 
 extern "C" size_t sdrm_batch_taps(const sdrm_batch *b, size_t c, int stage, float *dst, size_t cap) {
@@ -1110,7 +1183,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
             const float adv = floorf(p.omega_mid - p.omega_lim);
             uint32_t bound = p.max_len;
             if (adv >= 1.0f) {
-                bound = std::min<uint32_t>(bound, (uint32_t) ((h[c].nz + (uint32_t) SDRM_CLOCK_HCAP) / (uint32_t) adv) + 8u);
+                bound = std::min<uint32_t>(bound, (uint32_t) ((h[c].nz + carried_cap(p)) / (uint32_t) adv) + 8u);
             }
             most = std::max(most, bound);
         }
@@ -1195,6 +1268,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
             timing_begin(b, 1, b->s_dc, &ev);
         }
         sdrm::launch_dc(d, b->s_dc);
+        sdrm::launch_dc_generic(d, b->s_dc);
         if (b->timing) {
             timing_end(b, 1, b->s_dc, ev);
         }
@@ -1246,6 +1320,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         sdrm::launch_clock_company(d, b->k3_done_target, b->company_blocks, b->company_rounds, b->company_nops, b->s_company);
     }
     sdrm::launch_clock(d, s_clock);
+    sdrm::launch_clock_generic(d, s_clock);
     if (b->timing) {
         timing_end(b, 2, s_clock, ev);
     }
@@ -1449,7 +1524,7 @@ static const int SG_SLOT = SDRM_CTL_SLOTS - 1;
 
 static bool serial_graph_usable(const sdrm_batch_t *b, size_t n, const sdrm_nco_segment *segs) {
     return getenv("SDRM_NO_GRAPH") == nullptr &&  // escape hatch for measurements
-           !b->sg_broken && b->serial && b->plan.design.size() == 1 && segs == nullptr && !b->timing &&
+           !b->sg_broken && b->serial && b->plan.design.size() == 1 && b->n_gen == 0 && segs == nullptr && !b->timing &&
            b->d_timeline == nullptr && b->dev.k3_stamps == nullptr && b->d_out8_b == nullptr && b->calls > 0 && n > 0 &&
            n <= SDRM_GRAPH_MAX_SAMPLES && n <= b->plan.params[0].max_len;
 }
@@ -1473,7 +1548,7 @@ static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h
     uint32_t most = p.max_len;
     const float adv = floorf(p.omega_mid - p.omega_lim);
     if (adv >= 1.0f) {
-        most = std::min<uint32_t>(most, (uint32_t) ((nz_cap + (uint32_t) SDRM_CLOCK_HCAP) / (uint32_t) adv) + 8u);
+        most = std::min<uint32_t>(most, (uint32_t) ((nz_cap + carried_cap(p)) / (uint32_t) adv) + 8u);
     }
     d.max_symbols = most;
     d.z = b->d_z;
@@ -1760,7 +1835,7 @@ extern "C" int sdrm_batch_submit(sdrm_batch *b, size_t slot, const size_t *input
         const sdrm_chan_params &p = b->plan.params[c];
         const double step = std::max(1.0, (double) p.omega_mid - (double) p.omega_lim - 1.0);
         const double n_in = input_lens[c] == SDRM_LEN_ABSENT ? 0.0 : (double) input_lens[c];
-        const double bound = (n_in / (double) p.decim + SDRM_CLOCK_HCAP) / step + 16.0;
+        const double bound = (n_in / (double) p.decim + carried_cap(p)) / step + 16.0;
         width = std::max<uint32_t>(width, (uint32_t) std::min<double>(bound, (double) p.max_len));
     }
     width = std::min<uint32_t>((width + 63u) & ~63u, b->dev.out_stride);

@@ -25,6 +25,7 @@
 #define SDRM_CLOCK_HCAP 256  // max samples the clock stage carries between calls: < 1.01 samples/symbol + 8 (round 3: 64 -> 256,
                              // which admits 240 kHz / 1200 baud without decimation: 200 samples per symbol)
 #define SDRM_DC_MAX_LEN 7712  // longest boxcar of the DC blocker (32 x 241 samples per symbol)
+#define SDRM_GEN_MAX_SPS 16384  // generic channels: samples per symbol (a DC boxcar of up to 2^19 samples, 10 MB of state per channel)
 #define SDRM_INT_MIN (-2147483647 - 1)
 
 struct sdrm_f2 {

@@ -82,20 +82,22 @@ int design_channel(const sdrm_fsk_config &cfg, ChannelDesign &out) {
     out.gain_omega = (out.sps * (float) M_PI) / 100;                                  // :63
     out.gain_mu = 0.5f / 8.0f;
     out.omega_lim = out.sps * 0.01f;  // clock_recovery_mm.c:43
-    // limits of the device path (DESIGN.md "Supported range"):
-    //  - the clock stage carries < 1.01*sps + 6 samples between calls; SDRM_CLOCK_HCAP are provisioned
+    // What the fast, LDS-resident stages are sized for (DESIGN.md "Supported range"):
+    //  - the clock stage carries < 1.01*sps + 8 samples between calls; SDRM_CLOCK_HCAP are provisioned in its rings
     //  - the DC blocker keeps three delay lines of L + 64 floats per channel in LDS: one channel per workgroup still fits
     //    at L = 7712 (159 KB); the three-instruction quotient is proven for every length up to there (tools/dc_div_sweep)
-    //  - a decimating FIR needs decimation <= taps (the reference underflows otherwise, fir_filter.c:107)
-    if (!(out.sps >= 1.0f) || out.sps * 1.01f + 8.0f > (float) SDRM_CLOCK_HCAP) {
-        fprintf(stderr, "<3>samples per symbol %.3f outside the supported range [1, %d)\n", (double) out.sps,
-                (int) ((SDRM_CLOCK_HCAP - 8) / 1.01f));
+    // A channel beyond either (the reference accepts any samples per symbol, fsk_demod.c:53-63) is served by the generic forms
+    // of those two stages -- state in global memory, the IEEE division proper -- at a fraction of the speed, which such a
+    // channel (>= 245 samples per symbol: a few hundred symbols per call) does not notice.
+    if (!(out.sps >= 1.0f) || !(out.sps <= (float) SDRM_GEN_MAX_SPS)) {
+        fprintf(stderr, "<3>samples per symbol %.3f outside the supported range [1, %d]\n", (double) out.sps, SDRM_GEN_MAX_SPS);
         return -ENOTSUP;
     }
-    if (cfg.use_dc_block && (out.dc_length < 2 || out.dc_length > SDRM_DC_MAX_LEN)) {
-        fprintf(stderr, "<3>dc blocker length %u outside the supported range [2, %d]\n", out.dc_length, SDRM_DC_MAX_LEN);
+    if (cfg.use_dc_block && out.dc_length < 2) {
+        fprintf(stderr, "<3>dc blocker length %u outside the supported range\n", out.dc_length);
         return -ENOTSUP;
     }
+    out.generic = out.sps * 1.01f + 8.0f > (float) SDRM_CLOCK_HCAP || (cfg.use_dc_block && out.dc_length > SDRM_DC_MAX_LEN);
     if ((size_t) cfg.decimation > out.taps2.size()) {
         fprintf(stderr, "<3>decimation %u exceeds the filter length %zu\n", cfg.decimation, out.taps2.size());
         return -ENOTSUP;

@@ -26,6 +26,9 @@ struct ChannelDesign {
     float sps;
     uint32_t dc_length;  // 0 when the DC blocker is off
     float gain_omega, gain_mu, omega_lim;
+    // the symbols are longer (or the DC boxcar is) than the LDS-resident DC and clock stages are sized for: the channel's
+    // DC blocker and clock recovery run in their generic forms, state in global memory (sdrm_kernels.h, "generic channels")
+    bool generic;
 };
 
 // 0, -1 (bad parameters, as the reference), -ENOTSUP (outside what the device path sizes for)

@@ -146,6 +146,8 @@ struct sdrm_chan_params {
     float quad_gain;
     float dc_len_f, dc_inv_len;     // (float) L and RN(1 / L): sdrm_boxcar_out_fast
     float omega_mid, omega_lim, gain_omega, gain_mu;
+    uint32_t generic;               // the channel's DC blocker and clock recovery run in their generic forms (below: "generic channels")
+    uint32_t pad_[3];
 };
 
 // per-call, per-channel control block, written by the host before every launch
@@ -1394,6 +1396,73 @@ SDRM_HD void sdrm_k3_finish(const sdrm_k3_lane &L, int *from_n, int *new_kept) {
     }
     *from_n = (int) (from - L.kept);
     *new_kept = (int) keep;
+}
+
+// ------------------------------------------------------------------------------------------------ generic channels
+// A channel whose symbols are longer than the LDS-resident stages are sized for (more than ~244 samples per symbol: the clock
+// stage's rings hold at most 255 carried samples; a DC boxcar beyond 7712 samples does not fit a CU's LDS) keeps the fast
+// front-end and runs its DC blocker and clock recovery in these forms: all state in global memory, the reference's arithmetic
+// statement by statement (IEEE division, the NaN-aware symbol), one workgroup of 64 threads per channel.  Such a channel has
+// at most a few hundred symbols per call, so the stages' cost is what the DC blocker's four running sums cost: ~8 ms per
+// 131072-sample call, 1.5 % of the time such a signal takes to arrive.  Reference: src/dsp/dc_blocker.c:56-64,105-119,
+// src/dsp/clock_recovery_mm.c:78-139 -- which accept any samples per symbol (src/dsp/fsk_demod.c:53-63).
+//
+// Layout of a channel's state (floats):
+//   [0..3] running sums of the four boxcars   [4] ring position of the boxcars' delay lines (uint32 bits)
+//   [5] ring position of the output delay (uint32 bits)   [6..7] unused
+//   ring[s], s = 0..3: the last L inputs of boxcar s      xring: the last 2 (L - 1) inputs of the blocker
+//   work: 3 floats of padding (what an aligned dot product reads in front of position 0: zero taps), then the clock stage's
+//         working buffer = carried samples followed by the call's new ones (clock_recovery_mm.c:90)
+struct sdrm_gen_layout {
+    uint32_t L, XL;    // boxcar length (0: no DC blocker) and output delay 2 (L - 1)
+    uint32_t hcap;     // most samples the clock stage carries between calls (< 1.01 samples per symbol + 8)
+    uint32_t wcap;     // working buffer: hcap + the most new samples of a call + 8
+    uint32_t off_ring, off_x, off_work, total;
+};
+SDRM_HD sdrm_gen_layout sdrm_gen_layout_for(uint32_t dc_len, float sps, uint32_t max_len, uint32_t decim) {
+    sdrm_gen_layout g;
+    g.L = dc_len;
+    g.XL = dc_len ? 2u * (dc_len - 1u) : 0u;
+    g.hcap = (uint32_t) (sps * 1.01f) + 24u;
+    g.wcap = g.hcap + max_len / (decim ? decim : 1u) + 16u;
+    g.off_ring = 8u;
+    g.off_x = g.off_ring + 4u * g.L;
+    g.off_work = (g.off_x + g.XL + 3u) & ~3u;
+    g.total = g.off_work + 4u + g.wcap;
+    return g;
+}
+
+// the clock stage's view of a generic channel's working buffer: a ring that never wraps (positions count from the start of
+// the carried samples, as the reference's ii does), plain samples behind three floats of padding
+struct sdrm_k3_geom_linear {
+    static constexpr int lanes = 1;
+    static constexpr int ring = 1 << 30;
+    static constexpr int block = 1 << 28;
+    static constexpr bool plain = true;
+};
+
+// after the symbol loop of a generic channel: what to carry (clock_recovery_mm.c:127-135), bounded by the channel's own cap
+SDRM_HD void sdrm_k3_finish_linear(const sdrm_k3_lane &L, uint32_t hcap, int *from, int *keep) {
+    const int64_t len = (int64_t) L.nz;  // L.kept is 0: positions are absolute in the working buffer
+    int64_t f;
+    if (len < SDRM_MMSE_TAPS) {
+        f = 0;
+    } else {
+        const bool past = (L.st.ii < 0) || ((int64_t) L.st.ii > len);
+        const int prev = (int) ((uint32_t) L.st.ii - (uint32_t) L.st.inc);
+        f = past ? (int64_t) prev : (int64_t) L.st.ii;
+    }
+    int64_t k = len - f;
+    if (k > (int64_t) hcap) {
+        k = (int64_t) hcap;
+        f = len - k;
+    }
+    if (k < 0) {
+        k = 0;
+        f = len;
+    }
+    *from = (int) f;
+    *keep = (int) k;
 }
 
 #endif  // SDRM_KERNELS_H

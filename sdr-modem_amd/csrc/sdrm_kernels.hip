@@ -750,7 +750,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         if (tid < b.dc_group && c < b.n_channels) {
             const sdrm_chan_params p = b.params[c];
             const sdrm_chunk_ctl ctl = b.ctl[c];
-            if (p.dc_len != 0 && ctl.absent == 0) {
+            if (p.dc_len != 0 && ctl.absent == 0 && p.generic == 0) {  // generic channels: k2_dc_generic
                 sdrm_k2_slot_setup(s, c, p, ctl.nz);
                 atomicMax(&nb_sh, (int) ((ctl.nz + SDRM_K2_BLK - 1) / SDRM_K2_BLK));
             }
@@ -1573,7 +1573,8 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     bool clean = true;
     uint32_t flagged = 0;
     // a channel that takes no part in this call keeps its state as it is: the lane stays out of everything below
-    const bool absent = active && b.ctl[c].absent != 0;
+    // ... and so does a generic channel (k3_clock_generic runs it behind this kernel and writes its output count)
+    const bool absent = active && (b.ctl[c].absent != 0 || b.params[c].generic != 0);
     if (!producer) {
         int uses_dc = 0;
         if (active && !absent) {
@@ -2079,6 +2080,169 @@ void launch_clock(const DeviceBatch &b, hipStream_t s) {
     void *args[] = {(void *) &b};
     launch_described(describe_clock(b), args, s);
     launch_described(describe_quantize(b), args, s);
+}
+
+// ================================================================================================ generic channels
+// DC blocker and clock recovery of the channels the LDS-resident stages are not sized for (sdrm_kernels.h, "generic
+// channels"): one workgroup of one wave per channel, state in global memory.  Launched behind k2_dc / k3_clock on the same
+// streams, only when the batch has such channels.
+
+// reference src/dsp/dc_blocker.c:56-64,105-119.  A block of 64 samples per step; a boxcar of a generic channel is longer than
+// that, so the delayed samples of a block were all written before the block began: the terms u[n] - u[n - L] are pointwise,
+// the running sum is the in-order chain (one addition per sample, through the lanes), the quotient the IEEE division.
+__global__ __launch_bounds__(64) void k2_dc_generic(DeviceBatch b) {
+    const int c = b.gen_list[blockIdx.x];
+    const sdrm_chan_params p = b.params[c];
+    const sdrm_chunk_ctl ctl = b.ctl[c];
+    if (p.dc_len == 0 || ctl.absent != 0 || ctl.nz == 0) {
+        return;
+    }
+    const sdrm_gen_layout g = sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim);
+    float *st = b.gen_state[c];
+    const int lane = threadIdx.x;
+    float acc[4] = {st[0], st[1], st[2], st[3]};
+    uint32_t pos = sdrm_bits(st[4]), xpos = sdrm_bits(st[5]);  // where u[n - L] / x[n - 2 (L - 1)] of the call's first sample sit
+    const float *z = b.z + (size_t) c * b.z_stride;
+    float *out = b.dcout + (size_t) c * b.z_stride;
+    const float len_f = p.dc_len_f;
+    const int nz = (int) ctl.nz;
+    for (int n0 = 0; n0 < nz; n0 += 64) {
+        const int valid = nz - n0 < 64 ? nz - n0 : 64;
+        const bool on = lane < valid;
+        const float x = on ? z[n0 + lane] : 0.0f;
+        float u = x;
+        uint32_t idx = pos + (uint32_t) lane;
+        idx = idx >= g.L ? idx - g.L : idx;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            float *ring = st + g.off_ring + (size_t) s * g.L;
+            const float old = on ? ring[idx] : 0.0f;
+            if (on) {
+                ring[idx] = u;
+            }
+            const float t = sdrm_boxcar_term(u, old);
+            float y = 0.0f, run = acc[s];
+            for (int i = 0; i < valid; i++) {  // y[n] = t[n] + y[n - 1], in order
+                run = __shfl(t, i) + run;
+                y = lane == i ? run : y;
+            }
+            acc[s] = run;
+            u = sdrm_boxcar_out(y, len_f);
+        }
+        uint32_t xi = xpos + (uint32_t) lane;
+        xi = xi >= g.XL ? xi - g.XL : xi;
+        float *xring = st + g.off_x;
+        if (on) {
+            const float delayed = xring[xi];
+            xring[xi] = x;
+            out[n0 + lane] = delayed - u;
+        }
+        pos += (uint32_t) valid;
+        pos = pos >= g.L ? pos - g.L : pos;
+        xpos += (uint32_t) valid;
+        xpos = xpos >= g.XL ? xpos - g.XL : xpos;
+    }
+    __syncthreads();  // every lane's ring stores are issued before the state words say so
+    if (lane == 0) {
+        st[0] = acc[0];
+        st[1] = acc[1];
+        st[2] = acc[2];
+        st[3] = acc[3];
+        st[4] = sdrm_from_bits(pos);
+        st[5] = sdrm_from_bits(xpos);
+    }
+}
+
+// reference src/dsp/clock_recovery_mm.c:78-139 (+ fsk_demod.c:106): the call's samples go behind the carried ones in the
+// channel's working buffer (all lanes), one lane runs the symbol loop in its NaN-aware form (a few hundred symbols), all
+// lanes move what is carried to the front.
+__global__ __launch_bounds__(64) void k3_clock_generic(DeviceBatch b) {
+    const int c = b.gen_list[blockIdx.x];
+    const sdrm_chan_params p = b.params[c];
+    const sdrm_chunk_ctl ctl = b.ctl[c];
+    __shared__ float bank_rev[129 * SDRM_K3_BANKPITCH];
+    __shared__ int from_sh, keep_sh;
+    if (ctl.absent != 0) {
+        if (threadIdx.x == 0) {
+            b.out_len[c] = 0;
+        }
+        return;
+    }
+    const int lane = threadIdx.x;
+    for (int k = lane; k < 129 * 8; k += 64) {
+        bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];
+    }
+    const sdrm_gen_layout g = sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim);
+    float *work = b.gen_state[c] + g.off_work;  // work[3 + i] = position i of the reference's working buffer
+    sdrm_clock_state *cs = b.clock_state + c;
+    const int kept = (int) cs->kept;
+    const int nz = (int) ctl.nz;
+    const float *src = (p.dc_len ? b.dcout : b.z) + (size_t) c * b.z_stride;
+    for (int i = lane; i < nz; i += 64) {
+        work[3 + kept + i] = src[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        sdrm_k3_lane L;
+        L.k.omega_mid = p.omega_mid;
+        L.k.omega_lim = p.omega_lim;
+        L.k.gain_omega = p.gain_omega;
+        L.k.gain_mu = p.gain_mu;
+        L.kept = 0;
+        L.nz = kept + nz;  // positions count from the start of the carried samples
+        L.oo = 0;
+        L.cap = p.max_len;
+        L.st.mu = cs->mu;
+        L.st.omega = cs->omega;
+        L.st.last = cs->last;
+        L.st.ii = 0;
+        L.st.inc = 0;
+        const uint32_t lim = sdrm_k3_limit(L, L.nz);
+        float *of = b.out_f32 + (size_t) c * b.out_stride;
+        int8_t *o8 = b.out_i8 + (size_t) c * b.out_stride;
+        while (sdrm_k3_can_step(L, lim)) {
+            sdrm_k3_operands F;
+            sdrm_k3_fetch<false, sdrm_k3_geom_linear>(L, (const float *) work, (const float *) bank_rev, F);
+            const float soft = sdrm_k3_step<false>(L, F);
+            of[L.oo] = soft;
+            o8[L.oo] = sdrm_soft_to_i8(soft);
+            L.oo++;
+        }
+        int from, keep;
+        sdrm_k3_finish_linear(L, g.hcap, &from, &keep);
+        from_sh = from;
+        keep_sh = keep;
+        cs->mu = L.st.mu;
+        cs->omega = L.st.omega;
+        cs->last = L.st.last;
+        cs->kept = (uint32_t) keep;
+        cs->poison = 0;
+        b.nonfinite[c] = 0;
+        b.out_len[c] = L.oo;
+    }
+    __syncthreads();
+    const int from = from_sh, keep = keep_sh;
+    if (from > 0) {
+        for (int i0 = 0; i0 < keep; i0 += 64) {  // forward move, a block at a time: every block is read before it is written
+            const float v = i0 + lane < keep ? work[3 + from + i0 + lane] : 0.0f;
+            __syncthreads();
+            if (i0 + lane < keep) {
+                work[3 + i0 + lane] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+void launch_dc_generic(const DeviceBatch &b, hipStream_t s) {
+    if (b.n_gen > 0 && b.any_dc) {
+        hipLaunchKernelGGL(k2_dc_generic, dim3((unsigned) b.n_gen), dim3(64), 0, s, b);
+    }
+}
+void launch_clock_generic(const DeviceBatch &b, hipStream_t s) {
+    if (b.n_gen > 0) {
+        hipLaunchKernelGGL(k3_clock_generic, dim3((unsigned) b.n_gen), dim3(64), 0, s, b);
+    }
 }
 
 // ================================================================================================ probes

@@ -56,6 +56,9 @@ struct DeviceBatch {
     int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
     uint32_t *placed;                // [2] DC / clock-stage workgroups that have started, cumulative over calls (k_hold_until)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching
+    const int *gen_list;             // generic channels (sdrm_kernels.h): their indices, n_gen of them, and each one's state
+    int n_gen;
+    float *const *gen_state;         // [C] device pointers (null for the others)
     int k3_lanes, k3_ring, k3_plain; // clock-stage workgroup shape chosen for this batch (0: by channel count; SDRM_K3_LANES overrides both)
     int k3_wait;                     // the clock stage's workgroups wait for k3_done to reach k3_wait_for before they touch any
     uint32_t k3_wait_for;            //   state of the previous call (they were launched while that call's clock stage still ran)
@@ -89,6 +92,8 @@ void launch_nco_phase(const DeviceBatch &b, hipStream_t s);
 void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, uint32_t max_len, hipStream_t s);
 void launch_front(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride, hipStream_t s);
 void launch_dc(const DeviceBatch &b, hipStream_t s);
+void launch_dc_generic(const DeviceBatch &b, hipStream_t s);     // behind launch_dc, same stream (nothing without generic channels)
+void launch_clock_generic(const DeviceBatch &b, hipStream_t s);  // behind launch_clock, same stream
 // diagnostics buffer layout: 4 words per clock-stage workgroup (room for the smallest shape, 16 channels each), then 8
 // words of the front-end, then 10 of the DC blocker
 #define SDRM_STAMP_K3_WAVES(n_channels) (((n_channels) + 15) / 16)

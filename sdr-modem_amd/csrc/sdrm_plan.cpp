@@ -61,6 +61,7 @@ static int params_from_design(const ChannelDesign &d, sdrm_chan_params &p) {
         p.dc_len_f = (float) p.dc_len;
         p.dc_inv_len = 1.0f / p.dc_len_f;  // correctly rounded reciprocal: sdrm_boxcar_out_fast
     }
+    p.generic = d.generic ? 1u : 0u;
     return 0;
 }
 
@@ -110,11 +111,17 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
             p.taps2_off = (uint32_t) plan.tap_pool.size();
             append_taps(plan.tap_pool, d.taps2);
         }
+        // generic channels (sdrm_kernels.h) keep their DC and clock state in global memory: they size neither the DC stage's
+        // LDS rings nor the clock stage's; their DC output still goes through the batch's dcout buffers
         if (p.dc_len) {
             plan.any_dc = 1;
-            plan.dc_l_cap = std::max(plan.dc_l_cap, p.dc_len);
+            if (!p.generic) {
+                plan.dc_l_cap = std::max(plan.dc_l_cap, p.dc_len);
+            }
         }
-        plan.clock_carried_max = std::max(plan.clock_carried_max, (uint32_t) (d.sps * 1.01f + 8.0f));
+        if (!p.generic) {
+            plan.clock_carried_max = std::max(plan.clock_carried_max, (uint32_t) (d.sps * 1.01f + 8.0f));
+        }
         plan.t1_max = std::max(plan.t1_max, p.T1);
         plan.t2_max = std::max(plan.t2_max, p.T2);
         h_max = std::max(h_max, p.hist_len);
@@ -122,6 +129,9 @@ int plan_batch(const sdrm_fsk_config *cfgs, size_t n, BatchPlan &plan) {
     }
     // every channel gets a DC state region of the batch's largest size, so that a channel can later be given any
     // configuration the batch's geometry holds (replan_channel)
+    if (plan.any_dc && plan.dc_l_cap == 0) {
+        plan.dc_l_cap = 32;  // every DC blocker of the batch is a generic one: the fast stage keeps a minimal geometry
+    }
     plan.dc_hx_cap = plan.any_dc ? 2 * (plan.dc_l_cap - 1) : 0;
     plan.dc_region_floats = plan.any_dc ? sdrm_k2_state_floats(plan.dc_hx_cap, plan.dc_l_cap) : 0;
     // sixteen channels per DC workgroup while their delay rings fit beside the term rows (150 KB of the CU's 160)
@@ -163,8 +173,11 @@ int plan_growth(const BatchPlan &plan, const sdrm_fsk_config &cfg, GeometryGrowt
     g.t1_max = std::max(plan.t1_max, p.T1);
     g.t2_max = std::max(plan.t2_max, p.T2);
     g.hist_stride = std::max(plan.hist_stride, round_up_u32(p.hist_len, 8));
-    g.dc_l_cap = std::max(plan.dc_l_cap, p.dc_len);
+    g.dc_l_cap = std::max(plan.dc_l_cap, p.generic ? 0u : p.dc_len);  // a generic channel's boxcar lives in global memory
     g.any_dc = plan.any_dc || p.dc_len != 0;
+    if (g.any_dc && g.dc_l_cap == 0) {
+        g.dc_l_cap = 32;
+    }
     g.needed = g.t1_max != plan.t1_max || g.t2_max != plan.t2_max || g.hist_stride != plan.hist_stride ||
                g.dc_l_cap != plan.dc_l_cap || g.any_dc != plan.any_dc;
     if (g.any_dc && dc_lds_bytes_for(g.dc_l_cap, dc_group_for(g.dc_l_cap)) > 160 * 1024) {
@@ -216,7 +229,7 @@ int replan_channel(BatchPlan &plan, size_t c, const sdrm_fsk_config &cfg, std::v
     }
     // the batch's geometry (LDS sizes, strides, buffers) was fixed when it was created
     if (p.T1 > plan.t1_max || p.T2 > plan.t2_max || p.hist_len > plan.hist_stride || p.max_len > plan.in_stride ||
-        p.max_len + 64 > plan.z_stride || (p.dc_len && (!plan.any_dc || p.dc_len > plan.dc_l_cap))) {
+        p.max_len + 64 > plan.z_stride || (p.dc_len && (!plan.any_dc || (!p.generic && p.dc_len > plan.dc_l_cap)))) {
         fprintf(stderr, "<3>configuration does not fit the batch it is assigned to (filters of %u / %u taps, DC length %u, "
                         "buffer %u)\n", p.T1, p.T2, p.dc_len, p.max_len);
         return -ENOTSUP;
@@ -229,7 +242,9 @@ int replan_channel(BatchPlan &plan, size_t c, const sdrm_fsk_config &cfg, std::v
     std::copy(d.taps2.rbegin(), d.taps2.rend(), taps_slot.begin() + round_up_u32(plan.t1_max, 8));
     plan.design[c] = d;
     plan.params[c] = p;
-    plan.clock_carried_max = std::max(plan.clock_carried_max, (uint32_t) (d.sps * 1.01f + 8.0f));  // the clock stage follows with its ring
+    if (!p.generic) {
+        plan.clock_carried_max = std::max(plan.clock_carried_max, (uint32_t) (d.sps * 1.01f + 8.0f));  // the clock stage follows with its ring
+    }
     plan.phase[c] = 0;
     plan.parity[c] = 0;
     plan.zbase[c] = 0;

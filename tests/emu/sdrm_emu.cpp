@@ -30,7 +30,19 @@ struct EmuBatch {
     std::vector<float> nco_state;
     std::vector<std::vector<sdrm_f2>> mixed;
     std::vector<sdrm_nco_seg> nco_table;
+    std::vector<std::vector<float>> gen;  // generic channels (sdrm_kernels.h): the channel's state region, empty for the others
 };
+
+static void emu_sync_generic(EmuBatch *b, long only) {
+    const BatchPlan &pl = b->plan;
+    b->gen.resize(pl.params.size());
+    for (size_t c = 0; c < pl.params.size(); c++) {
+        if (only >= 0 && (size_t) only != c) continue;
+        const sdrm_chan_params &p = pl.params[c];
+        b->gen[c].clear();
+        if (p.generic) b->gen[c].assign(sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim).total, 0.0f);
+    }
+}
 
 extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out) {
     EmuBatch *b = new EmuBatch();
@@ -58,6 +70,7 @@ extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out)
     b->nonfinite.assign(n, 0);
     b->nco_state.assign(n, 0.0f);
     b->mixed.resize(n);
+    emu_sync_generic(b, -1);
     *out = b;
     return 0;
 }
@@ -113,6 +126,7 @@ extern "C" int emu_reset_channel(EmuBatch *b, size_t c, const sdrm_fsk_config *c
     b->clock[c].omega = pl.design[c].sps;
     b->nonfinite[c] = 0;
     b->nco_state[c] = 0.0f;
+    emu_sync_generic(b, (long) c);
     return 0;
 }
 
@@ -245,7 +259,7 @@ static void emu_dc(EmuBatch *b) {
             s.chan = -1;
             s.L = 1; s.A = 64; s.rcap = 128; s.nz = 0; s.HX = 0; s.Lf = 1.0f; s.invL = 1.0f;
             const int c = c0 + sl;
-            if (sl < G && c < C && pl.params[c].dc_len != 0 && b->ctl[c].absent == 0) {
+            if (sl < G && c < C && pl.params[c].dc_len != 0 && b->ctl[c].absent == 0 && pl.params[c].generic == 0) {
                 sdrm_k2_slot_setup(s, c, pl.params[c], b->ctl[c].nz);
                 nb = std::max(nb, (int) ((b->ctl[c].nz + SDRM_K2_BLK - 1) / SDRM_K2_BLK));
             }
@@ -353,7 +367,7 @@ static void emu_clock_as(EmuBatch *b) {
             sdrm_clock_state &cs = b->clock[c];
             sdrm_k3_lane &L = lanes[l];
             L.k = sdrm_mm_consts{p.omega_mid, p.omega_lim, p.gain_omega, p.gain_mu};
-            absent[l] = b->ctl[c].absent != 0;
+            absent[l] = b->ctl[c].absent != 0 || p.generic != 0;  // generic channels: emu_clock_generic, behind this stage
             L.cap = absent[l] ? 0u : p.max_len;  // an absent channel never steps and keeps its state
             L.nz = (int) b->ctl[c].nz;
             L.kept = absent[l] ? 0 : (int) cs.kept;
@@ -448,6 +462,112 @@ static void emu_clock(EmuBatch *b) {
     }
 }
 
+// generic channels, as k2_dc_generic / k3_clock_generic run them (same layout helpers, same per-sample bodies; the block
+// structure of the DC kernel is kept so that ring positions and the partial last block are exercised)
+static void emu_dc_generic(EmuBatch *b) {
+    const BatchPlan &pl = b->plan;
+    for (size_t c = 0; c < pl.params.size(); c++) {
+        const sdrm_chan_params &p = pl.params[c];
+        const sdrm_chunk_ctl &ctl = b->ctl[c];
+        if (!p.generic || p.dc_len == 0 || ctl.absent != 0 || ctl.nz == 0) continue;
+        const sdrm_gen_layout g = sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim);
+        float *st = b->gen[c].data();
+        float acc[4] = {st[0], st[1], st[2], st[3]};
+        uint32_t pos = sdrm_bits(st[4]), xpos = sdrm_bits(st[5]);
+        const float *z = b->z.data() + c * pl.z_stride;
+        float *out = b->dcout.data() + c * pl.z_stride;
+        const int nz = (int) ctl.nz;
+        for (int n0 = 0; n0 < nz; n0 += 64) {
+            const int valid = nz - n0 < 64 ? nz - n0 : 64;
+            float u[64], x[64];
+            for (int l = 0; l < valid; l++) x[l] = u[l] = z[n0 + l];
+            for (int s = 0; s < 4; s++) {
+                float *ring = st + g.off_ring + (size_t) s * g.L;
+                float t[64];
+                for (int l = 0; l < valid; l++) {  // pointwise, every lane at once
+                    uint32_t idx = pos + (uint32_t) l;
+                    idx = idx >= g.L ? idx - g.L : idx;
+                    const float old = ring[idx];
+                    ring[idx] = u[l];
+                    t[l] = sdrm_boxcar_term(u[l], old);
+                }
+                float run = acc[s];
+                for (int l = 0; l < valid; l++) {  // the in-order chain
+                    run = t[l] + run;
+                    u[l] = sdrm_boxcar_out(run, p.dc_len_f);
+                }
+                acc[s] = run;
+            }
+            float *xring = st + g.off_x;
+            for (int l = 0; l < valid; l++) {
+                uint32_t xi = xpos + (uint32_t) l;
+                xi = xi >= g.XL ? xi - g.XL : xi;
+                const float delayed = xring[xi];
+                xring[xi] = x[l];
+                out[n0 + l] = delayed - u[l];
+            }
+            pos += (uint32_t) valid;
+            pos = pos >= g.L ? pos - g.L : pos;
+            xpos += (uint32_t) valid;
+            xpos = xpos >= g.XL ? xpos - g.XL : xpos;
+        }
+        for (int s = 0; s < 4; s++) st[s] = acc[s];
+        st[4] = sdrm_from_bits(pos);
+        st[5] = sdrm_from_bits(xpos);
+    }
+}
+
+static void emu_clock_generic(EmuBatch *b) {
+    const BatchPlan &pl = b->plan;
+    float bank_rev[129 * SDRM_K3_BANKPITCH];
+    for (int k = 0; k < 129 * 8; k++) bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = (&sdrm_mmse_bank[0][0])[(k & ~7) + 7 - (k & 7)];
+    for (size_t c = 0; c < pl.params.size(); c++) {
+        const sdrm_chan_params &p = pl.params[c];
+        if (!p.generic) continue;
+        const sdrm_chunk_ctl &ctl = b->ctl[c];
+        if (ctl.absent != 0) {
+            b->outlen[c] = 0;
+            continue;
+        }
+        const sdrm_gen_layout g = sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim);
+        float *work = b->gen[c].data() + g.off_work;
+        sdrm_clock_state &cs = b->clock[c];
+        const int kept = (int) cs.kept, nz = (int) ctl.nz;
+        const float *src = (p.dc_len ? b->dcout.data() : b->z.data()) + c * pl.z_stride;
+        for (int i = 0; i < nz; i++) work[3 + kept + i] = src[i];
+        sdrm_k3_lane L;
+        L.k = sdrm_mm_consts{p.omega_mid, p.omega_lim, p.gain_omega, p.gain_mu};
+        L.kept = 0;
+        L.nz = kept + nz;
+        L.oo = 0;
+        L.cap = p.max_len;
+        L.st.mu = cs.mu;
+        L.st.omega = cs.omega;
+        L.st.last = cs.last;
+        L.st.ii = 0;
+        L.st.inc = 0;
+        const uint32_t lim = sdrm_k3_limit(L, L.nz);
+        while (sdrm_k3_can_step(L, lim)) {
+            sdrm_k3_operands F;
+            sdrm_k3_fetch<false, sdrm_k3_geom_linear>(L, (const float *) work, (const float *) bank_rev, F);
+            const float soft = sdrm_k3_step<false>(L, F);
+            b->outf[c * pl.out_stride + L.oo] = soft;
+            b->out8[c * pl.out_stride + L.oo] = sdrm_soft_to_i8(soft);
+            L.oo++;
+        }
+        int from, keep;
+        sdrm_k3_finish_linear(L, g.hcap, &from, &keep);
+        if (from > 0) memmove(work + 3, work + 3 + from, sizeof(float) * (size_t) keep);
+        cs.mu = L.st.mu;
+        cs.omega = L.st.omega;
+        cs.last = L.st.last;
+        cs.kept = (uint32_t) keep;
+        cs.poison = 0;
+        b->nonfinite[c] = 0;
+        b->outlen[c] = L.oo;
+    }
+}
+
 // inputs[c]: interleaved cf32, lens[c] samples.  Outputs: per channel pointers into emu-owned memory.
 extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t *lens, const int8_t **out8,
                            const float **outf, size_t *outlens) {
@@ -457,7 +577,9 @@ extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t
     for (size_t c = 0; c < C; c++) ins[c] = reinterpret_cast<const sdrm_f2 *>(inputs[c]);
     emu_front_any(b, ins.data());
     emu_dc(b);
+    emu_dc_generic(b);
     emu_clock(b);
+    emu_clock_generic(b);
     for (size_t c = 0; c < C; c++) {
         out8[c] = b->out8.data() + c * b->plan.out_stride;
         outf[c] = b->outf.data() + c * b->plan.out_stride;
@@ -498,7 +620,9 @@ extern "C" int emu_process_nco(EmuBatch *b, const float *const *inputs, const si
     }
     emu_front_any(b, ins.data());
     emu_dc(b);
+    emu_dc_generic(b);
     emu_clock(b);
+    emu_clock_generic(b);
     for (size_t c = 0; c < C; c++) {
         out8[c] = b->out8.data() + c * b->plan.out_stride;
         outf[c] = b->outf.data() + c * b->plan.out_stride;

@@ -29,7 +29,7 @@ def test_pipeline_kernels_do_not_spill(tmp_path):
         hits = [k for k in meta if all(p in k for p in parts)]
         assert len(hits) == 1, (parts, hits)
         return meta[hits[0]]
-    for parts in (("k1_front", "ILb0E"), ("k1_front", "ILb1E"), ("k2_dc",), ("k0_nco_phase",), ("k0_nco_mix",),
+    for parts in (("k1_front", "ILb0E"), ("k1_front", "ILb1E"), ("5k2_dcE",), ("k2_dc_generic",), ("k3_clock_generic",), ("k0_nco_phase",), ("k0_nco_mix",),
                   ("k3_clock", "ILi16ELi1024ELb0E"), ("k3_clock", "ILi32ELi512ELb0E"), ("k3_clock", "ILi64ELi256ELb1E"),
                   ("k3_clock", "ILi64ELi256ELb0E")):
         scratch, vgprs = find(*parts)

@@ -100,5 +100,35 @@ def test_long_symbols_up_to_two_hundred_samples(keep_soft):
             if keep_soft:
                 assert np.array_equal(g.last_soft(i).view(np.uint32), of.view(np.uint32)), (cfgs[i], call)
     g.close()
-    # beyond the ceiling the library still says so instead of misbehaving
-    assert binding.Batch([(240000, 900, 5000, 1, 2000, True, 4096)]).code == -95  # -ENOTSUP: 266 samples per symbol
+    # beyond the fast stages' ceiling (266 samples per symbol) a channel runs the generic ones: tests/test_gpu_parity.py
+
+
+def test_long_symbols_beyond_the_fast_stages_random_configurations():
+    """the same differential fuzz above the fast stages' range: 250 to 1600 samples per symbol (generic DC and clock stages,
+    filters up to ~2200 taps), mixed with ordinary channels in one batch, ragged calls"""
+    rng = np.random.default_rng(20261004)
+    cfgs = []
+    while len(cfgs) < 6:
+        fs = int(rng.choice([96000, 192000, 240000, 480000]))
+        baud = int(rng.choice([300, 600, 900, 1200]))
+        sps = fs / baud
+        if not (250 <= sps <= 1600):
+            continue
+        cfgs.append((fs, baud, int(rng.choice([2400, 5000])), 1, int(rng.choice([1000, 2000])), bool(rng.integers(0, 2))))
+    cfgs += [(48000, 9600, 5000, 1, 2000, True), (48000, 1200, 5000, 1, 2000, True)]
+    maxlen = 12000
+    sigs = [siggen.gmsk_channel(400 + i, 4 * maxlen, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    g = binding.Batch([c + (maxlen,) for c in cfgs], keep_soft=True)
+    assert g.code == 0
+    oracles = [orc.Fsk(*c, maxlen) for c in cfgs]
+    pos = [0] * len(cfgs)
+    for call in range(7):
+        lens = [int(rng.choice([0, 1, 9, 700, 5000, maxlen])) for _ in cfgs]
+        parts = [s[p:p + n] for s, p, n in zip(sigs, pos, lens)]
+        pos = [p + n for p, n in zip(pos, lens)]
+        g8 = g.process(parts)
+        for i, o in enumerate(oracles):
+            o8, of = o.process(parts[i])
+            assert np.array_equal(g8[i], o8), (cfgs[i], call, lens[i])
+            assert np.array_equal(g.last_soft(i).view(np.uint32), of.view(np.uint32)), (cfgs[i], call)
+    g.close()

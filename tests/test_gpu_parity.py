@@ -1314,3 +1314,51 @@ def test_plain_fsk_demod_handles_share_one_batcher_when_asked_to(monkeypatch):
             assert np.array_equal(got[i][k], o.process(sigs[i][k * n:(k + 1) * n])[0]), (i, k)
     for h in handles:
         h.close()
+
+
+# ---------------------------------------------------------------- any samples per symbol (generic DC / clock stages)
+
+def test_any_samples_per_symbol_on_the_device():
+    """fsk_demod_create accepts what the reference accepts (src/dsp/fsk_demod.c:53-63): 240 kHz / 600 baud without decimation is
+    400 samples per symbol -- a 1091-tap LPF1, a 12800-sample DC boxcar, up to 412 samples carried by the clock stage -- beyond
+    what the LDS-resident DC and clock stages hold; such a channel keeps the fast front-end and runs k2_dc_generic /
+    k3_clock_generic (state in global memory).  Plain handle over ragged calls (the one-channel graph replay must stay off),
+    and a batch that mixes generic and ordinary channels, absent calls included; int8 and float soft bits bit for bit."""
+    iq = siggen.gmsk_channel(6, 130000, fs=240000, baud=600)
+    chunks = [16384, 1000, 0, 16384, 7, 20000, 1, 1, 300, 20000, 20000, 20000, 15923]
+    assert run_stream((240000, 600, 5000, 1, 2000, True), iq, chunks, 20000) > 250
+    d = binding.FskDemod(240000, 600, 5000, 1, 2000, True, 20000)
+    o = orc.Fsk(240000, 600, 5000, 1, 2000, True, 20000)
+    assert d.code == 0
+    for k in range(5):  # equal lengths: a one-channel batch would replay a graph from the second call on
+        part = iq[k * 20000:(k + 1) * 20000]
+        assert np.array_equal(d.process(part), o.process(part)[0]), k
+    d.close()
+    iq2 = siggen.gmsk_channel(7, 60000, fs=240000, baud=900)
+    run_stream((240000, 900, 5000, 1, 2000, False), iq2, [9000, 300, 20700, 5, 20000, 9995], 20700)
+    run_stream((240000, 900, 5000, 1, 2000, True), iq2, [20700, 20700, 18600], 20700)
+    cfgs = [(240000, 600, 5000, 1, 2000, True, 8192), (48000, 9600, 5000, 1, 2000, True, 8192), (240000, 900, 5000, 1, 2000, False, 8192),
+            (48000, 4800, 5000, 2, 2000, False, 8192)] * 10  # 40 channels: the pipelined stages, 20 generic channels
+    sigs = [siggen.gmsk_channel(20 + i, 3 * 8192, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs[:4])]
+    g = binding.Batch(cfgs, keep_soft=True)
+    assert g.code == 0
+    oracles = [orc.Fsk(*c) for c in cfgs[:4]]
+    pos = [0] * 4
+    for lens in ([8192] * 4, [100, 8192, 0, 17], [8092, 3000, 8192, 8192]):
+        parts = [sigs[i % 4][pos[i % 4]:pos[i % 4] + lens[i % 4]] for i in range(len(cfgs))]
+        g8 = g.process(parts)
+        want = [o.process(parts[i]) for i, o in enumerate(oracles)]
+        for i in range(len(cfgs)):
+            o8, of = want[i % 4]
+            assert_same(of, g.last_soft(i), o8, g8[i], where="channel %d lens %s" % (i, lens))
+        pos = [pos[i] + lens[i] for i in range(4)]
+    # a slot handed from an ordinary client to a generic one and back
+    assert g.reset_channel(1, (240000, 600, 5000, 1, 2000, True, 8192)) == 0
+    o = orc.Fsk(240000, 600, 5000, 1, 2000, True, 8192)
+    got = g.process([binding.ABSENT, sigs[0][:8192]] + [binding.ABSENT] * (len(cfgs) - 2))
+    assert np.array_equal(got[1], o.process(sigs[0][:8192])[0]) and len(got[0]) == 0
+    assert g.reset_channel(1, (48000, 9600, 5000, 1, 2000, True, 8192)) == 0
+    o = orc.Fsk(48000, 9600, 5000, 1, 2000, True, 8192)
+    got = g.process([binding.ABSENT, sigs[1][:8192]] + [binding.ABSENT] * (len(cfgs) - 2))
+    assert np.array_equal(got[1], o.process(sigs[1][:8192])[0])
+    g.close()

@@ -128,6 +128,48 @@ def test_two_hundred_samples_per_symbol():
     run_both((240000, 1200, 5000, 1, 2000, False), iq[:30000], [9000, 300, 20700], 20700)
 
 
+def test_any_samples_per_symbol_through_the_generic_stages():
+    """The reference accepts any samples per symbol (src/dsp/fsk_demod.c:53-63).  Beyond what the LDS-resident stages are sized
+    for -- more than ~244 samples per symbol, or a DC boxcar longer than 7712 samples -- a channel keeps the fast front-end and
+    runs its DC blocker and clock recovery in their generic forms (state in global memory; -ENOTSUP until round 4):
+    240 kHz / 600 baud (400 samples per symbol, 1091-tap LPF1, a 12800-sample boxcar, up to 412 carried samples) and
+    240 kHz / 900 baud without DC blocker (266.7), over ragged calls including empty and tiny ones, and in one batch with an
+    ordinary channel, whose stream must not notice its neighbour."""
+    iq = siggen.gmsk_channel(6, 130000, fs=240000, baud=600)
+    chunks = [16384, 1000, 0, 16384, 7, 20000, 1, 1, 300, 20000, 20000, 20000, 15923]
+    assert run_both((240000, 600, 5000, 1, 2000, True), iq, chunks, 20000) == 130000
+    iq2 = siggen.gmsk_channel(7, 60000, fs=240000, baud=900)
+    run_both((240000, 900, 5000, 1, 2000, False), iq2, [9000, 300, 20700, 5, 20000, 9995], 20700)
+    run_both((240000, 900, 5000, 1, 2000, True), iq2, [20700, 20700, 18600], 20700)  # 8534-sample boxcar: DC generic, clock too
+    # one batch: generic, ordinary, generic without DC
+    cfgs = [(240000, 600, 5000, 1, 2000, True, 8192), (48000, 9600, 5000, 1, 2000, True, 8192), (240000, 900, 5000, 1, 2000, False, 8192)]
+    sigs = [siggen.gmsk_channel(20 + i, 3 * 8192, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    e = emu_api.EmuBatch(cfgs)
+    assert e.code == 0
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    for lens in ([8192, 8192, 8192], [100, 8192, 0], [8092, 3000, 8192]):
+        parts, nxt = [], []
+        for i, n in enumerate(lens):
+            used = getattr(test_any_samples_per_symbol_through_the_generic_stages, "_pos", [0, 0, 0])
+            parts.append(sigs[i][used[i]:used[i] + n])
+            nxt.append(used[i] + n)
+        test_any_samples_per_symbol_through_the_generic_stages._pos = nxt
+        e8, ef = e.process(parts)
+        for i, o in enumerate(oracles):
+            o8, of = o.process(parts[i])
+            assert np.array_equal(o8, e8[i]) and np.array_equal(of.view(np.uint32), ef[i].view(np.uint32)), (i, lens)
+    del test_any_samples_per_symbol_through_the_generic_stages._pos
+    # a slot handed from an ordinary client to a generic one and back (the batch neither grows its LDS rings nor keeps the state)
+    assert e.reset_channel(1, (240000, 600, 5000, 1, 2000, True, 8192)) == 0
+    o = orc.Fsk(240000, 600, 5000, 1, 2000, True, 8192)
+    e8, ef = e.process([emu_api.ABSENT, sigs[0][:8192], emu_api.ABSENT])
+    assert np.array_equal(o.process(sigs[0][:8192])[0], e8[1])
+    assert e.reset_channel(1, (48000, 9600, 5000, 1, 2000, True, 8192)) == 0
+    o = orc.Fsk(48000, 9600, 5000, 1, 2000, True, 8192)
+    e8, ef = e.process([emu_api.ABSENT, sigs[1][:8192], emu_api.ABSENT])
+    assert np.array_equal(o.process(sigs[1][:8192])[0], e8[1])
+
+
 def test_synthetic_gmsk_large_chunk():
     iq = siggen.gmsk_channel(0, 70000)
     run_both((48000, 9600, 5000, 1, 2000, True), iq, [65536, 4464], 65536)
