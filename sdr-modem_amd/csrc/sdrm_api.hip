@@ -1159,21 +1159,6 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     d.ctl = d_ctl;
     d.nonfinite = b->d_flags + (size_t) slot * C;
     d.max_tiles = max_tiles;
-    d.stream_tiles_per_wg = 0;
-    if (sdrm::front_streams(d.t1_max, d.t2_max, (int) C)) {
-        uint32_t longest = 0;
-        long total = 0;
-        for (size_t c = 0; c < C; c++) {
-            const uint32_t tiles = (h[c].n_in + SDRM_K1S_NY - 1) / SDRM_K1S_NY;
-            longest = std::max(longest, tiles);
-            total += tiles;
-        }
-        d.stream_max_tiles = longest;
-        d.stream_tiles_per_wg = sdrm_k1s_tiles_per_wg(total);
-        if (const char *e = getenv("SDRM_K1_STREAM_TILES")) {
-            d.stream_tiles_per_wg = std::max(1, atoi(e));
-        }
-    }
     {
         // no channel can produce more symbols than this in the call (grid of the int8 conversion): every symbol advances
         // by at least floor(omega_mid - omega_lim) samples of what the call brings plus the carried ones (< SDRM_CLOCK_HCAP)
@@ -1539,7 +1524,6 @@ static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h
     d.k3_stamps = nullptr;
     d.timeline = nullptr;
     d.placed = nullptr;
-    d.stream_tiles_per_wg = 0;
     d.nco_segs = nullptr;
     d.ctl = b->d_ctl + (size_t) SG_SLOT;
     d.nonfinite = b->d_flags + (size_t) SG_SLOT;

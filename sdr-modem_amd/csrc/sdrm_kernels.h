@@ -762,223 +762,6 @@ SDRM_HD void sdrm_k1_phase_store(int tid, const sdrm_k1_tile &t, const float *zs
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K1, streaming form
-//
-// The tiled front-end above joins the four waves of a workgroup with a barrier per phase; a wave that shares its SIMD with
-// a dependent-chain wave of the DC or clock stage holds the other three back.  In the streaming form
-// a workgroup is ONE wave that walks along one channel: S consecutive mini-tiles of 960 samples, LPF1 -> discriminator ->
-// LPF2 per mini-tile, the discriminator's predecessor sample and LPF2's T2 - 1 samples of overlap carried from mini-tile to
-// mini-tile in LDS instead of being recomputed (the tiled form recomputes them for every tile: 1.5 % of its LPF1 work).
-// Only the first mini-tile of a stretch has to warm up: T2 LPF1 outputs in front of it, one per lane.
-// Indices: n = sample index inside the call's input (negative: carried history).  y[n] = LPF1 output at n, q[n] =
-// discriminator output at n (uses y[n], y[n-1]), LPF2 output k uses q[i0 + k d - (T2-1) .. i0 + k d].
-// LDS of a workgroup (floats unless noted): xs[NY + T1 - 1] float2 raw samples of the mini-tile; aliased by qs[T2 - 1 + NY]
-// (q of the mini-tile behind the carried T2 - 1) and zs[NY] (LPF2 outputs staged for coalesced stores) once LPF1 is done;
-// bnd[64] float2; carry[T2 - 1]; the {entry, difference} arctangent table; both filters' taps.
-#define SDRM_K1S_LANES 64
-#define SDRM_K1S_NY (SDRM_K1S_LANES * SDRM_K1_R)  // samples per mini-tile
-#define SDRM_K1S_T2_MAX 480                       // the warm-up's scratch shares the raw tile's space: 2 T2 <= NY
-
-struct sdrm_k1s_view {      // a workgroup's LDS, carved once
-    sdrm_f2 *xs;            // raw mini-tile (+ T1 - 1 in front)
-    float *qs;              // = (float *) xs
-    float *zs;              // qs + zs_off
-    sdrm_f2 *bnd;           // [64] last LPF1 output of every lane
-    float *carry;           // [T2 - 1] the discriminator samples in front of the next mini-tile
-    float *tab2;            // [257][2]
-    float *taps1, *taps2;
-};
-SDRM_HD int sdrm_k1s_zs_off(int t2_max) { return (t2_max - 1 + SDRM_K1S_NY + 15) & ~3; }
-SDRM_HD size_t sdrm_k1s_xs_bytes(int t1_max, int t2_max) {
-    const size_t raw = (size_t) (SDRM_K1S_NY + t1_max - 1) * 8;
-    const size_t out = (size_t) (sdrm_k1s_zs_off(t2_max) + SDRM_K1S_NY) * 4;
-    return ((raw > out ? raw : out) + 15) & ~(size_t) 15;
-}
-
-// mini-tiles per workgroup: enough workgroups to balance ~3000 resident waves several times over, few enough that the
-// warm-up (one LPF1 output per lane: ~6 % of a mini-tile's instructions) stays small
-SDRM_HD int sdrm_k1s_tiles_per_wg(long total_tiles) {
-    const long s = total_tiles / 24576;
-    return s < 2 ? 2 : (s > 16 ? 16 : (int) s);
-}
-
-// ---- warm-up of a stretch that starts at sample n0: y[n0 - T2 .. n0 - 1], one per lane and pass
-// W0: the T1 + T2 - 1 samples in front of n0
-SDRM_HD void sdrm_k1s_warm_load(int lane, const sdrm_chan_params &p, const sdrm_f2 *in, const sdrm_f2 *hist, int n0, sdrm_f2 *xs) {
-    const int W = (int) p.hist_len;
-    for (int k = lane; k < W; k += SDRM_K1S_LANES) {
-        xs[k] = sdrm_ext_sample(in, hist, W, n0 - W + k);
-    }
-}
-// W1: y[n0 - T2 + w], w = 64 pass + lane, into ybuf[w]
-template <bool FUSED>
-SDRM_HD void sdrm_k1s_warm_lpf1(int lane, int pass, const sdrm_chan_params &p, const float *taps1_rev, const sdrm_f2 *xs, sdrm_f2 *ybuf) {
-    const int w = pass * SDRM_K1S_LANES + lane;
-    if (w < (int) p.T2) {
-        sdrm_f2 acc[1];
-        acc[0].x = 0.0f;
-        acc[0].y = 0.0f;
-        sdrm_fir_block_c<1, SDRM_K1_U, FUSED>(xs + w, taps1_rev, (int) p.T1, acc);
-        ybuf[w] = acc[0];
-    }
-}
-// W2: q[n0 - T2 + w] for w >= 1 into carry[w - 1]
-SDRM_HD void sdrm_k1s_warm_quad(int lane, int pass, const sdrm_chan_params &p, const float *tab2, const sdrm_f2 *ybuf, float *carry) {
-    const int w = pass * SDRM_K1S_LANES + lane;
-    if (w >= 1 && w < (int) p.T2) {
-        carry[w - 1] = sdrm_quad_sample_flat<2>(ybuf[w], ybuf[w - 1], p.quad_gain, tab2);
-    }
-}
-
-// ---- one mini-tile that starts at sample nt
-// T0: raw samples nt - (T1 - 1) .. nt + NY - 1 (zeros past the input's end)
-SDRM_HD void sdrm_k1s_tile_load(int lane, const sdrm_chan_params &p, const sdrm_f2 *in, const sdrm_f2 *hist, int nt, int n_in, sdrm_f2 *xs) {
-    const int nx = SDRM_K1S_NY + (int) p.T1 - 1;
-    const int first = nt - ((int) p.T1 - 1);
-    constexpr int DEPTH = SDRM_K1_R + 2;  // 17 x 64 = 1088 samples: a mini-tile with a halo of up to 128 in one go
-    if (first >= 0 && nt + SDRM_K1S_NY <= n_in && nx <= DEPTH * SDRM_K1S_LANES) {
-        // interior mini-tile: one base, constant offsets, every load in flight before the first store
-        const sdrm_f2 *src = in + first + lane;
-        sdrm_f2 v[DEPTH];
-#pragma unroll
-        for (int i = 0; i < DEPTH; i++) {
-            v[i].x = 0.0f;
-            v[i].y = 0.0f;
-            if (lane + i * SDRM_K1S_LANES < nx) {
-                v[i] = src[i * SDRM_K1S_LANES];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < DEPTH; i++) {
-            if (lane + i * SDRM_K1S_LANES < nx) {
-                xs[lane + i * SDRM_K1S_LANES] = v[i];
-            }
-        }
-        return;
-    }
-    for (int k = lane; k < nx; k += SDRM_K1S_LANES) {
-        sdrm_f2 v;
-        v.x = 0.0f;
-        v.y = 0.0f;
-        if (first + k < n_in) {
-            v = sdrm_ext_sample(in, hist, (int) p.hist_len, first + k);
-        }
-        xs[k] = v;
-    }
-}
-// T1: LPF1 on the lane's fifteen samples nt + 15 lane .. + 14
-template <bool FUSED>
-SDRM_HD void sdrm_k1s_tile_lpf1(int lane, const sdrm_chan_params &p, const float *taps1_rev, const sdrm_f2 *xs, sdrm_f2 *bnd, sdrm_k1_regs &regs) {
-#pragma unroll
-    for (int r = 0; r < SDRM_K1_R; r++) {
-        regs.y[r].x = 0.0f;
-        regs.y[r].y = 0.0f;
-    }
-    sdrm_fir_block_c<SDRM_K1_R, SDRM_K1_U, FUSED>(xs + lane * SDRM_K1_R, taps1_rev, (int) p.T1, regs.y);
-    bnd[lane] = regs.y[SDRM_K1_R - 1];
-}
-// T2: discriminator; qs[0 .. T2-2] = the carried samples, qs[T2 - 1 + 15 lane + r] = q[nt + 15 lane + r]
-SDRM_HD void sdrm_k1s_tile_quad(int lane, const sdrm_chan_params &p, const float *tab2, const sdrm_f2 *bnd, sdrm_f2 y_prev,
-                                const sdrm_k1_regs &regs, const float *carry, float *qs) {
-    const int T2m1 = (int) p.T2 - 1;
-    sdrm_f2 prev = y_prev;
-    if (lane > 0) {
-        prev = bnd[lane - 1];
-    }
-    float q[SDRM_K1_R];
-    bool done = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-    sdrm_lds_cf tab2_l = (sdrm_lds_cf) tab2;
-    asm volatile("" : "+s"(tab2_l));
-    done = __all(sdrm_quad_block_fast<SDRM_K1_R>(regs.y, prev, p.quad_gain, tab2_l, q));
-#endif
-    if (!done) {
-        sdrm_f2 pv = prev;
-#pragma unroll
-        for (int r = 0; r < SDRM_K1_R; r++) {
-            q[r] = sdrm_quad_sample_flat<2>(regs.y[r], pv, p.quad_gain, tab2);
-            pv = regs.y[r];
-        }
-    }
-    for (int k = lane; k < T2m1; k += SDRM_K1S_LANES) {
-        qs[k] = carry[k];
-    }
-    float *dst = qs + T2m1 + lane * SDRM_K1_R;
-#pragma unroll
-    for (int r = 0; r < SDRM_K1_R; r++) {
-        dst[r] = q[r];
-    }
-}
-// the LPF2 outputs whose last sample lies in the mini-tile: k in [k_lo, k_lo + m)
-SDRM_HD void sdrm_k1s_tile_outputs(const sdrm_chan_params &p, const sdrm_chunk_ctl &c, int nt, int *k_lo, int *m) {
-    const int d = (int) p.decim, i0 = (int) c.i0;
-    int lo = nt - i0;
-    lo = lo > 0 ? (lo + d - 1) / d : 0;                        // first k with i0 + k d >= nt
-    int hi = nt + SDRM_K1S_NY - i0;
-    hi = hi > 0 ? (hi + d - 1) / d : 0;                        // first k with i0 + k d >= nt + NY
-    hi = hi < (int) c.nz ? hi : (int) c.nz;
-    *k_lo = lo;
-    *m = hi > lo ? hi - lo : 0;
-}
-// T3: LPF2 (reference src/dsp/fir_filter.c:93-114) into zs[k - k_lo]; returns true when a result is not finite
-template <bool FUSED>
-SDRM_HD bool sdrm_k1s_tile_lpf2(int lane, const sdrm_chan_params &p, const sdrm_chunk_ctl &c, int nt, const float *taps2_rev,
-                                const float *qs, float *zs) {
-    int k_lo, m;
-    sdrm_k1s_tile_outputs(p, c, nt, &k_lo, &m);
-    bool odd = false;
-    if (p.decim == 1) {
-        // output k = nt + s reads qs[s .. s + T2 - 1]: the lane's fifteen adjacent ones, packed in pairs
-        const int base = lane * SDRM_K1_RZ;
-        if (base < m) {
-            float acc[SDRM_K1_RZ];
-#pragma unroll
-            for (int r = 0; r < SDRM_K1_RZ; r++) {
-                acc[r] = 0.0f;
-            }
-            sdrm_fir_block_rp<SDRM_K1_RZ, SDRM_K1_U, FUSED>(qs + base, taps2_rev, (int) p.T2, acc);
-#pragma unroll
-            for (int r = 0; r < SDRM_K1_RZ; r++) {
-                if (base + r < m) {
-                    zs[base + r] = acc[r];
-                    odd |= !(fabsf(acc[r]) < INFINITY);
-                }
-            }
-        }
-        return odd;
-    }
-    // decimating: output k_lo + j reads qs from i0 + (k_lo + j) d - nt on; lane takes j = lane, lane + 64, ... four at a time
-    const int d = (int) p.decim;
-    const int s0 = (int) c.i0 + k_lo * d - nt;
-    for (int j0 = lane; j0 < m; j0 += 4 * SDRM_K1S_LANES) {
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const int valid = (m - j0 + SDRM_K1S_LANES - 1) / SDRM_K1S_LANES;
-        sdrm_fir_block_rd<4, SDRM_K1_U, FUSED>(qs + s0 + j0 * d, SDRM_K1S_LANES * d, valid, taps2_rev, (int) p.T2, acc);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int j = j0 + r * SDRM_K1S_LANES;
-            if (j < m) {
-                zs[j] = acc[r];
-                odd |= !(fabsf(acc[r]) < INFINITY);
-            }
-        }
-    }
-    return odd;
-}
-// T4: staged outputs to memory (consecutive lanes, consecutive outputs); the last T2 - 1 discriminator samples to `carry`
-SDRM_HD void sdrm_k1s_tile_store(int lane, const sdrm_chan_params &p, const sdrm_chunk_ctl &c, int nt, const float *zs, const float *qs,
-                                 float *z_out, float *carry) {
-    int k_lo, m;
-    sdrm_k1s_tile_outputs(p, c, nt, &k_lo, &m);
-    for (int j = lane; j < m; j += SDRM_K1S_LANES) {
-        z_out[k_lo + j] = zs[j];
-    }
-    const int T2m1 = (int) p.T2 - 1;
-    for (int k = lane; k < T2m1; k += SDRM_K1S_LANES) {
-        carry[k] = qs[SDRM_K1S_NY + k];
-    }
-}
-
 // K1h: next call's history = the last hist_len samples of (history ++ input)
 SDRM_HD void sdrm_hist_roll(int tid, int nthreads, const sdrm_chan_params &p, const sdrm_chunk_ctl &c, const sdrm_f2 *in,
                             const sdrm_f2 *hist_cur, sdrm_f2 *hist_next) {

@@ -383,105 +383,6 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     }
 }
 
-// ---- streaming form (bodies and rationale: sdrm_kernels.h, "K1, streaming form").  One wave per workgroup, grid
-// (stretches, channels): no wave ever waits for another.
-size_t k1s_lds_bytes(uint32_t t1_max, uint32_t t2_max) {
-    return sdrm_k1s_xs_bytes((int) t1_max, (int) t2_max) + SDRM_K1S_LANES * sizeof(sdrm_f2) +
-           (size_t) (((t2_max + 3) & ~3u) + 516 + ((t1_max + 3) & ~3u) + ((t2_max + 3) & ~3u) + 8) * sizeof(float);
-}
-
-// An EXPERIMENT, off unless SDRM_K1_STREAM=1 (read per call): built to take the barrier coupling out of the front-end
-// (DESIGN.md section 9), bit-exact on every test -- and slower than the tiled form everywhere (alone 0.51 against 0.42 ms
-// per 256 channels, 4096 channels 9.9 against 9.2 ms per call, profiles/r03_k1_stream.txt): one wave per workgroup has to
-// hold a whole mini-tile, the tables and the carried samples (12 KB, 152 registers), which caps a CU at 12 waves, and its
-// memory phase is no longer covered by three other waves of the same workgroup's neighbours.
-bool front_streams(uint32_t t1_max, uint32_t t2_max, int n_channels) {
-    const char *e = getenv("SDRM_K1_STREAM");
-    const bool fits = t2_max <= SDRM_K1S_T2_MAX && k1s_lds_bytes(t1_max, t2_max) <= 60 * 1024;
-    (void) n_channels;
-    return fits && e != nullptr && atoi(e) != 0;
-}
-
-template <bool FUSED>
-__global__ __launch_bounds__(SDRM_K1S_LANES, 3) void k1_stream(DeviceBatch b, const sdrm_f2 *__restrict__ d_in, size_t in_stride) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char k1s_lds[];
-    const int c = blockIdx.y;
-    const int lane = threadIdx.x;
-    const sdrm_chunk_ctl ctl = b.ctl[c];
-    const sdrm_chan_params p = b.params[c];
-    const sdrm_f2 *in = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
-    const sdrm_f2 *hist = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
-    if (blockIdx.x == 0) {
-        sdrm_f2 *next = b.raw_hist + ((size_t) c * 2 + (ctl.parity ^ 1u)) * b.hist_stride;
-        sdrm_hist_roll(lane, SDRM_K1S_LANES, p, ctl, in, hist, next);
-    }
-    const int n_in = (int) ctl.n_in;
-    const int tiles = (n_in + SDRM_K1S_NY - 1) / SDRM_K1S_NY;
-    const int t_first = (int) blockIdx.x * b.stream_tiles_per_wg;
-    if (t_first >= tiles || ctl.nz == 0) {
-        return;
-    }
-    const int t_last = min(tiles, t_first + b.stream_tiles_per_wg);
-    tl_mark(b, 0, 0);
-    __builtin_amdgcn_s_setprio(1);
-    sdrm_k1s_view v;
-    v.xs = reinterpret_cast<sdrm_f2 *>(k1s_lds);
-    v.qs = reinterpret_cast<float *>(k1s_lds);
-    v.zs = v.qs + sdrm_k1s_zs_off((int) b.t2_max);
-    v.bnd = reinterpret_cast<sdrm_f2 *>(k1s_lds + sdrm_k1s_xs_bytes((int) b.t1_max, (int) b.t2_max));
-    v.carry = reinterpret_cast<float *>(v.bnd + SDRM_K1S_LANES);
-    v.tab2 = v.carry + ((b.t2_max + 3) & ~3u);
-    v.taps1 = v.tab2 + 516;
-    v.taps2 = v.taps1 + ((p.T1 + 3) & ~3u);
-    for (int k = lane; k < 257; k += SDRM_K1S_LANES) {
-        const float t0 = b.atan_tab[k];
-        v.tab2[2 * k] = t0;
-        v.tab2[2 * k + 1] = k < 256 ? b.atan_tab[k + 1] - t0 : 0.0f;  // the reference's subtraction (fast_atan2f.c:118)
-    }
-    for (uint32_t k = lane; k < p.T1; k += SDRM_K1S_LANES) {
-        v.taps1[k] = b.tap_pool[p.taps1_off + k];
-    }
-    for (uint32_t k = lane; k < p.T2; k += SDRM_K1S_LANES) {
-        v.taps2[k] = b.tap_pool[p.taps2_off + k];
-    }
-    // ---- warm-up: the T2 LPF1 outputs and T2 - 1 discriminator samples in front of the stretch
-    const int n0 = t_first * SDRM_K1S_NY;
-    sdrm_k1s_warm_load(lane, p, in, hist, n0, v.xs);
-    __builtin_amdgcn_wave_barrier();
-    sdrm_f2 *ybuf = v.xs + p.hist_len;
-    const int passes = ((int) p.T2 + SDRM_K1S_LANES - 1) / SDRM_K1S_LANES;
-    for (int pass = 0; pass < passes; pass++) {
-        sdrm_k1s_warm_lpf1<FUSED>(lane, pass, p, v.taps1, v.xs, ybuf);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int pass = 0; pass < passes; pass++) {
-        sdrm_k1s_warm_quad(lane, pass, p, v.tab2, ybuf, v.carry);
-    }
-    sdrm_f2 y_prev = ybuf[p.T2 - 1];
-    __builtin_amdgcn_wave_barrier();
-    bool odd = false;
-    float *z_out = b.z + (size_t) c * b.z_stride;
-    for (int t = t_first; t < t_last; t++) {
-        const int nt = t * SDRM_K1S_NY;
-        sdrm_k1s_tile_load(lane, p, in, hist, nt, n_in, v.xs);
-        __builtin_amdgcn_wave_barrier();
-        sdrm_k1_regs regs;
-        sdrm_k1s_tile_lpf1<FUSED>(lane, p, v.taps1, v.xs, v.bnd, regs);
-        __builtin_amdgcn_wave_barrier();
-        sdrm_k1s_tile_quad(lane, p, v.tab2, v.bnd, y_prev, regs, v.carry, v.qs);
-        __builtin_amdgcn_wave_barrier();
-        odd |= sdrm_k1s_tile_lpf2<FUSED>(lane, p, ctl, nt, v.taps2, v.qs, v.zs);
-        __builtin_amdgcn_wave_barrier();
-        sdrm_k1s_tile_store(lane, p, ctl, nt, v.zs, v.qs, z_out, v.carry);
-        y_prev = v.bnd[SDRM_K1S_LANES - 1];
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (odd) {
-        b.nonfinite[c] = 1u;  // tells the clock stage to take its general (NaN-aware) path for this channel
-    }
-    tl_mark(b, 0, 1);
-}
-
 // dynamic LDS above the 64 KiB default has to be requested per kernel (up to the CU's 160 KiB); the attribute belongs
 // to the kernel's code object on ONE device, so what has been granted is remembered per device (a process that drives
 // several GPUs gets it right for each)
@@ -513,21 +414,6 @@ static void launch_described(const KernelLaunch &k, void **args, hipStream_t s) 
 KernelLaunch describe_front(const DeviceBatch &b) {
     KernelLaunch k;
     static lds_grant granted, granted_fused;
-    if (b.stream_tiles_per_wg > 0) {
-        static lds_grant granted_s, granted_sf;
-        k.lds = k1s_lds_bytes(b.t1_max, b.t2_max);
-        if (b.fast_fma) {
-            allow_lds(k1_stream<true>, k.lds, &granted_sf);
-            k.func = reinterpret_cast<const void *>(k1_stream<true>);
-        } else {
-            allow_lds(k1_stream<false>, k.lds, &granted_s);
-            k.func = reinterpret_cast<const void *>(k1_stream<false>);
-        }
-        const unsigned stretches = (b.stream_max_tiles + (unsigned) b.stream_tiles_per_wg - 1) / (unsigned) b.stream_tiles_per_wg;
-        k.grid = dim3(stretches ? stretches : 1u, (unsigned) b.n_channels);  // stretch 0 of every channel also rolls its history
-        k.block = dim3(SDRM_K1S_LANES);
-        return k;
-    }
     k.lds = k1_lds_bytes(b.t1_max, b.t2_max);
     if (b.fast_fma) {
         allow_lds(k1_front<true>, k.lds, &granted_fused);

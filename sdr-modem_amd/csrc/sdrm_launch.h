@@ -48,8 +48,6 @@ struct DeviceBatch {
     uint32_t dc_group, dc_rpitch;    // channels per DC workgroup, floats between two of its delay rings in LDS
     uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
-    int stream_tiles_per_wg;         // > 0: the front-end runs in its streaming form, that many mini-tiles per one-wave workgroup
-    uint32_t stream_max_tiles;       // mini-tiles of the longest input of this call
     int k3_carried_max;              // most samples a channel can carry between calls of the clock stage (sizes its ring)
     int chain_prio;                  // measurements (SDRM_CHAIN_PRIO): issue priority of the DC chain wave and the clock stage's consumer (default 3)
     int quad_flat;                   // measurements (SDRM_K1_QUAD=flat): the discriminator always takes its general form
@@ -77,8 +75,6 @@ KernelLaunch describe_clock(const DeviceBatch &b);      // args: DeviceBatch
 KernelLaunch describe_quantize(const DeviceBatch &b);   // args: DeviceBatch (nothing to launch for the shapes that convert inside the clock stage)
 
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max);
-size_t k1s_lds_bytes(uint32_t t1_max, uint32_t t2_max);
-bool front_streams(uint32_t t1_max, uint32_t t2_max, int n_channels);
 bool front_waits_for_clock_start(int n_channels);
 sdrm_k3_shape describe_shape(const DeviceBatch &b);  // the clock-stage shape the next launch takes
 bool front_hold_is_forced();      // SDRM_FRONT_HOLD is set: measurements, not to be re-decided by the batch's calibration

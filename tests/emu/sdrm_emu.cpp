@@ -165,81 +165,8 @@ static void emu_front(EmuBatch *b, const sdrm_f2 *const *inputs) {
     }
 }
 
-// the streaming form of the front-end (k1_stream): one wave per workgroup walks along a channel; the per-lane bodies of
-// sdrm_kernels.h driven lane by lane, phase by phase, in the kernel's order
-static void emu_front_stream(EmuBatch *b, const sdrm_f2 *const *inputs, int tiles_per_wg) {
-    const BatchPlan &pl = b->plan;
-    const size_t C = pl.params.size();
-    const size_t xs_floats = sdrm_k1s_xs_bytes((int) pl.t1_max, (int) pl.t2_max) / 4;
-    std::vector<float> lds(xs_floats);
-    std::vector<sdrm_f2> bnd(SDRM_K1S_LANES);
-    std::vector<float> carry(pl.t2_max + 4), tab2(516);
-    std::vector<sdrm_k1_regs> regs(SDRM_K1S_LANES);
-    for (int k = 0; k < 257; k++) {
-        tab2[2 * k] = sdrm_atan_tab[k];
-        tab2[2 * k + 1] = k < 256 ? sdrm_atan_tab[k + 1] - sdrm_atan_tab[k] : 0.0f;
-    }
-    for (size_t c = 0; c < C; c++) {
-        const sdrm_chan_params &p = pl.params[c];
-        const sdrm_chunk_ctl &ctl = b->ctl[c];
-        const sdrm_f2 *in = inputs[c];
-        const sdrm_f2 *hist = b->hist.data() + (c * 2 + ctl.parity) * pl.hist_stride;
-        const float *taps1 = pl.tap_pool.data() + p.taps1_off, *taps2 = pl.tap_pool.data() + p.taps2_off;
-        const int n_in = (int) ctl.n_in;
-        const int tiles = (n_in + SDRM_K1S_NY - 1) / SDRM_K1S_NY;
-        sdrm_f2 *xs = reinterpret_cast<sdrm_f2 *>(lds.data());
-        float *qs = lds.data(), *zs = qs + sdrm_k1s_zs_off((int) pl.t2_max);
-        for (int t_first = 0; t_first < tiles && ctl.nz != 0; t_first += tiles_per_wg) {
-            const int t_last = std::min(tiles, t_first + tiles_per_wg);
-            for (auto &v : lds) v = NAN;  // a read of a slot nobody wrote shows up as NaN in the outputs
-            for (auto &v : carry) v = NAN;
-            const int n0 = t_first * SDRM_K1S_NY;
-            for (int lane = 0; lane < SDRM_K1S_LANES; lane++) sdrm_k1s_warm_load(lane, p, in, hist, n0, xs);
-            sdrm_f2 *ybuf = xs + p.hist_len;
-            const int passes = ((int) p.T2 + SDRM_K1S_LANES - 1) / SDRM_K1S_LANES;
-            for (int pass = 0; pass < passes; pass++)
-                for (int lane = 0; lane < SDRM_K1S_LANES; lane++) sdrm_k1s_warm_lpf1<false>(lane, pass, p, taps1, xs, ybuf);
-            for (int pass = 0; pass < passes; pass++)
-                for (int lane = 0; lane < SDRM_K1S_LANES; lane++) sdrm_k1s_warm_quad(lane, pass, p, tab2.data(), ybuf, carry.data());
-            sdrm_f2 y_prev = ybuf[p.T2 - 1];
-            for (int t = t_first; t < t_last; t++) {
-                const int nt = t * SDRM_K1S_NY;
-                for (int lane = 0; lane < SDRM_K1S_LANES; lane++) sdrm_k1s_tile_load(lane, p, in, hist, nt, n_in, xs);
-                for (int lane = 0; lane < SDRM_K1S_LANES; lane++) sdrm_k1s_tile_lpf1<false>(lane, p, taps1, xs, bnd.data(), regs[lane]);
-                for (int lane = 0; lane < SDRM_K1S_LANES; lane++)
-                    sdrm_k1s_tile_quad(lane, p, tab2.data(), bnd.data(), y_prev, regs[lane], carry.data(), qs);
-                bool odd = false;
-                for (int lane = 0; lane < SDRM_K1S_LANES; lane++) odd |= sdrm_k1s_tile_lpf2<false>(lane, p, ctl, nt, taps2, qs, zs);
-                if (odd) b->nonfinite[c] = 1u;
-                for (int lane = 0; lane < SDRM_K1S_LANES; lane++)
-                    sdrm_k1s_tile_store(lane, p, ctl, nt, zs, qs, b->z.data() + c * pl.z_stride, carry.data());
-                y_prev = bnd[SDRM_K1S_LANES - 1];
-            }
-        }
-        sdrm_f2 *next = b->hist.data() + (c * 2 + (ctl.parity ^ 1u)) * pl.hist_stride;
-        for (int tid = 0; tid < SDRM_K1S_LANES; tid++) sdrm_hist_roll(tid, SDRM_K1S_LANES, p, ctl, in, hist, next);
-    }
-}
+static void emu_front_any(EmuBatch *b, const sdrm_f2 *const *inputs) { emu_front(b, inputs); }
 
-// the form the library would launch (same switch: SDRM_K1_STREAM, SDRM_K1_STREAM_TILES)
-static void emu_front_any(EmuBatch *b, const sdrm_f2 *const *inputs) {
-    const BatchPlan &pl = b->plan;
-    const char *e = getenv("SDRM_K1_STREAM");
-    if (e != nullptr && atoi(e) != 0 && pl.t2_max <= SDRM_K1S_T2_MAX) {
-        long total = 0;
-        for (size_t c = 0; c < pl.params.size(); c++) total += (b->ctl[c].n_in + SDRM_K1S_NY - 1) / SDRM_K1S_NY;
-        int per = sdrm_k1s_tiles_per_wg(total);
-        if (const char *t = getenv("SDRM_K1_STREAM_TILES")) per = std::max(1, atoi(t));
-        emu_front_stream(b, inputs, per);
-    } else {
-        emu_front(b, inputs);
-    }
-}
-
-// K2: the device's roles (chain wave, feeder, three stage helpers, output; sdrm_kernels.h) driven lane by lane in the
-// kernel's iteration order.  Within an iteration the six waves run concurrently on the device and touch disjoint
-// buffers; here they run one after the other, in alternating order from iteration to iteration, so that a dependence
-// between two roles inside one iteration would show up as a wrong result.
 static void emu_dc(EmuBatch *b) {
     const BatchPlan &pl = b->plan;
     if (!pl.any_dc) return;

@@ -273,26 +273,6 @@ def test_fast_fma_mode_is_measured_against_the_references_tolerance(capsys):
     run_stream((48000, 4800, 5000, 2, 2000, True), iq[:20000], [4096] * 4 + [3616], 4096)
 
 
-def test_streaming_form_of_the_front_end_on_the_device(monkeypatch):
-    """k1_stream (SDRM_K1_STREAM=1, an experiment kept for the record: DESIGN.md section 9): the same bits as the tiled
-    front-end -- ragged chunks, decimation, 289-tap LPF2, a 70-channel batch"""
-    monkeypatch.setenv("SDRM_K1_STREAM", "1")
-    monkeypatch.setenv("SDRM_K1_STREAM_TILES", "3")
-    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
-    chunks = [0, 1, 7, 959, 960, 961, 5000, 9000, 1, 8191, 12000, 64, 65]
-    for cfg in [(48000, 9600, 5000, 1, 2000, True), (48000, 4800, 5000, 2, 2000, False)]:
-        run_stream(cfg, iq, chunks, 12000)
-    sig = siggen.gmsk_channel(3, 30000, fs=240000, baud=19200)
-    run_stream((240000, 19200, 5000, 5, 2000, True), sig, [10000, 5, 19995], 20000)
-    cfg = (48000, 9600, 5000, 1, 2000, True)
-    sigs = siggen.gmsk_batch(70, 9000)
-    g = binding.Batch([cfg + (9000,)] * 70)
-    got = g.process([sigs[c] for c in range(70)])
-    for c in (0, 33, 69):
-        assert np.array_equal(got[c], orc.demod_stream(cfg, sigs[c], 9000)[0]), c
-    g.close()
-
-
 def test_ragged_chunks():
     iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
     chunks = [0, 1, 1, 1, 7, 0, 100, 3839, 3840, 3841, 5000, 9000, 1, 2, 8191, 12000, 64, 63, 65, 1]

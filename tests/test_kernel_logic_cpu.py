@@ -459,25 +459,6 @@ def test_nco_sample_is_the_correctly_rounded_float_of_the_exact_cosine():
             assert np.float32(got) == best, float(ph)
 
 
-@pytest.mark.parametrize("tiles", ["1", "3", "16"])
-def test_streaming_front_end_equals_the_tiled_one(tiles, monkeypatch):
-    """The front-end's streaming form (k1_stream: one wave per workgroup walks along a channel, the discriminator's
-    predecessor and LPF2's overlap carried between 960-sample mini-tiles, a one-output-per-lane warm-up in front of every
-    stretch) against the oracle: ragged chunks around the mini-tile size, decimation 1 / 2 / 3 / 5 / 8, filters longer than a
-    warm-up pass (289 taps), the NaN fixture, stretches of 1, 3 and 16 mini-tiles."""
-    monkeypatch.setenv("SDRM_K1_STREAM", "1")
-    monkeypatch.setenv("SDRM_K1_STREAM_TILES", tiles)
-    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.expected.cf32"), dtype=np.complex64)
-    chunks = [0, 1, 1, 7, 0, 100, 959, 960, 961, 1919, 1921, 5000, 9000, 1, 2, 8191, 12000, 64, 63, 65, 1]
-    for cfg in [(48000, 9600, 5000, 1, 2000, True), (48000, 4800, 5000, 2, 2000, True), (48000, 4800, 5000, 3, 2000, False)]:
-        assert run_both(cfg, iq, chunks, 12000) <= len(iq)
-    for cfg, fs, baud in [((240000, 19200, 5000, 5, 2000, True), 240000, 19200), ((48000, 1200, 5000, 8, 2000, True), 48000, 1200),
-                          ((240000, 19200, 5000, 1, 2000, False), 240000, 19200)]:
-        sig = siggen.gmsk_channel(3, 30000, fs=fs, baud=baud)
-        run_both(cfg, sig, [10000, 5, 19995], 20000)
-    nan = np.fromfile(os.path.join(GOLDEN, "inputnan.cf32"), dtype=np.complex64)
-    run_both((240000, 9600, 5000, 1, 2000, True), nan, [4096], 4096)
-
 
 def test_batch_geometry_grows_with_a_new_clients_configuration():
     """plan_growth / apply_growth (shared with the device path's grow_geometry): a batch of small no-DC channels takes, slot
