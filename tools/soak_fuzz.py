@@ -1,6 +1,7 @@
 """Soak: seeded differential fuzz of the HIP path against the oracle for a given number of seconds (GPU box).
 Every round draws a batch of random configurations (as tests/test_gpu_fuzz.py), random signals -- GMSK, white noise over
 many decades, silence, denormal-scale and constant stretches spliced in -- and random call lengths up to 20000 samples;
+every fifth round adds channels of 267 to 400 samples per symbol (generic stages);
 every third round also drives one plain fsk_demod handle with repeated lengths (the graph replay), every fourth the
 pinned-arena pipeline with three calls in flight, every fifth device-resident calls queued back to back, every 25th a batch
 of 400 to 2100 channels.  Bit-exact or it stops.
@@ -45,6 +46,9 @@ while time.time() < t_end:
     if seed % 7 == 2:  # round 3: long symbols (up to 240 samples each, DC boxcars up to 7680) inside an ordinary batch
         cfgs += [c + (maxlen,) for c in [(240000, 1200, 5000, 1, 2000, True), (192000, 1200, 2400, 1, 4000, bool(rng.integers(0, 2))),
                                          (240000, 1000, 5000, 1, 2000, True), (96000, 1200, 7500, 1, 1000, False)]]
+    if seed % 5 == 1:  # round 4: symbols beyond the fast stages' range (generic DC / clock stages) inside an ordinary batch
+        cfgs += [c + (maxlen,) for c in [(240000, 600, 5000, 1, 2000, True), (240000, 900, 2400, 1, 1000, bool(rng.integers(0, 2))),
+                                         (480000, 1200, 5000, 1, 2000, False), (96000, 300, 5000, 1, 2000, True)]]
     oracles = [orc.Fsk(*c) for c in cfgs]
     keep = [o.code == 0 for o in oracles]
     cfgs = [c for c, k in zip(cfgs, keep) if k]; oracles = [o for o, k in zip(oracles, keep) if k]

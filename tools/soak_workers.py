@@ -1,6 +1,7 @@
 """Soak of the dsp_worker surface (create / put / destroy, file sinks): rounds of several workers at once, each fed by its own
-thread with random buffer sizes and pauses -- private demodulators (blocking file-source queues) and workers bound to a shared
-batcher -- then destroyed; every rx.demod2client.<id>.s8 must be byte-identical to the oracle's soft bits of that worker's
+thread with random buffer sizes and pauses -- private demodulators (blocking file-source queues), workers bound to a shared
+batcher, and (round 4) workers placed by a node of two batchers on the device, some with the file source's frequency offset,
+some with symbols beyond the fast stages' range -- then destroyed; every rx.demod2client.<id>.s8 must be byte-identical to the oracle's soft bits of that worker's
 stream and every rx.sdr2demod.<id>.cf32 to what was put.  python tools/soak_workers.py [seconds] [first seed]"""
 import ctypes as C, os, sys, time, threading, tempfile
 import numpy as np
@@ -27,9 +28,19 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed)
     bufsize = int(rng.choice([2048, 4096]))
     cfgs = [c for c in _cases(seed, int(rng.integers(1, 10))) if orc.Fsk(*c, bufsize).code == 0]
-    shared = bool(rng.integers(0, 2)) and len(cfgs) > 1
+    layout = int(rng.integers(0, 3))  # 0 private, 1 one shared batcher, 2 a node of two batchers
+    shared = layout == 1 and len(cfgs) > 1
+    if layout == 2 and seed % 4 == 0:
+        cfgs.append((240000, 600, 5000, 1, 2000, bool(rng.integers(0, 2))))  # 400 samples per symbol: the generic stages
+    offsets = [int(rng.choice([0, 0, 1000, -2500])) for _ in cfgs]
     with tempfile.TemporaryDirectory() as tmp:
         bt = None
+        node = None
+        if layout == 2:
+            node = binding.Node(cfgs[0] + (bufsize,), max(2, (len(cfgs) + 1) // 2 + 1), n_batchers=2, devices=[0, 0],
+                                batcher=(4, int(rng.choice([300, 3000])), True))
+            if node.code != 0:
+                fail("node create failed: %d (seed %d)" % (node.code, seed))
         if shared:  # geometry of the batcher = the configuration with the longest filters, so that every client fits
             order = sorted(range(len(cfgs)), key=lambda i: (-cfgs[i][0] / max(cfgs[i][4], 1), -cfgs[i][0] / cfgs[i][1]))
             geom = cfgs[order[0]] + (bufsize,)
@@ -42,6 +53,10 @@ while time.time() < t_end:
             if shared:
                 wc.batcher = bt.h
                 wc.batcher_channel = i
+            if node is not None:
+                wc.node = node.h
+                wc.source_id = 1 + i % 2
+            wc.rx_offset_hz = offsets[i]
             w = C.c_void_p()
             code = L.dsp_worker_create(100 + i, -1, C.byref(wc), C.byref(w))
             if code != 0:
@@ -76,19 +91,27 @@ while time.time() < t_end:
                 continue
             sig, sizes, _ = streams[i]
             o = orc.Fsk(*c, bufsize)
+            osc = orc.Nco(1.0, c[0], bufsize) if offsets[i] else None
             want, p = [], 0
             for n in sizes:
-                want.append(o.process(sig[p:p + n])[0]); p += n
+                part = sig[p:p + n]
+                if osc is not None:
+                    part = osc.multiply(offsets[i], np.ascontiguousarray(part).view(np.float32))
+                want.append(o.process(part)[0]); p += n
             want = np.concatenate(want) if want else np.zeros(0, np.int8)
             got = np.fromfile(os.path.join(tmp, "rx.demod2client.%d.s8" % (100 + i)), dtype=np.int8)
             dump = np.fromfile(os.path.join(tmp, "rx.sdr2demod.%d.cf32" % (100 + i)), dtype=np.complex64)
             if not np.array_equal(dump, sig[:p]):
                 fail("MISMATCH iq dump: seed %d worker %d (%s)" % (seed, i, "batcher-bound" if shared else "private"))
             if not np.array_equal(got, want):
-                fail("MISMATCH soft bits: seed %d worker %d cfg %s sizes %s (%s): %d vs %d bytes" % (
-                    seed, i, c, sizes, "batcher-bound" if shared else "private", len(got), len(want)))
+                fail("MISMATCH soft bits: seed %d worker %d cfg %s sizes %s offset %d (%s): %d vs %d bytes" % (
+                    seed, i, c, sizes, offsets[i], ("private", "batcher-bound", "node-placed")[layout], len(got), len(want)))
             files += 1
         if bt is not None:
             bt.close()
+        if node is not None:
+            if sum(node.stat(k).clients for k in range(2)) != 0:
+                fail("node still counts clients after every worker is gone: seed %d" % seed)
+            node.close()
     rounds += 1; seed += 1
 print("worker soak ok: %d rounds, %d output files identical, %.0f s" % (rounds, files, budget), flush=True)
