@@ -63,6 +63,55 @@ def fir_stream(x, taps, decim):
     return acc
 
 
+def fir_stream_lanes(x, taps, decim, lanes, naccs):
+    """The same FIR with the summation order of a SIMD dot product (what libvolk's tuned kernels do where the reference's CI
+    forces the generic ones): `naccs` accumulator vectors of `lanes` floats take the products round-robin, the vectors are then
+    added to the first in turn, the lanes of the result summed left to right, the taps that do not fill a block added last one
+    by one.  For complex input the products (re t, im t) interleave, so a lane pair holds one tap.  Not what the reference pins
+    (its tests run VOLK_GENERIC=1) -- used to show where the golden files' +-1 LSB against the generic order comes from."""
+    r = taps[::-1].astype(np.float32)
+    t, n = len(r), len(x)
+    cplx = x.ndim == 2
+    pad = np.zeros((t - 1,) + x.shape[1:], dtype=np.float32)
+    xp = np.concatenate([pad, x])
+    k = (n + decim - 1) // decim
+
+    def seg(j):
+        return xp[j: j + (k - 1) * decim + 1: decim]
+    per_block = lanes * naccs // (2 if cplx else 1)
+    nblocks = t // per_block
+    accs = [[np.zeros(k, np.float32) for _ in range(lanes)] for _ in range(naccs)]
+    for b in range(nblocks):
+        for a in range(naccs):
+            for ln in range(lanes):
+                if cplx:
+                    j = b * per_block + a * (lanes // 2) + ln // 2
+                    p = (seg(j)[:, ln % 2] * r[j]).astype(np.float32)
+                else:
+                    j = b * per_block + a * lanes + ln
+                    p = (seg(j) * r[j]).astype(np.float32)
+                accs[a][ln] = (accs[a][ln] + p).astype(np.float32)
+    v = accs[0]
+    for a in range(1, naccs):
+        v = [(v[ln] + accs[a][ln]).astype(np.float32) for ln in range(lanes)]
+    if cplx:
+        re, im = v[0], v[1]
+        for ln in range(2, lanes, 2):
+            re = (re + v[ln]).astype(np.float32)
+            im = (im + v[ln + 1]).astype(np.float32)
+        for j in range(nblocks * per_block, t):
+            sj = seg(j)
+            re = (re + (sj[:, 0] * r[j]).astype(np.float32)).astype(np.float32)
+            im = (im + (sj[:, 1] * r[j]).astype(np.float32)).astype(np.float32)
+        return np.stack([re, im], axis=1)
+    d = v[0]
+    for ln in range(1, lanes):
+        d = (d + v[ln]).astype(np.float32)
+    for j in range(nblocks * per_block, t):
+        d = (d + (seg(j) * r[j]).astype(np.float32)).astype(np.float32)
+    return d
+
+
 def fast_atan2(y, x):
     """B4 (fast_atan2f.c:87-157), vectorised.  Finite inputs."""
     ya, xa = np.abs(y), np.abs(x)
@@ -153,9 +202,10 @@ def soft_to_int8(o):
     return np.rint(np.clip(r, F(-128.0), F(127.0))).astype(np.int8)
 
 
-def demod_stream(cfg, iq):
+def demod_stream(cfg, iq, simd_order=None):
     """cfg = (fs, baud, deviation, decimation, transition_width, use_dc); iq: interleaved float32 or complex64.
-    Returns (int8 soft bits, float32 soft bits) of the whole stream.  fsk_demod.c:28-110."""
+    Returns (int8 soft bits, float32 soft bits) of the whole stream.  fsk_demod.c:28-110.
+    simd_order = (lanes, accumulators): both FIRs sum in that SIMD order (fir_stream_lanes) instead of the generic one."""
     fs, baud, dev, decim, tw, dc = cfg
     iq = np.ascontiguousarray(iq)
     x = (iq.view(np.float32) if iq.dtype == np.complex64 else iq.astype(np.float32)).reshape(-1, 2)
@@ -164,9 +214,14 @@ def demod_stream(cfg, iq):
     taps2 = design_taps(fs, baud // 2, tw)                               # :47
     gain = F(float(fs) / (2.0 * math.pi * float(dev)))                    # :42
     sps = F(float(fs) / baud / decim)                                    # :53
-    y = fir_stream(x, taps1, 1)
-    q = quad_demod(y, gain)
-    z = fir_stream(q, taps2, decim)
+    if simd_order is None:
+        y = fir_stream(x, taps1, 1)
+        q = quad_demod(y, gain)
+        z = fir_stream(q, taps2, decim)
+    else:
+        y = fir_stream_lanes(x, taps1, 1, *simd_order)
+        q = quad_demod(y, gain)
+        z = fir_stream_lanes(q, taps2, decim, *simd_order)
     if dc:
         z = dc_block(z, int(math.ceil(float(F(sps * F(32.0))))))         # :55-56
     soft = clock_recover(z, sps)
