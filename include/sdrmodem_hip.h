@@ -90,7 +90,7 @@ typedef struct {
                                     * interpolator-filter choice).  Never the default; for throughput experiments. */
 
 /* device < 0: current HIP device.  Returns 0, -ENOMEM, -1 (bad parameters), -ENODEV (no usable GPU), -ENOTSUP (a filter too long
- * for a tile's LDS -- tens of thousands of taps --, fewer than one or more than 16384 samples per symbol, decimation beyond the
+ * for a tile's LDS -- about ten thousand taps --, fewer than one or more than 16384 samples per symbol, decimation beyond the
  * filter length).  Any samples per symbol the reference accepts (src/dsp/fsk_demod.c:53-63) is accepted: up to ~244 a channel
  * runs the fast LDS-resident DC and clock stages, beyond that (or with a DC boxcar longer than 7712 samples) their generic
  * forms with the state in global memory ("generic channels") -- same bits, a few milliseconds per call. */

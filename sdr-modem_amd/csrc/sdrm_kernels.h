@@ -41,6 +41,13 @@
          ? (size_t) (SDRM_K1_NY + (t1_max)) * 8                                      \
          : (size_t) (2 * SDRM_K1_NY + SDRM_K1_QPAD) * 4)
 
+// dynamic LDS of a front-end workgroup for filters of up to t1_max / t2_max taps (the kernel's own layout: raw tile + halo,
+// boundary samples, the arctangent tables, both filters' taps); the planner refuses what does not fit a CU's 160 KiB
+static inline size_t sdrm_k1_lds_bytes_for(uint32_t t1_max, uint32_t t2_max) {
+    return SDRM_K1_XS_BYTES(t1_max) + (size_t) SDRM_K1_THREADS * 8 + (260 + 512) * sizeof(float) +
+           (size_t) (((t1_max + 3) & ~3u) + ((t2_max + 3) & ~3u) + 8) * sizeof(float);
+}
+
 // Channels per clock-recovery workgroup (one per consumer lane).  The rings of a workgroup fill most of a CU's LDS
 // (which also keeps the other stages' workgroups off that CU), so channels x ring length is fixed: fewer channels =
 // longer rings = longer staging steps, i.e. fewer hand-overs (barrier, limits, loop entry with its exposed first loads)

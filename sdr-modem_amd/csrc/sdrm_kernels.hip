@@ -255,16 +255,7 @@ void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride,
 
 // ================================================================================================ K1
 
-size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) {
-    // the quadrature-demod tile (NY + pad floats) reuses the raw-IQ tile's space: LPF1 is done with it by then
-    size_t xs = SDRM_K1_XS_BYTES(t1_max);
-    size_t bnd = (size_t) SDRM_K1_THREADS * sizeof(sdrm_f2);
-    size_t tab = (260 + 512) * sizeof(float);  // the arctangent table, and the same as {entry, difference} pairs
-    // both filters' taps, staged per workgroup: read from LDS next to the samples instead of waited for from global
-    // memory inside the tap loop
-    size_t taps = (size_t) (((t1_max + 3) & ~3u) + ((t2_max + 3) & ~3u) + 8) * sizeof(float);
-    return xs + bnd + tab + taps;
-}
+size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) { return sdrm_k1_lds_bytes_for(t1_max, t2_max); }
 
 // grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
 // per-thread boundary samples | arctan table.

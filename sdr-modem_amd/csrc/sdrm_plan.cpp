@@ -44,8 +44,9 @@ static int params_from_design(const ChannelDesign &d, sdrm_chan_params &p) {
     p.decim = d.cfg.decimation;
     p.dc_len = d.dc_length;
     p.hist_len = p.T1 + p.T2 - 1;
-    if (p.T2 + 2 > (uint32_t) SDRM_K1_NY) {
-        fprintf(stderr, "<3>low-pass filter of %u taps does not fit a tile\n", p.T2);
+    if (p.T2 + 2 > (uint32_t) SDRM_K1_NY || sdrm_k1_lds_bytes_for(p.T1, p.T2) > 160 * 1024) {
+        // the front-end stages a tile and its T1 - 1 samples of halo, and both filters' taps, in a CU's LDS
+        fprintf(stderr, "<3>low-pass filters of %u / %u taps do not fit a tile\n", p.T1, p.T2);
         return -ENOTSUP;
     }
     // a tile computes SDRM_K1_NY LPF1 positions: (m-1)*d + T2 + 1 of them are needed for m outputs

@@ -52,6 +52,10 @@ def test_bad_parameters_are_reported_before_touching_the_device():
     assert binding.Batch([(48000, 1200, 5000, 1, 2000, True, 4096), (480000, 1200, 5000, 1, 2000, True, 4096)]).code in (0, -errno.ENODEV)
     assert binding.Batch([(240000, 1200, 5000, 1, 2000, True, 4096)]).code in (0, -errno.ENODEV)
     assert binding.Batch([(48000000, 1200, 5000, 1, 2000, True, 4096)]).code == -errno.ENOTSUP
+    # ... and one whose tile + halo + taps exceed a CU's 160 KiB of LDS (2.4 MHz / 600 baud: 10909 + 2891 taps) is refused
+    # when the batch is planned, not when its first kernel is launched; the same channel at 9600 baud fits
+    assert binding.Batch([(2400000, 600, 5000, 1, 2000, True, 4096)]).code == -errno.ENOTSUP
+    assert binding.Batch([(2400000, 9600, 5000, 1, 2000, True, 4096)]).code in (0, -errno.ENODEV)
 
 
 @pytest.mark.skipif(binding.load().sdrm_device_count() > 0, reason="a GPU is present")
