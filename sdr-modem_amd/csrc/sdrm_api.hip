@@ -753,6 +753,8 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         d.quad_flat = (q != nullptr && strcmp(q, "flat") == 0) ? 1 : 0;
         const char *cp = getenv("SDRM_CHAIN_PRIO");
         d.chain_prio = cp != nullptr ? atoi(cp) : 3;
+        const char *dp = getenv("SDRM_DC_PRIO");
+        d.dc_prio = dp != nullptr ? atoi(dp) : d.chain_prio;
     }
     b->in_stride = pl.in_stride;
     code = sync_generic(b, -1);

@@ -677,11 +677,11 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
             acc = sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4];
         }
         // one dependent chain: issue ahead of whatever shares the SIMD
-        if (b.chain_prio >= 3) {
+        if (b.dc_prio >= 3) {
             __builtin_amdgcn_s_setprio(3);
-        } else if (b.chain_prio == 2) {
+        } else if (b.dc_prio == 2) {
             __builtin_amdgcn_s_setprio(2);
-        } else if (b.chain_prio == 1) {
+        } else if (b.dc_prio == 1) {
             __builtin_amdgcn_s_setprio(1);
         } else {
             __builtin_amdgcn_s_setprio(0);

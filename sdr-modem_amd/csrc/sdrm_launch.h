@@ -49,6 +49,7 @@ struct DeviceBatch {
     uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
     int k3_carried_max;              // most samples a channel can carry between calls of the clock stage (sizes its ring)
+    int dc_prio;                     // measurements (SDRM_DC_PRIO): the DC chain wave's alone (default: chain_prio)
     int chain_prio;                  // measurements (SDRM_CHAIN_PRIO): issue priority of the DC chain wave and the clock stage's consumer (default 3)
     int quad_flat;                   // measurements (SDRM_K1_QUAD=flat): the discriminator always takes its general form
     int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
