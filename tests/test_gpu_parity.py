@@ -1316,6 +1316,11 @@ def test_any_samples_per_symbol_on_the_device():
     d.close()
     iq2 = siggen.gmsk_channel(7, 60000, fs=240000, baud=900)
     run_stream((240000, 900, 5000, 1, 2000, False), iq2, [9000, 300, 20700, 5, 20000, 9995], 20700)
+    # the longest filters a tile's LDS holds: 2.4 MHz / 9600 baud, 5899 + 2891 taps (118 of the CU's 160 KiB; the halo is longer than
+    # the tile and the history longer than most calls); one size up (10909 taps) is refused when the batch is planned
+    iq3 = siggen.gmsk_channel(9, 30000, fs=2400000, baud=9600)
+    run_stream((2400000, 9600, 5000, 1, 2000, True), iq3, [4096, 4096, 100, 4096, 7, 8192, 3000], 8192)
+    assert binding.Batch([(2400000, 600, 5000, 1, 2000, True, 4096)]).code == -95  # -ENOTSUP, no launch attempted
     run_stream((240000, 900, 5000, 1, 2000, True), iq2, [20700, 20700, 18600], 20700)
     cfgs = [(240000, 600, 5000, 1, 2000, True, 8192), (48000, 9600, 5000, 1, 2000, True, 8192), (240000, 900, 5000, 1, 2000, False, 8192),
             (48000, 4800, 5000, 2, 2000, False, 8192)] * 10  # 40 channels: the pipelined stages, 20 generic channels

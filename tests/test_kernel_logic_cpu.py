@@ -140,6 +140,9 @@ def test_any_samples_per_symbol_through_the_generic_stages():
     assert run_both((240000, 600, 5000, 1, 2000, True), iq, chunks, 20000) == 130000
     iq2 = siggen.gmsk_channel(7, 60000, fs=240000, baud=900)
     run_both((240000, 900, 5000, 1, 2000, False), iq2, [9000, 300, 20700, 5, 20000, 9995], 20700)
+    # the longest filters that fit a tile's LDS (5899 + 2891 taps: halo longer than the tile, history longer than the calls)
+    iq3 = siggen.gmsk_channel(9, 30000, fs=2400000, baud=9600)
+    run_both((2400000, 9600, 5000, 1, 2000, True), iq3, [4096, 4096, 100, 4096, 7, 8192, 3000], 8192)
     run_both((240000, 900, 5000, 1, 2000, True), iq2, [20700, 20700, 18600], 20700)  # 8534-sample boxcar: DC generic, clock too
     # one batch: generic, ordinary, generic without DC
     cfgs = [(240000, 600, 5000, 1, 2000, True, 8192), (48000, 9600, 5000, 1, 2000, True, 8192), (240000, 900, 5000, 1, 2000, False, 8192)]
