@@ -213,7 +213,7 @@ int sdrm_batch_k3_stamps(sdrm_batch *batch, int enable, unsigned long long *out,
 int sdrm_batch_timeline(sdrm_batch *batch, int enable, unsigned long long *out, size_t max_rows);
 
 /* The schedule a batch runs with.  A batch of 32 channels or more calibrates itself when it is created: it times full-length
- * calls of its own pipeline on a synthetic row (a few calls per candidate: clock-stage workgroup shape, the front-end's hold
+ * calls of its own pipeline on a synthetic row (a few calls, at least ~4 ms, per candidate: clock-stage workgroup shape, the front-end's hold
  * for the clock stage's placement, the companion grid beside the clock stage), keeps what is fastest by more than 3 %, and
  * puts every stream back to its initial state.  SDRM_AUTOTUNE=0 keeps the built-in starting point (channel-count rules). */
 typedef struct {

@@ -373,7 +373,7 @@ static int sync_generic(sdrm_batch_t *b, long only_channel) {
 // a companion grid used to be decided by constants fitted on one box at one power state (channel-count thresholds, 18.4e12
 // multiply-adds per second, 97 ns per symbol).  Those constants now only give the STARTING point: a batch of at least 32
 // channels times its own pipeline at creation -- full-length calls on a synthetic row that every channel reads (input
-// stride 0: no buffer of the batch's size is needed), a few calls per candidate setting, one dimension after the other --
+// stride 0: no buffer of the batch's size is needed), a few calls per candidate setting (at least ~4 ms of them: short calls are launch-bound and noisy), one dimension after the other --
 // keeps what was fastest by more than the noise, and then puts every stream back to its initial state.  Costs a few dozen
 // calls (tens of milliseconds for 256 channels, a few hundred for 4096) once per batch.
 // SDRM_AUTOTUNE=0 switches it off; SDRM_K3_LANES / SDRM_FRONT_HOLD / SDRM_K3_COMPANY pin their dimension as before.
