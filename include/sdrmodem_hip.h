@@ -223,6 +223,12 @@ typedef struct {
     int calibrated;                  /* 1: measured at creation; 0: the starting point (small batch, switched off, forced) */
     float ms_before, ms_after;       /* ms per full-length call with the starting point / with what was kept */
     float ms_spent;                  /* what the calibration took */
+    /* The calibration times calls without Doppler correction.  The first calls that carry NCO batches re-decide the two settings
+     * that may change between any two calls -- front hold, companion grid -- on the caller's own workload: four settings, eight
+     * calls each, timed by the clock stages' completions on the device; results never depend on the schedule. */
+    int online_state;                /* 0: not started (no call with NCO batches yet), 1: measuring, 2: settled */
+    int online_choice;               /* -1, or what was kept: 0 as it was, bit 0: hold toggled, bit 1: companion grid toggled */
+    float online_ms[4];              /* ms per call measured for the four settings (0: not measured) */
 } sdrm_batch_schedule_info;
 int sdrm_batch_schedule(const sdrm_batch *batch, sdrm_batch_schedule_info *info);
 

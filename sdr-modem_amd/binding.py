@@ -79,7 +79,7 @@ class BatcherConfig(C.Structure):
 class ScheduleInfo(C.Structure):
     _fields_ = [("k3_lanes", C.c_int), ("k3_ring", C.c_int), ("k3_plain", C.c_int), ("front_hold", C.c_int),
                 ("company_blocks", C.c_int), ("calibrated", C.c_int), ("ms_before", C.c_float), ("ms_after", C.c_float),
-                ("ms_spent", C.c_float)]
+                ("ms_spent", C.c_float), ("online_state", C.c_int), ("online_choice", C.c_int), ("online_ms", C.c_float * 4)]
 
 
 class NodeConfig(C.Structure):
@@ -402,7 +402,8 @@ class Batch:
         return {"clock_stage": "%dx%d%s" % (inf.k3_lanes, inf.k3_ring, "p" if inf.k3_plain else ""), "front_hold": bool(inf.front_hold),
                 "company_blocks": inf.company_blocks, "calibrated": bool(inf.calibrated),
                 "ms_per_call_before": round(inf.ms_before, 3), "ms_per_call_after": round(inf.ms_after, 3),
-                "calibration_ms": round(inf.ms_spent, 1)}
+                "calibration_ms": round(inf.ms_spent, 1),
+                "online": {"state": inf.online_state, "choice": inf.online_choice, "ms_per_call": [round(v, 3) for v in inf.online_ms]}}
 
     def timing_enable(self, on=True):
         self.L.sdrm_batch_timing_enable(self.h, 1 if on else 0)

@@ -115,6 +115,19 @@ struct sdrm_batch_t {
     // what the batch's self-calibration decided (sdrm_batch_create -> calibrate), for inspection: sdrm_batch_schedule
     bool calibrated = false;
     float calib_ms[3] = {0.0f, 0.0f, 0.0f};  // ms per full-length call: before, after, and what the calibration itself took
+    // Online refinement (online_tune_*): the calibration at creation times calls WITHOUT Doppler correction; the first
+    // stretch of calls that carry NCO batches re-decides the two settings that may change between any two calls (front
+    // hold, companion grid) on the caller's own workload, from the device-side spacing of the clock stages' completions.
+    struct OnlineTune {
+        int state = 0;            // 0 not started, 1 measuring, 2 settled
+        int cand = 0, n = 0;      // candidate being run (bit 0: hold toggled, bit 1: companion grid toggled), calls of its block so far
+        hipEvent_t ev[4][2] = {};
+        float ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // ms per call of each candidate (0 until measured)
+        bool base_hold = false;
+        int base_company = 0;
+        uint64_t sig = 0;         // the block's calls must look alike (total samples)
+        int chosen = -1;
+    } tune;
     float *d_z2 = nullptr, *d_dcout2 = nullptr;
     bool any_nodc = false;
     bool serial = false;
@@ -183,6 +196,13 @@ static void batch_free(sdrm_batch_t *b) {
         (void) hipStreamSynchronize(b->stream);
     }
     (void) hipDeviceSynchronize();
+    for (auto &pair : b->tune.ev) {
+        for (hipEvent_t e : pair) {
+            if (e != nullptr) {
+                (void) hipEventDestroy(e);
+            }
+        }
+    }
     for (float *g : b->gen_ptr) {
         if (g != nullptr) {
             (void) hipFree(g);
@@ -791,6 +811,11 @@ extern "C" int sdrm_batch_schedule(const sdrm_batch *b, sdrm_batch_schedule_info
     info->ms_before = b->calib_ms[0];
     info->ms_after = b->calib_ms[1];
     info->ms_spent = b->calib_ms[2];
+    info->online_state = b->tune.state;
+    info->online_choice = b->tune.chosen;
+    for (int k = 0; k < 4; k++) {
+        info->online_ms[k] = b->tune.ms[k];
+    }
     return 0;
 }
 
@@ -1115,6 +1140,99 @@ static int ensure_nco(sdrm_batch_t *b) {
     return code;
 }
 
+// ---- online refinement of the schedule for calls with Doppler correction --------------------------------------------
+// Why: the NCO stages are a fourth pipeline stage (a dependent chain as long as the clock stage's in BASELINE configs[4]'s mix);
+// what the creation-time calibration found best without them (there: front hold on, companion grid on, -14 %) cost that
+// workload 9 % (profiles/r04_config5_schedule.txt).  The streams hold the caller's state by then, so nothing can be replayed:
+// four settings are run for eight calls each as the calls come, the clock stages' completion events of the last five give each
+// setting's period, and the best stays if it beats the starting point by more than 3 %.  Results do not depend on any of it.
+#define SDRM_TUNE_SKIP 3   // calls of a block before its first timed completion (the pipeline holds three calls)
+#define SDRM_TUNE_TIMED 5
+static void online_tune_apply(sdrm_batch_t *b, int cand) {
+    b->hold_front = (cand & 1) ? !b->tune.base_hold : b->tune.base_hold;
+    b->company_blocks = (cand & 2) ? (b->tune.base_company > 0 ? 0 : b->company_grid) : b->tune.base_company;
+}
+static void online_tune_settle(sdrm_batch_t *b, int cand) {
+    online_tune_apply(b, cand);
+    b->tune.chosen = cand;
+    b->tune.state = 2;
+    if (getenv("SDRM_AUTOTUNE_LOG") != nullptr) {
+        fprintf(stderr, "sdrmodem_hip: refined online for calls with NCO batches: %.3f / %.3f / %.3f / %.3f ms per call (as is, hold "
+                        "toggled, companion grid toggled, both); front hold %s, companion grid %d\n", b->tune.ms[0], b->tune.ms[1],
+                b->tune.ms[2], b->tune.ms[3], b->hold_front ? "on" : "off", b->company_blocks);
+    }
+}
+static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
+    sdrm_batch_t::OnlineTune &t = b->tune;
+    if (t.state == 2 || (t.state == 0 && !with_nco)) {
+        return;
+    }
+    if (t.state == 0) {
+        static const char *env = getenv("SDRM_AUTOTUNE");
+        if (b->serial || b->clock_early || b->plan.design.size() < 32 || (env != nullptr && atoi(env) == 0) || b->n_gen > 0 ||
+            sdrm::front_hold_is_forced() || getenv("SDRM_K3_COMPANY") != nullptr) {
+            t.state = 2;
+            return;
+        }
+        if (b->calls < 4) {
+            return;
+        }
+        for (auto &pair : t.ev) {
+            for (hipEvent_t &e : pair) {
+                if (hipEventCreate(&e) != hipSuccess) {
+                    t.state = 2;
+                    return;
+                }
+            }
+        }
+        t.base_hold = b->hold_front;
+        t.base_company = b->company_blocks;
+        t.sig = sig;
+        t.cand = 0;
+        t.n = 0;
+        t.state = 1;
+    }
+    if (!with_nco || sig != t.sig) {
+        online_tune_settle(b, 0);  // the calls stopped looking alike: nothing to compare, the starting point stays
+        return;
+    }
+    if (t.cand < 4) {
+        online_tune_apply(b, t.cand);
+        return;
+    }
+    online_tune_apply(b, 0);  // every block is enqueued: as before until the last one's completions are in
+    if (hipEventQuery(t.ev[3][1]) != hipSuccess) {
+        return;
+    }
+    int best = 0;
+    for (int k = 0; k < 4; k++) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, t.ev[k][0], t.ev[k][1]) != hipSuccess) {
+            online_tune_settle(b, 0);
+            return;
+        }
+        t.ms[k] = ms / SDRM_TUNE_TIMED;
+        if (t.ms[k] < t.ms[best]) {
+            best = k;
+        }
+    }
+    online_tune_settle(b, t.ms[best] < t.ms[0] * 0.97f ? best : 0);
+}
+static void online_tune_after(sdrm_batch_t *b, hipStream_t s_clock) {
+    sdrm_batch_t::OnlineTune &t = b->tune;
+    if (t.state != 1 || t.cand >= 4) {
+        return;
+    }
+    t.n++;
+    if (t.n == SDRM_TUNE_SKIP) {
+        (void) hipEventRecord(t.ev[t.cand][0], s_clock);
+    } else if (t.n == SDRM_TUNE_SKIP + SDRM_TUNE_TIMED) {
+        (void) hipEventRecord(t.ev[t.cand][1], s_clock);
+        t.cand++;
+        t.n = 0;
+    }
+}
+
 static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
                         const sdrm_nco_segment *segs, size_t n_segs) {
     const size_t C = b->plan.design.size();
@@ -1155,6 +1273,13 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
                 }
             }
         }
+    }
+    {
+        uint64_t sig = 0;
+        for (size_t c = 0; c < C; c++) {
+            sig += h[c].n_in;
+        }
+        online_tune_before(b, with_nco, sig);
     }
     d.nco_segs = with_nco ? b->d_nco_segs + (size_t) slot * b->nco_seg_cap : nullptr;
     d.nco_phase_state = b->d_nco_state;
@@ -1317,6 +1442,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->slot_done[slot], s_clock));
+    online_tune_after(b, s_clock);
     b->slot_used[slot] = true;
     b->last_slot = slot;
     b->calls++;

@@ -75,11 +75,14 @@ def test_sweep_shapes_at_full_call_length(torch_dev, channels):
 
 def test_config5_workload_as_benchmarked(torch_dev):
     """bench.py's `config5` block: 256 channels, 240 kHz / 19200 baud / decimation 5 interleaved with 48 kHz / 1200 baud /
-    decimation 8, 131072-sample calls, three NCO batches per channel and call; 4 warm-up + 3 timed steps; 6 spot channels
+    decimation 8, 131072-sample calls, three NCO batches per channel and call; 44 warm-up steps (the batch refines its schedule
+    online over the first calls with NCO batches: front hold and companion grid change between calls) + 3 timed steps; 6 spot channels
     against orc.Nco + orc.Fsk after every timed step."""
     torch, dev = torch_dev
     res = bench.config5_single(torch, binding, siggen, dev, 256, N, steps=3, verify=True, check_at=(1, 2))
     assert res["verified_vs_oracle"] is True, res["verify_mismatches"]
+    assert res["schedule"]["online"]["state"] == 2 and res["schedule"]["online"]["choice"] in (0, 1, 2, 3), res["schedule"]
+    assert all(ms > 0 for ms in res["schedule"]["online"]["ms_per_call"]), res["schedule"]
 
 
 def test_bench_line_carries_the_spot_check(torch_dev, capsys):
