@@ -1,4 +1,4 @@
-"""one cell of the heuristics sweep: python tools/sweep_cell.py <channels> <chunk> [steps] -> "<ms per step> <Msamples/s> <kernel ms x3>"
+"""one cell of the heuristics sweep: python tools/sweep_cell.py <channels> <chunk> [steps] [batch buffer length] -> "<ms per step> <Msamples/s> <kernel ms x3>"
 (the stream holds, the companion grid and the clock stage's shape are chosen by the library from the batch, or forced
 through SDRM_FRONT_HOLD / SDRM_DC_FIRST / SDRM_K3_COMPANY / SDRM_K3_LANES; every variant is its own process because the
 library reads those once)"""
@@ -10,7 +10,8 @@ import sdrm_pkg; sdrm_pkg.load()
 from sdr_modem_amd import binding, siggen
 Cn, N = int(sys.argv[1]), int(sys.argv[2])
 K = int(sys.argv[3]) if len(sys.argv) > 3 else max(12, min(200, int(3.0e9 / (Cn * N))))
-cfg = (48000, 9600, 5000, 1, 2000, True, N)
+MAXN = int(sys.argv[4]) if len(sys.argv) > 4 else N  # the batch's buffer length (calls of N samples on a longer-buffer batch)
+cfg = (48000, 9600, 5000, 1, 2000, True, MAXN)
 base = np.stack([siggen.gmsk_channel(i, 2 * N) for i in range(8)]).view(np.float32)
 bt = torch.from_numpy(base).cuda()
 x = torch.empty((Cn, 4 * N), dtype=torch.float32, device="cuda")
@@ -20,7 +21,7 @@ b = binding.Batch([cfg] * Cn)
 assert b.code == 0
 st = torch.cuda.current_stream().cuda_stream
 lens = (binding.C.c_size_t * Cn)(*([N] * Cn))
-for i in range(6):
+for i in range(76):  # fill + (calls the calibration did not cover) the online refinement
     b.process_device(x.data_ptr() + (i % 2) * N * 8, 2 * N, lens, st)
 torch.cuda.synchronize()
 b.timing_enable(True)
