@@ -1155,10 +1155,6 @@ static int ensure_nco(sdrm_batch_t *b) {
 #define SDRM_TUNE_SKIP 3   // calls of a block before its first timed completion (the pipeline holds three calls)
 #define SDRM_TUNE_TIMED 5  // completion-to-completion intervals per block (ev[][TIMED + 1])
 static void online_tune_apply(sdrm_batch_t *b, int cand) {
-    static const char *diag = getenv("SDRM_TUNE_DIAG");  // measurements: every block runs the starting point
-    if (diag != nullptr) {
-        cand = 0;
-    }
     b->hold_front = (cand & 1) ? !b->tune.base_hold : b->tune.base_hold;
     b->company_blocks = (cand & 2) ? (b->tune.base_company > 0 ? 0 : b->company_grid) : b->tune.base_company;
 }
