@@ -284,7 +284,7 @@ def end_to_end(binding, siggen, channels, chunk, calls=24, slots=4):
                     "soft bits and counts back to pinned memory, 3 calls in flight (PCIe-inclusive)"}
 
 
-WARMUP5 = 76
+WARMUP5 = 160
 
 
 def config5_table(total, chunk):
@@ -322,8 +322,8 @@ def config5(torch, binding, siggen, dev, cfgs, chunk, steps=24, plan_step=None, 
     def step(i):
         b.process_device_nco(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens_c, plan_step(), st)
         fed.append(i % 2)
-    # warm-up: the pipeline's fill, then the batch's online refinement for calls with NCO batches (six blocks of eight calls from the 17th call on,
-    # sdrm_batch_schedule_info.online_*) -- outside the timed region, like the creation-time calibration
+    # warm-up: the pipeline's fill, then the batch's online refinement for calls with NCO batches (about 130 calls from the 17th on:
+    # steady state, six blocks of eight calls, the winner's probation; sdrm_batch_schedule_info.online_*) -- outside the timed region, like the creation-time calibration
     for i in range(WARMUP5):
         step(i)
     torch.cuda.synchronize()

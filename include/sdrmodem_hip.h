@@ -226,11 +226,13 @@ typedef struct {
     /* The calibration times calls without Doppler correction.  The first calls that carry NCO batches re-decide the two settings
      * that may change between any two calls -- front hold, companion grid -- on the caller's own workload: four settings, eight
      * calls each, timed by the clock stages' completions on the device (median interval), then the starting point and the winner
-     * once more: the winner stays if it wins both times by more than 3 %.  The same for calls of less than half the calibrated
-     * length.  Other calls keep the calibrated setting; results never depend on the schedule. */
+     * once more; a winner of both rounds (by more than 3 %) then has to beat the starting point's steady state (40 calls before
+     * the blocks) with its own (40 calls after them).  The same for calls of less than half the calibrated length.  Other calls
+     * keep the calibrated setting; results never depend on the schedule. */
     int online_state;                /* 0: not started (no such calls yet), 1: measuring, 2: settled */
     int online_choice;               /* -1, or what was kept: 0 as it was, bit 0: hold toggled, bit 1: companion grid toggled */
-    float online_ms[6];              /* ms per call: the four settings, then as it was / the winner again (0: not measured) */
+    float online_ms[8];              /* ms per call: the four settings, as it was / the winner again, the starting point's and the
+                                      * winner's steady state (0: not measured) */
 } sdrm_batch_schedule_info;
 int sdrm_batch_schedule(const sdrm_batch *batch, sdrm_batch_schedule_info *info);
 

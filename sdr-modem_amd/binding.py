@@ -79,7 +79,7 @@ class BatcherConfig(C.Structure):
 class ScheduleInfo(C.Structure):
     _fields_ = [("k3_lanes", C.c_int), ("k3_ring", C.c_int), ("k3_plain", C.c_int), ("front_hold", C.c_int),
                 ("company_blocks", C.c_int), ("calibrated", C.c_int), ("ms_before", C.c_float), ("ms_after", C.c_float),
-                ("ms_spent", C.c_float), ("online_state", C.c_int), ("online_choice", C.c_int), ("online_ms", C.c_float * 6)]
+                ("ms_spent", C.c_float), ("online_state", C.c_int), ("online_choice", C.c_int), ("online_ms", C.c_float * 8)]
 
 
 class NodeConfig(C.Structure):

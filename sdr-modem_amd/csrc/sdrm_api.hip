@@ -120,16 +120,23 @@ struct sdrm_batch_t {
     // hold, companion grid) on the caller's own workload, from the device-side spacing of the clock stages' completions.
     struct OnlineTune {
         int state = 0;            // 0 not started, 1 measuring, 2 settled
-        int cand = 0, n = 0;      // candidate being run (bit 0: hold toggled, bit 1: companion grid toggled), calls of its block so far
-        hipEvent_t ev[6][6] = {};  // per block: the clock stage's completion of the calls SKIP .. SKIP + TIMED of the block
-        float ms[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // ms per call: the four settings, then the starting point and the winner again
-        int best = -1;            // the first round's winner (block 5 runs it again)
-        bool idle = false;        // this call is not part of a block (waiting for the first round's completions)
+        int phase = 0;            // while measuring: 1 the starting point's steady state, 2 the blocks, 3 the winner's probation
+        int cand = 0, n = 0;      // block being run (0-3: bit 0 hold toggled, bit 1 companion grid toggled; 4 as is again; 5 the winner again), calls of the phase / block so far
+        hipEvent_t ev[6][6] = {};     // per block: the clock stage's completion of the calls SKIP .. SKIP + TIMED of the block
+        hipEvent_t watch[2][33] = {};  // the same over 32 intervals: [0] the starting point before the blocks, [1] the winner after them
+        // ms per call: the four settings, as is / the winner again, the starting point's and the winner's steady state
+        float ms[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        int best = -1;            // the first round's winner
+        bool idle = false;        // this call is not part of a block (waiting for completions)
         bool base_hold = false;
         int base_company = 0;
         uint64_t sig = 0;         // the class of calls being refined: total samples (calls within a factor of two count as alike
         bool nco = false;         // once settled) and whether they carry NCO batches
         int chosen = -1;
+        // after a winner has been kept: every 64th call of its class starts a sample of five intervals; two bad samples in a row
+        // (more than 5 % behind the starting point's steady state) give the starting point back for good
+        int guard_n = 0, guard_bad = 0;
+        bool guard_pending = false, guard_alike = false;
     } tune;
     float *d_z2 = nullptr, *d_dcout2 = nullptr;
     bool any_nodc = false;
@@ -201,6 +208,13 @@ static void batch_free(sdrm_batch_t *b) {
     (void) hipDeviceSynchronize();
     for (auto &pair : b->tune.ev) {
         for (hipEvent_t e : pair) {
+            if (e != nullptr) {
+                (void) hipEventDestroy(e);
+            }
+        }
+    }
+    for (auto &row : b->tune.watch) {
+        for (hipEvent_t e : row) {
             if (e != nullptr) {
                 (void) hipEventDestroy(e);
             }
@@ -816,7 +830,7 @@ extern "C" int sdrm_batch_schedule(const sdrm_batch *b, sdrm_batch_schedule_info
     info->ms_spent = b->calib_ms[2];
     info->online_state = b->tune.state;
     info->online_choice = b->tune.chosen;
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < 8; k++) {
         info->online_ms[k] = b->tune.ms[k];
     }
     return 0;
@@ -1146,14 +1160,23 @@ static int ensure_nco(sdrm_batch_t *b) {
 // ---- online refinement of the schedule for calls the calibration did not cover ---------------------------------------
 // Why: the NCO stages are a fourth pipeline stage (a dependent chain as long as the clock stage's in BASELINE configs[4]'s mix);
 // what the creation-time calibration found best without them (there: front hold on, companion grid on, -14 %) cost that
-// workload 9 % (profiles/r04_config5_schedule.txt).  The streams hold the caller's state by then, so nothing can be replayed:
-// four settings are run for eight calls each as the calls come, the clock stages' completion events of the last five give each
-// setting's period, and the best stays -- for calls of that class: with / without NCO batches, total length within a factor of
-// two -- if it beats the starting point by more than 3 %; other calls keep the calibrated setting.  Calls of less than half the
-// calibrated length are the second uncovered class (the companion grid cost 4096-sample calls 14 % at 256 channels in round 3).
-// Results do not depend on any of it.
+// workload 9 % (profiles/r04_config5_schedule.txt).  Calls of less than half the calibrated length are the second class it does
+// not cover (the companion grid cost 4096-sample calls 14 % at 256 channels in round 3).  The streams hold the caller's state by
+// then, so nothing can be replayed -- but front hold and companion grid may change between any two calls without touching a
+// result.  So, on the caller's own calls, from the 17th call of such a class on:
+//   1. the starting point's steady state: 40 calls, the median of the last 32 completion-to-completion intervals of the clock stage;
+//   2. four settings for eight calls each (the median of the last five intervals), then the starting point and the winner again:
+//      a winner must win both rounds by more than 3 %;
+//   3. the winner's probation: 40 calls like (1); it stays only if its steady state beats (1) by more than 3 % -- a block of
+//      eight calls can flatter a setting whose cost builds up over tens of calls (seen: 1.05 ms per call in its blocks, 2.9 in
+//      the steady state, profiles/r04_online_refinement.txt).
+// Medians, because the host may stall between two calls (the HIP runtime grows its pools 6 ms at a time during a process's first
+// dozens of calls) and the device then idles for reasons no setting is to blame for.  The winner serves calls of its class (same
+// NCO flag, total length within a factor of two), other calls keep the calibrated setting.  Results do not depend on any of it.
 #define SDRM_TUNE_SKIP 3   // calls of a block before its first timed completion (the pipeline holds three calls)
 #define SDRM_TUNE_TIMED 5  // completion-to-completion intervals per block (ev[][TIMED + 1])
+#define SDRM_WATCH_SKIP 8
+#define SDRM_WATCH_TIMED 32
 static void online_tune_apply(sdrm_batch_t *b, int cand) {
     b->hold_front = (cand & 1) ? !b->tune.base_hold : b->tune.base_hold;
     b->company_blocks = (cand & 2) ? (b->tune.base_company > 0 ? 0 : b->company_grid) : b->tune.base_company;
@@ -1163,11 +1186,12 @@ static void online_tune_settle(sdrm_batch_t *b, int cand) {
     b->tune.chosen = cand;
     b->tune.state = 2;
     if (getenv("SDRM_AUTOTUNE_LOG") != nullptr) {
-        fprintf(stderr, "sdrmodem_hip: refined online for calls %s NCO batches, %llu samples per call: %.3f / %.3f / %.3f / %.3f ms per "
-                        "call (as is, hold toggled, companion grid toggled, both), again %.3f as is / %.3f the winner; front hold %s, "
-                        "companion grid %d\n",
-                b->tune.nco ? "with" : "without", (unsigned long long) b->tune.sig, b->tune.ms[0], b->tune.ms[1], b->tune.ms[2],
-                b->tune.ms[3], b->tune.ms[4], b->tune.ms[5], b->hold_front ? "on" : "off", b->company_blocks);
+        const float *ms = b->tune.ms;
+        fprintf(stderr, "sdrmodem_hip: refined online for calls %s NCO batches, %llu samples per call: steady %.3f ms per call; %.3f / %.3f / "
+                        "%.3f / %.3f (as is, hold toggled, companion grid toggled, both), again %.3f as is / %.3f the winner, the winner's "
+                        "steady state %.3f; front hold %s, companion grid %d\n",
+                b->tune.nco ? "with" : "without", (unsigned long long) b->tune.sig, ms[6], ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[7],
+                b->hold_front ? "on" : "off", b->company_blocks);
     }
 }
 // what the creation-time calibration measured: full-length calls without NCO batches
@@ -1178,6 +1202,18 @@ static uint64_t full_length_samples(const sdrm_batch_t *b) {
     }
     return n;
 }
+// median of the intervals between n + 1 consecutive completion events
+static bool median_interval(const hipEvent_t *ev, int n, float *out) {
+    float iv[SDRM_WATCH_TIMED];
+    for (int j = 0; j < n; j++) {
+        if (hipEventElapsedTime(&iv[j], ev[j], ev[j + 1]) != hipSuccess) {
+            return false;
+        }
+    }
+    std::sort(iv, iv + n);
+    *out = iv[n / 2];
+    return true;
+}
 static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
     sdrm_batch_t::OnlineTune &t = b->tune;
     if (t.state == 2) {
@@ -1186,6 +1222,22 @@ static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
         }
         // settled: the refined setting serves the class of calls it was measured on, the calibrated one everything else
         const bool alike = t.chosen > 0 && with_nco == t.nco && sig * 2 >= t.sig && sig <= t.sig * 2;
+        if (t.guard_pending && hipEventQuery(t.ev[0][SDRM_TUNE_TIMED]) == hipSuccess) {
+            t.guard_pending = false;
+            float ms = 0.0f;
+            if (t.chosen > 0 && median_interval(t.ev[0], SDRM_TUNE_TIMED, &ms) && ms > t.ms[6] * 1.05f) {
+                if (++t.guard_bad >= 2) {
+                    if (getenv("SDRM_AUTOTUNE_LOG") != nullptr) {
+                        fprintf(stderr, "sdrmodem_hip: the refined setting fell behind (%.3f ms per call, the starting point's steady state was "
+                                        "%.3f): the starting point is back\n", ms, t.ms[6]);
+                    }
+                    t.chosen = 0;
+                }
+            } else {
+                t.guard_bad = 0;
+            }
+        }
+        t.guard_alike = alike && sig == t.sig;
         online_tune_apply(b, alike ? t.chosen : 0);
         return;
     }
@@ -1203,18 +1255,26 @@ static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
         if (b->calls < 16 || sig == 0) {
             return;
         }
-        for (auto &pair : t.ev) {
-            for (hipEvent_t &e : pair) {
-                if (hipEventCreate(&e) != hipSuccess) {
-                    t.state = 2;
-                    return;
-                }
+        bool ok = true;
+        for (auto &row : t.ev) {
+            for (hipEvent_t &e : row) {
+                ok = ok && hipEventCreate(&e) == hipSuccess;
             }
+        }
+        for (auto &row : t.watch) {
+            for (hipEvent_t &e : row) {
+                ok = ok && hipEventCreate(&e) == hipSuccess;
+            }
+        }
+        if (!ok) {
+            t.state = 2;
+            return;
         }
         t.base_hold = b->hold_front;
         t.base_company = b->company_blocks;
         t.sig = sig;
         t.nco = with_nco;
+        t.phase = 1;
         t.cand = 0;
         t.n = 0;
         t.state = 1;
@@ -1223,21 +1283,25 @@ static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
         online_tune_settle(b, 0);  // the calls stopped looking alike: nothing to compare, the starting point stays
         return;
     }
-    // the MEDIAN of a block's completion-to-completion intervals: the host may stall between two calls (the HIP runtime grows its
-    // pools during a process's first dozens of calls, 6 ms at a time: profiles/r04_online_refinement.txt), and the device then idles
-    // for reasons no setting is to blame for
-    auto block_ms = [&](int k, float *out) -> bool {
-        float iv[SDRM_TUNE_TIMED];
-        for (int j = 0; j < SDRM_TUNE_TIMED; j++) {
-            if (hipEventElapsedTime(&iv[j], t.ev[k][j], t.ev[k][j + 1]) != hipSuccess) {
-                return false;
-            }
-        }
-        std::sort(iv, iv + SDRM_TUNE_TIMED);
-        *out = iv[SDRM_TUNE_TIMED / 2];
-        return true;
-    };
     t.idle = false;
+    if (t.phase == 1) {
+        online_tune_apply(b, 0);
+        return;
+    }
+    if (t.phase == 3) {
+        online_tune_apply(b, t.best);
+        if (t.n < SDRM_WATCH_SKIP + SDRM_WATCH_TIMED) {
+            return;
+        }
+        t.idle = true;  // every call of the probation is enqueued: the winner stays on until their completions are in
+        if (hipEventQuery(t.watch[1][SDRM_WATCH_TIMED]) != hipSuccess) {
+            return;
+        }
+        const bool ok = median_interval(t.watch[1], SDRM_WATCH_TIMED, &t.ms[7]);
+        online_tune_settle(b, ok && t.ms[7] < t.ms[6] * 0.97f ? t.best : 0);
+        return;
+    }
+    // phase 2: the blocks
     if (t.cand == 5 && t.best < 0) {
         // the first round is enqueued (blocks 0-3, then the starting point again as block 4): its winner runs again as block 5
         if (hipEventQuery(t.ev[3][SDRM_TUNE_TIMED]) != hipSuccess) {
@@ -1247,13 +1311,13 @@ static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
         }
         int best = 0;
         for (int k = 0; k < 4; k++) {
-            if (!block_ms(k, &t.ms[k])) {
+            if (!median_interval(t.ev[k], SDRM_TUNE_TIMED, &t.ms[k])) {
                 online_tune_settle(b, 0);
                 return;
             }
             best = t.ms[k] < t.ms[best] ? k : best;
         }
-        if (best == 0 || t.ms[best] >= t.ms[0] * 0.97f) {
+        if (!median_interval(t.watch[0], SDRM_WATCH_TIMED, &t.ms[6]) || best == 0 || t.ms[best] >= t.ms[0] * 0.97f) {
             online_tune_settle(b, 0);
             return;
         }
@@ -1266,20 +1330,62 @@ static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
     } else if (t.cand == 5) {
         online_tune_apply(b, t.best);
     } else {
-        // everything is enqueued: the starting point until the confirmation's completions are in; the winner stays only if it
-        // wins the second time too (a block is eight calls: one round alone took host-side noise for a 10 % gain now and then)
+        // both rounds are enqueued: the starting point until the second round's completions are in
         online_tune_apply(b, 0);
+        t.idle = true;
         if (hipEventQuery(t.ev[5][SDRM_TUNE_TIMED]) != hipSuccess) {
-            t.idle = true;
             return;
         }
-        const bool ok = block_ms(4, &t.ms[4]) && block_ms(5, &t.ms[5]);
-        online_tune_settle(b, ok && t.ms[5] < t.ms[4] * 0.97f ? t.best : 0);
+        const bool ok = median_interval(t.ev[4], SDRM_TUNE_TIMED, &t.ms[4]) && median_interval(t.ev[5], SDRM_TUNE_TIMED, &t.ms[5]);
+        if (!ok || t.ms[5] >= t.ms[4] * 0.97f) {
+            online_tune_settle(b, 0);
+            return;
+        }
+        t.phase = 3;  // the winner's probation starts with this call
+        t.n = 0;
+        t.idle = false;
+        online_tune_apply(b, t.best);
     }
 }
 static void online_tune_after(sdrm_batch_t *b, hipStream_t s_clock) {
     sdrm_batch_t::OnlineTune &t = b->tune;
-    if (t.state != 1 || t.cand >= 6 || t.idle) {
+    if (t.state == 2 && t.chosen > 0) {
+        // the guard's samples (see OnlineTune): calls 64 + SKIP .. 64 + SKIP + TIMED of a run of like calls
+        if (!t.guard_alike) {
+            t.guard_n = 0;
+            return;
+        }
+        t.guard_n++;
+        const int k = t.guard_n - 64;
+        if (k >= SDRM_TUNE_SKIP && k <= SDRM_TUNE_SKIP + SDRM_TUNE_TIMED && !t.guard_pending) {
+            (void) hipEventRecord(t.ev[0][k - SDRM_TUNE_SKIP], s_clock);
+        }
+        if (k == SDRM_TUNE_SKIP + SDRM_TUNE_TIMED) {
+            t.guard_pending = true;
+            t.guard_n = 0;
+        }
+        return;
+    }
+    if (t.state != 1 || t.idle) {
+        return;
+    }
+    if (t.phase == 1 || t.phase == 3) {
+        hipEvent_t *w = t.watch[t.phase == 1 ? 0 : 1];
+        if (t.n >= SDRM_WATCH_SKIP + SDRM_WATCH_TIMED) {
+            return;
+        }
+        t.n++;
+        if (t.n >= SDRM_WATCH_SKIP) {
+            (void) hipEventRecord(w[t.n - SDRM_WATCH_SKIP], s_clock);
+        }
+        if (t.n == SDRM_WATCH_SKIP + SDRM_WATCH_TIMED && t.phase == 1) {
+            t.phase = 2;
+            t.cand = 0;
+            t.n = 0;
+        }
+        return;
+    }
+    if (t.cand >= 6) {
         return;
     }
     t.n++;

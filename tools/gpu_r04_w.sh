@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-4 session W: online refinement by call class: short calls on a long-buffer batch, configs[4]'s mix again, tests, bench
+# Round-4 session W: online refinement by call class: short calls on a long-buffer batch, configs[4]'s mix (default and forced clock-stage
+# shapes), tests, bench
 set +e
 export TMPDIR=/tmp PYTHONFAULTHANDLER=1
 R=${GRAFT_REPO_ROOT:?}
@@ -17,13 +18,19 @@ for n in 4096 16384 32768; do
     done
   done
 done
+O2=gpurun_out/r04_config5_shapes.txt
+: > $O2
 for rep in 1 2; do
-  timeout 300 env SDRM_AUTOTUNE_LOG=1 python tools/config5.py 256 2>&1 | grep -E "channels:|refined" | tee -a $O
+for sh in default 16x512 16x256 32x512; do
+  if [ $sh = default ]; then e="A=1"; else e="SDRM_K3_LANES=$sh"; fi
+  r=$(env $e SDRM_AUTOTUNE_LOG=1 timeout 300 python tools/config5.py 256 2>&1 | grep -E "channels:|refined" | sed 's/.*channels: //; s/sdrmodem_hip: refined online for calls with NCO batches, [0-9]* samples per call: //' | tr '\n' '|')
+  printf "  %-8s %s\n" $sh "$r" | tee -a $O2
+done
 done
 timeout 900 python -u -m pytest tests -m gpu -x -q --timeout 250 --timeout-method=thread > gpurun_out/r04_pytest_w.log 2>&1; echo "suite exit $?"; grep -E "passed|failed" gpurun_out/r04_pytest_w.log | tail -1
 timeout 600 python bench.py > gpurun_out/r04_bench_w.json 2> gpurun_out/r04_bench_w.err; echo "bench exit $?"
 python - <<'PY'
 import json
 d=json.loads([l for l in open('gpurun_out/r04_bench_w.json') if l.startswith('{')][-1])
-print(d['value'], d['verified_vs_oracle'], d['config5']['value'], d['config5']['verified_vs_oracle'], d['config5'].get('schedule'), d['config']['schedule'])
+print(d['value'], d['verified_vs_oracle'], d['config5']['value'], d['config5']['verified_vs_oracle'], d['config5'].get('schedule'))
 PY
