@@ -3,5 +3,5 @@ set +e
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:?}
 mkdir -p gpurun_out
-MIX=1 FIRST=20 SDRM_K3_LANES=16x512 SDRM_K3_COMPANY=4096,1,100000 timeout 300 python tools/timeline_first_calls.py 256 131072 131072 > gpurun_out/r04_timeline_mix_company.txt 2>&1
-tail -64 gpurun_out/r04_timeline_mix_company.txt
+MIX=1 FIRST=200 timeout 300 python tools/timeline_first_calls.py 256 131072 131072 > gpurun_out/r04_timeline_mix.txt 2>&1
+tail -64 gpurun_out/r04_timeline_mix.txt
