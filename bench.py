@@ -254,7 +254,7 @@ def spot_channels(channels):
     return sorted(set(c for c in (0, 15, 16, channels // 2 + 1, channels - 1) if 0 <= c < channels))
 
 
-def end_to_end(binding, siggen, channels, chunk, calls=24, slots=4):
+def end_to_end(binding, siggen, channels, chunk, calls=72, slots=4):
     """host buffers in, soft bits out (sdrm_batch_arena / _submit / _collect): every call copies its pinned slot to the
     device, runs the path and copies the soft bits back; three calls in flight.  PCIe-inclusive -- never `value`."""
     b = binding.Batch([(FS, BAUD, DEV, DECIM, TW, DC, chunk)] * channels)
