@@ -1169,7 +1169,9 @@ static int ensure_nco(sdrm_batch_t *b) {
 //      a winner must win both rounds by more than 3 %;
 //   3. the winner's probation: 40 calls like (1); it stays only if its steady state beats (1) by more than 3 % -- a block of
 //      eight calls can flatter a setting whose cost builds up over tens of calls (seen: 1.05 ms per call in its blocks, 2.9 in
-//      the steady state, profiles/r04_online_refinement.txt).
+//      the steady state, profiles/r04_online_refinement.txt);
+//   4. a standing guard: every 64th call of the class starts a five-interval sample; two bad samples in a row (5 % behind (1)) give
+//      the starting point back for good.
 // Medians, because the host may stall between two calls (the HIP runtime grows its pools 6 ms at a time during a process's first
 // dozens of calls) and the device then idles for reasons no setting is to blame for.  The winner serves calls of its class (same
 // NCO flag, total length within a factor of two), other calls keep the calibrated setting.  Results do not depend on any of it.
@@ -1246,7 +1248,7 @@ static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
         if (!with_nco && sig * 2 > full_length_samples(b)) {
             return;
         }
-        static const char *env = getenv("SDRM_AUTOTUNE");
+        const char *env = getenv("SDRM_AUTOTUNE");  // read per batch, like the calibration does
         if (b->serial || b->clock_early || b->plan.design.size() < 32 || (env != nullptr && atoi(env) == 0) || b->n_gen > 0 ||
             sdrm::front_hold_is_forced() || getenv("SDRM_K3_COMPANY") != nullptr) {
             t.state = 2;
