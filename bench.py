@@ -284,7 +284,7 @@ def end_to_end(binding, siggen, channels, chunk, calls=72, slots=4):
                     "soft bits and counts back to pinned memory, 3 calls in flight (PCIe-inclusive)"}
 
 
-WARMUP5 = 160
+WARMUP5 = 192
 
 
 def config5_table(total, chunk):

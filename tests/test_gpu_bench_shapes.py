@@ -75,7 +75,7 @@ def test_sweep_shapes_at_full_call_length(torch_dev, channels):
 
 def test_config5_workload_as_benchmarked(torch_dev):
     """bench.py's `config5` block: 256 channels, 240 kHz / 19200 baud / decimation 5 interleaved with 48 kHz / 1200 baud /
-    decimation 8, 131072-sample calls, three NCO batches per channel and call; 160 warm-up steps (the batch refines its schedule
+    decimation 8, 131072-sample calls, three NCO batches per channel and call; 192 warm-up steps (the batch refines its schedule
     online over the first calls with NCO batches: front hold and companion grid change between calls) + 3 timed steps; 6 spot channels
     against orc.Nco + orc.Fsk after every timed step."""
     torch, dev = torch_dev
@@ -148,17 +148,17 @@ def test_short_calls_on_a_long_buffer_batch_refine_the_schedule_online(torch_dev
     cfg = (48000, 9600, 5000, 1, 2000, True, 65536)
     C_ = 64
     n = 8192
-    sig = siggen.gmsk_batch(4, 160 * n + 65536, first_channel=70)
+    sig = siggen.gmsk_batch(4, 192 * n + 65536, first_channel=70)
     g = binding.Batch([cfg] * C_, keep_soft=True)
     assert g.code == 0 and g.schedule()["online"]["state"] == 0
     oracles = {c: orc.Fsk(*cfg) for c in (0, 17, 63)}
-    for k in range(160):
+    for k in range(192):
         out = g.process([sig[c % 4, k * n:(k + 1) * n] for c in range(C_)])
         for c, o in oracles.items():
             assert np.array_equal(out[c], o.process(sig[c % 4, k * n:(k + 1) * n])[0]), (k, c)
     sch = g.schedule()["online"]
     assert sch["state"] == 2 and sch["choice"] in (0, 1, 2, 3) and all(ms > 0 for ms in sch["ms_per_call"][:4]), sch
-    out = g.process([sig[c % 4, 160 * n:160 * n + 65536] for c in range(C_)])
+    out = g.process([sig[c % 4, 192 * n:192 * n + 65536] for c in range(C_)])
     for c, o in oracles.items():
-        assert np.array_equal(out[c], o.process(sig[c % 4, 160 * n:160 * n + 65536])[0]), c
+        assert np.array_equal(out[c], o.process(sig[c % 4, 192 * n:192 * n + 65536])[0]), c
     g.close()

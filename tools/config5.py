@@ -24,7 +24,7 @@ segs = (binding.NcoSegment * (3 * Cn))(*[binding.NcoSegment(c, n, -10000 + (80 *
                                          for c in range(Cn) for k, n in enumerate((40000, 40000, N - 80000))])
 def call(i):
     assert L.sdrm_batch_process_device_nco(b.h, C.c_void_p(x.data_ptr() + (i % 2) * N * 8), 2 * N, lens, segs, 3 * Cn, C.c_void_p(st)) == 0
-WARM = int(sys.argv[2]) if len(sys.argv) > 2 else 160
+WARM = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 for i in range(WARM):  # the pipeline's fill + the online refinement for calls with NCO batches (~130 calls from the 17th on)
     call(i)
 torch.cuda.synchronize()

@@ -21,7 +21,7 @@ b = binding.Batch([cfg] * Cn)
 assert b.code == 0
 st = torch.cuda.current_stream().cuda_stream
 lens = (binding.C.c_size_t * Cn)(*([N] * Cn))
-for i in range(160):  # fill + (calls the calibration did not cover) the online refinement
+for i in range(192):  # fill + (calls the calibration did not cover) the online refinement
     b.process_device(x.data_ptr() + (i % 2) * N * 8, 2 * N, lens, st)
 torch.cuda.synchronize()
 b.timing_enable(True)
