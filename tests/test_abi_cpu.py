@@ -407,3 +407,27 @@ def test_reference_signature_adapter_places_workers_through_a_node(tmp_path):
         assert np.array_equal(got, want), i
     A.sdrm_ref_attach_node(None)
     node.close()
+
+
+def test_binding_structures_have_the_headers_sizes_and_offsets(tmp_path):
+    """The ctypes mirrors in sdr-modem_amd/binding.py (test and bench infrastructure) against include/sdrmodem_hip.h as a C
+    compiler lays it out: size of every structure, offset of its last field.  A field added on one side only shows here."""
+    import ctypes as C
+    import subprocess
+    pairs = [("sdrm_fsk_config", binding.FskConfig), ("sdrm_fsk_info", binding.FskInfo), ("sdrm_nco_segment", binding.NcoSegment),
+             ("sdrm_worker_config", binding.WorkerConfig), ("sdrm_batcher_config", binding.BatcherConfig),
+             ("sdrm_batch_schedule_info", binding.ScheduleInfo), ("sdrm_node_config", binding.NodeConfig),
+             ("sdrm_node_slot", binding.NodeSlot), ("sdrm_node_stat", binding.NodeStat)]
+    src = tmp_path / "sizes.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sdrmodem_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        last = cls._fields_[-1][0]
+        lines.append('    printf("%s %%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (cname, cname, cname, last))
+    lines += ['    return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict((ln.split()[0], (int(ln.split()[1]), int(ln.split()[2]))) for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in pairs:
+        last = cls._fields_[-1][0]
+        assert out[cname] == (C.sizeof(cls), getattr(cls, last).offset), (cname, out[cname], C.sizeof(cls), getattr(cls, last).offset)
