@@ -431,3 +431,13 @@ def test_binding_structures_have_the_headers_sizes_and_offsets(tmp_path):
     for cname, cls in pairs:
         last = cls._fields_[-1][0]
         assert out[cname] == (C.sizeof(cls), getattr(cls, last).offset), (cname, out[cname], C.sizeof(cls), getattr(cls, last).offset)
+
+
+def test_public_header_is_plain_c99_and_cxx11(tmp_path):
+    """include/sdrmodem_hip.h is what a C host (sdr-modem is C99) and a C++ host include: no torch, no HIP types"""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "sdrmodem_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    includes = [ln for ln in open(hdr) if ln.lstrip().startswith("#include")]
+    assert all(any(std in ln for std in ("<stdbool.h>", "<stddef.h>", "<stdint.h>", "<complex.h>")) for ln in includes), includes
