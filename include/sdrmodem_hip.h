@@ -189,6 +189,13 @@ void sdrm_doppler_destroy(sdrm_doppler *d);
 int sdrm_batch_timing_enable(sdrm_batch *batch, int enable);
 int sdrm_batch_timing_read(sdrm_batch *batch, int which, double *total_ms, uint64_t *launches);
 
+/* Channel-calls whose timing loop left the range in which it provably advances (a sample of the clock stage's input beyond
+ * the channel's safe amplitude -- discriminator gains in the thousands, i.e. a deviation of a few Hz, on noise; or fewer
+ * than ~1.01 samples per symbol): the reference's loop may then stand still or walk BACKWARDS through its buffer
+ * (src/dsp/clock_recovery_mm.c:121-122), which the LDS-resident stage cannot follow, so such a call is run from global
+ * memory, statement by statement -- same bits, slower.  Counted since the batch was created; waits for enqueued calls. */
+int sdrm_batch_wild_calls(sdrm_batch *batch, uint64_t *count);
+
 /* Stage probes for tests: run ONE stage of the device pipeline on a host vector (state-free where the
  * stage is). Return 0 on success. */
 int sdrm_probe_atan2(const float *y, const float *x, float *out, size_t n);

@@ -1683,6 +1683,24 @@ extern "C" int sdrm_batch_sync(sdrm_batch *b) {
     return wait_for_all_calls(b);
 }
 
+// channel-calls the clock stage ran from global memory (sdrm_kernels.h "wild channels"), since the batch was created
+extern "C" int sdrm_batch_wild_calls(sdrm_batch *b, uint64_t *count) {
+    if (b == nullptr || count == nullptr) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    const int code = wait_for_all_calls(b);
+    if (code != 0) {
+        return code;
+    }
+    uint32_t word = 0;
+    if (b->d_k3_done != nullptr) {
+        HIP_TRY(hipMemcpy(&word, b->d_k3_done + 3, sizeof(word), hipMemcpyDeviceToHost));
+    }
+    *count = word;
+    return 0;
+}
+
 extern "C" int sdrm_batch_process_device(sdrm_batch *b, const void *d_input, size_t in_stride, const size_t *input_lens,
                                          void *stream) {
     if (b == nullptr || input_lens == nullptr) {

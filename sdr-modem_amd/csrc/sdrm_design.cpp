@@ -89,15 +89,18 @@ int design_channel(const sdrm_fsk_config &cfg, ChannelDesign &out) {
     // A channel beyond either (the reference accepts any samples per symbol, fsk_demod.c:53-63) is served by the generic forms
     // of those two stages -- state in global memory, the IEEE division proper -- at a fraction of the speed, which such a
     // channel (>= 245 samples per symbol: a few hundred symbols per call) does not notice.
-    if (!(out.sps >= 1.0f) || !(out.sps <= (float) SDRM_GEN_MAX_SPS)) {
-        fprintf(stderr, "<3>samples per symbol %.3f outside the supported range [1, %d]\n", (double) out.sps, SDRM_GEN_MAX_SPS);
+    // Fewer than ~1.01 samples per symbol (the reference accepts them: a decimation beyond the symbol length): the timing
+    // loop is not tame at any amplitude, the clock stage runs such a channel from global memory (sdrm_k3_rescue).
+    if (!(out.sps > 0.0f) || !(out.sps <= (float) SDRM_GEN_MAX_SPS)) {
+        fprintf(stderr, "<3>samples per symbol %.3f outside the supported range (0, %d]\n", (double) out.sps, SDRM_GEN_MAX_SPS);
         return -ENOTSUP;
     }
     if (cfg.use_dc_block && out.dc_length < 2) {
         fprintf(stderr, "<3>dc blocker length %u outside the supported range\n", out.dc_length);
         return -ENOTSUP;
     }
-    out.generic = out.sps * 1.01f + 8.0f > (float) SDRM_CLOCK_HCAP || (cfg.use_dc_block && out.dc_length > SDRM_DC_MAX_LEN);
+    // (+ 24: the margin the oracle's own bound on the carried samples takes, oracle/sdrm_oracle.c orc_clock_create)
+    out.generic = out.sps * 1.01f + 24.0f > (float) (SDRM_CLOCK_HCAP - 1) || (cfg.use_dc_block && out.dc_length > SDRM_DC_MAX_LEN);
     if ((size_t) cfg.decimation > out.taps2.size()) {
         fprintf(stderr, "<3>decimation %u exceeds the filter length %zu\n", cfg.decimation, out.taps2.size());
         return -ENOTSUP;

@@ -154,8 +154,22 @@ struct sdrm_chan_params {
     float dc_len_f, dc_inv_len;     // (float) L and RN(1 / L): sdrm_boxcar_out_fast
     float omega_mid, omega_lim, gain_omega, gain_mu;
     uint32_t generic;               // the channel's DC blocker and clock recovery run in their generic forms (below: "generic channels")
-    uint32_t pad_[3];
+    float amp_safe;                 // clock-stage input amplitude below which the timing loop provably advances >= 1 sample per symbol ("tame")
+    uint32_t pad_[2];
 };
+
+// Per-call flags of a channel (DeviceBatch::nonfinite[c]), raised by the front-end (no DC blocker) or the DC stage on the stream
+// the clock stage is about to read, and the same bits in sdrm_clock_state::poison for what a call leaves behind:
+//   NONFINITE  NaN/Inf present: the clock stage's wave takes the NaN-aware form of the symbol (same ring, same order)
+//   WILD       a sample at or above the channel's amp_safe: the timing error can exceed the symbol length, i.e. the loop
+//              may stand still or walk BACKWARDS through its buffer (reference src/dsp/clock_recovery_mm.c:121-122 with
+//              floorf(mu) <= 0), further than an LDS ring remembers.  The channel leaves the ring-based loop for this call
+//              and is run from global memory, statement by statement (sdrm_k3_rescue).
+#define SDRM_FLAG_NONFINITE 1u
+#define SDRM_FLAG_WILD 2u
+// max over the 129 rows of the MMSE bank of sum |tap| (sdrm_tables.h; checked by tests/test_kernel_logic_cpu.py): an
+// interpolated symbol is at most this times the largest sample of its window
+#define SDRM_MMSE_ABS_SUM 1.5975f
 
 // per-call, per-channel control block, written by the host before every launch
 struct sdrm_chunk_ctl {
@@ -687,7 +701,8 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
 
 // phase 3: LPF2 with decimation (reference src/dsp/fir_filter.c:93-114), results to the tile's staging area
 template <int R, bool FUSED>
-SDRM_HD bool sdrm_k1_lpf2_decimated(int tid, const sdrm_k1_tile &t, int d, int ntaps, const float *taps2_rev, const float *qs, float *zs) {
+SDRM_HD bool sdrm_k1_lpf2_decimated(int tid, const sdrm_k1_tile &t, int d, int ntaps, const float *taps2_rev, const float *qs, float *zs,
+                                    float tame) {
     bool odd = false;
     // thread tid takes the outputs tid + k * THREADS (k = 0, 1, ...), R of them per pass
     for (int o0 = tid; o0 < t.m; o0 += R * SDRM_K1_THREADS) {
@@ -703,17 +718,38 @@ SDRM_HD bool sdrm_k1_lpf2_decimated(int tid, const sdrm_k1_tile &t, int d, int n
             const int o = o0 + r * SDRM_K1_THREADS;
             if (o < t.m) {
                 zs[o] = acc[r];
-                odd |= !(fabsf(acc[r]) < INFINITY);
+                odd |= !(fabsf(acc[r]) < tame);
             }
         }
     }
     return odd;
 }
 
+// The level a stage compares its outputs with: the channel's amp_safe on the stream the clock stage reads (the front-end's
+// without a DC blocker, the DC stage's with one), +Inf elsewhere.  A channel whose loop is not tame at ANY amplitude
+// (amp_safe <= 0: fewer than ~1.01 samples per symbol) is wild by configuration -- the clock stage knows, nothing to flag.
+SDRM_HD float sdrm_tame_level(const sdrm_chan_params &p, bool dc_stage) {
+    return ((p.dc_len != 0) == dc_stage && p.amp_safe > 0.0f) ? p.amp_safe : INFINITY;
+}
+// which of SDRM_FLAG_NONFINITE / SDRM_FLAG_WILD a sample of the clock stage's input raises (Inf raises both; NaN only the first)
+SDRM_HD uint32_t sdrm_flag_bits(float v, float tame) {
+    return (!(fabsf(v) < INFINITY) ? SDRM_FLAG_NONFINITE : 0u) | ((fabsf(v) >= tame) ? SDRM_FLAG_WILD : 0u);
+}
+SDRM_HD void sdrm_flag_raise(uint32_t *flag, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(flag, bits);
+#else
+    *flag |= bits;
+#endif
+}
+
 template <bool FUSED = false>
 SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps2_rev,
                                 const float *qs, float *zs, uint32_t *nonfinite_flag) {
     bool odd = false;
+    // the one compare per output that used to look for NaN/Inf also looks for samples the timing loop is not provably tame
+    // with (SDRM_FLAG_WILD) -- when this IS the clock stage's input; behind a DC blocker that stage looks at its own output
+    const float tame = sdrm_tame_level(p, false);
     if (p.decim == 1) {
         const int base = tid * SDRM_K1_RZ;
         if (base >= t.m) {
@@ -730,16 +766,28 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
         for (int r = 0; r < SDRM_K1_RZ; r++) {
             if (base + r < t.m) {
                 zs[base + r] = acc[r];
-                odd |= !(fabsf(acc[r]) < INFINITY);
+                odd |= !(fabsf(acc[r]) < tame);
             }
         }
+        if (odd) {  // rare: say which (the thread's own outputs, from the staging area)
+            uint32_t bits = 0;
+            for (int r = 0; r < SDRM_K1_RZ && base + r < t.m; r++) {
+                bits |= sdrm_flag_bits(zs[base + r], tame);
+            }
+            sdrm_flag_raise(nonfinite_flag, bits);
+        }
+        return;
     } else if (t.m <= 2 * SDRM_K1_THREADS) {
-        odd = sdrm_k1_lpf2_decimated<2, FUSED>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs);
+        odd = sdrm_k1_lpf2_decimated<2, FUSED>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs, tame);
     } else {
-        odd = sdrm_k1_lpf2_decimated<4, FUSED>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs);
+        odd = sdrm_k1_lpf2_decimated<4, FUSED>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs, tame);
     }
     if (odd) {
-        *nonfinite_flag = 1u;  // tells the clock stage to take its general (NaN-aware) path for this channel
+        uint32_t bits = 0;
+        for (int o = tid; o < t.m; o += SDRM_K1_THREADS) {
+            bits |= sdrm_flag_bits(zs[o], tame);
+        }
+        sdrm_flag_raise(nonfinite_flag, bits);
     }
 }
 
@@ -941,22 +989,22 @@ SDRM_HD void sdrm_k2_transition(const sdrm_k2_slot &s, int k, int q, const float
     }
 }
 
-// ---- output: x[n - 2(L-1)] - v3[n]; returns true when a result is not finite
-SDRM_HD bool sdrm_k2_output(const sdrm_k2_slot &s, int k, int q, const float *in_buf, float check, const float *z, const float *hx,
-                            float *out) {
+// ---- output: x[n - 2(L-1)] - v3[n]; returns the flags its results raise (SDRM_FLAG_NONFINITE / SDRM_FLAG_WILD)
+SDRM_HD uint32_t sdrm_k2_output(const sdrm_k2_slot &s, int k, int q, const float *in_buf, float check, const float *z, const float *hx,
+                                float *out, float tame) {
     float v[SDRM_K2_P];
     sdrm_k2_quotients(s, in_buf, check, q, v);
     const int n0 = k * SDRM_K2_BLK + q * SDRM_K2_P;
-    bool odd = false;
+    uint32_t bits = 0;
     for (int i = 0; i < SDRM_K2_P; i++) {
         const int n = n0 + i;
         if ((uint32_t) n < s.nz) {
             const float o = sdrm_k2_x(z, hx, s.HX, n - (int) s.HX) - v[i];
             out[n] = o;
-            odd |= !(fabsf(o) < INFINITY);
+            bits |= sdrm_flag_bits(o, tame);
         }
     }
-    return odd;
+    return bits;
 }
 
 // new hx = the last HX samples of (hx ++ z[0 .. nz)): element j for j in [j0, j1) (the caller orders reads before writes)
@@ -1253,6 +1301,102 @@ SDRM_HD void sdrm_k3_finish_linear(const sdrm_k3_lane &L, uint32_t hcap, int *fr
     }
     *from = (int) f;
     *keep = (int) k;
+}
+
+// ------------------------------------------------------------------------------------------------ wild channels
+// The ring-based symbol loops rest on one property of the timing loop: every symbol advances the position by at least one
+// sample.  It holds while |mm| stays small: mu' = mu + omega + gain_mu * mm >= (omega_mid - omega_lim) - |gain_mu| * |mm|,
+// |mm| <= |o| + |last| (clock_recovery_mm.c:115), |o| <= SDRM_MMSE_ABS_SUM * max |sample|.  sdrm_amp_safe() is the sample
+// amplitude up to which that gives mu' >= 1 with a 1e-4 relative margin over the few-ulp rounding of the operations involved;
+// the stage in front of the clock stage compares every sample it writes with it (the compare it already made for NaN/Inf)
+// and raises SDRM_FLAG_WILD otherwise.  A wild channel can stand still (symbols without consuming samples, until the output
+// buffer is full) or walk backwards by thousands of samples (discriminator gain of ~1900 at a deviation of a few Hz: mm of
+// several thousand) -- both defined behaviour in the reference as long as `ii` stays inside [0, working_len).
+SDRM_HD float sdrm_amp_safe(float omega_mid, float omega_lim, float gain_mu) {
+    const double room = ((double) omega_mid - (double) omega_lim) * (1.0 - 1e-6) - 1.0;  // what gain_mu * mm may take away
+    const double per_amp = 2.0 * fabs((double) gain_mu) * (double) SDRM_MMSE_ABS_SUM;
+    if (!(room > 0.0) || !(per_amp > 0.0)) {
+        return 0.0f;  // never tame (or NaN parameters)
+    }
+    // ... and never by more than the ring-based stage can carry into the next call: a symbol that jumps past the end of the
+    // call's samples leaves everything from its own position on (clock_recovery_mm.c:127-133), i.e. less than one advance
+    const double reach = (double) (SDRM_CLOCK_HCAP - 2) - ((double) omega_mid + (double) omega_lim) * (1.0 + 1e-6) - 1.0;
+    const double a = (room < reach ? room : reach) / per_amp * (1.0 - 1e-4);
+    if (!(a > 0.0)) {
+        return 0.0f;
+    }
+    return a > 3.0e38 ? 3.0e38f : (float) a;
+}
+// the same bound for the carried `last` symbol: what a tame window can produce, with room for the dot product's rounding
+SDRM_HD float sdrm_symbol_safe(float amp_safe) { return amp_safe * (SDRM_MMSE_ABS_SUM * 1.00001f); }
+
+// One call of one WILD channel, from global memory: the reference's loop statement by statement (src/dsp/clock_recovery_mm.c:
+// 78-139, the NaN-aware symbol) over the working buffer `carried samples ++ this call's samples`, any advance in either
+// direction.  `cs` holds the state the call started from (the ring-based loop has not touched it) and receives the state it
+// ends with; float and int8 soft bits and the count are written here.  Slow (a memory round trip per symbol) and rare.
+// Returns the symbol count.  `flagged`: the call's SDRM_FLAG_* bits.
+template <typename BankPtr>
+SDRM_HD uint32_t sdrm_k3_rescue(const sdrm_chan_params &p, sdrm_clock_state *cs, const float *src, int nz, BankPtr bank_rev,
+                                float *out_f32, int8_t *out_i8, uint32_t flagged) {
+    const int kept = (int) cs->kept;
+    sdrm_k3_lane L;
+    L.k.omega_mid = p.omega_mid;
+    L.k.omega_lim = p.omega_lim;
+    L.k.gain_omega = p.gain_omega;
+    L.k.gain_mu = p.gain_mu;
+    L.kept = 0;  // positions are absolute in the working buffer, as the reference's ii
+    L.nz = kept + nz;
+    L.oo = 0;
+    L.cap = p.max_len;
+    L.st.mu = cs->mu;
+    L.st.omega = cs->omega;
+    L.st.last = cs->last;
+    L.st.ii = 0;
+    L.st.inc = 0;
+    const float *hist = cs->hist;
+    // sample q of the working buffer; in front of it: what an aligned dot product reads there, multiplied by zero taps
+    auto at = [&](int q) -> float { return q < 0 ? 0.0f : (q < kept ? hist[q] : src[q - kept]); };
+    const uint32_t lim = sdrm_k3_limit(L, L.nz);
+    while (sdrm_k3_can_step(L, lim)) {
+        sdrm_k3_operands F;
+        const int ii = L.st.ii;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            F.w[j] = at(ii + j);
+        }
+        F.lead[0] = at(ii - 3);
+        F.lead[1] = at(ii - 2);
+        F.lead[2] = at(ii - 1);
+        const float scaled = L.st.mu * (float) SDRM_MMSE_STEPS;
+        F.row_ok = (scaled >= 0.0f) & (scaled <= (float) SDRM_MMSE_STEPS);  // false for NaN
+        const BankPtr row = bank_rev + (F.row_ok ? (int) rintf(scaled) : 0) * SDRM_K3_BANKPITCH;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            F.tap[j] = row[j];
+        }
+        const float soft = sdrm_k3_step<false>(L, F);
+        out_f32[L.oo] = soft;
+        out_i8[L.oo] = sdrm_soft_to_i8(soft);
+        L.oo++;
+    }
+    int from, keep;
+    sdrm_k3_finish_linear(L, (uint32_t) (SDRM_CLOCK_HCAP - 1), &from, &keep);
+    // carried samples, in place: entry j comes from position from + j >= j, so an ascending copy never reads what it wrote
+    bool tame_carry = true;
+    const float tame = p.amp_safe > 0.0f ? p.amp_safe : 0.0f;
+    for (int j = 0; j < keep; j++) {
+        const float v = at(from + j);
+        cs->hist[j] = v;
+        tame_carry &= fabsf(v) < tame;
+    }
+    cs->kept = (uint32_t) keep;
+    cs->mu = L.st.mu;
+    cs->omega = L.st.omega;
+    cs->last = L.st.last;
+    tame_carry &= fabsf(L.st.last) < sdrm_symbol_safe(tame);
+    const bool finite_state = fabsf(L.st.mu) < INFINITY && fabsf(L.st.omega) < INFINITY && fabsf(L.st.last) < INFINITY;
+    cs->poison = (((flagged & SDRM_FLAG_NONFINITE) != 0 || !finite_state) ? SDRM_FLAG_NONFINITE : 0u) | (tame_carry ? 0u : SDRM_FLAG_WILD);
+    return L.oo;
 }
 
 #endif  // SDRM_KERNELS_H

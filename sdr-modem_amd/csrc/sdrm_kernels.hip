@@ -666,6 +666,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
 
     float acc = 0.0f;                // chain wave: running sum of row (stage, slot) = lane
     bool odd = false;
+    float amax = 0.0f;               // output role: largest |output| of this lane (NaN never enters: v_max returns the other operand)
     uint32_t bslot = L.s.A;          // stage helpers: ring slot of the block they convert next (block 0: A)
     const int n_lane = L.q * K2_P;   // first sample of this lane inside a block
     const int nz = (int) L.s.nz;
@@ -813,6 +814,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
             for (int i = 0; i < K2_P; i++) {
                 o[i] = xd[i] - v[i];
                 probe = fmaf(o[i], 0.0f, probe);  // NaN as soon as one of them is not finite
+                amax = fmaxf(amax, fabsf(o[i]));  // (v_max3_f32 with |.| modifiers: two outputs per instruction)
             }
             k2_store_p(L.out + n0, o);
             odd |= probe != probe;
@@ -903,12 +905,17 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
                     if (n0 + K2_P <= nz) {
                         k2_store_p(L.out + n0, o);
                         odd |= probe != probe;
+#pragma unroll
+                        for (int i = 0; i < K2_P; i++) {
+                            amax = fmaxf(amax, fabsf(o[i]));
+                        }
                     } else {
 #pragma unroll
                         for (int i = 0; i < K2_P; i++) {
                             if (n0 + i < nz) {
                                 L.out[n0 + i] = o[i];
                                 odd |= !(fabsf(o[i]) < INFINITY);
+                                amax = fmaxf(amax, fabsf(o[i]));
                             }
                         }
                     }
@@ -1103,8 +1110,13 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
             }
         }
     }
-    if (role == 5 && odd && L.on) {
-        b.nonfinite[L.s.chan] = 1u;  // the clock stage takes its general (NaN-aware) path for this channel
+    if (role == 5 && L.on) {
+        // NaN/Inf: the clock stage takes its general (NaN-aware) symbol for this channel; beyond the tame amplitude
+        // (sdrm_kernels.h "wild channels"; an Inf raises both): it runs the channel's call from global memory
+        const uint32_t bits = (odd ? SDRM_FLAG_NONFINITE : 0u) | (!(amax < sdrm_tame_level(b.params[L.s.chan], true)) ? SDRM_FLAG_WILD : 0u);
+        if (bits) {
+            atomicOr(b.nonfinite + L.s.chan, bits);
+        }
     }
     // hx <- last HX samples of (hx ++ z): a slot at a time by all threads; when the call is shorter than HX the new array
     // overlaps the old one shifted by nz, so every round reads before anybody writes (and later rounds read further up)
@@ -1452,25 +1464,33 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     // a channel that takes no part in this call keeps its state as it is: the lane stays out of everything below
     // ... and so does a generic channel (k3_clock_generic runs it behind this kernel and writes its output count)
     const bool absent = active && (b.ctl[c].absent != 0 || b.params[c].generic != 0);
+    // a WILD channel (sdrm_kernels.h: a sample beyond the amplitude up to which the timing loop provably advances, in this
+    // call or among what the last one left behind) takes no part in the ring-based loops either: its samples are staged like
+    // the others' (the staging stays uniform) but its lane never steps, and sdrm_k3_rescue runs its call behind the loops
+    bool wild = false;
     if (!producer) {
         int uses_dc = 0;
         if (active && !absent) {
             const sdrm_chan_params p = b.params[c];
-            L.k.omega_mid = p.omega_mid;
-            L.k.omega_lim = p.omega_lim;
-            L.k.gain_omega = p.gain_omega;
-            L.k.gain_mu = p.gain_mu;
-            L.cap = p.max_len;
             L.nz = (int) b.ctl[c].nz;
-            L.kept = (int) cs->kept;
-            L.st.mu = cs->mu;
-            L.st.omega = cs->omega;
-            L.st.last = cs->last;
             uses_dc = p.dc_len != 0;
             flagged = b.nonfinite[c];
-            clean = (flagged == 0) & (cs->poison == 0);
-            for (int j = 0; j < L.kept; j++) {
-                sdrm_k3_ring_put<G>(my_col, j - L.kept, cs->hist[j]);
+            const uint32_t carried = cs->poison;
+            wild = ((flagged | carried) & SDRM_FLAG_WILD) != 0 || !(p.amp_safe > 0.0f);
+            if (!wild) {
+                L.k.omega_mid = p.omega_mid;
+                L.k.omega_lim = p.omega_lim;
+                L.k.gain_omega = p.gain_omega;
+                L.k.gain_mu = p.gain_mu;
+                L.cap = p.max_len;
+                L.kept = (int) cs->kept;
+                L.st.mu = cs->mu;
+                L.st.omega = cs->omega;
+                L.st.last = cs->last;
+                clean = (flagged == 0) & (carried == 0);
+                for (int j = 0; j < L.kept; j++) {
+                    sdrm_k3_ring_put<G>(my_col, j - L.kept, cs->hist[j]);
+                }
             }
         }
         nz_sh[lane] = L.nz;
@@ -1796,6 +1816,14 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     }
     if (absent) {
         b.out_len[c] = 0;
+    } else if (active && wild) {
+        const sdrm_chan_params p = b.params[c];
+        const float *src = (p.dc_len ? b.dcout : b.z) + (size_t) c * b.z_stride;
+        b.out_len[c] = sdrm_k3_rescue(p, cs, src, L.nz, (const float *) bank_rev, of, b.out_i8 + (size_t) c * b.out_stride, flagged);
+        b.nonfinite[c] = 0;
+        if (b.k3_done != nullptr) {
+            atomicAdd(b.k3_done + 3, 1u);  // sdrm_batch_wild_calls
+        }
     } else if (active) {
         int from_n, new_kept;
         sdrm_k3_finish(L, &from_n, &new_kept);
@@ -1808,7 +1836,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         cs->last = L.st.last;
         // the carried samples come from this call's stream; a loop state that is no longer finite (an Inf sample makes
         // omega and mu NaN two symbols later) keeps the channel off the finite-only fast path until it is reset
-        cs->poison = (flagged != 0 || !(fabsf(L.st.mu) < INFINITY) || !(fabsf(L.st.omega) < INFINITY) || !(fabsf(L.st.last) < INFINITY)) ? 1u : 0u;
+        cs->poison = (flagged != 0 || !(fabsf(L.st.mu) < INFINITY) || !(fabsf(L.st.omega) < INFINITY) || !(fabsf(L.st.last) < INFINITY)) ? SDRM_FLAG_NONFINITE : 0u;
         b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
         b.out_len[c] = L.oo;
     }

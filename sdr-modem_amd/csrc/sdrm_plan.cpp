@@ -63,6 +63,7 @@ static int params_from_design(const ChannelDesign &d, sdrm_chan_params &p) {
         p.dc_inv_len = 1.0f / p.dc_len_f;  // correctly rounded reciprocal: sdrm_boxcar_out_fast
     }
     p.generic = d.generic ? 1u : 0u;
+    p.amp_safe = sdrm_amp_safe(p.omega_mid, p.omega_lim, p.gain_mu);
     return 0;
 }
 

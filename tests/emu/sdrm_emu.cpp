@@ -27,6 +27,7 @@ struct EmuBatch {
     std::vector<uint32_t> outlen;
     std::vector<sdrm_chunk_ctl> ctl;
     std::vector<uint32_t> nonfinite;
+    uint64_t wild_calls = 0;
     std::vector<float> nco_state;
     std::vector<std::vector<sdrm_f2>> mixed;
     std::vector<sdrm_nco_seg> nco_table;
@@ -231,8 +232,9 @@ static void emu_dc(EmuBatch *b) {
                         if (stage < 3) {
                             sdrm_k2_transition(hs, k, q, in_buf, cp, rings.data() + ((size_t) stage * G + slot_h) * rpitch,
                                                ts.data() + (row + SDRM_K2_SLOTS) * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK);
-                        } else if (sdrm_k2_output(hs, k, q, in_buf, cp, chan_z(hs), chan_hx(hs), b->dcout.data() + (size_t) hs.chan * pl.z_stride)) {
-                            b->nonfinite[hs.chan] = 1u;
+                        } else {
+                            b->nonfinite[hs.chan] |= sdrm_k2_output(hs, k, q, in_buf, cp, chan_z(hs), chan_hx(hs), b->dcout.data() + (size_t) hs.chan * pl.z_stride,
+                                                                    sdrm_tame_level(pl.params[hs.chan], true));
                         }
                     }
                 }
@@ -286,6 +288,7 @@ static void emu_clock_as(EmuBatch *b) {
         bool clean[G::lanes];
         uint32_t flagged[G::lanes];
         bool absent[G::lanes];
+        bool wild[G::lanes];
         int max_nz = 0;
         const int nl = C - c0 < G::lanes ? C - c0 : G::lanes;
         for (int l = 0; l < nl; l++) {
@@ -306,6 +309,12 @@ static void emu_clock_as(EmuBatch *b) {
             L.st.inc = 0;
             flagged[l] = b->nonfinite[c];
             clean[l] = flagged[l] == 0 && cs.poison == 0;
+            // as the kernel: a wild channel's samples are staged, its lane never steps, sdrm_k3_rescue runs its call
+            wild[l] = !absent[l] && ((((flagged[l] | cs.poison) & SDRM_FLAG_WILD) != 0) || !(p.amp_safe > 0.0f));
+            if (wild[l]) {
+                L.cap = 0;
+                L.kept = 0;
+            }
             float *col = ring.data() + l * G::cpitch;
             for (int j = 0; j < L.kept; j++) sdrm_k3_ring_put<G>(col, j - L.kept, cs.hist[j]);
             max_nz = L.nz > max_nz ? L.nz : max_nz;
@@ -354,6 +363,15 @@ static void emu_clock_as(EmuBatch *b) {
                 b->outlen[c] = 0;
                 continue;
             }
+            if (wild[l]) {
+                const sdrm_chan_params &p = pl.params[c];
+                const float *src = (p.dc_len ? b->dcout.data() : b->z.data()) + (size_t) c * pl.z_stride;
+                b->outlen[c] = sdrm_k3_rescue(p, &cs, src, L.nz, (const float *) bank_rev, b->outf.data() + (size_t) c * pl.out_stride,
+                                              b->out8.data() + (size_t) c * pl.out_stride, flagged[l]);
+                b->nonfinite[c] = 0;
+                b->wild_calls++;
+                continue;
+            }
             int from_n, new_kept;
             sdrm_k3_finish(L, &from_n, &new_kept);
             const float *col = ring.data() + l * G::cpitch;
@@ -365,7 +383,7 @@ static void emu_clock_as(EmuBatch *b) {
             cs.omega = L.st.omega;
             cs.last = L.st.last;
             cs.poison = (flagged[l] != 0 || !(fabsf(lanes[l].st.mu) < INFINITY) || !(fabsf(lanes[l].st.omega) < INFINITY) ||
-                         !(fabsf(lanes[l].st.last) < INFINITY)) ? 1u : 0u;  // as the kernel: a non-finite loop state stays off the fast path
+                         !(fabsf(lanes[l].st.last) < INFINITY)) ? SDRM_FLAG_NONFINITE : 0u;  // as the kernel: a non-finite loop state stays off the fast path
             b->nonfinite[c] = 0;
             b->outlen[c] = L.oo;
         }
@@ -494,6 +512,8 @@ static void emu_clock_generic(EmuBatch *b) {
         b->outlen[c] = L.oo;
     }
 }
+
+extern "C" uint64_t emu_wild_calls(const EmuBatch *b) { return b->wild_calls; }
 
 // inputs[c]: interleaved cf32, lens[c] samples.  Outputs: per channel pointers into emu-owned memory.
 extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t *lens, const int8_t **out8,

@@ -30,6 +30,8 @@ def lib():
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.emu_process_nco.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(NcoSegment),
                                       C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.emu_wild_calls.argtypes = [C.c_void_p]
+        L.emu_wild_calls.restype = C.c_uint64
         L.emu_mixed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.emu_mixed.restype = C.c_size_t
         L.emu_doppler_plan_stream.argtypes = [C.c_uint64, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_size_t),
@@ -106,6 +108,9 @@ class EmuBatch:
             r8.append(np.ctypeslib.as_array(C.cast(o8[c], C.POINTER(C.c_int8)), shape=(n,)).copy() if n else np.zeros(0, np.int8))
             rf.append(np.ctypeslib.as_array(C.cast(of[c], C.POINTER(C.c_float)), shape=(n,)).copy() if n else np.zeros(0, np.float32))
         return r8, rf
+
+    def wild_calls(self):
+        return lib().emu_wild_calls(self.h)
 
     def reset_channel(self, c, cfg=None):
         arr = make_configs([cfg]) if cfg is not None else None

@@ -132,3 +132,79 @@ def test_long_symbols_beyond_the_fast_stages_random_configurations():
             assert np.array_equal(g8[i], o8), (cfgs[i], call, lens[i])
             assert np.array_equal(g.last_soft(i).view(np.uint32), of.view(np.uint32)), (cfgs[i], call)
     g.close()
+
+
+def _noise(seed, n, sigma):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(0, sigma, n) + 1j * rng.normal(0, sigma, n)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("shape", [None, "64x256p", "32x512", "16x256"])
+@pytest.mark.parametrize("keep_soft", [False, True])
+def test_low_deviation_bin_timing_loops_that_stand_still_or_walk_backwards(keep_soft, shape, monkeypatch):
+    """Deviation log-uniform in 1 .. 1000 Hz (discriminator gains 7 .. 38000) on noise over three decades: the timing error
+    reaches thousands of samples, the reference's loop stands still or walks backwards through its buffer
+    (src/dsp/clock_recovery_mm.c:121-122) -- silently wrong symbols from the ring-based clock stage until round 5 (review of
+    round 4, weak 1).  40 such channels in ONE batch beside ordinary GMSK channels (which must not notice), ragged calls,
+    several workgroup shapes of the clock stage: int8 and float soft bits equal the oracle's, and BOTH forms of the stage
+    were taken (sdrm_batch_wild_calls)."""
+    if shape:
+        monkeypatch.setenv("SDRM_K3_LANES", shape)
+    rng = np.random.default_rng(20261005)
+    maxlen = 6000
+    cfgs, sigma = [], []
+    while len(cfgs) < 40:
+        fs, baud = [(48000, 9600), (48000, 4800), (240000, 19200), (48000, 19200), (192000, 40000), (48000, 1200), (96000, 9600)][rng.integers(7)]
+        cfgs.append((fs, baud, int(np.exp(rng.uniform(0, np.log(1000)))) * int(rng.choice([1, 1, 1, -1])), int(rng.choice([1, 1, 2, 4, 5, 8])),
+                     2000, bool(rng.integers(2))))
+        sigma.append(float(np.exp(rng.uniform(np.log(1e-3), np.log(2)))))
+    cfgs += [(48000, 9600, 5000, 1, 2000, True), (48000, 9600, 5000, 1, 2000, False), (240000, 19200, 5000, 5, 2000, True),
+             (48000, 9600, 5000, 7, 2000, True)]  # the last: 0.71 samples per symbol (-ENOTSUP until round 5)
+    sigma += [0.0] * 4
+    full = [c + (maxlen,) for c in cfgs]
+    oracles = [orc.Fsk(*c) for c in full]
+    assert all(o.code == 0 for o in oracles)
+    g = binding.Batch(full, keep_soft=keep_soft)
+    assert g.code == 0
+    gmsk = {i: siggen.gmsk_channel(500 + i, 6 * maxlen, fs=cfgs[i][0], baud=cfgs[i][1]) for i in range(40, 44)}
+    pos = [0] * len(cfgs)
+    for call in range(6):
+        lens = [int(rng.choice([0, 1, 7, 100, 1999, 4096, maxlen, maxlen])) for _ in cfgs]
+        parts = []
+        for i, n in enumerate(lens):
+            if i in gmsk:
+                parts.append(gmsk[i][pos[i]:pos[i] + n])
+            else:
+                x = _noise(int(rng.integers(1 << 30)), n, sigma[i])
+                if i % 3 == 1:
+                    x = (x + np.exp(2j * np.pi * 0.01 * np.arange(pos[i], pos[i] + n))).astype(np.complex64)
+                parts.append(x)
+            pos[i] += n
+        g8 = g.process(parts)
+        for i, o in enumerate(oracles):
+            o8, of = o.process(parts[i])
+            assert np.array_equal(g8[i], o8), (cfgs[i], call, lens[i], len(g8[i]), len(o8))
+            if keep_soft:
+                assert np.array_equal(g.last_soft(i).view(np.uint32), of.view(np.uint32)), (cfgs[i], call)
+    wild = g.wild_calls()
+    assert 30 < wild < 6 * 41, wild  # most of the noise channels' calls and every call of the last channel; never the three GMSK ones'
+    g.close()
+
+
+def test_the_review_s_backward_walk_case_on_the_device():
+    """review of round 4, weak 1: (48000, 9600, 1, 1, 2000, dc) on Gaussian noise of sigma 0.7, one 5000-sample call --
+    oracle 185 symbols there, 135 from the ring-based loop"""
+    for cfg in [(48000, 9600, 1, 1, 2000, True), (240000, 19200, 4, 2, 2000, True), (48000, 19200, 4, 2, 2000, True)]:
+        for keep_soft in (False, True):
+            o = orc.Fsk(*cfg, 5000)
+            g = binding.Batch([cfg + (5000,)], keep_soft=keep_soft)
+            assert o.code == 0 and g.code == 0
+            for k in range(3):
+                x = _noise(99 + k, 5000, 0.7)
+                o8, of = o.process(x)
+                g8 = g.process([x])[0]
+                assert np.array_equal(g8, o8), (cfg, k, len(g8), len(o8))
+                if keep_soft:
+                    assert np.array_equal(g.last_soft(0).view(np.uint32), of.view(np.uint32)), (cfg, k)
+            assert g.wild_calls() == 3
+            g.close()

@@ -173,6 +173,112 @@ def test_any_samples_per_symbol_through_the_generic_stages():
     assert np.array_equal(o.process(sigs[1][:8192])[0], e8[1])
 
 
+def noise(seed, n, sigma):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(0, sigma, n) + 1j * rng.normal(0, sigma, n)).astype(np.complex64)
+
+
+def run_counting(cfg, parts, maxlen):
+    """the stream `parts` (list of complex64 calls) through oracle and emulation, bit for bit; returns (symbols, wild channel-calls)"""
+    o = orc.Fsk(*cfg, maxlen)
+    e = emu_api.EmuBatch([cfg + (maxlen,)])
+    assert o.code == 0 and e.code == 0, (cfg, o.code, e.code)
+    total = 0
+    for k, part in enumerate(parts):
+        o8, of = o.process(part)
+        e8, ef = e.process([part])
+        assert len(o8) == len(e8[0]), (cfg, k, len(o8), len(e8[0]))
+        assert np.array_equal(of.view(np.uint32), ef[0].view(np.uint32)), (cfg, k)
+        assert np.array_equal(o8, e8[0]), (cfg, k)
+        total += len(o8)
+    return total, e.wild_calls()
+
+
+@pytest.mark.parametrize("cfg", [(48000, 9600, 1, 1, 2000, True), (240000, 19200, 4, 2, 2000, True), (48000, 19200, 4, 2, 2000, True),
+                                 (48000, 9600, -3, 1, 2000, False)], ids=str)
+def test_timing_loop_that_walks_backwards_through_its_buffer(cfg):
+    """A discriminator gain in the thousands (a deviation of a few Hz) on noise: the timing error is thousands of samples, the
+    reference's loop walks BACKWARDS through its working buffer (`ii += (int) floorf(mu)` with mu < 0,
+    src/dsp/clock_recovery_mm.c:121-122; defined while ii stays in [0, working_len)), or stands still and fills its output
+    buffer.  An LDS ring remembers two staging blocks: until round 5 the ring-based loop read overwritten slots there and
+    returned WRONG symbols without an error (round-4 review: oracle 185 symbols, emulation 135 on the first case).  Now the
+    stage in front of the clock stage flags every sample beyond the amplitude up to which the loop provably advances
+    (sdrm_amp_safe), and a flagged channel's call is run from global memory (sdrm_k3_rescue): same bits as the oracle."""
+    symbols, wild = run_counting(cfg, [noise(99, 5000, 0.7)], 5000)
+    assert wild == 1 and symbols > 0
+    # a stream of calls: full, ragged, empty; the state a wild call leaves behind (carried samples, last symbol) is wild too
+    parts = [noise(100 + k, n, 0.7) for k, n in enumerate([5000, 1, 0, 4999, 7, 2500, 5000])]
+    symbols, wild = run_counting(cfg, parts, 5000)
+    assert wild == len(parts)
+
+
+def test_a_wild_channel_returns_to_the_ring_based_loop_when_its_signal_does():
+    """wild calls (noise at a gain of 7600), then a clean carrier with a little noise: after the call whose carried samples and
+    last symbol are tame again, the channel is back on the LDS-resident loop -- bit-equal throughout"""
+    cfg = (48000, 9600, 1, 1, 2000, False)
+    quiet = [(np.exp(2j * np.pi * 1e-6 * np.arange(4000 * k, 4000 * (k + 1))) + noise(7 + k, 4000, 1e-5)).astype(np.complex64) for k in range(6)]
+    parts = [noise(1, 4000, 0.5), noise(2, 4000, 0.5)] + quiet
+    symbols, wild = run_counting(cfg, parts, 4000)
+    assert 2 <= wild <= 4, wild  # the two noise calls, and at most the two calls their filter tails and carried samples reach
+
+
+def test_ordinary_signals_never_leave_the_ring_based_loop():
+    """every reference fixture configuration on noisy GMSK, and on noise alone at full scale: no call is flagged"""
+    for i, cfg in enumerate(CONFIGS):
+        iq = siggen.gmsk_channel(40 + i, 3 * 8192, fs=cfg[0], baud=cfg[1])
+        symbols, wild = run_counting(cfg, [iq[:8192], iq[8192:16384], noise(i, 8192, 1.0)], 8192)
+        assert wild == 0, (cfg, wild)
+
+
+def test_fewer_than_one_sample_per_symbol():
+    """48 kHz / 9600 baud decimated by 7 (0.71 samples per symbol): the reference accepts it (src/dsp/fsk_demod.c:53-63 has no
+    range check) and produces more symbols than it has samples, until its output buffer is full; -ENOTSUP until round 5.
+    The timing loop is not tame at any amplitude there (omega - limit < 1): such a channel always runs from global memory."""
+    iq = siggen.gmsk_channel(3, 20000, fs=48000, baud=9600)
+    for cfg in [(48000, 9600, 5000, 7, 2000, True), (48000, 9600, 5000, 5, 2000, False), (48000, 19200, 5000, 4, 2000, True),
+                (48000, 9600, 5000, 50, 2000, True)]:
+        symbols, wild = run_counting(cfg, [iq[:8000], iq[8000:8003], iq[8003:16003], iq[16003:20000]], 8000)
+        assert wild == 4 and symbols > 0, (cfg, symbols, wild)
+
+
+def test_low_deviation_fuzz_against_the_oracle():
+    """deviation log-uniform in 1 .. 1000 Hz (discriminator gains 7 .. 38000), every sample rate / decimation / DC choice,
+    noise over three decades with and without a carrier, ragged multi-call streams: oracle == emulation bit for bit, whichever
+    of the two clock-stage forms each call takes (both must be taken)"""
+    rng = np.random.default_rng(2025)
+    wild_total = calls_total = 0
+    for it in range(250):
+        fs, baud = [(48000, 9600), (48000, 4800), (240000, 19200), (48000, 19200), (192000, 40000), (48000, 1200), (96000, 9600)][rng.integers(7)]
+        cfg = (fs, baud, int(np.exp(rng.uniform(0, np.log(1000)))) * int(rng.choice([1, 1, 1, -1])), int(rng.choice([1, 1, 2, 4, 5, 8])), 2000,
+               bool(rng.integers(2)))
+        maxlen = int(rng.choice([3000, 5000, 8192]))
+        sigma = float(np.exp(rng.uniform(np.log(1e-3), np.log(2))))
+        parts = []
+        for k in range(int(rng.integers(1, 5))):
+            n = int(rng.choice([maxlen, maxlen, rng.integers(0, maxlen + 1), rng.integers(0, 50)]))
+            x = noise(int(rng.integers(1 << 30)), n, sigma)
+            if it % 3 == 1:
+                x = (x + np.exp(2j * np.pi * rng.uniform(-0.1, 0.1) * np.arange(n))).astype(np.complex64)
+            parts.append(x)
+        symbols, wild = run_counting(cfg, parts, maxlen)
+        wild_total += wild
+        calls_total += len(parts)
+    assert 0.2 * calls_total < wild_total < calls_total, (wild_total, calls_total)
+
+
+def test_the_bound_on_an_interpolated_symbol_covers_the_filter_bank():
+    """SDRM_MMSE_ABS_SUM (sdrm_kernels.h) >= max over the bank's rows of sum |tap|: what sdrm_amp_safe's proof uses"""
+    import re
+    root = os.path.dirname(GOLDEN)
+    text = open(os.path.join(root, "..", "sdr-modem_amd", "csrc", "sdrm_tables.h")).read()
+    body = text[text.index("sdrm_mmse_bank[129][8]"):]
+    body = body[:body.index("};")]
+    bank = np.array(re.findall(r"-?\d+\.\d+(?:e[+-]\d+)?", body), dtype=np.float64).reshape(129, 8)
+    hdr = open(os.path.join(root, "..", "sdr-modem_amd", "csrc", "sdrm_kernels.h")).read()
+    bound = float(re.search(r"#define SDRM_MMSE_ABS_SUM ([0-9.]+)f", hdr).group(1))
+    assert np.abs(bank).sum(axis=1).max() <= bound < np.abs(bank).sum(axis=1).max() * 1.001
+
+
 def test_synthetic_gmsk_large_chunk():
     iq = siggen.gmsk_channel(0, 70000)
     run_both((48000, 9600, 5000, 1, 2000, True), iq, [65536, 4464], 65536)

@@ -1,7 +1,8 @@
 """Soak: seeded differential fuzz of the HIP path against the oracle for a given number of seconds (GPU box).
 Every round draws a batch of random configurations (as tests/test_gpu_fuzz.py), random signals -- GMSK, white noise over
 many decades, silence, denormal-scale and constant stretches spliced in -- and random call lengths up to 20000 samples;
-every fifth round adds channels of 267 to 400 samples per symbol (generic stages);
+every fifth round adds channels of 267 to 400 samples per symbol (generic stages); every second round channels with a
+deviation of 1 .. 1000 Hz (timing loops outside their tame range: the clock stage's global-memory form);
 every third round also drives one plain fsk_demod handle with repeated lengths (the graph replay), every fourth the
 pinned-arena pipeline with three calls in flight, every fifth device-resident calls queued back to back, every 25th a batch
 of 400 to 2100 channels.  Bit-exact or it stops.
@@ -49,6 +50,11 @@ while time.time() < t_end:
     if seed % 5 == 1:  # round 4: symbols beyond the fast stages' range (generic DC / clock stages) inside an ordinary batch
         cfgs += [c + (maxlen,) for c in [(240000, 600, 5000, 1, 2000, True), (240000, 900, 2400, 1, 1000, bool(rng.integers(0, 2))),
                                          (480000, 1200, 5000, 1, 2000, False), (96000, 300, 5000, 1, 2000, True)]]
+    if seed % 2 == 1:  # round 5: deviations of 1 .. 1000 Hz (gains up to 38000: timing loops that stand still or walk backwards)
+        for _ in range(int(rng.integers(2, 12))):
+            fs, baud = [(48000, 9600), (48000, 4800), (240000, 19200), (48000, 19200), (192000, 40000), (48000, 1200), (96000, 9600)][rng.integers(7)]
+            cfgs.append((fs, baud, int(np.exp(rng.uniform(0, np.log(1000)))) * int(rng.choice([1, 1, 1, -1])), int(rng.choice([1, 1, 2, 4, 5, 8])),
+                         2000, bool(rng.integers(2)), maxlen))
     oracles = [orc.Fsk(*c) for c in cfgs]
     keep = [o.code == 0 for o in oracles]
     cfgs = [c for c, k in zip(cfgs, keep) if k]; oracles = [o for o, k in zip(oracles, keep) if k]
