@@ -192,7 +192,8 @@ def load():
         L.sdrm_batch_schedule.argtypes = [vp, C.POINTER(ScheduleInfo)]
     L.sdrm_batch_timing_enable.argtypes = [vp, C.c_int]
     L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
-    L.sdrm_batch_wild_calls.argtypes = [vp, C.POINTER(C.c_uint64)]
+    if hasattr(L, "sdrm_batch_wild_calls"):  # absent only from older builds loaded through SDRM_LIB_PATH for A/B measurements
+        L.sdrm_batch_wild_calls.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.sdrm_probe_atan2.argtypes = [vp, vp, vp, C.c_size_t]
     L.sdrm_probe_boxcar_div.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
     L.sdrm_probe_quad.argtypes = [vp, C.c_size_t, C.c_float, vp, vp]

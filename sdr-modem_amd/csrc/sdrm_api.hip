@@ -102,6 +102,7 @@ struct sdrm_batch_t {
     hipStream_t s_company = nullptr;
     hipEvent_t ev_company = nullptr;
     uint32_t *d_k3_done = nullptr;   // clock-stage workgroups finished, all launches
+    uint32_t *d_counters = nullptr;  // [16] batch-lifetime device counters (DeviceBatch::counters)
     uint32_t *d_placed = nullptr;    // [2] DC / clock-stage workgroups started, all launches (what the stream holds wait for)
     uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started
     uint32_t k3_placed_after[SDRM_CTL_SLOTS] = {};        // ... once the clock stage of the call in that slot has
@@ -256,6 +257,7 @@ static void batch_free(sdrm_batch_t *b) {
     }
     (void) hipFree(b->d_k3_done);
     (void) hipFree(b->d_placed);
+    (void) hipFree(b->d_counters);
     for (hipStream_t st : streams) {
         if (st) {
             (void) hipStreamDestroy(st);
@@ -354,6 +356,20 @@ static uint32_t carried_cap(const sdrm_chan_params &p) {
     return p.generic ? sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim).hcap : (uint32_t) SDRM_CLOCK_HCAP;
 }
 
+// The most symbols a call that brings `nz` samples to the channel's clock stage can produce: what sizes the int8 conversion's
+// grid and the copy back to the host.  In lock a symbol advances by at least floor(omega_mid - omega_lim) samples; a channel
+// whose timing loop can leave its tame range (sdrm_kernels.h "wild channels") may stand still and fill its output buffer
+// (clock_recovery_mm.c:103 `oo < output_len`).  A tame channel far out of lock can exceed the first bound too (it advances
+// by at least ONE sample per symbol): the conversion kernel's last workgroup then walks on to the real count, the blocking
+// calls fetch the tail with a second copy, the pipelined path drops it with a message (sdrm_batch_collect).
+static uint32_t symbols_bound(const sdrm_chan_params &p, uint32_t nz) {
+    const float adv = floorf(p.omega_mid - p.omega_lim);
+    if (p.can_wild || !(adv >= 1.0f)) {
+        return p.max_len;
+    }
+    return std::min<uint32_t>(p.max_len, (uint32_t) ((nz + carried_cap(p)) / (uint32_t) adv) + 8u);
+}
+
 // ---- generic channels: one device allocation per such channel (its DC rings and clock working buffer), zeroed -------------
 static int sync_generic(sdrm_batch_t *b, long only_channel) {
     const sdrm::BatchPlan &pl = b->plan;
@@ -435,6 +451,7 @@ static int reset_all_streams(sdrm_batch_t *b) {
     HIP_TRY(hipMemcpy(b->d_clock, cs.data(), sizeof(sdrm_clock_state) * C, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b->d_flags, 0, sizeof(uint32_t) * C * SDRM_CTL_SLOTS));
     HIP_TRY(hipMemset(b->d_outlen, 0, sizeof(uint32_t) * C));
+    HIP_TRY(hipMemset(b->d_counters, 0, 64));  // sdrm_batch_wild_calls counts the caller's calls, not the calibration's
     HIP_TRY(hipDeviceSynchronize());
     std::fill(b->plan.phase.begin(), b->plan.phase.end(), 0u);
     std::fill(b->plan.parity.begin(), b->plan.parity.end(), 0u);
@@ -667,6 +684,8 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     e = e ? e : hipMemcpy(b->d_atan, sdrm_atan_tab, sizeof(float) * 257, hipMemcpyHostToDevice);
     e = e ? e : hipMemcpy(b->d_bank, sdrm_mmse_bank, sizeof(float) * 129 * 8, hipMemcpyHostToDevice);
     e = e ? e : hipMemcpy(b->d_clock, cs.data(), sizeof(sdrm_clock_state) * C, hipMemcpyHostToDevice);
+    e = e ? e : hipMalloc((void **) &b->d_counters, 64);
+    e = e ? e : hipMemset(b->d_counters, 0, 64);
     e = e ? e : hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     // HIP multiplexes streams onto a few hardware queues, and two streams on one queue run back to back.  Streams of
     // different priority never share a queue, so give each stage its own level: the clock stage (the longest
@@ -768,6 +787,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.tap_pool = b->d_taps;
     d.atan_tab = b->d_atan;
     d.mmse_bank = b->d_bank;
+    d.counters = b->d_counters;
     d.raw_hist = b->d_hist;
     d.hist_stride = hist_stride;
     d.z = b->d_z;
@@ -1462,13 +1482,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         // by at least floor(omega_mid - omega_lim) samples of what the call brings plus the carried ones (< SDRM_CLOCK_HCAP)
         uint32_t most = 0;
         for (size_t c = 0; c < C; c++) {
-            const sdrm_chan_params &p = b->plan.params[c];
-            const float adv = floorf(p.omega_mid - p.omega_lim);
-            uint32_t bound = p.max_len;
-            if (adv >= 1.0f) {
-                bound = std::min<uint32_t>(bound, (uint32_t) ((h[c].nz + carried_cap(p)) / (uint32_t) adv) + 8u);
-            }
-            most = std::max(most, bound);
+            most = std::max(most, symbols_bound(b->plan.params[c], h[c].nz));
         }
         d.max_symbols = most;
         b->last_max_symbols = most;
@@ -1694,9 +1708,7 @@ extern "C" int sdrm_batch_wild_calls(sdrm_batch *b, uint64_t *count) {
         return code;
     }
     uint32_t word = 0;
-    if (b->d_k3_done != nullptr) {
-        HIP_TRY(hipMemcpy(&word, b->d_k3_done + 3, sizeof(word), hipMemcpyDeviceToHost));
-    }
+    HIP_TRY(hipMemcpy(&word, b->d_counters, sizeof(word), hipMemcpyDeviceToHost));
     *count = word;
     return 0;
 }
@@ -1846,11 +1858,7 @@ static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h
     d.nonfinite = b->d_flags + (size_t) SG_SLOT;
     const uint32_t nz_cap = (uint32_t) ((n + p.decim - 1) / p.decim) + 1u;
     d.max_tiles = (nz_cap + p.tile_m - 1) / p.tile_m;
-    uint32_t most = p.max_len;
-    const float adv = floorf(p.omega_mid - p.omega_lim);
-    if (adv >= 1.0f) {
-        most = std::min<uint32_t>(most, (uint32_t) ((nz_cap + carried_cap(p)) / (uint32_t) adv) + 8u);
-    }
+    const uint32_t most = symbols_bound(p, nz_cap);
     d.max_symbols = most;
     d.z = b->d_z;
     d.dcout = b->d_dcout;
@@ -1952,6 +1960,9 @@ static int serial_graph_call(sdrm_batch_t *b, const sdrm_cf32 *input, size_t n, 
     HIP_TRY(hipGraphLaunch(b->sg_exec, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     const uint32_t got = b->h_outlen[0];
+    if (got > b->sg_width) {  // more symbols than the bound the graph's copy was sized for: the rest, now
+        HIP_TRY(hipMemcpy(b->h_out8 + b->sg_width, b->d_out8 + b->sg_width, got - b->sg_width, hipMemcpyDeviceToHost));
+    }
     b->last_lens[0] = got;
     b->last_max_symbols = b->sg_width;
     b->last_slot = -1;  // nothing of this call is left in flight
@@ -2011,6 +2022,10 @@ static int process_host(sdrm_batch *b, const sdrm_cf32 *const *inputs, const siz
     HIP_TRY(hipStreamSynchronize(b->stream));
     for (size_t c = 0; c < C; c++) {
         const uint32_t n = b->h_outlen[c];
+        if (n > width) {  // a loop far out of lock produced more symbols than the bound (symbols_bound): the rest, now
+            HIP_TRY(hipMemcpy(b->h_out8 + c * (size_t) b->dev.out_stride + width, out8_of(b, me) + c * (size_t) b->dev.out_stride + width,
+                              n - width, hipMemcpyDeviceToHost));
+        }
         b->last_lens[c] = n;
         outputs[c] = b->h_out8 + c * (size_t) b->dev.out_stride;
         output_lens[c] = n;
@@ -2136,7 +2151,7 @@ extern "C" int sdrm_batch_submit(sdrm_batch *b, size_t slot, const size_t *input
         const sdrm_chan_params &p = b->plan.params[c];
         const double step = std::max(1.0, (double) p.omega_mid - (double) p.omega_lim - 1.0);
         const double n_in = input_lens[c] == SDRM_LEN_ABSENT ? 0.0 : (double) input_lens[c];
-        const double bound = (n_in / (double) p.decim + carried_cap(p)) / step + 16.0;
+        const double bound = p.can_wild ? (double) p.max_len : (n_in / (double) p.decim + carried_cap(p)) / step + 16.0;
         width = std::max<uint32_t>(width, (uint32_t) std::min<double>(bound, (double) p.max_len));
     }
     width = std::min<uint32_t>((width + 63u) & ~63u, b->dev.out_stride);

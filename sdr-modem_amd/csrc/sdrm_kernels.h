@@ -155,7 +155,8 @@ struct sdrm_chan_params {
     float omega_mid, omega_lim, gain_omega, gain_mu;
     uint32_t generic;               // the channel's DC blocker and clock recovery run in their generic forms (below: "generic channels")
     float amp_safe;                 // clock-stage input amplitude below which the timing loop provably advances >= 1 sample per symbol ("tame")
-    uint32_t pad_[2];
+    uint32_t can_wild;              // the stages in front of the clock stage CAN produce a sample beyond amp_safe (host-side bounds only)
+    uint32_t pad_[1];
 };
 
 // Per-call flags of a channel (DeviceBatch::nonfinite[c]), raised by the front-end (no DC blocker) or the DC stage on the stream

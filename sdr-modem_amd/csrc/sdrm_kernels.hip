@@ -1821,9 +1821,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         const float *src = (p.dc_len ? b.dcout : b.z) + (size_t) c * b.z_stride;
         b.out_len[c] = sdrm_k3_rescue(p, cs, src, L.nz, (const float *) bank_rev, of, b.out_i8 + (size_t) c * b.out_stride, flagged);
         b.nonfinite[c] = 0;
-        if (b.k3_done != nullptr) {
-            atomicAdd(b.k3_done + 3, 1u);  // sdrm_batch_wild_calls
-        }
+        atomicAdd(b.counters + 0, 1u);  // sdrm_batch_wild_calls
     } else if (active) {
         int from_n, new_kept;
         sdrm_k3_finish(L, &from_n, &new_kept);
@@ -1855,26 +1853,30 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 // int8 soft bits from the float ones (reference src/dsp/fsk_demod.c:106), pointwise behind the clock stage, for the
 // workgroup shapes whose staging wave has no time for it (K3_FUSED_INT8).
 // grid (ceil(max_symbols / 1024), channels), 256 threads, four symbols per thread
+// The grid covers the most symbols a channel in lock can have produced (sdrm_api.hip, symbols_bound); a channel far out of
+// lock can have more: the row's LAST workgroup walks on to the real count.
 __global__ __launch_bounds__(256) void k3_quantize(DeviceBatch b) {
     const int c = blockIdx.y;
     const uint32_t n = b.out_len[c];
-    const uint32_t j = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (j >= n) {
-        return;
-    }
-    const float4 v = *reinterpret_cast<const float4 *>(b.out_f32 + (size_t) c * b.out_stride + j);
-    int8_t *dst = b.out_i8 + (size_t) c * b.out_stride + j;
-    if (j + 4 <= n) {
-        char4 q;
-        q.x = sdrm_soft_to_i8(v.x);
-        q.y = sdrm_soft_to_i8(v.y);
-        q.z = sdrm_soft_to_i8(v.z);
-        q.w = sdrm_soft_to_i8(v.w);
-        *reinterpret_cast<char4 *>(dst) = q;
-    } else {
-        const float t[4] = {v.x, v.y, v.z, v.w};
-        for (uint32_t i = 0; j + i < n; i++) {
-            dst[i] = sdrm_soft_to_i8(t[i]);
+    const bool last = blockIdx.x + 1 == gridDim.x;
+    for (uint32_t j = (blockIdx.x * 256 + threadIdx.x) * 4; j < n; j += 1024) {
+        const float4 v = *reinterpret_cast<const float4 *>(b.out_f32 + (size_t) c * b.out_stride + j);
+        int8_t *dst = b.out_i8 + (size_t) c * b.out_stride + j;
+        if (j + 4 <= n) {
+            char4 q;
+            q.x = sdrm_soft_to_i8(v.x);
+            q.y = sdrm_soft_to_i8(v.y);
+            q.z = sdrm_soft_to_i8(v.z);
+            q.w = sdrm_soft_to_i8(v.w);
+            *reinterpret_cast<char4 *>(dst) = q;
+        } else {
+            const float t[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t i = 0; j + i < n; i++) {
+                dst[i] = sdrm_soft_to_i8(t[i]);
+            }
+        }
+        if (!last) {
+            break;
         }
     }
 }

@@ -61,6 +61,7 @@ struct DeviceBatch {
     int k3_lanes, k3_ring, k3_plain; // clock-stage workgroup shape chosen for this batch (0: by channel count; SDRM_K3_LANES overrides both)
     int k3_wait;                     // the clock stage's workgroups wait for k3_done to reach k3_wait_for before they touch any
     uint32_t k3_wait_for;            //   state of the previous call (they were launched while that call's clock stage still ran)
+    uint32_t *counters;              // [16] batch-lifetime device counters: [0] channel-calls run by sdrm_k3_rescue (sdrm_batch_wild_calls)
 };
 
 // one kernel launch, described: what launch_* puts on a stream and what the explicitly built graph of the one-channel

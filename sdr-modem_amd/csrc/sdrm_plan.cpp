@@ -64,6 +64,16 @@ static int params_from_design(const ChannelDesign &d, sdrm_chan_params &p) {
     }
     p.generic = d.generic ? 1u : 0u;
     p.amp_safe = sdrm_amp_safe(p.omega_mid, p.omega_lim, p.gain_mu);
+    // Can the clock stage's input ever exceed it?  |discriminator| <= |gain| * pi (fast_atan2f.c:87-157 returns within a
+    // table step of [-pi, pi]), LPF2 scales by at most sum |tap|, the DC blocker subtracts a running mean of the same stream
+    // (|x - mean| <= 2 max |x|; 5 % on top for what its running sums drift over a long stream).  Only host-side bounds hang
+    // on this (how many symbols a call can produce at most); the kernels compare every sample they write.
+    double abs_sum = 0.0;
+    for (float t : d.taps2) {
+        abs_sum += fabs((double) t);
+    }
+    const double reach = fabs((double) d.quad_gain) * 3.1416 * 1.001 * abs_sum * (p.dc_len ? 2.05 : 1.0) * 1.001;
+    p.can_wild = !(reach < (double) p.amp_safe) ? 1u : 0u;
     return 0;
 }
 
