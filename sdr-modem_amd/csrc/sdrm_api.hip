@@ -103,6 +103,14 @@ struct sdrm_batch_t {
     hipEvent_t ev_company = nullptr;
     uint32_t *d_k3_done = nullptr;   // clock-stage workgroups finished, all launches
     uint32_t *d_counters = nullptr;  // [16] batch-lifetime device counters (DeviceBatch::counters)
+    // in-call hand-off (DESIGN.md "stages of one call overlap"): tile stamps [C][hand_tiles_cap], DC-blocker counts [C]
+    uint32_t *d_hand_tiles = nullptr;
+    uint32_t hand_tiles_cap = 0;
+    unsigned long long *d_hand_prog = nullptr;
+    hipEvent_t ev_ctl[SDRM_CTL_SLOTS] = {};  // the call's control block is on the device
+    bool hand_allowed = true;        // SDRM_HANDOFF=0 switches it off
+    bool hand_used = false;          // a hand-off call has been enqueued since the device error word was last looked at
+    uint64_t hand_calls = 0;         // diagnostics: calls enqueued with the hand-off
     uint32_t *d_placed = nullptr;    // [2] DC / clock-stage workgroups started, all launches (what the stream holds wait for)
     uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started
     uint32_t k3_placed_after[SDRM_CTL_SLOTS] = {};        // ... once the clock stage of the call in that slot has
@@ -258,6 +266,13 @@ static void batch_free(sdrm_batch_t *b) {
     (void) hipFree(b->d_k3_done);
     (void) hipFree(b->d_placed);
     (void) hipFree(b->d_counters);
+    (void) hipFree(b->d_hand_tiles);
+    (void) hipFree(b->d_hand_prog);
+    for (hipEvent_t e2 : b->ev_ctl) {
+        if (e2) {
+            (void) hipEventDestroy(e2);
+        }
+    }
     for (hipStream_t st : streams) {
         if (st) {
             (void) hipStreamDestroy(st);
@@ -771,6 +786,10 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         e = e ? e : hipEventCreateWithFlags(&b->ev_in[i], hipEventDisableTiming);
         e = e ? e : hipEventCreateWithFlags(&b->ev_front[i], hipEventDisableTiming);
         e = e ? e : hipEventCreateWithFlags(&b->ev_dc[i], hipEventDisableTiming);
+        e = e ? e : hipEventCreateWithFlags(&b->ev_ctl[i], hipEventDisableTiming);
+    }
+    if (const char *env = getenv("SDRM_HANDOFF")) {
+        b->hand_allowed = atoi(env) != 0;
     }
     for (size_t c = 0; c < C; c++) {
         b->any_nodc = b->any_nodc || pl.params[c].dc_len == 0;
@@ -1494,6 +1513,45 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     const int prev2 = (int) ((i + SDRM_CTL_SLOTS - 2) % SDRM_CTL_SLOTS);  // the call that last used these buffers
     const bool have_prev2 = i >= 2;
 
+    // ---- in-call hand-off?  A call that meets an idle batch -- every blocking call, the first of a pipelined run -- cannot
+    // hide its front-end and DC blocker behind an earlier call's clock stage: its three stages are made resident together
+    // instead, each starting on the first finished pieces of the one in front (tile stamps / output counts, sdrm_launch.h).
+    // Waiting workgroups hold their CUs, so this is bounded: few workgroups (a batch that fills the chip is front-end bound
+    // anyway), a DC workgroup that leaves room for a front-end workgroup beside it, and the clock stage launched only when
+    // the DC stage's workgroups are resident -- then the front-end, which waits for nobody, always finds a CU, the DC
+    // stage waits only for the front-end and the clock stage only for the DC stage.
+    bool hand = false;
+    if (b->hand_allowed && !b->serial && b->n_gen == 0 && !b->clock_early && b->d_placed != nullptr && max_tiles > 0) {
+        const bool idle = b->last_slot < 0 || hipEventQuery(b->slot_done[b->last_slot]) == hipSuccess;
+        const unsigned waiting = sdrm::clock_workgroups(d) + (d.any_dc ? sdrm::dc_workgroups(d) : 0u);
+        const bool room = !d.any_dc || (size_t) d.dc_lds + sdrm::k1_lds_bytes(d.t1_max, d.t2_max) <= 160 * 1024;
+        hand = idle && waiting <= 64 && room;
+    }
+    if (hand && (b->d_hand_prog == nullptr || b->hand_tiles_cap < max_tiles)) {
+        // stamps and counts: allocated on first use, grown when a call has more tiles (the batch is idle here)
+        (void) hipFree(b->d_hand_tiles);
+        b->d_hand_tiles = nullptr;
+        b->hand_tiles_cap = 0;
+        const uint32_t cap = std::max<uint32_t>(max_tiles, 64u);
+        if (dev_alloc_zero(&b->d_hand_tiles, C * (size_t) cap) != 0 || (b->d_hand_prog == nullptr && dev_alloc_zero(&b->d_hand_prog, C) != 0)) {
+            hand = false;
+        } else {
+            b->hand_tiles_cap = cap;
+        }
+    }
+    if (hand) {
+        d.handoff = 1;
+        if (const char *env = getenv("SDRM_HAND_MODE")) {
+            d.hand_mode = atoi(env);
+        }
+        d.epoch = (uint32_t) (i % 0xfffffff0ull) + 1u;
+        d.hand_tiles = b->d_hand_tiles;
+        d.hand_tiles_cap = b->hand_tiles_cap;
+        d.hand_prog = b->d_hand_prog;
+        b->hand_used = true;
+        b->hand_calls++;
+    }
+
     // ---- NCO phases: need neither the input nor an earlier stage, only the phase buffer released by the mix of call i-2
     const bool nco_aside = with_nco && b->s_nco != b->s_front;
     if (nco_aside) {
@@ -1532,6 +1590,18 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     } else {
         HIP_TRY(hipMemcpyAsync(d_ctl, h, sizeof(sdrm_chunk_ctl) * C, hipMemcpyHostToDevice, b->s_front));
     }
+    if (hand) {
+        HIP_TRY(hipEventRecord(b->ev_ctl[slot], b->s_front));  // what the other stages need before they can start: the control block
+        // The two stages behind must have their workgroups placed BEFORE the front-end's grid covers the chip (a DC workgroup
+        // needs 117 KB of a CU's LDS, a clock-stage workgroup 141 KB: neither finds that between front-end workgroups, and
+        // the dispatcher reserves nothing -- measured: the DC stage started at 0.56 ms of a 0.62 ms front-end).  Bounded.
+        if (d.any_dc && getenv("SDRM_HAND_ORDERED") == nullptr) {
+            sdrm::launch_hold_until(b->d_placed + 0, b->k2_placed_target + sdrm::dc_workgroups(d), 400, b->s_front);
+        }
+        if (getenv("SDRM_HAND_ORDERED") == nullptr) {
+            sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_target + sdrm::clock_workgroups(d), 400, b->s_front);
+        }
+    }
     if (with_nco) {
         if (!nco_aside) {
             HIP_TRY(hipMemcpyAsync(b->d_nco_segs + (size_t) slot * b->nco_seg_cap, b->h_nco_segs + (size_t) slot * b->nco_seg_cap,
@@ -1551,8 +1621,9 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     HIP_TRY(hipEventRecord(b->ev_front[slot], b->s_front));
 
     // ---- DC blocker: needs z of this call, and dcout[i&1] released by the clock stage of call i-2
+    const bool hand_ordered = hand && getenv("SDRM_HAND_ORDERED") != nullptr;  // experiments: the hand-off's kernels, one after the other
     if (d.any_dc) {
-        HIP_TRY(hipStreamWaitEvent(b->s_dc, b->ev_front[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(b->s_dc, (hand && !hand_ordered) ? b->ev_ctl[slot] : b->ev_front[slot], 0));
         if (have_prev2) {
             HIP_TRY(hipStreamWaitEvent(b->s_dc, b->slot_done[prev2], 0));
         }
@@ -1586,9 +1657,19 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         b->clock_prev_alt = s_clock == b->s_clock_alt;
         b->clock_prev_converts = sdrm::describe_quantize(d).func != nullptr;
     }
-    HIP_TRY(hipStreamWaitEvent(s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
-    if (d.any_dc && b->any_nodc) {
-        HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_front[slot], 0));
+    if (hand_ordered) {
+        HIP_TRY(hipStreamWaitEvent(s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
+    } else if (hand) {
+        HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_ctl[slot], 0));
+        if (d.any_dc) {
+            // ... and the DC stage's workgroups resident (they count themselves in, k2_dc): bounded, ~2 ms
+            sdrm::launch_hold_until(b->d_placed + 0, b->k2_placed_target, 2000, s_clock);
+        }
+    } else {
+        HIP_TRY(hipStreamWaitEvent(s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
+        if (d.any_dc && b->any_nodc) {
+            HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_front[slot], 0));
+        }
     }
     if (b->out_busy[i & 1]) {
         HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_out_free[i & 1], 0));  // that output set is still being copied back
@@ -1622,6 +1703,13 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         timing_end(b, 2, s_clock, ev);
     }
     HIP_TRY(hipGetLastError());
+    if (hand) {
+        // the clock stage can be through before the DC kernel has written its last state back: the call is done when both are
+        HIP_TRY(hipStreamWaitEvent(s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
+        if (d.any_dc && b->any_nodc) {
+            HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_front[slot], 0));
+        }
+    }
     HIP_TRY(hipEventRecord(b->slot_done[slot], s_clock));
     online_tune_after(b, s_clock);
     b->slot_used[slot] = true;
@@ -1662,6 +1750,16 @@ extern "C" int sdrm_batch_wait_input(sdrm_batch *b, void *stream) {
 // A clock stage that was resident early and gave up waiting for its predecessor (k3_clock, bounded look) raises the word
 // at d_k3_done[2]: its results cannot be trusted, and neither can any later call's -- the batch is in error for good.
 static int check_device_error(sdrm_batch_t *b) {
+    if (b->device_error == 0 && b->hand_used) {
+        // in-call hand-off: a stage that gave up waiting for the one in front (bounded looks, ~2 s) has said so
+        b->hand_used = false;
+        uint32_t word = 0;
+        HIP_TRY(hipMemcpy(&word, b->d_counters + 1, sizeof(word), hipMemcpyDeviceToHost));
+        if (word != 0) {
+            b->device_error = -ETIMEDOUT;
+            fprintf(stderr, "<3>sdrmodem_hip: a stage timed out waiting for the stage in front of it inside a call; the batch is unusable\n");
+        }
+    }
     if (b->device_error == 0 && b->clock_early && b->d_k3_done != nullptr) {
         uint32_t word = 0;
         HIP_TRY(hipMemcpy(&word, b->d_k3_done + 2, sizeof(word), hipMemcpyDeviceToHost));
@@ -2020,6 +2118,15 @@ static int process_host(sdrm_batch *b, const sdrm_cf32 *const *inputs, const siz
         }
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->hand_used) {
+        for (size_t c = 0; c < C; c++) {
+            if (b->h_outlen[c] == SDRM_OUT_LEN_FAILED) {  // a stage gave up waiting inside the call: says so, once, and fails the batch
+                const int failed = check_device_error(b);
+                return failed != 0 ? failed : -EIO;
+            }
+        }
+        b->hand_used = false;  // every count is a real one: nobody gave up
+    }
     for (size_t c = 0; c < C; c++) {
         const uint32_t n = b->h_outlen[c];
         if (n > width) {  // a loop far out of lock produced more symbols than the bound (symbols_bound): the rest, now
@@ -2546,7 +2653,7 @@ extern "C" int sdrm_batch_k3_stamps(sdrm_batch *b, int enable, unsigned long lon
     }
     if (out != nullptr && b->dev.k3_stamps != nullptr) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out, b->dev.k3_stamps, (std::min(waves, max_waves) * 4 + 18) * sizeof(unsigned long long),
+        HIP_TRY(hipMemcpy(out, b->dev.k3_stamps, (std::min(waves, max_waves) * 4 + 24) * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost));
     }
     return (int) waves;

@@ -793,6 +793,19 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
 }
 
 // the tile's LPF2 outputs, staged by sdrm_k1_phase_lpf2, written with consecutive lanes on consecutive samples
+// THROUGH (device code, in-call hand-off): device-scope stores, written through this XCD's L2 -- a stage that is already
+// running on another XCD reads them with the same scope as soon as they are acknowledged; no cache write-back needed
+template <bool THROUGH>
+SDRM_HD void sdrm_store_out(float *dst, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (THROUGH) {
+        __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+#endif
+    *dst = v;
+}
+template <bool THROUGH = false>
 SDRM_HD void sdrm_k1_phase_store(int tid, const sdrm_k1_tile &t, const float *zs, float *z_out) {
     float *dst = z_out + t.o_lo + tid;
     const float *src = zs + tid;
@@ -806,15 +819,15 @@ SDRM_HD void sdrm_k1_phase_store(int tid, const sdrm_k1_tile &t, const float *zs
         }
 #pragma unroll
         for (int i = 0; i < FULL; i++) {
-            dst[i * SDRM_K1_THREADS] = v[i];
+            sdrm_store_out<THROUGH>(dst + i * SDRM_K1_THREADS, v[i]);
         }
         for (int i = tid + FULL * SDRM_K1_THREADS; i < t.m; i += SDRM_K1_THREADS) {
-            z_out[t.o_lo + i] = zs[i];
+            sdrm_store_out<THROUGH>(z_out + t.o_lo + i, zs[i]);
         }
         return;
     }
     for (int i = tid; i < t.m; i += SDRM_K1_THREADS) {
-        z_out[t.o_lo + i] = zs[i];
+        sdrm_store_out<THROUGH>(z_out + t.o_lo + i, zs[i]);
     }
 }
 

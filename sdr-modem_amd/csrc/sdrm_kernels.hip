@@ -264,10 +264,13 @@ template <bool FUSED>
 __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
                                                             size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
-    const int c = blockIdx.y;
+    // grid (tiles, channels); with the in-call hand-off (channels, tiles): workgroups are dispatched x first, so every channel's
+    // tile 0 comes before anybody's tile 1 and the stages behind can start on all channels at once
+    const int c = b.handoff ? blockIdx.x : blockIdx.y;
+    const unsigned tile_id = b.handoff ? blockIdx.y : blockIdx.x;
     const sdrm_chunk_ctl ctl = b.ctl[c];
     const sdrm_chan_params p = b.params[c];
-    if (blockIdx.x == 0) {
+    if (tile_id == 0) {
         // The channel's first workgroup also rolls the raw history for the next call (the last T1 + T2 - 1 samples of
         // history ++ input, into the other of the two history buffers: the tiles of THIS call read the current one).
         // Every channel gets this workgroup, also one without a tile this call (an empty or absent input still rolls).
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
         const sdrm_f2 *src = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
         sdrm_hist_roll((int) threadIdx.x, SDRM_K1_THREADS, p, ctl, src, cur, next);
     }
-    if (blockIdx.x >= ctl.tiles) {
+    if (tile_id >= ctl.tiles) {
         return;
     }
     tl_mark(b, 0, 0);
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     float *tab = reinterpret_cast<float *>(bnd + SDRM_K1_THREADS);
 
     const int tid = threadIdx.x;
-    const sdrm_k1_tile t = sdrm_k1_tile_setup(p, ctl, (int) blockIdx.x);
+    const sdrm_k1_tile t = sdrm_k1_tile_setup(p, ctl, (int) tile_id);
     const sdrm_f2 *in = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
     const sdrm_f2 *hist = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
 
@@ -361,7 +364,20 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_lpf2<FUSED>(tid, t, p, taps2, qs, zs, b.nonfinite + c);
     __syncthreads();
-    sdrm_k1_phase_store(tid, t, zs, b.z + (size_t) c * b.z_stride);
+    if (b.handoff) {
+        // The tile is in memory (and any flag it raised, sdrm_k1_phase_lpf2) before its stamp says so: written THROUGH this
+        // XCD's L2 with device-scope stores, every wave waits for the acknowledgement of its own, then one thread stamps.
+        // (Not a release fence: that is a write-back of the whole L2, and 8960 of them in half a millisecond stalled every
+        // other client of the cache -- the clock stage's soft-bit stores waited ~1800 cycles per staging step for theirs.)
+        sdrm_k1_phase_store<true>(tid, t, zs, b.z + (size_t) c * b.z_stride);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(b.hand_tiles + (size_t) c * b.hand_tiles_cap + tile_id, b.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        sdrm_k1_phase_store(tid, t, zs, b.z + (size_t) c * b.z_stride);
+    }
     tl_mark(b, 0, 1);
     if (stamp && tid == 0) {
         unsigned long long t4 = __builtin_amdgcn_s_memtime();
@@ -414,6 +430,9 @@ KernelLaunch describe_front(const DeviceBatch &b) {
         k.func = reinterpret_cast<const void *>(k1_front<false>);
     }
     k.grid = dim3(b.max_tiles ? b.max_tiles : 1u, (unsigned) b.n_channels);  // tile 0 of every channel also rolls its history
+    if (b.handoff) {
+        k.grid = dim3((unsigned) b.n_channels, b.max_tiles ? b.max_tiles : 1u);
+    }
     k.block = dim3(SDRM_K1_THREADS);
     return k;
 }
@@ -502,7 +521,48 @@ typedef float k2_f4 __attribute__((ext_vector_type(4)));
 // and expose a full memory latency per iteration.
 #define K2_HANDOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// ---- in-call hand-off: what a stage behind the front-end looks at before it reads samples of THIS call
+// (every look is bounded: a producer that never comes -- a failed launch -- must not hang the device; the call then fails
+// loudly, DeviceBatch::counters[1] and SDRM_OUT_LEN_FAILED)
+// has the front-end tile that holds output `last` (>= 0) of channel c been written?  (relaxed; the caller fences)
+__device__ __forceinline__ bool hand_tile_done(const DeviceBatch &b, int c, uint32_t tile_m, int last) {
+    const uint32_t tile = (uint32_t) last / tile_m;
+    return __hip_atomic_load(b.hand_tiles + (size_t) c * b.hand_tiles_cap + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == b.epoch;
+}
+// DC-blocker outputs of this call published for channel c (0 while the stamp is an older call's)
+__device__ __forceinline__ uint32_t hand_prog_of(const DeviceBatch &b, int c) {
+    const unsigned long long v = __hip_atomic_load(b.hand_prog + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (uint32_t) (v >> 32) == b.epoch ? (uint32_t) v : 0u;
+}
+// Device-scope (sc1) vector accesses through a raw buffer resource over the whole array: written THROUGH / read PAST this XCD's
+// L2, so that a producer and a consumer running at the same time on different XCDs meet in memory -- a store is there once it
+// has been acknowledged (s_waitcnt vmcnt), a load issued after that sees it; no cache write-back or invalidation involved.
+// (Buffer instructions because the cache policy of a 16-byte access cannot be said otherwise; the compiler tracks them like any load.)
+typedef unsigned int hand_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int hand_u2 __attribute__((ext_vector_type(2)));
+#define HAND_SC1 16  // cache policy bit: device scope
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t hand_rsrc(const float *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ void hand_store4(__amdgpu_buffer_rsrc_t r, size_t index, float x, float y, float z, float w) {
+    const hand_u4 v = {__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int) (uint32_t) (index * sizeof(float)), 0, HAND_SC1);
+}
+__device__ __forceinline__ void hand_load4(__amdgpu_buffer_rsrc_t r, size_t index, float *v) {
+    const hand_u4 t = __builtin_amdgcn_raw_buffer_load_b128(r, (int) (uint32_t) (index * sizeof(float)), 0, HAND_SC1);
+    v[0] = __uint_as_float(t.x);
+    v[1] = __uint_as_float(t.y);
+    v[2] = __uint_as_float(t.z);
+    v[3] = __uint_as_float(t.w);
+}
+__device__ __forceinline__ void hand_load2(__amdgpu_buffer_rsrc_t r, size_t index, float *v) {
+    const hand_u2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int) (uint32_t) (index * sizeof(float)), 0, HAND_SC1);
+    v[0] = __uint_as_float(t.x);
+    v[1] = __uint_as_float(t.y);
+}
+
 struct k2_lane {
+    uint32_t tile_m;     // hand-off: front-end outputs per tile of this channel
     sdrm_k2_slot s;
     int q;               // which P-sample piece of a block this lane owns
     const float *z;      // the channel's front-end output of this call
@@ -647,6 +707,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     L.s = slots[slot_h];
     L.q = lane % SDRM_K2_LPS;
     L.on = L.s.chan >= 0;
+    L.tile_m = L.on ? b.params[L.s.chan].tile_m : 1u;
     L.hx = b.dc_state + (L.on ? b.params[L.s.chan].dc_state_off : 0);
     L.z = b.z + (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
     L.out = b.dcout + (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
@@ -690,9 +751,77 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     } else {
         __builtin_amdgcn_s_setprio(1);  // the helpers: ahead of the clock stage's companion waves (priority 0)
     }
+    // In-call hand-off: the feeder (the only role that reads the front-end's output inside the loop) makes sure, before it
+    // touches outputs [.., upto) of this call, that the tiles holding them are in memory for every slot of its wave.  One
+    // acquire per newly finished tile row; z_ready remembers how far that reaches.
+    int z_ready = b.handoff ? 0 : 0x7fffffff;  // wave-uniform: outputs [0, z_ready) of every slot of this wave are known to be there
+    int my_ready = L.on ? 0 : 0x7fffffff;      // this lane's slot alone
+    auto await_z = [&](int upto) {
+        if (upto <= z_ready) {
+            return;
+        }
+        const int need = upto < nz ? upto : nz;  // this lane's slot: nothing beyond its own call
+        auto look = [&]() {  // walk over the tiles that are there, in order (a tile may be shorter than a block)
+            while (my_ready < need && hand_tile_done(b, L.s.chan, L.tile_m, my_ready)) {
+                my_ready = (int) (((uint32_t) my_ready / L.tile_m + 1u) * L.tile_m);
+            }
+            return my_ready >= need;
+        };
+        bool there = look();
+        for (int looks = 0; !__all(there) && looks < SDRM_HAND_MAX_LOOKS; looks++) {
+            __builtin_amdgcn_s_sleep(16);
+            there = look();
+        }
+        if (!__all(there)) {
+            atomicOr(b.counters + 1, 1u);  // gave up: what follows is computed from whatever is there, the call is void
+        }
+        int reach = my_ready >= nz ? 0x7fffffff : my_ready;
+        for (int sl = 0; sl < SDRM_K2_P; sl++) {
+            const int r = __builtin_amdgcn_readlane(reach, sl * SDRM_K2_LPS);
+            reach = r < reach ? r : reach;
+        }
+        z_ready = __builtin_amdgcn_readfirstlane(reach);
+        if (z_ready < upto) {
+            z_ready = upto;  // (a wait that ran into its bound: do not come back for every block)
+        }
+    };
+    // this call's front-end output as the feeder reads it: plainly, or -- while the front-end is still running (hand-off) -- with
+    // device scope, past this XCD's L2 (hand_load*)
+    const __amdgpu_buffer_rsrc_t z_rsrc = hand_rsrc(b.z);
+    const size_t z_row = (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
+    auto x4 = [&](int m, float *v) {    // x[m .. m+3]: any alignment, maybe carried samples
+        if (m >= 0 && (m & 3) == 0) {
+            if (b.handoff) {
+                hand_load4(z_rsrc, z_row + (size_t) m, v);
+            } else {
+                const k2_f4 t = *reinterpret_cast<const k2_f4 *>(L.z + m);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            }
+        } else {
+            for (int e = 0; e < 4; e++) {
+                v[e] = (b.handoff && m + e >= 0) ? __hip_atomic_load(L.z + (m + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                 : sdrm_k2_x(L.z, L.hx, L.s.HX, m + e);
+            }
+        }
+    };
     if (role == 1) {
-        if (L.on) {
+        await_z(SDRM_K2_BLK);
+        if (L.on && !b.handoff) {
             sdrm_k2_feed(L.s, 0, L.q, L.z, L.hx, ts + slot_h * SDRM_K2_TSPITCH);  // block 0 of stage 0
+        } else if (L.on) {
+            // the same terms (sdrm_k2_feed: t = x[n] - x[n - L] for the P samples of this lane), the samples read with device scope
+            for (int g = 0; g < K2_P / 4; g++) {
+                const int n = L.q * K2_P + 4 * g;
+                float va[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (n < nz) {
+                    x4(n, va);
+                    x4(n - (int) L.s.L, vb);
+                }
+                float *dst = ts + slot_h * SDRM_K2_TSPITCH + n;
+                for (int e = 0; e < 4; e++) {
+                    dst[e] = (n + e < nz) ? sdrm_boxcar_term(va[e], vb[e]) : 0.0f;
+                }
+            }
         }
     }
     __syncthreads();
@@ -723,6 +852,61 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     // control flow, and the compiler's bookkeeping of outstanding loads and stores of one role (the feeder's operands in
     // flight across the barrier, the output role's stores) cannot make another role wait for them.
     const int role_rt = role;
+    // In-call hand-off, output role: block k of this lane's slot goes to memory with device-scope (write-through) stores, and
+    // the slot's count of finished outputs follows ONE ITERATION LATER -- by then the stores (and any flag the block raised:
+    // the clock stage must see it before the samples) have long been acknowledged, so the wait in front of the count costs
+    // nothing and no cache write-back is needed.  Every lane of the wave comes here once per block, `valid` of its P outputs count.
+    const float tame5 = (role == 5 && L.on) ? sdrm_tame_level(b.params[L.s.chan], true) : INFINITY;
+    // `whole`: the straight-line iterations, where every lane stores its P outputs with exactly K2_V4 store instructions: the
+    // count then lags K2_LAG blocks, so that only stores issued K2_LAG - 1 iterations ago are waited for (a write through to
+    // memory takes longer than one iteration: waiting for the previous block's stalled the whole workgroup at its barrier,
+    // 0.54 -> 1.02 us per block).  Stores of a wave are acknowledged in order.
+#define K2_LAG 4
+    int done_said = 0;
+    const __amdgpu_buffer_rsrc_t out_rsrc = hand_rsrc(b.dcout);
+    const size_t out_row = (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
+    auto publish = [&](int k, int n0, const float (&o)[K2_P], int valid, bool whole, bool suspicious) {
+        int done;  // blocks 0 .. done - 1 of this wave's slots are in memory
+        if (whole) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K2_V4 * (K2_LAG - 1)) : "memory");
+            done = k - (K2_LAG - 1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            done = k;
+        }
+        if (b.hand_mode & 1) {
+            __threadfence();
+        }
+        const bool further = done > done_said;  // (the straight-line iterations lag: never take a count back)
+        done_said = further ? done : done_said;
+        if (L.on && L.q == 0 && further) {
+            const uint32_t have = (uint32_t) (done * SDRM_K2_BLK < nz ? done * SDRM_K2_BLK : nz);
+            __hip_atomic_store(b.hand_prog + L.s.chan, ((unsigned long long) b.epoch << 32) | have, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (suspicious) {  // rare: NaN/Inf among this lane's outputs so far, or one beyond the tame amplitude -- say which, now
+            uint32_t bits = 0;
+#pragma unroll
+            for (int i = 0; i < K2_P; i++) {
+                bits |= i < valid ? sdrm_flag_bits(o[i], tame5) : 0u;
+            }
+            if (bits) {
+                atomicOr(b.nonfinite + L.s.chan, bits);
+            }
+        }
+        if (valid == K2_P) {
+#pragma unroll
+            for (int g = 0; g < K2_V4; g++) {
+                hand_store4(out_rsrc, out_row + (size_t) (n0 + 4 * g), o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < K2_P; i++) {
+                if (i < valid) {
+                    __hip_atomic_store(L.out + n0 + i, o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
     auto body = [&](auto role_c, auto fast_c, int it, unsigned long long w0) {
         constexpr int R = decltype(role_c)::value;  // 0 chain, 2 any of the three stages, 5 output (the feeder has its own loops)
         constexpr bool FAST = decltype(fast_c)::value;  // interior iteration: straight-line code
@@ -816,8 +1000,12 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
                 probe = fmaf(o[i], 0.0f, probe);  // NaN as soon as one of them is not finite
                 amax = fmaxf(amax, fabsf(o[i]));  // (v_max3_f32 with |.| modifiers: two outputs per instruction)
             }
-            k2_store_p(L.out + n0, o);
             odd |= probe != probe;
+            if (b.handoff) {
+                publish(k, n0, o, K2_P, true, odd | !(amax < tame5));
+            } else {
+                k2_store_p(L.out + n0, o);
+            }
         } else if (FAST) {
         } else
         if (role == 0) {
@@ -886,39 +1074,51 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         } else {
             // ---- output: x[n - 2(L-1)] - v3[n]
             const int k = it - 7;
-            if (k >= 0 && k < nb && L.on) {
-                const int buf = k % SDRM_K2_NBUF;
-                const int row = 3 * SDRM_K2_SLOTS + slot_h;
+            if (k >= 0 && k < nb) {
                 const int n0 = k * SDRM_K2_BLK + n_lane;
-                float t[K2_P], v[K2_P];
-                k2_load_p(ts + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK + n_lane, t);
-                k2_quotients(L, t, check[(row * SDRM_K2_NBUF + buf) * SDRM_K2_LPS + L.q], v);
-                if (n0 < nz) {
-                    float o[K2_P], xd[K2_P];
-                    k2_load_p(xdt + (slot_h * 2 + (k & 1)) * SDRM_K2_BLK + n_lane, xd);
-                    float probe = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < K2_P; i++) {
-                        o[i] = xd[i] - v[i];
-                        probe = fmaf(o[i], 0.0f, probe);  // NaN as soon as one of them is not finite
-                    }
-                    if (n0 + K2_P <= nz) {
-                        k2_store_p(L.out + n0, o);
-                        odd |= probe != probe;
+                float o[K2_P] = {};
+                int valid = 0;
+                if (L.on) {
+                    const int buf = k % SDRM_K2_NBUF;
+                    const int row = 3 * SDRM_K2_SLOTS + slot_h;
+                    float t[K2_P], v[K2_P];
+                    k2_load_p(ts + row * SDRM_K2_TSPITCH + buf * SDRM_K2_BLK + n_lane, t);
+                    k2_quotients(L, t, check[(row * SDRM_K2_NBUF + buf) * SDRM_K2_LPS + L.q], v);
+                    if (n0 < nz) {
+                        float xd[K2_P];
+                        k2_load_p(xdt + (slot_h * 2 + (k & 1)) * SDRM_K2_BLK + n_lane, xd);
+                        float probe = 0.0f;
 #pragma unroll
                         for (int i = 0; i < K2_P; i++) {
-                            amax = fmaxf(amax, fabsf(o[i]));
+                            o[i] = xd[i] - v[i];
+                            probe = fmaf(o[i], 0.0f, probe);  // NaN as soon as one of them is not finite
                         }
-                    } else {
+                        valid = nz - n0 < K2_P ? nz - n0 : K2_P;
+                        if (valid == K2_P) {
+                            odd |= probe != probe;
 #pragma unroll
-                        for (int i = 0; i < K2_P; i++) {
-                            if (n0 + i < nz) {
-                                L.out[n0 + i] = o[i];
-                                odd |= !(fabsf(o[i]) < INFINITY);
+                            for (int i = 0; i < K2_P; i++) {
                                 amax = fmaxf(amax, fabsf(o[i]));
+                            }
+                            if (!b.handoff) {
+                                k2_store_p(L.out + n0, o);
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < K2_P; i++) {
+                                if (i < valid) {
+                                    odd |= !(fabsf(o[i]) < INFINITY);
+                                    amax = fmaxf(amax, fabsf(o[i]));
+                                    if (!b.handoff) {
+                                        L.out[n0 + i] = o[i];
+                                    }
+                                }
                             }
                         }
                     }
+                }
+                if (b.handoff) {
+                    publish(k, n0, o, valid, false, odd | !(amax < tame5));
                 }
             }
         }
@@ -970,17 +1170,10 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         };
         typedef float k2_f2 __attribute__((ext_vector_type(2)));
         const int piece = 4 * SDRM_K2_LPS;  // samples between two pieces of a lane
-        auto x4 = [&](int m, float *v) {    // x[m .. m+3]: any alignment, maybe carried samples
-            if (m >= 0 && (m & 3) == 0) {
-                const k2_f4 t = *reinterpret_cast<const k2_f4 *>(L.z + m);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
-                for (int e = 0; e < 4; e++) v[e] = sdrm_k2_x(L.z, L.hx, L.s.HX, m + e);
-            }
-        };
         // any iteration: operands fetched and used on the spot (the first and last blocks, ragged or partial groups)
         auto feed_generic = [&](int it) {
             const int k = it + 1, ko = it - 6;
+            await_z((k + 1) * SDRM_K2_BLK);
             if (!L.on) {
                 return;
             }
@@ -1009,8 +1202,24 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         };
         // interior iterations [f0, f1): whole blocks of every slot, nothing from the carried samples, x[n-L] 16-byte aligned
         auto feed_load = [&](int it, feed_set &S) {
+            await_z((it + 2) * SDRM_K2_BLK);
             const float *za = L.z + (it + 1) * SDRM_K2_BLK + 4 * L.q, *zb = za - (int) L.s.L;
             const float *zc = L.z + (it - 6) * SDRM_K2_BLK + 4 * L.q - (int) L.s.HX;
+            if (b.handoff) {
+                const size_t ia = z_row + (size_t) ((it + 1) * SDRM_K2_BLK + 4 * L.q), ib = ia - L.s.L;
+                const size_t ic = z_row + (size_t) ((it - 6) * SDRM_K2_BLK + 4 * L.q) - L.s.HX;
+#pragma unroll
+                for (int g = 0; g < K2_V4; g++) {
+                    hand_load4(z_rsrc, ia + (size_t) (g * piece), S.a + 4 * g);
+                    hand_load4(z_rsrc, ib + (size_t) (g * piece), S.b + 4 * g);
+                }
+#pragma unroll
+                for (int g = 0; g < K2_V4; g++) {
+                    hand_load2(z_rsrc, ic + (size_t) (g * piece), S.c + 4 * g);
+                    hand_load2(z_rsrc, ic + (size_t) (g * piece) + 2, S.c + 4 * g + 2);
+                }
+                return;
+            }
 #pragma unroll
             for (int g = 0; g < K2_V4; g++) {
                 const k2_f4 ta = *reinterpret_cast<const k2_f4 *>(za + g * piece);
@@ -1117,6 +1326,15 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         if (bits) {
             atomicOr(b.nonfinite + L.s.chan, bits);
         }
+        if (b.handoff) {  // the last block (and those flags) are out: the channel's count reaches its end
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (L.q == 0) {
+                __hip_atomic_store(b.hand_prog + L.s.chan, ((unsigned long long) b.epoch << 32) | (uint32_t) nz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (b.handoff) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // what follows reads the call's last samples plainly: nothing stale from this XCD's L2
     }
     // hx <- last HX samples of (hx ++ z): a slot at a time by all threads; when the call is shorter than HX the new array
     // overlaps the old one shifted by nz, so every round reads before anybody writes (and later rounds read further up)
@@ -1192,7 +1410,7 @@ void launch_dc(const DeviceBatch &b, hipStream_t s) {
 // hands block k to the consumer while block k+1 is written.
 size_t k3_lds_bytes(int lanes, int ring, int plain) {
     const size_t rings = (size_t) lanes * (plain ? 1 : 2) * (SDRM_K3_PRE + ring + SDRM_K3_POST);
-    return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 3 * SDRM_K3_WAVE) * sizeof(float);
+    return (rings + 129 * SDRM_K3_BANKPITCH + 4 + 4 * SDRM_K3_WAVE) * sizeof(float);
 }
 
 // Order of work inside a symbol:
@@ -1407,6 +1625,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     int *nz_sh = reinterpret_cast<int *>(ring + G::lanes * G::cpitch);  // [64] samples per channel
     int *dc_sh = nz_sh + SDRM_K3_WAVE;                                           // [64] reads dcout (1) or z (0)
     int *safe_sh = dc_sh + SDRM_K3_WAVE;                                         // [64] float soft bits the staging wave may convert
+    int *flag_sh = safe_sh + SDRM_K3_WAVE;                                       // [64] hand-off: the call's SDRM_FLAG_* bits seen so far, per channel
     if (b.placed != nullptr && threadIdx.x == 0) {
         atomicAdd(b.placed + 1, 1u);  // this workgroup has its CU (k_hold_until)
     }
@@ -1474,7 +1693,8 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             const sdrm_chan_params p = b.params[c];
             L.nz = (int) b.ctl[c].nz;
             uses_dc = p.dc_len != 0;
-            flagged = b.nonfinite[c];
+            // (in-call hand-off: the stages in front are still running, their flags arrive block by block through flag_sh)
+            flagged = b.handoff ? 0u : b.nonfinite[c];
             const uint32_t carried = cs->poison;
             wild = ((flagged | carried) & SDRM_FLAG_WILD) != 0 || !(p.amp_safe > 0.0f);
             if (!wild) {
@@ -1495,6 +1715,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         }
         nz_sh[lane] = L.nz;
         dc_sh[lane] = uses_dc;
+        flag_sh[lane] = 0;
     }
     __shared__ unsigned hw_sh;  // diagnostics: where the producer wave runs (HW_ID: SIMD in bits 5:4, CU 11:8, SE 15:13)
     if (producer && lane == 0) {
@@ -1520,14 +1741,18 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         const float *row0 = (__builtin_amdgcn_readfirstlane(my_dc) ? b.dcout : b.z) + (size_t) c0 * b.z_stride;
         float pre[G::lanes * G::segs];  // prefetched row segments: pre[r * SEGS + h] = sample h*64 + lane of channel c0+r's next block
 #define K3_ROW_SRC(r) ((__builtin_amdgcn_readlane(my_dc, (r)) ? b.dcout : b.z) + (size_t) (c0 + (r)) * b.z_stride)
-#define K3_ISSUE(k)                                                                                          \
+#define K3_LOAD_PLAIN(ptr) (*(ptr))
+        // in-call hand-off: the sample was written by a kernel that is still running, maybe on another XCD -- read it with
+        // device scope (past this XCD's L2; each sample is read once, so nothing is lost by that)
+#define K3_LOAD_DEVICE(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define K3_ISSUE_AS(k, LOAD)                                                                                 \
     {                                                                                                        \
         const int n_ = (k) * G::block + lane;                                                            \
         if (uniform && ((k) + 1) * G::block <= min_nz) {                                                 \
             const float *p_ = row0 + n_;                                                                      \
             _Pragma("unroll") for (int r = 0; r < G::lanes; r++) {                                       \
                 _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                    \
-                    pre[r * G::segs + h] = p_[h * SDRM_K3_WAVE];                                         \
+                    pre[r * G::segs + h] = LOAD(p_ + h * SDRM_K3_WAVE);                                  \
                 }                                                                                            \
                 p_ += b.z_stride;                                                                             \
             }                                                                                                \
@@ -1536,11 +1761,68 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
                 _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                    \
                     pre[r * G::segs + h] = 0.0f;                                                         \
                     if (r < nrows && n_ + h * SDRM_K3_WAVE < __builtin_amdgcn_readlane(my_nz, r)) {           \
-                        pre[r * G::segs + h] = K3_ROW_SRC(r)[n_ + h * SDRM_K3_WAVE];                     \
+                        pre[r * G::segs + h] = LOAD(K3_ROW_SRC(r) + n_ + h * SDRM_K3_WAVE);              \
                     }                                                                                        \
                 }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
+    }
+        // In-call hand-off: before block k of this call is fetched, every channel's samples up to its end must be in memory --
+        // the DC blocker's count for the channels behind one (hand_prog), the front-end's tile stamps for the others -- and
+        // the flags those samples raised go to the consumer wave with the block (flag_sh, read behind the hand-over barrier).
+        int my_ready = 0;  // lane = channel (row): samples of this call known to be there
+        const uint32_t tile_m = (b.handoff && lane < nrows) ? b.params[c0 + lane].tile_m : 1u;
+        auto await_block = [&](int k) {
+            const int cr = c0 + lane;
+            const bool mine = lane < nrows;
+            const int lead_ = (b.hand_mode >> 8) * 256;  // experiments: stay this many samples behind the stage in front
+            const int need = ((k) + 1) * G::block + lead_ < my_nz ? ((k) + 1) * G::block + lead_ : my_nz;
+            auto look = [&]() {
+                if (!mine || my_ready >= need) {
+                    return true;
+                }
+                if (my_dc) {
+                    my_ready = (int) hand_prog_of(b, cr);
+                } else {
+                    while (my_ready < need && hand_tile_done(b, cr, tile_m, my_ready)) {
+                        my_ready = (int) (((uint32_t) my_ready / tile_m + 1u) * tile_m);
+                    }
+                }
+                return my_ready >= need;
+            };
+            // (a look is a round trip to memory, ~1 us: none while what the last one saw still covers the block -- the stage in
+            // front runs ahead -- and the flags are read behind a look only: whatever was raised for samples an earlier look
+            // covered was read then)
+            if (__all(!mine || my_ready >= need)) {
+                return;
+            }
+            bool there = look();
+            for (int looks = 0; !__all(there) && looks < SDRM_HAND_MAX_LOOKS; looks++) {
+                __builtin_amdgcn_s_sleep(8);
+                there = look();
+            }
+            if (!__all(there)) {
+                atomicOr(b.counters + 1, 1u);  // gave up: the call is void (SDRM_OUT_LEN_FAILED)
+            }
+            if (mine && lane < SDRM_K3_WAVE) {
+                flag_sh[lane] = (int) __hip_atomic_load(b.nonfinite + cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+#define K3_ISSUE(k)                                                                                          \
+    if (b.handoff && (b.hand_mode & 2)) {                                                                    \
+        await_block(k);                                                                                      \
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);                                                             \
+        K3_ISSUE_AS(k, K3_LOAD_PLAIN)                                                                        \
+    } else if (b.handoff && (b.hand_mode & 16)) {                                                            \
+        await_block(k);                                                                                      \
+        K3_ISSUE_AS(k, K3_LOAD_PLAIN)                                                                        \
+    } else if (b.handoff) {                                                                                  \
+        if (!(b.hand_mode & 8)) {                                                                            \
+            await_block(k);                                                                                  \
+        }                                                                                                    \
+        K3_ISSUE_AS(k, K3_LOAD_DEVICE)                                                                       \
+    } else {                                                                                                 \
+        K3_ISSUE_AS(k, K3_LOAD_PLAIN)                                                                        \
     }
         // transpose the prefetched rows into the ring; the full-block path writes rows directly and refreshes the
         // mirror rows with a small copy pass, the ragged path goes element by element through sdrm_k3_ring_put
@@ -1664,15 +1946,26 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         if (nblocks > 0) {
             K3_ISSUE(0)
         }
+        // diagnostics (workgroup 0 with the stamps on): cycles the staging wave spends writing the ring, converting soft bits,
+        // fetching the next block, and at the hand-over barrier
+        const bool pstamp = b.k3_stamps != nullptr && blockIdx.x == 0;
+        unsigned long long pt[4] = {0, 0, 0, 0};
         for (int k = 0; k < nblocks; k++) {
+            const unsigned long long p0 = pstamp ? __builtin_amdgcn_s_memtime() : 0;
             K3_COMMIT(k)
+            if (pstamp) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            const unsigned long long p1 = pstamp ? __builtin_amdgcn_s_memtime() : 0;
             if (K3_FUSED_INT8(G)) {
                 q_store();
                 q_load((k % (G::lanes / 16)) * 16, false);
             }
+            const unsigned long long p2 = pstamp ? __builtin_amdgcn_s_memtime() : 0;
             if (k + 1 < nblocks) {
                 K3_ISSUE(k + 1)
             }
+            const unsigned long long p3 = pstamp ? __builtin_amdgcn_s_memtime() : 0;
             // block k is in the ring; the consumer works on it while block k+1 is written
             if (K3_FUSED_INT8(G)) {
                 // LDS traffic only: the loads and stores above stay in flight across the hand-over
@@ -1680,6 +1973,20 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             } else {
                 __syncthreads();
             }
+            if (pstamp) {
+                const unsigned long long p4 = __builtin_amdgcn_s_memtime();
+                pt[0] += p1 - p0;
+                pt[1] += p2 - p1;
+                pt[2] += p3 - p2;
+                pt[3] += p4 - p3;
+            }
+        }
+        if (pstamp && lane == 0) {
+            unsigned long long *ps = b.k3_stamps + SDRM_STAMP_K3_WAVES(b.n_channels) * 4 + 18;
+            ps[0] = pt[0];
+            ps[1] = pt[1];
+            ps[2] = pt[2];
+            ps[3] = pt[3];
         }
         if (!K3_FUSED_INT8(G)) {
             tl_mark(b, 2, 1);
@@ -1697,6 +2004,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             }
         }
 #undef K3_ISSUE
+#undef K3_ISSUE_AS
+#undef K3_LOAD_PLAIN
+#undef K3_LOAD_DEVICE
 #undef K3_COMMIT
 #undef K3_ROW_SRC
         tl_mark(b, 2, 1);
@@ -1716,7 +2026,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     }
     // the stage writes the float soft bits; k3_quantize turns them into the int8 output behind it
     float *of = b.out_f32 + (size_t) (active ? c : 0) * b.out_stride;
-    const bool wave_clean = __all(clean);
+    bool wave_clean = __all(clean);
     const bool positions_fit = __all(L.nz < (1 << 22) - 2 * SDRM_CLOCK_HCAP);  // the hand-scheduled loop counts positions in a float's mantissa
     // Run every lane's loop as far as the staged samples allow.  A lane that cannot step now cannot step later in
     // the same block either, so the loop only ever shrinks the exec mask.  The operands of the NEXT symbol are issued
@@ -1766,6 +2076,19 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
                 safe_sh[lane] = L.oo > K3_STORE_SLACK ? (int) (L.oo - K3_STORE_SLACK) : 0;
             }
             __syncthreads();  // block k staged
+            if (b.handoff) {
+                // what the stages in front have flagged up to this block: a channel that has turned wild stops here (its call
+                // is run again from its start by sdrm_k3_rescue, the state it started from is untouched), NaN/Inf moves the
+                // wave to the general form of the symbol
+                const uint32_t f = active && !absent ? (uint32_t) flag_sh[lane] : 0u;
+                flagged |= f;
+                if ((f & SDRM_FLAG_WILD) != 0 && !wild) {
+                    wild = true;
+                    L.cap = 0;
+                }
+                clean = wild || (clean && f == 0);
+                wave_clean = __all(clean);
+            }
         }
         unsigned long long t1 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         int avail = (k + 1) * G::block;
@@ -1819,6 +2142,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     } else if (active && wild) {
         const sdrm_chan_params p = b.params[c];
         const float *src = (p.dc_len ? b.dcout : b.z) + (size_t) c * b.z_stride;
+        if (b.handoff) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the samples were written while this kernel ran: nothing stale from this XCD's L2
+        }
         b.out_len[c] = sdrm_k3_rescue(p, cs, src, L.nz, (const float *) bank_rev, of, b.out_i8 + (size_t) c * b.out_stride, flagged);
         b.nonfinite[c] = 0;
         atomicAdd(b.counters + 0, 1u);  // sdrm_batch_wild_calls
@@ -1837,6 +2163,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         cs->poison = (flagged != 0 || !(fabsf(L.st.mu) < INFINITY) || !(fabsf(L.st.omega) < INFINITY) || !(fabsf(L.st.last) < INFINITY)) ? SDRM_FLAG_NONFINITE : 0u;
         b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
         b.out_len[c] = L.oo;
+    }
+    if (b.handoff && active && __hip_atomic_load(b.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        b.out_len[c] = SDRM_OUT_LEN_FAILED;  // a hand-off wait of this batch ran into its bound: no result of this call can be trusted
     }
     if (b.k3_done != nullptr) {
         // this wave's writes of the channels' state are out (and written back past this XCD's L2) before the count says so:

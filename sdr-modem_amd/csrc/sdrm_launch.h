@@ -61,8 +61,20 @@ struct DeviceBatch {
     int k3_lanes, k3_ring, k3_plain; // clock-stage workgroup shape chosen for this batch (0: by channel count; SDRM_K3_LANES overrides both)
     int k3_wait;                     // the clock stage's workgroups wait for k3_done to reach k3_wait_for before they touch any
     uint32_t k3_wait_for;            //   state of the previous call (they were launched while that call's clock stage still ran)
-    uint32_t *counters;              // [16] batch-lifetime device counters: [0] channel-calls run by sdrm_k3_rescue (sdrm_batch_wild_calls)
+    uint32_t *counters;              // [16] batch-lifetime device counters: [0] channel-calls run by sdrm_k3_rescue (sdrm_batch_wild_calls),
+                                     //   [1] in-call hand-off waits that ran into their bound (the call's results are void: its clock stage answers
+                                     //   with the count SDRM_OUT_LEN_FAILED)
+    // In-call hand-off (DESIGN.md "stages of one call overlap"): the three stages of ONE call are resident together, the DC
+    // blocker starts on a channel's first finished front-end tiles, the clock stage on the first DC blocks.
+    int handoff;                     // 0: stages ordered by stream events (each kernel finds its input complete)
+    int hand_mode;                   // experiments (SDRM_HAND_MODE): 1 DC count behind a full release fence, 2 clock stage acquires + plain loads, 4 front-end waves wait for their stores
+    uint32_t epoch;                  // this call's stamp in hand_tiles / hand_prog (never 0)
+    uint32_t *hand_tiles;            // [C][hand_tiles_cap]: == epoch once that front-end tile's outputs are in memory
+    uint32_t hand_tiles_cap;
+    unsigned long long *hand_prog;   // [C]: epoch << 32 | DC-blocker outputs of this call that are in memory
 };
+#define SDRM_OUT_LEN_FAILED 0xffffffffu
+#define SDRM_HAND_MAX_LOOKS (1 << 21)  // bounded waits: ~2 s of looks 1 us apart, then the call fails loudly instead of hanging the device
 
 // one kernel launch, described: what launch_* puts on a stream and what the explicitly built graph of the one-channel
 // blocking call holds as a node (func == nullptr: nothing to launch this call)

@@ -19,6 +19,8 @@ L.sdrm_batch_k3_stamps(b.h, int(os.environ.get("MID", "1")), None, 0)
 st = torch.cuda.current_stream().cuda_stream
 for i in range(NCALLS):
     b.process_device(x.data_ptr() + (i % 2) * N * 8, 2 * N, [N] * Cn, st)
+    if os.environ.get("BLOCKING"):  # one call at a time: what the in-call hand-off (SDRM_HANDOFF) is for
+        b.sync()
 if os.environ.get("LOAD"):  # keep the rest of the chip busy (fp32 GEMMs on a side stream) while the last call runs
     side = torch.cuda.Stream()
     a = torch.randn(8192, 8192, device="cuda")
@@ -33,6 +35,7 @@ out = np.zeros(slots * 4 + 24, dtype=np.uint64)
 L.sdrm_batch_k3_stamps(b.h, 1, out.ctypes.data, slots)
 k1 = [int(v) for v in out[slots * 4:slots * 4 + 5]]
 k2 = [int(v) for v in out[slots * 4 + 8:slots * 4 + 18]]
+k3p = [int(v) for v in out[slots * 4 + 18:slots * 4 + 22]]
 out = out[:slots * 4].reshape(slots, 4)
 if k1[4]:
     print("K1 per workgroup (cycles): load %.0f, lpf1 %.0f, quad %.0f, lpf2+store %.0f  (%d workgroups)" % (
@@ -50,6 +53,9 @@ for w in range(min(waves, 2)):
     nb, ticks = packed & 0xffffffff, packed >> 32
     print("wave %d: wait-for-producer %.0f cyc/step, loops %.0f cyc/step, %d steps, %.1f iterations/step, %.0f cyc/iteration, "
           "%.3f ms at %.0f MHz" % (w, stg / nb, drn / nb, nb, it / nb, drn / max(it, 1), ticks / 1e5, (stg + drn) / max(ticks, 1) * 100))
+if k3p[0]:
+    nb0 = (int(out[0][2]) & 0xffffffff) or 1
+    print("staging wave of workgroup 0, cycles per step: ring writes %.0f, int8 conversion %.0f, next block's fetch %.0f, at the barrier %.0f" % tuple(v / nb0 for v in k3p))
 print("cycles per iteration, all %d consumer waves: %s" % (waves, " ".join("%.0f" % (int(out[w][1]) / max(int(out[w][3]), 1)) for w in range(waves))))
 if k2[9]:
     print("K2 workgroup 0: %d iterations, %.0f cycles each; busy per iteration: chain %.0f, feeder %.0f, stages %.0f %.0f %.0f, output %.0f" % (
