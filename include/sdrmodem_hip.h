@@ -196,6 +196,15 @@ int sdrm_batch_timing_read(sdrm_batch *batch, int which, double *total_ms, uint6
  * memory, statement by statement -- same bits, slower.  Counted since the batch was created; waits for enqueued calls. */
 int sdrm_batch_wild_calls(sdrm_batch *batch, uint64_t *count);
 
+/* In-call hand-off.  A call that meets an idle batch -- every blocking call (the reference's caller waits for
+ * fsk_demod_process, src/dsp_worker.c:75), the first call of a pipelined run -- cannot hide its front-end and DC blocker behind
+ * an earlier call's clock recovery.  Its three stages are then made resident together: the DC blocker starts on a channel's
+ * first finished front-end tiles, the clock recovery on the first DC blocks (per-tile stamps and per-channel output counts in
+ * device memory, device-scope accesses; DESIGN.md "stages of one call overlap").  Same bits; 256 channels x 131072 samples
+ * blocking: 4.28 -> 2.72 ms.  Used for batches small enough that waiting workgroups cannot starve the stage they wait for;
+ * SDRM_HANDOFF=0 (environment, read at batch creation) switches it off.  This counts the calls that took it. */
+int sdrm_batch_handoff_calls(sdrm_batch *batch, uint64_t *count);
+
 /* Stage probes for tests: run ONE stage of the device pipeline on a host vector (state-free where the
  * stage is). Return 0 on success. */
 int sdrm_probe_atan2(const float *y, const float *x, float *out, size_t n);

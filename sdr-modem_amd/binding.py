@@ -55,7 +55,7 @@ EXPORTS = [
     "fsk_demod_create", "fsk_demod_process", "fsk_demod_destroy",
     "sdrm_batch_create", "sdrm_batch_destroy", "sdrm_batch_channels", "sdrm_batch_info", "sdrm_batch_taps",
     "sdrm_batch_process", "sdrm_batch_process_device", "sdrm_batch_device_outputs", "sdrm_batch_last_soft",
-    "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read", "sdrm_batch_wild_calls",
+    "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read", "sdrm_batch_wild_calls", "sdrm_batch_handoff_calls",
     "sdrm_batch_process_nco", "sdrm_batch_process_device_nco", "sdrm_batch_last_mixed",
     "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect", "sdrm_batch_reset_channel",
     "sdrm_dsp_worker_create", "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt", "sdrm_batcher_abandon", "sdrm_fsk_demod_error", "sdrm_last_error", "sdrm_batch_wait_input", "sdrm_wire_write_response",
@@ -192,6 +192,8 @@ def load():
         L.sdrm_batch_schedule.argtypes = [vp, C.POINTER(ScheduleInfo)]
     L.sdrm_batch_timing_enable.argtypes = [vp, C.c_int]
     L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    if hasattr(L, "sdrm_batch_handoff_calls"):
+        L.sdrm_batch_handoff_calls.argtypes = [vp, C.POINTER(C.c_uint64)]
     if hasattr(L, "sdrm_batch_wild_calls"):  # absent only from older builds loaded through SDRM_LIB_PATH for A/B measurements
         L.sdrm_batch_wild_calls.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.sdrm_probe_atan2.argtypes = [vp, vp, vp, C.c_size_t]
@@ -414,6 +416,12 @@ class Batch:
         ms, n = C.c_double(), C.c_uint64()
         self.L.sdrm_batch_timing_read(self.h, which, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def handoff_calls(self):
+        """calls of this batch that ran with the in-call hand-off (stages of one call resident together)"""
+        n = C.c_uint64()
+        assert self.L.sdrm_batch_handoff_calls(self.h, C.byref(n)) == 0
+        return n.value
 
     def wild_calls(self):
         """channel-calls the clock stage ran from global memory (timing loop outside its tame range)"""

@@ -110,6 +110,8 @@ struct sdrm_batch_t {
     hipEvent_t ev_ctl[SDRM_CTL_SLOTS] = {};  // the call's control block is on the device
     bool hand_allowed = true;        // SDRM_HANDOFF=0 switches it off
     bool hand_used = false;          // a hand-off call has been enqueued since the device error word was last looked at
+    hipStream_t s_hand_dc = nullptr, s_hand_clock = nullptr;  // a one-stream (serial) batch: side streams for a hand-off call's DC and clock stages, created on first use
+    bool hand_side_last = false;     // the call enqueued last ran on them: the next call's first stream waits for its end
     uint64_t hand_calls = 0;         // diagnostics: calls enqueued with the hand-off
     uint32_t *d_placed = nullptr;    // [2] DC / clock-stage workgroups started, all launches (what the stream holds wait for)
     uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started
@@ -266,6 +268,12 @@ static void batch_free(sdrm_batch_t *b) {
     (void) hipFree(b->d_k3_done);
     (void) hipFree(b->d_placed);
     (void) hipFree(b->d_counters);
+    if (b->s_hand_dc) {
+        (void) hipStreamDestroy(b->s_hand_dc);
+    }
+    if (b->s_hand_clock) {
+        (void) hipStreamDestroy(b->s_hand_clock);
+    }
     (void) hipFree(b->d_hand_tiles);
     (void) hipFree(b->d_hand_prog);
     for (hipEvent_t e2 : b->ev_ctl) {
@@ -365,6 +373,12 @@ static int dev_alloc_zero(T **ptr, size_t count) {
     e = e ? e : hipStreamSynchronize(nullptr);
     return e == hipSuccess ? 0 : -EIO;
 }
+
+// One-stream batches (plain handles): from this many clock-stage input samples on, a blocking call is served faster by the
+// in-call hand-off on the handle's stream plus two side streams (enqueue_call) than by the graph replay of the three stages
+// one after the other -- measured, 48 kHz / 4800 baud / decimation 2: 16384 outputs 735 -> 650 us, 32768: 1340 -> 1178;
+// below, the replay's saved launches win (2048 outputs: 157 against 185 us).  profiles/r05_latency.txt
+#define SDRM_HAND_SERIAL_MIN_NZ 12288u
 
 // the most samples a channel's clock stage carries from one call into the next (what bounds a call's symbol count from above)
 static uint32_t carried_cap(const sdrm_chan_params &p) {
@@ -1521,12 +1535,37 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     // the DC stage's workgroups are resident -- then the front-end, which waits for nobody, always finds a CU, the DC
     // stage waits only for the front-end and the clock stage only for the DC stage.
     bool hand = false;
-    if (b->hand_allowed && !b->serial && b->n_gen == 0 && !b->clock_early && b->d_placed != nullptr && max_tiles > 0) {
+    if (b->hand_allowed && b->n_gen == 0 && !b->clock_early && (b->serial || b->d_placed != nullptr) && max_tiles > 0) {
         const bool idle = b->last_slot < 0 || hipEventQuery(b->slot_done[b->last_slot]) == hipSuccess;
         const unsigned waiting = sdrm::clock_workgroups(d) + (d.any_dc ? sdrm::dc_workgroups(d) : 0u);
         const bool room = !d.any_dc || (size_t) d.dc_lds + sdrm::k1_lds_bytes(d.t1_max, d.t2_max) <= 160 * 1024;
-        hand = idle && waiting <= 64 && room;
+        hand = idle && waiting <= 64 && room && sdrm::clock_shape_hands_off(d);
+        if (hand && b->serial) {
+            // a plain handle keeps its stages on one stream (a server holds one per client); a call long enough for the overlap
+            // to pay (SDRM_HAND_SERIAL_MIN_NZ) gets two side streams, created when the first such call comes
+            uint32_t longest = 0;
+            for (size_t c = 0; c < C; c++) {
+                longest = std::max(longest, h[c].nz);
+            }
+            hand = longest >= SDRM_HAND_SERIAL_MIN_NZ;
+            if (hand && b->s_hand_clock == nullptr) {
+                int prio_low = 0, prio_high = 0;
+                (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+                if (hipStreamCreateWithPriority(&b->s_hand_dc, hipStreamNonBlocking, (prio_low + prio_high) / 2) != hipSuccess ||
+                    hipStreamCreateWithPriority(&b->s_hand_clock, hipStreamNonBlocking, prio_high) != hipSuccess) {
+                    (void) hipGetLastError();
+                    hand = false;
+                }
+            }
+        }
     }
+    // the streams of this call's DC and clock stages
+    const bool hand_side = hand && b->serial;
+    hipStream_t s_dc = hand_side ? b->s_hand_dc : b->s_dc;
+    if (b->hand_side_last && b->last_slot >= 0) {
+        HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[b->last_slot], 0));  // the previous call ended on a side stream
+    }
+    b->hand_side_last = hand_side;
     if (hand && (b->d_hand_prog == nullptr || b->hand_tiles_cap < max_tiles)) {
         // stamps and counts: allocated on first use, grown when a call has more tiles (the batch is idle here)
         (void) hipFree(b->d_hand_tiles);
@@ -1541,9 +1580,6 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     }
     if (hand) {
         d.handoff = 1;
-        if (const char *env = getenv("SDRM_HAND_MODE")) {
-            d.hand_mode = atoi(env);
-        }
         d.epoch = (uint32_t) (i % 0xfffffff0ull) + 1u;
         d.hand_tiles = b->d_hand_tiles;
         d.hand_tiles_cap = b->hand_tiles_cap;
@@ -1595,10 +1631,11 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         // The two stages behind must have their workgroups placed BEFORE the front-end's grid covers the chip (a DC workgroup
         // needs 117 KB of a CU's LDS, a clock-stage workgroup 141 KB: neither finds that between front-end workgroups, and
         // the dispatcher reserves nothing -- measured: the DC stage started at 0.56 ms of a 0.62 ms front-end).  Bounded.
-        if (d.any_dc && getenv("SDRM_HAND_ORDERED") == nullptr) {
+        // (a one-stream batch has one channel: a few dozen front-end workgroups, nothing to hold back)
+        if (d.any_dc && b->d_placed != nullptr) {
             sdrm::launch_hold_until(b->d_placed + 0, b->k2_placed_target + sdrm::dc_workgroups(d), 400, b->s_front);
         }
-        if (getenv("SDRM_HAND_ORDERED") == nullptr) {
+        if (b->d_placed != nullptr) {
             sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_target + sdrm::clock_workgroups(d), 400, b->s_front);
         }
     }
@@ -1621,26 +1658,25 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     HIP_TRY(hipEventRecord(b->ev_front[slot], b->s_front));
 
     // ---- DC blocker: needs z of this call, and dcout[i&1] released by the clock stage of call i-2
-    const bool hand_ordered = hand && getenv("SDRM_HAND_ORDERED") != nullptr;  // experiments: the hand-off's kernels, one after the other
     if (d.any_dc) {
-        HIP_TRY(hipStreamWaitEvent(b->s_dc, (hand && !hand_ordered) ? b->ev_ctl[slot] : b->ev_front[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(s_dc, hand ? b->ev_ctl[slot] : b->ev_front[slot], 0));
         if (have_prev2) {
-            HIP_TRY(hipStreamWaitEvent(b->s_dc, b->slot_done[prev2], 0));
+            HIP_TRY(hipStreamWaitEvent(s_dc, b->slot_done[prev2], 0));
         }
         if (!b->serial && have_prev2 && sdrm::dc_waits_for_clock_start(d)) {
             // many channels: the clock stage of call i-1, released by the same event (the end of call i-2's), takes its CUs first
-            sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_after[(i + SDRM_CTL_SLOTS - 1) % SDRM_CTL_SLOTS], 200, b->s_dc);
+            sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_after[(i + SDRM_CTL_SLOTS - 1) % SDRM_CTL_SLOTS], 200, s_dc);
         }
         b->k2_placed_target += sdrm::dc_workgroups(d);
         if (b->timing) {
-            timing_begin(b, 1, b->s_dc, &ev);
+            timing_begin(b, 1, s_dc, &ev);
         }
-        sdrm::launch_dc(d, b->s_dc);
-        sdrm::launch_dc_generic(d, b->s_dc);
+        sdrm::launch_dc(d, s_dc);
+        sdrm::launch_dc_generic(d, s_dc);
         if (b->timing) {
-            timing_end(b, 1, b->s_dc, ev);
+            timing_end(b, 1, s_dc, ev);
         }
-        HIP_TRY(hipEventRecord(b->ev_dc[slot], b->s_dc));
+        HIP_TRY(hipEventRecord(b->ev_dc[slot], s_dc));
     }
 
     // ---- clock recovery + int8
@@ -1648,7 +1684,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     // between them is then kept inside the kernel (k3_wait_for), the order two calls apart by the stream
     // (a call whose int8 conversion is a kernel of its own behind the clock stage reads the float soft bits there: the
     // next call's clock stage, which writes them, stays behind it on the same stream)
-    hipStream_t s_clock = b->s_clock;
+    hipStream_t s_clock = hand_side ? b->s_hand_clock : b->s_clock;
     if (b->clock_early) {
         hipStream_t prev = b->clock_prev_alt ? b->s_clock_alt : b->s_clock;
         hipStream_t other = b->clock_prev_alt ? b->s_clock : b->s_clock_alt;
@@ -1657,11 +1693,9 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         b->clock_prev_alt = s_clock == b->s_clock_alt;
         b->clock_prev_converts = sdrm::describe_quantize(d).func != nullptr;
     }
-    if (hand_ordered) {
-        HIP_TRY(hipStreamWaitEvent(s_clock, d.any_dc ? b->ev_dc[slot] : b->ev_front[slot], 0));
-    } else if (hand) {
+    if (hand) {
         HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_ctl[slot], 0));
-        if (d.any_dc) {
+        if (d.any_dc && b->d_placed != nullptr) {
             // ... and the DC stage's workgroups resident (they count themselves in, k2_dc): bounded, ~2 ms
             sdrm::launch_hold_until(b->d_placed + 0, b->k2_placed_target, 2000, s_clock);
         }
@@ -1793,6 +1827,15 @@ extern "C" int sdrm_batch_sync(sdrm_batch *b) {
         return -1;
     }
     return wait_for_all_calls(b);
+}
+
+// calls enqueued with the in-call hand-off since the batch was created
+extern "C" int sdrm_batch_handoff_calls(sdrm_batch *b, uint64_t *count) {
+    if (b == nullptr || count == nullptr) {
+        return -1;
+    }
+    *count = b->hand_calls;
+    return 0;
 }
 
 // channel-calls the clock stage ran from global memory (sdrm_kernels.h "wild channels"), since the batch was created
@@ -1934,8 +1977,14 @@ extern "C" int sdrm_batch_process_nco(sdrm_batch *b, const sdrm_cf32 *const *inp
 #define SDRM_GRAPH_MAX_SAMPLES 65536u
 static const int SG_SLOT = SDRM_CTL_SLOTS - 1;
 
+static bool serial_call_hands_off(const sdrm_batch_t *b, size_t n) {
+    const sdrm_chan_params &p = b->plan.params[0];
+    return b->hand_allowed && !b->clock_early && b->n_gen == 0 && n / p.decim >= SDRM_HAND_SERIAL_MIN_NZ;
+}
+
 static bool serial_graph_usable(const sdrm_batch_t *b, size_t n, const sdrm_nco_segment *segs) {
     return getenv("SDRM_NO_GRAPH") == nullptr &&  // escape hatch for measurements
+           !serial_call_hands_off(b, n) &&
            !b->sg_broken && b->serial && b->plan.design.size() == 1 && b->n_gen == 0 && segs == nullptr && !b->timing &&
            b->d_timeline == nullptr && b->dev.k3_stamps == nullptr && b->d_out8_b == nullptr && b->calls > 0 && n > 0 &&
            n <= SDRM_GRAPH_MAX_SAMPLES && n <= b->plan.params[0].max_len;
@@ -1971,22 +2020,19 @@ static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h
         (void) hipGetLastError();
         return -1;
     }
-    hipGraphNode_t prev = nullptr;
     bool ok = true;
-    auto after = [&](hipGraphNode_t node) { prev = node; };
-    auto add_copy = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    typedef std::vector<hipGraphNode_t> deps_t;
+    auto add_copy = [&](const deps_t &deps, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) -> hipGraphNode_t {
         hipGraphNode_t node = nullptr;
-        ok = ok && bytes > 0 &&
-             hipGraphAddMemcpyNode1D(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, dst, src, bytes, kind) == hipSuccess;
-        if (ok) {
-            after(node);
-        }
+        ok = ok && bytes > 0 && hipGraphAddMemcpyNode1D(&node, graph, deps.data(), deps.size(), dst, src, bytes, kind) == hipSuccess;
+        return node;
     };
     const sdrm_f2 *d_in = b->d_in;
     size_t in_stride = b->in_stride;
-    auto add_kernel = [&](const sdrm::KernelLaunch &k) {  // a kernel takes as many of the three arguments as it declares
+    // a kernel takes as many of the three arguments as it declares; nullptr: nothing to launch (the dependences pass through)
+    auto add_kernel = [&](const deps_t &deps, const sdrm::KernelLaunch &k) -> hipGraphNode_t {
         if (k.func == nullptr || !ok) {
-            return;
+            return nullptr;
         }
         void *args[3] = {(void *) &d, (void *) &d_in, (void *) &in_stride};
         hipKernelNodeParams kp = {};
@@ -1997,20 +2043,24 @@ static int serial_graph_build(sdrm_batch_t *b, size_t n, const sdrm_chunk_ctl *h
         kp.kernelParams = args;
         kp.extra = nullptr;
         hipGraphNode_t node = nullptr;
-        ok = hipGraphAddKernelNode(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp) == hipSuccess;
-        if (ok) {
-            after(node);
-        }
+        ok = hipGraphAddKernelNode(&node, graph, deps.data(), deps.size(), &kp) == hipSuccess;
+        return node;
     };
-    add_copy(b->d_in, b->h_in_stage, n * sizeof(sdrm_f2), hipMemcpyHostToDevice);
-    add_copy(b->d_ctl + (size_t) SG_SLOT, h, sizeof(sdrm_chunk_ctl), hipMemcpyHostToDevice);
-    add_kernel(sdrm::describe_front(d));
-    add_kernel(sdrm::describe_dc(d));
-    add_kernel(sdrm::describe_clock(d));
-    add_kernel(sdrm::describe_quantize(d));
-    add_copy(b->h_outlen, d.out_len, sizeof(uint32_t), hipMemcpyDeviceToHost);
-    if (b->sg_width > 0) {
-        add_copy(b->h_out8, d.out_i8, b->sg_width, hipMemcpyDeviceToHost);
+    hipGraphNode_t n_in = add_copy({}, b->d_in, b->h_in_stage, n * sizeof(sdrm_f2), hipMemcpyHostToDevice);
+    hipGraphNode_t n_ctl = add_copy({n_in}, b->d_ctl + (size_t) SG_SLOT, h, sizeof(sdrm_chunk_ctl), hipMemcpyHostToDevice);
+    hipGraphNode_t last = n_ctl;
+    // (The stages stay a chain here.  The in-call hand-off as three parallel branches of a graph was measured and lost --
+    // 4096 samples 157 -> 376 us, 65536: 1340 -> 1985 -- while on the handle's stream plus two side streams it wins from
+    // ~24000 samples on: calls that long leave the graph to it, process_host.)
+    if (ok) {
+        for (const sdrm::KernelLaunch &k : {sdrm::describe_front(d), sdrm::describe_dc(d), sdrm::describe_clock(d), sdrm::describe_quantize(d)}) {
+            hipGraphNode_t node = add_kernel({last}, k);
+            last = node ? node : last;
+        }
+        last = add_copy({last}, b->h_outlen, d.out_len, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    }
+    if (ok && b->sg_width > 0) {
+        last = add_copy({last}, b->h_out8, d.out_i8, b->sg_width, hipMemcpyDeviceToHost);
     }
     if (!ok) {
         (void) hipGraphDestroy(graph);

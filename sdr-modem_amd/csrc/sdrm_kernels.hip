@@ -260,14 +260,14 @@ size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) { return sdrm_k1_lds_bytes
 // grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
 // per-thread boundary samples | arctan table.
 // FUSED: the opt-in fast mode (SDRM_FLAG_FAST_FMA): both filters' taps as fused multiply-adds.  Never the default.
-template <bool FUSED>
+template <bool FUSED, bool HAND>
 __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
                                                             size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
     // grid (tiles, channels); with the in-call hand-off (channels, tiles): workgroups are dispatched x first, so every channel's
     // tile 0 comes before anybody's tile 1 and the stages behind can start on all channels at once
-    const int c = b.handoff ? blockIdx.x : blockIdx.y;
-    const unsigned tile_id = b.handoff ? blockIdx.y : blockIdx.x;
+    const int c = HAND ? blockIdx.x : blockIdx.y;
+    const unsigned tile_id = HAND ? blockIdx.y : blockIdx.x;
     const sdrm_chunk_ctl ctl = b.ctl[c];
     const sdrm_chan_params p = b.params[c];
     if (tile_id == 0) {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_lpf2<FUSED>(tid, t, p, taps2, qs, zs, b.nonfinite + c);
     __syncthreads();
-    if (b.handoff) {
+    if (HAND) {
         // The tile is in memory (and any flag it raised, sdrm_k1_phase_lpf2) before its stamp says so: written THROUGH this
         // XCD's L2 with device-scope stores, every wave waits for the acknowledgement of its own, then one thread stamps.
         // (Not a release fence: that is a write-back of the whole L2, and 8960 of them in half a millisecond stalled every
@@ -422,12 +422,19 @@ KernelLaunch describe_front(const DeviceBatch &b) {
     KernelLaunch k;
     static lds_grant granted, granted_fused;
     k.lds = k1_lds_bytes(b.t1_max, b.t2_max);
-    if (b.fast_fma) {
-        allow_lds(k1_front<true>, k.lds, &granted_fused);
-        k.func = reinterpret_cast<const void *>(k1_front<true>);
+    static lds_grant granted_hand, granted_fused_hand;
+    if (b.fast_fma && b.handoff) {
+        allow_lds(k1_front<true, true>, k.lds, &granted_fused_hand);
+        k.func = reinterpret_cast<const void *>(k1_front<true, true>);
+    } else if (b.fast_fma) {
+        allow_lds(k1_front<true, false>, k.lds, &granted_fused);
+        k.func = reinterpret_cast<const void *>(k1_front<true, false>);
+    } else if (b.handoff) {
+        allow_lds(k1_front<false, true>, k.lds, &granted_hand);
+        k.func = reinterpret_cast<const void *>(k1_front<false, true>);
     } else {
-        allow_lds(k1_front<false>, k.lds, &granted);
-        k.func = reinterpret_cast<const void *>(k1_front<false>);
+        allow_lds(k1_front<false, false>, k.lds, &granted);
+        k.func = reinterpret_cast<const void *>(k1_front<false, false>);
     }
     k.grid = dim3(b.max_tiles ? b.max_tiles : 1u, (unsigned) b.n_channels);  // tile 0 of every channel also rolls its history
     if (b.handoff) {
@@ -654,6 +661,9 @@ __device__ __forceinline__ void k2_quotients(const k2_lane &L, const float (&t)[
     }
 }
 
+// HAND: the in-call hand-off (the front-end is still running; DeviceBatch::handoff) -- a build of its own, so that the
+// ordinary one carries none of its code
+template <bool HAND>
 __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     extern __shared__ __attribute__((aligned(16))) float k2_lds[];
     float *ts = k2_lds;                                                  // [64 rows][TSPITCH]
@@ -754,7 +764,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     // In-call hand-off: the feeder (the only role that reads the front-end's output inside the loop) makes sure, before it
     // touches outputs [.., upto) of this call, that the tiles holding them are in memory for every slot of its wave.  One
     // acquire per newly finished tile row; z_ready remembers how far that reaches.
-    int z_ready = b.handoff ? 0 : 0x7fffffff;  // wave-uniform: outputs [0, z_ready) of every slot of this wave are known to be there
+    int z_ready = HAND ? 0 : 0x7fffffff;  // wave-uniform: outputs [0, z_ready) of every slot of this wave are known to be there
     int my_ready = L.on ? 0 : 0x7fffffff;      // this lane's slot alone
     auto await_z = [&](int upto) {
         if (upto <= z_ready) {
@@ -774,6 +784,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         }
         if (!__all(there)) {
             atomicOr(b.counters + 1, 1u);  // gave up: what follows is computed from whatever is there, the call is void
+            my_ready = 0x7fffffff;         // ... and nobody waits again (one bound per kernel, not one per block)
         }
         int reach = my_ready >= nz ? 0x7fffffff : my_ready;
         for (int sl = 0; sl < SDRM_K2_P; sl++) {
@@ -791,7 +802,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     const size_t z_row = (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
     auto x4 = [&](int m, float *v) {    // x[m .. m+3]: any alignment, maybe carried samples
         if (m >= 0 && (m & 3) == 0) {
-            if (b.handoff) {
+            if (HAND) {
                 hand_load4(z_rsrc, z_row + (size_t) m, v);
             } else {
                 const k2_f4 t = *reinterpret_cast<const k2_f4 *>(L.z + m);
@@ -799,14 +810,14 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
             }
         } else {
             for (int e = 0; e < 4; e++) {
-                v[e] = (b.handoff && m + e >= 0) ? __hip_atomic_load(L.z + (m + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                v[e] = (HAND && m + e >= 0) ? __hip_atomic_load(L.z + (m + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                  : sdrm_k2_x(L.z, L.hx, L.s.HX, m + e);
             }
         }
     };
     if (role == 1) {
         await_z(SDRM_K2_BLK);
-        if (L.on && !b.handoff) {
+        if (L.on && !HAND) {
             sdrm_k2_feed(L.s, 0, L.q, L.z, L.hx, ts + slot_h * SDRM_K2_TSPITCH);  // block 0 of stage 0
         } else if (L.on) {
             // the same terms (sdrm_k2_feed: t = x[n] - x[n - L] for the P samples of this lane), the samples read with device scope
@@ -873,9 +884,6 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             done = k;
-        }
-        if (b.hand_mode & 1) {
-            __threadfence();
         }
         const bool further = done > done_said;  // (the straight-line iterations lag: never take a count back)
         done_said = further ? done : done_said;
@@ -1001,7 +1009,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
                 amax = fmaxf(amax, fabsf(o[i]));  // (v_max3_f32 with |.| modifiers: two outputs per instruction)
             }
             odd |= probe != probe;
-            if (b.handoff) {
+            if (HAND) {
                 publish(k, n0, o, K2_P, true, odd | !(amax < tame5));
             } else {
                 k2_store_p(L.out + n0, o);
@@ -1100,7 +1108,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
                             for (int i = 0; i < K2_P; i++) {
                                 amax = fmaxf(amax, fabsf(o[i]));
                             }
-                            if (!b.handoff) {
+                            if (!HAND) {
                                 k2_store_p(L.out + n0, o);
                             }
                         } else {
@@ -1109,7 +1117,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
                                 if (i < valid) {
                                     odd |= !(fabsf(o[i]) < INFINITY);
                                     amax = fmaxf(amax, fabsf(o[i]));
-                                    if (!b.handoff) {
+                                    if (!HAND) {
                                         L.out[n0 + i] = o[i];
                                     }
                                 }
@@ -1117,7 +1125,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
                         }
                     }
                 }
-                if (b.handoff) {
+                if (HAND) {
                     publish(k, n0, o, valid, false, odd | !(amax < tame5));
                 }
             }
@@ -1205,7 +1213,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
             await_z((it + 2) * SDRM_K2_BLK);
             const float *za = L.z + (it + 1) * SDRM_K2_BLK + 4 * L.q, *zb = za - (int) L.s.L;
             const float *zc = L.z + (it - 6) * SDRM_K2_BLK + 4 * L.q - (int) L.s.HX;
-            if (b.handoff) {
+            if (HAND) {
                 const size_t ia = z_row + (size_t) ((it + 1) * SDRM_K2_BLK + 4 * L.q), ib = ia - L.s.L;
                 const size_t ic = z_row + (size_t) ((it - 6) * SDRM_K2_BLK + 4 * L.q) - L.s.HX;
 #pragma unroll
@@ -1326,14 +1334,14 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         if (bits) {
             atomicOr(b.nonfinite + L.s.chan, bits);
         }
-        if (b.handoff) {  // the last block (and those flags) are out: the channel's count reaches its end
+        if (HAND) {  // the last block (and those flags) are out: the channel's count reaches its end
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (L.q == 0) {
                 __hip_atomic_store(b.hand_prog + L.s.chan, ((unsigned long long) b.epoch << 32) | (uint32_t) nz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
-    if (b.handoff) {
+    if (HAND) {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);  // what follows reads the call's last samples plainly: nothing stale from this XCD's L2
     }
     // hx <- last HX samples of (hx ++ z): a slot at a time by all threads; when the call is shorter than HX the new array
@@ -1380,9 +1388,14 @@ KernelLaunch describe_dc(const DeviceBatch &b) {
         return k;
     }
     k.lds = b.dc_lds;
-    static lds_grant granted;
-    allow_lds(k2_dc, k.lds, &granted);
-    k.func = reinterpret_cast<const void *>(k2_dc);
+    static lds_grant granted, granted_hand;
+    if (b.handoff) {
+        allow_lds(k2_dc<true>, k.lds, &granted_hand);
+        k.func = reinterpret_cast<const void *>(k2_dc<true>);
+    } else {
+        allow_lds(k2_dc<false>, k.lds, &granted);
+        k.func = reinterpret_cast<const void *>(k2_dc<false>);
+    }
     k.grid = dim3((unsigned) ((b.n_channels + b.dc_group - 1) / b.dc_group));
     k.block = dim3(64 * SDRM_K2_WAVES);
     return k;
@@ -1616,7 +1629,9 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     L.st.inc = inc;
 }
 
-template <int LANES, int RING, bool PLAIN>
+// HAND: the in-call hand-off (the stages in front are still running; DeviceBatch::handoff) -- a build of its own (one shape:
+// 16 x 1024, what a batch small enough for the hand-off takes), so that the ordinary builds carry none of its code
+template <int LANES, int RING, bool PLAIN, bool HAND = false>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     typedef sdrm_k3_geom<LANES, RING, PLAIN> G;
     extern __shared__ __attribute__((aligned(16))) float k3_lds[];
@@ -1694,7 +1709,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             L.nz = (int) b.ctl[c].nz;
             uses_dc = p.dc_len != 0;
             // (in-call hand-off: the stages in front are still running, their flags arrive block by block through flag_sh)
-            flagged = b.handoff ? 0u : b.nonfinite[c];
+            flagged = HAND ? 0u : b.nonfinite[c];
             const uint32_t carried = cs->poison;
             wild = ((flagged | carried) & SDRM_FLAG_WILD) != 0 || !(p.amp_safe > 0.0f);
             if (!wild) {
@@ -1771,12 +1786,11 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         // the DC blocker's count for the channels behind one (hand_prog), the front-end's tile stamps for the others -- and
         // the flags those samples raised go to the consumer wave with the block (flag_sh, read behind the hand-over barrier).
         int my_ready = 0;  // lane = channel (row): samples of this call known to be there
-        const uint32_t tile_m = (b.handoff && lane < nrows) ? b.params[c0 + lane].tile_m : 1u;
+        const uint32_t tile_m = (HAND && lane < nrows) ? b.params[c0 + lane].tile_m : 1u;
         auto await_block = [&](int k) {
             const int cr = c0 + lane;
             const bool mine = lane < nrows;
-            const int lead_ = (b.hand_mode >> 8) * 256;  // experiments: stay this many samples behind the stage in front
-            const int need = ((k) + 1) * G::block + lead_ < my_nz ? ((k) + 1) * G::block + lead_ : my_nz;
+            const int need = ((k) + 1) * G::block < my_nz ? ((k) + 1) * G::block : my_nz;
             auto look = [&]() {
                 if (!mine || my_ready >= need) {
                     return true;
@@ -1803,23 +1817,15 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
             }
             if (!__all(there)) {
                 atomicOr(b.counters + 1, 1u);  // gave up: the call is void (SDRM_OUT_LEN_FAILED)
+                my_ready = 0x7fffffff;         // ... and nobody waits again (one bound per kernel, not one per block)
             }
             if (mine && lane < SDRM_K3_WAVE) {
                 flag_sh[lane] = (int) __hip_atomic_load(b.nonfinite + cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
 #define K3_ISSUE(k)                                                                                          \
-    if (b.handoff && (b.hand_mode & 2)) {                                                                    \
+    if (HAND) {                                                                                              \
         await_block(k);                                                                                      \
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);                                                             \
-        K3_ISSUE_AS(k, K3_LOAD_PLAIN)                                                                        \
-    } else if (b.handoff && (b.hand_mode & 16)) {                                                            \
-        await_block(k);                                                                                      \
-        K3_ISSUE_AS(k, K3_LOAD_PLAIN)                                                                        \
-    } else if (b.handoff) {                                                                                  \
-        if (!(b.hand_mode & 8)) {                                                                            \
-            await_block(k);                                                                                  \
-        }                                                                                                    \
         K3_ISSUE_AS(k, K3_LOAD_DEVICE)                                                                       \
     } else {                                                                                                 \
         K3_ISSUE_AS(k, K3_LOAD_PLAIN)                                                                        \
@@ -2076,7 +2082,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
                 safe_sh[lane] = L.oo > K3_STORE_SLACK ? (int) (L.oo - K3_STORE_SLACK) : 0;
             }
             __syncthreads();  // block k staged
-            if (b.handoff) {
+            if (HAND) {
                 // what the stages in front have flagged up to this block: a channel that has turned wild stops here (its call
                 // is run again from its start by sdrm_k3_rescue, the state it started from is untouched), NaN/Inf moves the
                 // wave to the general form of the symbol
@@ -2142,7 +2148,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     } else if (active && wild) {
         const sdrm_chan_params p = b.params[c];
         const float *src = (p.dc_len ? b.dcout : b.z) + (size_t) c * b.z_stride;
-        if (b.handoff) {
+        if (HAND) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the samples were written while this kernel ran: nothing stale from this XCD's L2
         }
         b.out_len[c] = sdrm_k3_rescue(p, cs, src, L.nz, (const float *) bank_rev, of, b.out_i8 + (size_t) c * b.out_stride, flagged);
@@ -2164,7 +2170,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
         b.out_len[c] = L.oo;
     }
-    if (b.handoff && active && __hip_atomic_load(b.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    if (HAND && active && __hip_atomic_load(b.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         b.out_len[c] = SDRM_OUT_LEN_FAILED;  // a hand-off wait of this batch ran into its bound: no result of this call can be trusted
     }
     if (b.k3_done != nullptr) {
@@ -2235,10 +2241,23 @@ sdrm_k3_shape k3_shape(const DeviceBatch &b) {
 
 sdrm_k3_shape describe_shape(const DeviceBatch &b) { return k3_shape(b); }
 
+static KernelLaunch describe_clock_hand(const DeviceBatch &b) {
+    KernelLaunch k = describe_clock_as<16, 1024, false>(b);
+    static lds_grant granted;
+    allow_lds(k3_clock<16, 1024, false, true>, k.lds, &granted);
+    k.func = reinterpret_cast<const void *>(k3_clock<16, 1024, false, true>);
+    return k;
+}
+// the in-call hand-off exists for this clock-stage shape only
+bool clock_shape_hands_off(const DeviceBatch &b) {
+    const sdrm_k3_shape sh = k3_shape(b);
+    return sh.lanes == 16 && sh.ring == 1024 && !sh.plain;
+}
+
 KernelLaunch describe_clock(const DeviceBatch &b) {
     const sdrm_k3_shape sh = k3_shape(b);
     switch ((sh.lanes * 10000 + sh.ring) * (sh.plain ? -1 : 1)) {
-        case 16 * 10000 + 1024: return describe_clock_as<16, 1024, false>(b);
+        case 16 * 10000 + 1024: return b.handoff ? describe_clock_hand(b) : describe_clock_as<16, 1024, false>(b);
         case 16 * 10000 + 512: return describe_clock_as<16, 512, false>(b);
         case 16 * 10000 + 256: return describe_clock_as<16, 256, false>(b);
         case 32 * 10000 + 512: return describe_clock_as<32, 512, false>(b);

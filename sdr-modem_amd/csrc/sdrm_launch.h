@@ -67,7 +67,6 @@ struct DeviceBatch {
     // In-call hand-off (DESIGN.md "stages of one call overlap"): the three stages of ONE call are resident together, the DC
     // blocker starts on a channel's first finished front-end tiles, the clock stage on the first DC blocks.
     int handoff;                     // 0: stages ordered by stream events (each kernel finds its input complete)
-    int hand_mode;                   // experiments (SDRM_HAND_MODE): 1 DC count behind a full release fence, 2 clock stage acquires + plain loads, 4 front-end waves wait for their stores
     uint32_t epoch;                  // this call's stamp in hand_tiles / hand_prog (never 0)
     uint32_t *hand_tiles;            // [C][hand_tiles_cap]: == epoch once that front-end tile's outputs are in memory
     uint32_t hand_tiles_cap;
@@ -110,6 +109,7 @@ void launch_clock_generic(const DeviceBatch &b, hipStream_t s);  // behind launc
 void launch_clock(const DeviceBatch &b, hipStream_t s);
 void launch_clock_company(const DeviceBatch &b, uint32_t target, int blocks, int max_rounds, int nops, hipStream_t s);
 unsigned clock_workgroups(const DeviceBatch &b);
+bool clock_shape_hands_off(const DeviceBatch &b);  // the in-call hand-off build of the clock stage exists for this batch's shape
 
 // test probes
 void launch_probe_boxcar_div(const float *d_sums, uint32_t length, float *d_out, size_t n, hipStream_t s);
