@@ -147,6 +147,21 @@ def newest_traffic(channels, chunk):
     return (best[0], best[1], best[3]) if best else (None, None, {})
 
 
+def newest_kernels(channels, chunk):
+    """per-kernel figures of the newest committed PMC measurement of this workload (profiles/*_kernels.json,
+    tools/collect_profiles.py): {kernel: {avg_ms_alone, algorithmic_bytes, counter_bytes, valu_issue, ...}}, ratio, source"""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernels.json"))):
+        try:
+            kj = json.load(open(path))
+        except Exception:
+            continue
+        if kj.get("channels") == channels and kj.get("chunk") == chunk and kj.get("kernels"):
+            if best is None or str(kj.get("round", "")) >= best[0]:
+                best = (str(kj.get("round", "")), kj, os.path.relpath(path, ROOT))
+    return (best[1]["kernels"], best[1].get("whole_step_traffic_ratio"), best[2]) if best else ({}, None, None)
+
+
 class Rig:
     """the device-resident workload of one rank: C channels x `resident` chunks of synthetic GMSK in HBM + a batch"""
 
@@ -456,11 +471,20 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         rig.step(args.warmup + i)
+    torch.cuda.synchronize()
+    own_done = time.perf_counter() - t0  # this rank's K steps, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     k_ms = rig.kernel_ms()
     batch.timing_enable(False)
+    own_elapsed = own_done
     elapsed = max_over_ranks(elapsed)
+    # every rank's own time for the same K steps (before the closing barrier it is what that rank needed): an imbalance shows here
+    per_rank = [own_elapsed]
+    if world > 1:
+        t_all = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(t_all, torch.tensor([own_elapsed], dtype=torch.float64, device=coll_dev))
+        per_rank = [float(t.item()) for t in t_all]
 
     samples_per_step = C * N * world
     msps = samples_per_step * args.steps / elapsed / 1e6
@@ -471,6 +495,31 @@ def main():
     if not args.no_verify and rank == 0:
         checker = SpotChecker(cfgs, rig.row, N, spot_channels(C))
         verify, verify_detail = checker.check(batch, rig.fed)
+
+    # AFTER the timed region as well: the steady-state step, fill excluded -- 33 more calls with the device timeline on, the
+    # spacing of their clock stages' ends (the first call of a run cannot hide its front-end and DC blocker behind an earlier
+    # call's clock stage; a 20-step region carries that once)
+    steady = None
+    if rank == 0:
+        try:
+            barrier_local = torch.cuda.synchronize
+            barrier_local()
+            batch.timeline_begin()
+            for i in range(33):
+                rig.step(args.warmup + args.steps + i)
+            barrier_local()
+            tl = batch.timeline_read()
+            if len(tl) >= 9:
+                ends = tl[:, 5]
+                steady = {"ms_per_step": round(float(ends[-1] - ends[8]) / (len(ends) - 9), 4), "calls": int(len(ends) - 9),
+                          "first_call_ms": round(float(ends[0] - tl[0, 0]), 4),
+                          "how": "device timeline (100 MHz clock): spacing of the clock stages' ends over calls 9.. of a 33-call run "
+                                 "made after the timed region; first_call_ms = the run's first call, first front-end workgroup to "
+                                 "last clock-stage workgroup (its stages resident together: in-call hand-off)"}
+        except Exception as exc:
+            steady = {"error": str(exc)[:200]}
+    elif world > 1:
+        pass
 
     row0 = rig.x[0].cpu().numpy().view(np.complex64)[:2 * N] if rank == 0 else None
     base = rig.base
@@ -531,6 +580,10 @@ def main():
         front_ms = k_ms[0]
         achieved = (C * N * 8.0) / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
         traffic, traffic_src, pmc = newest_traffic(C, N)
+        per_kernel, traffic_ratio, per_kernel_src = newest_kernels(C, N)
+        live = {"k1_front": k_ms[0], "k2_dc": k_ms[1], "k3_clock": k_ms[2]}
+        for name, rec in per_kernel.items():
+            rec["avg_ms"] = round(live.get(name, 0.0), 4)  # live, this run: HIP events on the kernel's own stream, inside the timed region
         macs_per_sample = 2 * T1 + T2
         ceiling_gbs = VALU_EXACT_MACS / macs_per_sample * 8.0 / 1e9
         out = {
@@ -541,6 +594,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_per_rank": {"max": round(max(per_rank) / args.steps * 1e3, 4), "min": round(min(per_rank) / args.steps * 1e3, 4)},
+            "steady_state": steady,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -560,6 +615,9 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": C * N * 8,
+                         # every kernel of the step: live average duration (this run), algorithmic bytes, HBM bytes and issue
+                         # share from the newest committed counter passes; the step's counted traffic over its algorithmic bytes
+                         "kernels": per_kernel, "kernels_source": per_kernel_src, "whole_step_traffic_ratio": traffic_ratio,
                          # SURVEY 8d also defines the fused-pipeline figure: 8 B in + baud/fs B out per sample at the
                          # whole-path rate.  It is far below the front-end's because the step time is the clock
                          # recovery chain (latency-bound), not a memory stream.
@@ -582,7 +640,11 @@ def main():
                          "note": "8 B of IQ read per input sample (SURVEY 8d LPF-stage HBM-read term). The kernel is "
                                  "fp32-VALU-bound: bit-exact parity needs a separately rounded multiply and add per tap "
                                  "(v_pk_mul_f32 + v_pk_add_f32: 16 component-MACs per SIMD and cycle; %d MACs per sample), "
-                                 "which caps it at exact_valu_ceiling GB/s of IQ" % macs_per_sample},
+                                 "which caps it at exact_valu_ceiling GB/s of IQ. THE STEP of this workload is not this kernel: "
+                                 "it is the clock-recovery recursion (k3_clock, one lane per channel, 16 waves on the chip), "
+                                 "a float-recursive loop with a data-dependent stride at its floor of ~36 vector instructions "
+                                 "x ~4.4 cycles + one exposed LDS round trip per symbol; `frac` describes the LPF stage the north "
+                                 "star asks about, whole_path_hbm_frac the step" % macs_per_sample},
         }
         if verify is not None:
             out["verified_vs_oracle"] = verify
@@ -693,6 +755,8 @@ def main():
         if world == 1 and not args.no_extras:
             try:
                 out["end_to_end"] = end_to_end(binding, siggen, C, N)
+                # the reference's boundary hands over HOST buffers: what the same box sustains through it (PCIe-bound)
+                out["channels_at_realtime_host_path"] = int(out["end_to_end"]["value"] * 1e6 / FS)
             except Exception as exc:
                 out["end_to_end"] = {"error": str(exc)[:200]}
         print(json.dumps(out), flush=True)

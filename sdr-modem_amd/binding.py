@@ -417,6 +417,18 @@ class Batch:
         self.L.sdrm_batch_timing_read(self.h, which, C.byref(ms), C.byref(n))
         return ms.value, n.value
 
+    def timeline_begin(self):
+        """diagnostics: from the next call on (up to 64 calls) every stage records when its first workgroup started and its
+        last one ended (device clock, 100 MHz ticks)"""
+        self.L.sdrm_batch_timeline.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        self.L.sdrm_batch_timeline(self.h, 1, None, 0)
+
+    def timeline_read(self):
+        """rows [front start, front end, dc start, dc end, clock start, clock end] in ms, one per recorded call"""
+        tl = np.zeros(64 * 6, dtype=np.uint64)
+        rows = self.L.sdrm_batch_timeline(self.h, 0, tl.ctypes.data, 64)
+        return tl[:rows * 6].reshape(rows, 6).astype(np.float64) / 1e5
+
     def handoff_calls(self):
         """calls of this batch that ran with the in-call hand-off (stages of one call resident together)"""
         n = C.c_uint64()

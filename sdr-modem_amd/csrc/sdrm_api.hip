@@ -490,6 +490,7 @@ static int reset_all_streams(sdrm_batch_t *b) {
         b->slot_used[i] = false;
     }
     b->calls = 0;
+    b->hand_calls = 0;
     b->last_slot = -1;
     return 0;
 }
@@ -1530,16 +1531,18 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     // ---- in-call hand-off?  A call that meets an idle batch -- every blocking call, the first of a pipelined run -- cannot
     // hide its front-end and DC blocker behind an earlier call's clock stage: its three stages are made resident together
     // instead, each starting on the first finished pieces of the one in front (tile stamps / output counts, sdrm_launch.h).
-    // Waiting workgroups hold their CUs, so this is bounded: few workgroups (a batch that fills the chip is front-end bound
-    // anyway), a DC workgroup that leaves room for a front-end workgroup beside it, and the clock stage launched only when
-    // the DC stage's workgroups are resident -- then the front-end, which waits for nobody, always finds a CU, the DC
-    // stage waits only for the front-end and the clock stage only for the DC stage.
+    // Waiting workgroups hold their CUs, so this is bounded: at most 64 of them (a quarter of the chip; a batch that fills it is
+    // front-end bound anyway) when a DC workgroup leaves room for a front-end workgroup beside it, 16 when it does not; the
+    // clock stage is launched only when the DC stage's workgroups are resident, the front-end only when both are -- then the
+    // front-end, which waits for nobody, always finds a CU, the DC stage waits only for the front-end and the clock stage
+    // only for the DC stage.  Every wait in the kernels is bounded besides (a void call, loudly, never a hung device).
     bool hand = false;
     if (b->hand_allowed && b->n_gen == 0 && !b->clock_early && (b->serial || b->d_placed != nullptr) && max_tiles > 0) {
         const bool idle = b->last_slot < 0 || hipEventQuery(b->slot_done[b->last_slot]) == hipSuccess;
         const unsigned waiting = sdrm::clock_workgroups(d) + (d.any_dc ? sdrm::dc_workgroups(d) : 0u);
         const bool room = !d.any_dc || (size_t) d.dc_lds + sdrm::k1_lds_bytes(d.t1_max, d.t2_max) <= 160 * 1024;
-        hand = idle && waiting <= 64 && room && sdrm::clock_shape_hands_off(d);
+        // (a DC workgroup that fills its CU -- long boxcars -- leaves the front-end no room beside it: then only a handful may wait)
+        hand = idle && waiting <= (room ? 64u : 16u) && sdrm::clock_shape_hands_off(d);
         if (hand && b->serial) {
             // a plain handle keeps its stages on one stream (a server holds one per client); a call long enough for the overlap
             // to pay (SDRM_HAND_SERIAL_MIN_NZ) gets two side streams, created when the first such call comes

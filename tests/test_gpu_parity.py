@@ -1347,3 +1347,79 @@ def test_any_samples_per_symbol_on_the_device():
     got = g.process([binding.ABSENT, sigs[1][:8192]] + [binding.ABSENT] * (len(cfgs) - 2))
     assert np.array_equal(got[1], o.process(sigs[1][:8192])[0])
     g.close()
+
+
+# ---------------------------------------------------------------- stages of ONE call overlap (in-call hand-off, round 5)
+
+@pytest.mark.parametrize("handoff", ["1", "0"])
+def test_blocking_calls_with_the_stages_of_one_call_resident_together(handoff, monkeypatch):
+    """A blocking call meets an idle batch (the reference's caller waits for fsk_demod_process, src/dsp_worker.c:75): its
+    front-end, DC blocker and clock recovery are then resident TOGETHER, each starting on the first finished pieces of the one
+    in front (tile stamps / output counts in device memory, device-scope accesses) instead of on its end.  Same bits as
+    the oracle for everything that travels through that hand-over: channels with and without DC blocker (the clock stage then
+    reads the front-end's tiles directly), decimation (tiles shorter than a staging block), ragged, empty and absent inputs,
+    NaN / Inf / beyond-the-tame-amplitude samples LATE in a call (their flags reach the clock stage block by block, after it
+    has produced symbols: the NaN-aware form from there on, or the call run again from its start by sdrm_k3_rescue), and a
+    channel with fewer than one sample per symbol.  SDRM_HANDOFF=0: the same calls with the stages one after the other."""
+    monkeypatch.setenv("SDRM_HANDOFF", handoff)
+    maxlen = 40000
+    cfgs = [(48000, 9600, 5000, 1, 2000, True), (48000, 9600, 5000, 1, 2000, False), (48000, 4800, 5000, 2, 2000, True),
+            (240000, 19200, 5000, 5, 2000, True), (48000, 1200, 5000, 8, 2000, False), (192000, 40000, 5000, 1, 2000, True),
+            (48000, 9600, 3, 1, 2000, True), (48000, 9600, 3, 1, 2000, False), (48000, 9600, 5000, 7, 2000, True),
+            (48000, 9600, 5000, 1, 2000, True), (48000, 9600, 5000, 1, 2000, False), (240000, 9600, 5000, 1, 2000, True)]
+    full = [c + (maxlen,) for c in cfgs]
+    g = binding.Batch(full, keep_soft=True)
+    assert g.code == 0
+    oracles = [orc.Fsk(*c) for c in full]
+    sigs = [siggen.gmsk_channel(700 + i, 5 * maxlen, fs=c[0], baud=c[1]).copy() for i, c in enumerate(cfgs)]
+    rng = np.random.default_rng(5)
+    # channels 9 and 10: a NaN, an Inf and a burst of huge samples three quarters into the second and third calls
+    for i in (9, 10):
+        sigs[i][maxlen + 30000] = np.nan
+        sigs[i][2 * maxlen + 31000] = np.inf
+        sigs[i][3 * maxlen + 29000:3 * maxlen + 29040] *= np.float32(1e30)
+    # channels 6 and 7 (discriminator gain 2546): quiet until three quarters into each call, then full-scale noise
+    for i in (6, 7):
+        quiet = np.exp(2j * np.pi * 1e-6 * np.arange(5 * maxlen)).astype(np.complex64)
+        loud = (rng.normal(0, 0.7, 5 * maxlen) + 1j * rng.normal(0, 0.7, 5 * maxlen)).astype(np.complex64)
+        mask = (np.arange(5 * maxlen) % maxlen) > 30000
+        sigs[i] = np.where(mask, loud, quiet).astype(np.complex64)
+    pos = [0] * len(cfgs)
+    plans = [[maxlen] * len(cfgs), [maxlen] * len(cfgs), [maxlen] * len(cfgs), [maxlen] * len(cfgs),
+             [int(rng.choice([0, 1, 7, 100, 3839, 3840, 3841, 20000, maxlen])) for _ in cfgs]]
+    for call, lens in enumerate(plans):
+        parts = [s[p:p + n] for s, p, n in zip(sigs, pos, lens)]
+        if call == 4:
+            parts[2] = binding.ABSENT if hasattr(binding, "ABSENT") else parts[2]
+        g8 = g.process(parts)
+        for i, o in enumerate(oracles):
+            if call == 4 and i == 2 and hasattr(binding, "ABSENT"):
+                assert len(g8[i]) == 0
+                continue
+            pos[i] += lens[i]
+            o8, of = o.process(parts[i])
+            gf = g.last_soft(i)
+            assert len(o8) == len(g8[i]), (cfgs[i], call, len(o8), len(g8[i]))
+            same = (of.view(np.uint32) == gf.view(np.uint32)) | (np.isnan(of) & np.isnan(gf))
+            assert same.all() and np.array_equal(o8, g8[i]), (cfgs[i], call)
+    assert (g.handoff_calls() > 0) == (handoff == "1")
+    assert g.wild_calls() >= 8  # channels 6, 7 (every call), 8 (every call), 9 / 10 (the burst)
+    g.close()
+
+
+def test_a_plain_handle_takes_the_hand_off_for_long_calls_and_the_graph_replay_for_short_ones():
+    """fsk_demod_process on one handle: repeated short calls are a replayed graph of the three stages, calls long enough for the
+    overlap to pay run the in-call hand-off on the handle's stream plus two side streams -- every mix of the two, and ragged
+    lengths in between, must continue the same stream bit for bit"""
+    cfg = (48000, 9600, 5000, 1, 2000, True, 131072)
+    d = binding.FskDemod(*cfg)
+    o = orc.Fsk(*cfg)
+    sig = siggen.gmsk_channel(77, 600000)
+    pos = 0
+    for n in [4096, 4096, 4096, 131072, 131072, 4096, 4096, 50000, 50000, 50000, 7, 131072, 0, 4096, 4096, 100000]:
+        part = sig[pos:pos + n]
+        pos += n
+        want, _ = o.process(part)
+        got = d.process(part)
+        assert np.array_equal(got, want), (n, pos, len(got), len(want))
+    d.close()

@@ -1,8 +1,10 @@
-"""Copies the summaries of tools/gpu_profiles_r04.sh (gpurun_out/r04/) into profiles/ (tracked) under round-4 names and
-derives profiles/r04_k1_front_traffic.json and profiles/r04_pmc_summary.txt from the PMC passes."""
-import collections, csv, glob, json, os, shutil
+"""python tools/collect_profiles.py <round>: copies the summaries of tools/gpu_profiles.sh <round> (gpurun_out/<round>/) into
+profiles/ (tracked) under that round's names and derives profiles/<round>_k1_front_traffic.json, <round>_kernels.json (what
+bench.py's roofline.kernels quotes) and <round>_pmc_summary.txt from the PMC passes."""
+import collections, csv, glob, json, os, shutil, sys
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r04")
+SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -42,17 +44,17 @@ def durations(tag, name):
     return {k: sum(v[2:]) / max(len(v[2:]), 1) for k, v in d.items()}
 
 
-copy("bench.json", "r04_bench.json")
-copy("bench_under_rocprof.json", "r04_bench_under_rocprof.json")
-copy("bench_stats/*/*kernel_stats.csv", "r04_kernel_stats.csv")
-copy("sweep_1024_stats/*/*kernel_stats.csv", "r04_sweep1024_kernel_stats.csv")
-copy("sweep_4096_stats/*/*kernel_stats.csv", "r04_sweep4096_kernel_stats.csv")
-copy("config5_stats/*/*kernel_stats.csv", "r04_config5_kernel_stats.csv")
+copy("bench.json", RND + "_bench.json")
+copy("bench_under_rocprof.json", RND + "_bench_under_rocprof.json")
+copy("bench_stats/*/*kernel_stats.csv", RND + "_kernel_stats.csv")
+copy("sweep_1024_stats/*/*kernel_stats.csv", RND + "_sweep1024_kernel_stats.csv")
+copy("sweep_4096_stats/*/*kernel_stats.csv", RND + "_sweep4096_kernel_stats.csv")
+copy("config5_stats/*/*kernel_stats.csv", RND + "_config5_kernel_stats.csv")
 for tag in ("c256", "c4096"):
     for name in ("sq1", "sq2", "grbm", "fetch", "write"):
-        copy("pmc_%s_%s/*/*counter_collection.csv" % (tag, name), "r04_pmc_%s_%s.csv" % (tag, name))
+        copy("pmc_%s_%s/*/*counter_collection.csv" % (tag, name), RND + "_pmc_%s_%s.csv" % (tag, name))
 
-lines = ["Round-4 PMC summary (tools/gpu_profiles_r04.sh: tools/stage_times.py <channels>, stages serialised, 131072-sample calls;",
+lines = ["PMC summary of round " + RND + " (tools/gpu_profiles.sh: tools/stage_times.py <channels>, stages serialised, 131072-sample calls;",
          "means over the launches after the two warm-up calls; one rocprofv3 --pmc pass per counter group).",
          "clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; valu_issue = SQ_INSTS_VALU * 4 cycles / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8);",
          "HBM bytes: FETCH_SIZE (KiB) doubled (gfx950 tallies 128-byte reads as 64, MI355X_MICROARCH.md), WRITE_SIZE (KiB) as is.", ""]
@@ -75,22 +77,43 @@ for tag, ch in (("c256", 256), ("c4096", 4096)):
                          fe.get(k, {}).get("FETCH_SIZE", 0.0) * 2 * 1024 / 1e6, wr.get(k, {}).get("WRITE_SIZE", 0.0) * 1024 / 1e6))
     lines.append("")
     if ch == 256:
+        # per kernel, what bench.py's roofline.kernels quotes: time alone on the chip, algorithmic and counted HBM bytes, issue share
+        algo = {"k1_front": 256 * 131072 * (8 + 4), "k2_dc": 256 * 131072 * (4 + 4), "k3_clock": 256 * 131072 * 4 + 256 * 26215 * (4 + 1)}
+        kj = {"round": RND, "channels": 256, "chunk": 131072, "kernels": {},
+              "algorithmic_bytes": "front-end: 8 B of IQ read + 4 B of LPF2 output written per sample; DC blocker: 4 B read + 4 B "
+                                   "written; clock stage: 4 B read per sample + 4 B (float) + 1 B (int8) written per symbol",
+              "method": "tools/gpu_profiles.sh: rocprofv3 --kernel-trace --pmc <group>, one pass per group, over tools/stage_times.py 256 "
+                        "(stages one after the other); FETCH_SIZE doubled for gfx950, WRITE_SIZE as is (KiB)"}
+        for k in sorted(sq1):
+            stem = "k1_front" if k.startswith("k1_front") else "k2_dc" if k.startswith("k2_dc") and "generic" not in k else \
+                   "k3_clock" if k.startswith("k3_clock") and "generic" not in k else None
+            if stem is None or not dur.get(k):
+                continue
+            gui = grbm.get(k, {}).get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            kj["kernels"][stem] = {"avg_ms_alone": round(dur[k] / 1e6, 4), "algorithmic_bytes": algo[stem],
+                                   "counter_bytes": int(fe.get(k, {}).get("FETCH_SIZE", 0.0) * 2 * 1024 + wr.get(k, {}).get("WRITE_SIZE", 0.0) * 1024),
+                                   "valu_issue": round(sq1[k].get("SQ_INSTS_VALU", 0.0) * 4 / 1024 / gui, 4) if gui else None,
+                                   "shader_clock_ghz": round(gui / dur[k], 3)}
+        total_algo = 256 * 131072 * 8 + 256 * 26215
+        total_counted = sum(v["counter_bytes"] for v in kj["kernels"].values())
+        kj["whole_step_traffic_ratio"] = round(total_counted / total_algo, 2) if total_counted else None
+        json.dump(kj, open(os.path.join(DST, RND + "_kernels.json"), "w"), indent=1)
+        print("wrote kernels.json", kj["whole_step_traffic_ratio"])
         k = [x for x in fe if x.startswith("k1_front")][0]
         rd, wrb = fe[k]["FETCH_SIZE"] * 2 * 1024, wr[k]["WRITE_SIZE"] * 1024
         gui = grbm[k]["GRBM_GUI_ACTIVE"] / 8.0
-        tj = {"kernel": "k1_front", "round": "r04", "channels": 256, "chunk": 131072,
+        tj = {"kernel": "k1_front", "round": RND, "channels": 256, "chunk": 131072,
               "fetch_size_kib_raw": round(fe[k]["FETCH_SIZE"], 1), "write_size_kib_raw": round(wr[k]["WRITE_SIZE"], 1),
               "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wrb), "hbm_bytes_per_launch": int(rd + wrb),
               "algorithmic_read_bytes": 256 * 131072 * 8, "algorithmic_write_bytes": 256 * 131072 * 4,
               "sq_insts_valu": int(sq1[k]["SQ_INSTS_VALU"]), "duration_ms_alone": round(dur[k] / 1e6, 4),
               "shader_clock_ghz": round(gui / dur[k], 3), "valu_issue_busy": round(sq1[k]["SQ_INSTS_VALU"] * 4 / 1024 / gui, 4),
-              "source": ["profiles/r04_pmc_c256_fetch.csv", "profiles/r04_pmc_c256_write.csv", "profiles/r04_pmc_c256_sq1.csv",
-                         "profiles/r04_pmc_c256_grbm.csv"],
-              "method": "tools/gpu_profiles_r04.sh + tools/collect_profiles_r04.py: rocprofv3 --kernel-trace --pmc <group> in separate "
+              "source": ["profiles/%s_pmc_c256_%s.csv" % (RND, g) for g in ("fetch", "write", "sq1", "grbm")],
+              "method": "tools/gpu_profiles.sh + tools/collect_profiles.py: rocprofv3 --kernel-trace --pmc <group> in separate "
                         "passes over tools/stage_times.py 256, mean over the launches after two warm-up calls; FETCH_SIZE / WRITE_SIZE are "
                         "KiB, FETCH_SIZE doubled for gfx950 (MI355X_MICROARCH.md, HBM section); shader clock = GRBM_GUI_ACTIVE / 8 XCDs / "
                         "kernel duration; valu_issue_busy = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / those cycles"}
-        json.dump(tj, open(os.path.join(DST, "r04_k1_front_traffic.json"), "w"), indent=1)
-        print("wrote r04_k1_front_traffic.json", tj["hbm_bytes_per_launch"], tj["shader_clock_ghz"], tj["valu_issue_busy"])
-open(os.path.join(DST, "r04_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+        json.dump(tj, open(os.path.join(DST, RND + "_k1_front_traffic.json"), "w"), indent=1)
+        print("wrote k1_front_traffic.json", tj["hbm_bytes_per_launch"], tj["shader_clock_ghz"], tj["valu_issue_busy"])
+open(os.path.join(DST, RND + "_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -1,11 +1,13 @@
 #!/bin/bash
-# Round-4 evidence for profiles/: rocprofv3 kernel stats of the bench command, PMC passes (separate: SQ, FETCH_SIZE,
+# usage (on the gpurun box): tools/gpu_profiles.sh <round, e.g. r05>
+# A round's evidence for profiles/: rocprofv3 kernel stats of the bench command, PMC passes (separate: SQ, FETCH_SIZE,
 # WRITE_SIZE) over tools/stage_times.py at 256 and 4096 channels, kernel stats of the 1024 / 4096 sweep points and of the
-# mixed-rate Doppler workload.  Everything lands under gpurun_out/r04/; summaries are then copied into profiles/ by hand.
+# mixed-rate Doppler workload.  Everything lands under gpurun_out/<round>/; tools/collect_profiles.py <round> (run at home) copies the summaries into profiles/.
 set +e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:?run this on the gpurun box (GRAFT_REPO_ROOT is the snapshot root)}
-OUT=$R/gpurun_out/r04
+RND=${1:-r05}
+OUT=$R/gpurun_out/$RND
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 # the profiled passes run the schedule's starting point (no calibration launches among the averaged kernels); the plain bench at the
