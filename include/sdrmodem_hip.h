@@ -401,6 +401,8 @@ typedef struct {
      * frequency on the device, phase carried across buffers, in front of the demodulator.  Not together with
      * doppler_shift (the reference then runs two oscillators in series; -ENOTSUP here). */
     int64_t rx_offset_hz;
+    /* optional: called with doppler_user when the worker is destroyed (a factory's state, integration/doppler_factory_ref.c) */
+    void (*doppler_release)(void *doppler_user);
 } sdrm_worker_config;
 
 typedef struct dsp_worker_t dsp_worker;

@@ -48,9 +48,15 @@ void sdrm_ref_attach_node(sdrm_node *node) {
  * integrator supplies a factory that turns the request into "shift in Hz for second k of the pass". */
 static int (*g_doppler_factory)(const struct RxRequest *req, const struct server_config *config, sdrm_doppler_shift_fn *fn,
                                 void **user) = NULL;
+static void (*g_doppler_release)(void *user) = NULL;
 void sdrm_ref_set_doppler_factory(int (*factory)(const struct RxRequest *, const struct server_config *, sdrm_doppler_shift_fn *,
                                                  void **)) {
     g_doppler_factory = factory;
+}
+/* ... and what frees the state such a factory hands out, when the worker is destroyed (may stay NULL).  The shipped pair:
+ * integration/doppler_factory_ref.c -- sdrm_ref_doppler_factory / sdrm_ref_doppler_close, on the reference's own src/sgpsdp */
+void sdrm_ref_set_doppler_release(void (*release)(void *user)) {
+    g_doppler_release = release;
 }
 
 int dsp_worker_create(uint32_t id, int client_socket, struct server_config *server_config, struct RxRequest *req,
@@ -88,6 +94,7 @@ int dsp_worker_create(uint32_t id, int client_socket, struct server_config *serv
             fprintf(stderr, "<3>[%d] unable to create doppler correction block\n", (int) id);
             return code;
         }
+        c.doppler_release = g_doppler_release;
     }
     if (g_batcher != NULL) {
         c.batcher = g_batcher;

@@ -47,7 +47,7 @@ class WorkerConfig(C.Structure):
                 ("buffer_size", C.c_uint32), ("queue_size", C.c_uint16), ("rx_file_source", C.c_bool),
                 ("base_path", C.c_char_p), ("doppler_shift", C.c_void_p), ("doppler_user", C.c_void_p),
                 ("batcher", C.c_void_p), ("batcher_channel", C.c_size_t),
-                ("node", C.c_void_p), ("source_id", C.c_uint64), ("rx_offset_hz", C.c_int64)]
+                ("node", C.c_void_p), ("source_id", C.c_uint64), ("rx_offset_hz", C.c_int64), ("doppler_release", C.c_void_p)]
 
 
 # every symbol include/sdrmodem_hip.h declares

@@ -32,6 +32,9 @@ struct dsp_worker_t {
     sdrm_node *node;       /* the node that placed this client on `batcher` (borrowed), NULL otherwise */
     sdrm_node_slot slot;   /* ... and the slot to give back */
     int64_t rx_offset_hz;  /* the file source's frequency offset, what the built-in shift callback returns */
+    void (*doppler_release)(void *);  /* frees the caller's shift callback state when the worker goes */
+    void *doppler_user;
+    bool dump_failed;      /* batcher path: the IQ dump could not be written, the client has been ended */
     queue *inbox;
     pthread_t thread;
     bool thread_started;
@@ -49,8 +52,16 @@ void dsp_worker_put(sdrm_cf32 *output, size_t output_len, dsp_worker *worker) {
     if (worker->batcher != NULL) {
         /* the IQ goes straight into the batcher's pinned arena; the dump the reference writes from its DSP thread
          * (src/dsp_worker.c:59-64) is written here, by the source thread, because no other thread sees the samples */
+        if (worker->dump_failed) {
+            return;
+        }
         if (worker->iq_dump != NULL && fwrite(output, sizeof(sdrm_cf32), output_len, worker->iq_dump) < output_len) {
+            /* the reference's DSP thread stops at this point (src/dsp_worker.c:56-64: message, break): the client is ended --
+             * the buffer that could not be dumped is not demodulated, what was put before it is still delivered */
             fprintf(stderr, "<3>[%d] unable to write sdr data\n", worker->id);
+            worker->dump_failed = true;
+            sdrm_batcher_interrupt(worker->batcher, worker->channel);
+            return;
         }
         sdrm_batcher_put(worker->batcher, worker->channel, output, output_len);
         return;
@@ -202,6 +213,14 @@ static double constant_offset(void *user, uint64_t second) {
     return (double) *(const int64_t *) user;
 }
 
+/* a worker that never started: what dsp_worker_destroy would free of it */
+static void discard(dsp_worker *w) {
+    if (w->doppler_release != NULL) {
+        w->doppler_release(w->doppler_user);
+    }
+    free(w);
+}
+
 int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *cfg, dsp_worker **result) {
     dsp_worker *w = calloc(1, sizeof(*w));
     if (w == NULL) {
@@ -210,6 +229,8 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
     w->id = id;
     w->client_socket = client_socket;
     w->rx_offset_hz = cfg->rx_offset_hz;
+    w->doppler_release = cfg->doppler_release;
+    w->doppler_user = cfg->doppler_user;
     int code = 0;
     sdrm_doppler_shift_fn shift_fn = cfg->doppler_shift;
     void *shift_user = cfg->doppler_user;
@@ -217,7 +238,7 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
         if (cfg->doppler_shift != NULL) {
             /* the reference runs the file source's oscillator and the Doppler one in series (two roundings per sample) */
             fprintf(stderr, "<3>[%d] rx offset and doppler correction together are not supported\n", w->id);
-            free(w);
+            discard(w);
             return -ENOTSUP;
         }
         shift_fn = constant_offset;
@@ -230,7 +251,7 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
         if (cfg->batcher != NULL) {
             if (cfg->batcher_channel >= sdrm_batcher_channels(cfg->batcher)) {
                 fprintf(stderr, "<3>[%d] batcher has no channel %zu\n", w->id, cfg->batcher_channel);
-                free(w);
+                discard(w);
                 return -1;
             }
             w->batcher = cfg->batcher;
@@ -263,7 +284,7 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
         }
         if (code != 0) {
             fprintf(stderr, "<3>[%d] unable to create demodulator\n", w->id);
-            free(w);
+            discard(w);
             return code;
         }
         if (shift_fn != NULL) {
@@ -365,6 +386,9 @@ void dsp_worker_destroy(void *data) {
     }
     if (w->node != NULL) {
         sdrm_node_detach(w->node, &w->slot); /* the slot serves the node's next client, on whichever device that is */
+    }
+    if (w->doppler_release != NULL) {
+        w->doppler_release(w->doppler_user);
     }
     free(w);
 }

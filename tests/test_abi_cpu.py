@@ -441,3 +441,108 @@ def test_public_header_is_plain_c99_and_cxx11(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
     includes = [ln for ln in open(hdr) if ln.lstrip().startswith("#include")]
     assert all(any(std in ln for std in ("<stdbool.h>", "<stddef.h>", "<stdint.h>", "<complex.h>")) for ln in includes), includes
+
+
+# ---------------------------------------------------------------- the shipped Doppler factory (build container: reference tree present)
+
+FACTORY_SO = os.path.join(ROOT, "oracle", "_ref", "libsdrm_doppler_factory.so")
+LUCKY7_TLE = [b"LUCKY-7", b"1 44406U 19038W   20069.88080907  .00000505  00000-0  32890-4 0  9992",
+              b"2 44406  97.5270  32.5584 0026284 107.4758 252.9348 15.12089395 37524"]
+
+
+class _DopplerSettings(C.Structure):
+    _fields_ = [("base", _PbBase), ("n_tle", C.c_size_t), ("tle", C.POINTER(C.c_char_p)), ("latitude", C.c_uint32),
+                ("longitude", C.c_uint32), ("altitude", C.c_uint32)]
+
+
+class _FileSettings(C.Structure):
+    _fields_ = [("base", _PbBase), ("filename", C.c_char_p), ("start_time_seconds", C.c_uint64)]
+
+
+@pytest.mark.skipif(not os.path.exists(FACTORY_SO), reason="oracle/_ref is built where the reference tree is (make -C oracle)")
+def test_shipped_doppler_factory_returns_the_references_shifts():
+    """integration/doppler_factory_ref.c: the factory the reference-signature adapter wants (sdrm_ref_set_doppler_factory), on
+    the reference's own vendored SGP4 (src/sgpsdp, compiled where it lies into oracle/_ref).  With doppler_create's arguments
+    of the reference's Doppler test (test/test_doppler.c:14,38: LUCKY-7, 53.72F N 47.57F E, 437.525 MHz, 1583840449) the
+    per-second shifts are the fixture's doubles, bit for bit -- the fixture comes from oracle/ref_doppler_shifts.c, a second
+    statement of src/dsp/doppler.c:31-42,151-172 --; asked out of order they are the same; and through the request
+    (RxRequest.doppler as src/dsp_worker.c:120-136 reads it: degrees x 10E6 in uint32 fields) they are the shifts of that
+    station."""
+    import json
+    import struct
+    F = C.CDLL(FACTORY_SO)
+    SHIFT = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_uint64)
+    F.sdrm_ref_doppler_open.argtypes = [C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64,
+                                        C.c_char * 80 * 3, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    F.sdrm_ref_doppler_close.argtypes = [C.c_void_p]
+    F.sdrm_ref_doppler_factory.argtypes = [C.POINTER(_RxRequest), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "doppler_shifts_lucky7.json")))["shifts_hz"]
+    tle = (C.c_char * 80 * 3)()
+    for i, line in enumerate(LUCKY7_TLE):
+        tle[i].value = line
+    f32 = lambda v: struct.unpack("<f", struct.pack("<f", v))[0]  # noqa: E731  (the test passes float literals)
+    fn, user = C.c_void_p(), C.c_void_p()
+    assert F.sdrm_ref_doppler_open(f32(53.72), f32(47.57), 0.0, 48000, 437525000, 0, 1583840449, tle, C.byref(fn), C.byref(user)) == 0
+    shift = SHIFT(fn.value)
+    got = [shift(user, k) for k in range(len(want))]
+    assert got == want
+    assert shift(user, 5) == want[5] and shift(user, 2) == want[2] and shift(user, 3) == want[3]  # any order: the same sums
+    F.sdrm_ref_doppler_close(user)
+    bad = (C.c_char * 80 * 3)()
+    assert F.sdrm_ref_doppler_open(53.72, 47.57, 0.0, 48000, 437525000, 0, 1583840449, bad, C.byref(fn), C.byref(user)) == -1
+    # through the request
+    lines = (C.c_char_p * 3)(*LUCKY7_TLE)
+    ds = _DopplerSettings(n_tle=3, tle=lines, latitude=537200000, longitude=475700000, altitude=0)
+    fs_ = _FileSettings(filename=b"x.cf32", start_time_seconds=1583840449)
+    req = _request(48000, 4800, 5000, 2, 2000, True, False, 0)
+    req.doppler = C.cast(C.pointer(ds), C.c_void_p)
+    req.file_settings = C.cast(C.pointer(fs_), C.c_void_p)
+    assert F.sdrm_ref_doppler_factory(C.byref(req), None, C.byref(fn), C.byref(user)) == 0
+    via_request = [SHIFT(fn.value)(user, k) for k in range(len(want))]
+    F.sdrm_ref_doppler_close(user)
+    assert F.sdrm_ref_doppler_open(537200000 / 10E6, 475700000 / 10E6, 0 / 10E3, 48000, 437525000, 0, 1583840449, tle, C.byref(fn),
+                                   C.byref(user)) == 0
+    assert via_request == [SHIFT(fn.value)(user, k) for k in range(len(want))]
+    F.sdrm_ref_doppler_close(user)
+    assert max(abs(a - b) for a, b in zip(via_request, want)) < 0.01  # 53.72F is not 53.72: the same pass to a hundredth of a hertz
+    req.doppler = None
+    assert F.sdrm_ref_doppler_factory(C.byref(req), None, C.byref(fn), C.byref(user)) == -1
+
+
+def test_a_batcher_client_whose_iq_dump_cannot_be_written_is_ended(tmp_path, capfd):
+    """rx_dump_file with a full disk: the reference's DSP thread prints "<3>[id] unable to write sdr data" and leaves its loop
+    (src/dsp_worker.c:56-64) -- the client gets no more soft bits.  On a shared batcher the dump is written by the source thread
+    in dsp_worker_put; until round 5 that path printed and carried on.  Now: message, the client's channel closed, later
+    buffers dropped, its neighbour on the same batcher untouched."""
+    import emu_api
+    import orc
+    from sdr_modem_amd import siggen
+    L = binding.load()
+    cfg = (48000, 4800, 5000, 2, 2000, True, 4096)
+    bt = emu_api.emu_batcher([cfg] * 2, slots=4, max_wait_us=20000, blocking=True)
+    os.symlink("/dev/full", os.path.join(str(tmp_path), "rx.sdr2demod.71.cf32"))
+    L.dsp_worker_put.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.dsp_worker_destroy.argtypes = [C.c_void_p]
+    L.sdrm_dsp_worker_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(binding.WorkerConfig), C.POINTER(C.c_void_p)]
+    ws = []
+    for i in range(2):
+        wc = binding.WorkerConfig(rx_sampling_freq=48000, demod_baud_rate=4800, demod_fsk_deviation=5000, demod_decimation=2,
+                                  demod_fsk_transition_width=2000, demod_fsk_use_dc_block=True, rx_dump_file=(i == 1), demod_destination=0,
+                                  buffer_size=4096, queue_size=4, rx_file_source=True, base_path=str(tmp_path).encode(),
+                                  batcher=bt.h, batcher_channel=i)
+        w = C.c_void_p()
+        assert L.sdrm_dsp_worker_create(70 + i, -1, C.byref(wc), C.byref(w)) == 0
+        ws.append(w)
+    sigs = [siggen.gmsk_channel(95 + i, 3 * 4096, fs=48000, baud=4800) for i in range(2)]
+    for off in range(0, 3 * 4096, 4096):
+        for i in (1, 0):
+            part = np.ascontiguousarray(sigs[i][off:off + 4096]).view(np.float32)
+            L.dsp_worker_put(part.ctypes.data, len(part) // 2, ws[i])
+    for w in ws:
+        L.dsp_worker_destroy(w)
+    err = capfd.readouterr().err
+    assert err.count("<3>[71] unable to write sdr data") == 1
+    got0 = np.fromfile(os.path.join(str(tmp_path), "rx.demod2client.70.s8"), dtype=np.int8)
+    assert np.array_equal(got0, orc.demod_stream(cfg[:6], sigs[0], 4096)[0])
+    assert os.path.getsize(os.path.join(str(tmp_path), "rx.demod2client.71.s8")) == 0  # ended before its first buffer was demodulated
+    bt.close()

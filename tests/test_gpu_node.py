@@ -142,3 +142,98 @@ def test_file_source_frequency_offset_on_the_device(layout):
         # and the recording is demodulated: same symbols as the un-moved file up to the oscillator's rounding (hard bits)
         plain, _ = orc.demod_stream((48000, 4800, 5000, 2, 2000, True), iq, 4096)
         assert len(plain) == len(want) and np.mean((plain >= 0) == (want >= 0)) > 0.995
+
+
+def test_reference_signature_adapter_on_the_device(tmp_path):
+    """integration/dsp_worker_ref.c -- dsp_worker_create with the REFERENCE'S parameter list (src/dsp_worker.h:22: id, socket,
+    struct server_config *, struct RxRequest *, &worker) -- built here and driven on the device (until round 5 only over the
+    kernel emulation): (1) workers that own a private demodulator, as the reference lays them out, one of them dumping its IQ;
+    (2) workers placed by a node of two batchers on this device; (3) a worker with RxRequest.doppler set, the predictor built
+    by the shipped factory (integration/doppler_factory_ref.c on the reference's own src/sgpsdp, prebuilt into oracle/_ref)
+    from the TLE and the station of the reference's Doppler test.  The files the reference's worker writes
+    (rx.demod2client.<id>.s8, rx.sdr2demod.<id>.cf32; src/dsp_worker.c:154,165) hold the oracle's bytes."""
+    import test_abi_cpu as T
+    A = T._ref_adapter(tmp_path)
+    A.dsp_worker_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(T._ServerConfig), C.POINTER(T._RxRequest), C.POINTER(C.c_void_p)]
+    A.sdrm_ref_attach_node.argtypes = [C.c_void_p]
+    L = binding.load()
+    L.dsp_worker_put.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.dsp_worker_destroy.argtypes = [C.c_void_p]
+    cfg = (48000, 4800, 5000, 2, 2000, True, 4096)
+    sc = T._ServerConfig(buffer_size=4096, queue_size=4, rx_sdr_type=2, base_path=str(tmp_path).encode())
+
+    def run(ids, make_request, sigs):
+        ws = []
+        for k, i in enumerate(ids):
+            req = make_request(k)
+            w = C.c_void_p()
+            assert A.dsp_worker_create(i, -1, C.byref(sc), C.byref(req), C.byref(w)) == 0, i
+            ws.append(w)
+
+        def feed(k):
+            for off in range(0, len(sigs[k]), 4096):
+                part = np.ascontiguousarray(sigs[k][off:off + 4096]).view(np.float32)
+                L.dsp_worker_put(part.ctypes.data, len(part) // 2, ws[k])
+        th = [threading.Thread(target=feed, args=(k,)) for k in range(len(ids))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(120)
+            assert not t.is_alive()
+        for w in ws:
+            L.dsp_worker_destroy(w)
+        return [np.fromfile(os.path.join(str(tmp_path), "rx.demod2client.%d.s8" % i), dtype=np.int8) for i in ids]
+
+    # (1) private demodulators
+    sigs = [siggen.gmsk_channel(600 + k, 5 * 4096 + 77, fs=48000, baud=4800) for k in range(3)]
+    got = run([801, 802, 803], lambda k: T._request(48000, 4800, 5000, 2, 2000, True, k == 1, 0), sigs)
+    for k in range(3):
+        assert np.array_equal(got[k], orc.demod_stream(cfg[:6], sigs[k], 4096)[0]), k
+    assert np.array_equal(np.fromfile(os.path.join(str(tmp_path), "rx.sdr2demod.802.cf32"), dtype=np.complex64), sigs[1])
+    # (2) placed by a node
+    node = binding.Node(cfg, 4, n_batchers=2, devices=[0, 0], batcher=(4, 50000, True))
+    assert node.code == 0
+    A.sdrm_ref_attach_node(node.h)
+
+    def node_request(k):
+        req = T._request(48000, 4800, 5000, 2, 2000, True, False, 0)
+        req.rx_center_freq = 437525000 if k % 2 == 0 else 145800000
+        return req
+    sigs = [siggen.gmsk_channel(610 + k, 3 * 4096 + 5, fs=48000, baud=4800) for k in range(4)]
+    got = run([811, 812, 813, 814], node_request, sigs)
+    for k in range(4):
+        assert np.array_equal(got[k], orc.demod_stream(cfg[:6], sigs[k], 4096)[0]), k
+    assert [node.stat(d).clients for d in range(2)] == [0, 0]
+    A.sdrm_ref_attach_node(None)
+    node.close()
+    # (3) Doppler from the request, through the shipped factory
+    if not os.path.exists(T.FACTORY_SO):
+        pytest.skip("oracle/_ref/libsdrm_doppler_factory.so is built where the reference tree is")
+    F = C.CDLL(T.FACTORY_SO)
+    A.sdrm_ref_set_doppler_factory.argtypes = [C.c_void_p]
+    A.sdrm_ref_set_doppler_release.argtypes = [C.c_void_p]
+    A.sdrm_ref_set_doppler_factory(C.cast(F.sdrm_ref_doppler_factory, C.c_void_p))
+    A.sdrm_ref_set_doppler_release(C.cast(F.sdrm_ref_doppler_close, C.c_void_p))
+    lines = (C.c_char_p * 3)(*T.LUCKY7_TLE)
+    ds = T._DopplerSettings(n_tle=3, tle=lines, latitude=537200000, longitude=475700000, altitude=0)
+    fs_ = T._FileSettings(filename=b"x.cf32", start_time_seconds=1583840449)
+
+    def doppler_request(k):
+        req = T._request(48000, 4800, 5000, 2, 2000, True, False, 0)
+        req.doppler = C.cast(C.pointer(ds), C.c_void_p)
+        req.file_settings = C.cast(C.pointer(fs_), C.c_void_p)
+        return req
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.complex64)
+    got = run([821], doppler_request, [iq])
+    # the oracle's Doppler block with the same station's shifts (the factory evaluated directly), then its demodulator
+    fn, user = C.c_void_p(), C.c_void_p()
+    F.sdrm_ref_doppler_factory.argtypes = [C.POINTER(T._RxRequest), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    req = doppler_request(0)
+    assert F.sdrm_ref_doppler_factory(C.byref(req), None, C.byref(fn), C.byref(user)) == 0
+    SHIFT = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_uint64)
+    shifts = [SHIFT(fn.value)(user, k) for k in range(len(iq) // 48000 + 3)]
+    o = orc.Fsk(*cfg)
+    d = orc.Doppler(48000, shifts, 4096)
+    want = np.concatenate([o.process(d.process(iq[off:off + 4096].view(np.float32)))[0] for off in range(0, len(iq), 4096)])
+    assert np.array_equal(got[0], want)
+    A.sdrm_ref_set_doppler_factory(None)
