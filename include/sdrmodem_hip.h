@@ -156,6 +156,12 @@ int sdrm_batch_process_device_nco(sdrm_batch *batch, const void *d_input, size_t
  * channels keep their streams); only the buffer length is fixed for the batch's life: max_input_buffer_length must not
  * exceed the largest the batch was created with (-ENOTSUP).  Waits for all enqueued calls first. */
 int sdrm_batch_reset_channel(sdrm_batch *batch, size_t channel, const sdrm_fsk_config *config);
+/* From the next call on the channel's input is mixed with ONE oscillator at the integer frequency freq_hz (fp32 phase carried
+ * across calls, started at 0 now) in front of everything else: what the reference's file source does with RxRequest.rx_offset
+ * (src/sdr/file_source.c:120-128) before the samples reach dsp_worker_put.  NCO batches of the same call (the Doppler
+ * correction) run BEHIND it -- two oscillators in series, every sample rounded to fp32 in between.  0 switches it off;
+ * sdrm_batch_reset_channel switches it off for the channel's next client.  Waits for enqueued calls. */
+int sdrm_batch_set_pre_offset(sdrm_batch *batch, size_t channel, int64_t freq_hz);
 
 /* Pipelined host-buffer path.  The reference's boundary hands over HOST buffers (src/dsp/fsk_demod.h:13, filled by
  * queue_put's memcpy, src/queue.c:99-154), so at batch scale the host link decides the rate.  sdrm_batch_arena pins
@@ -288,6 +294,9 @@ void sdrm_batcher_abandon(sdrm_batcher *batcher, size_t channel);
  * consumed, lets the rounds in flight finish, then resets the channel as sdrm_batch_reset_channel does (config NULL =
  * same configuration) and reopens it if it had been interrupted.  Other channels keep their streams. */
 int sdrm_batcher_reset_channel(sdrm_batcher *batcher, size_t channel, const sdrm_fsk_config *config);
+/* the same, and the new client's input passes the constant-frequency oscillator of sdrm_batch_set_pre_offset first (the file
+ * source's RxRequest.rx_offset; 0 = none) */
+int sdrm_batcher_reset_channel_offset(sdrm_batcher *batcher, size_t channel, const sdrm_fsk_config *config, int64_t rx_offset_hz);
 /* Doppler pre-correction for one channel: `planner` (borrowed, see sdrm_doppler_create) is asked for the segments of
  * every buffer of that channel when its round is launched; NULL switches it off */
 int sdrm_batcher_set_doppler(sdrm_batcher *batcher, size_t channel, sdrm_doppler *planner);
@@ -366,6 +375,7 @@ void complete_buffer_processing(queue *queue);
 void interrupt_waiting_the_data(queue *queue);
 void destroy_queue(queue *queue);
 
+typedef void (*sdrm_release_fn)(void *user);
 typedef struct {
     /* from RxRequest (src/api.pb-c.h:104-121, read at src/dsp_worker.c:120-163) */
     uint64_t rx_sampling_freq;
@@ -398,11 +408,12 @@ typedef struct {
     uint64_t source_id;
     /* optional: the file source's frequency offset (RxRequest.rx_offset applied by src/sdr/file_source.c:120-128 with a
      * sig_source of its own, upstream of dsp_worker_put): every buffer is mixed with ONE oscillator at this integer
-     * frequency on the device, phase carried across buffers, in front of the demodulator.  Not together with
-     * doppler_shift (the reference then runs two oscillators in series; -ENOTSUP here). */
+     * frequency on the device, phase carried across buffers, in front of everything else (sdrm_batch_set_pre_offset).
+     * Together with doppler_shift the two oscillators run in series with separate phases, every sample rounded to fp32 in
+     * between, as in the reference (file_source.c:122, then src/dsp_worker.c:65-71). */
     int64_t rx_offset_hz;
     /* optional: called with doppler_user when the worker is destroyed (a factory's state, integration/doppler_factory_ref.c) */
-    void (*doppler_release)(void *doppler_user);
+    sdrm_release_fn doppler_release;
 } sdrm_worker_config;
 
 typedef struct dsp_worker_t dsp_worker;

@@ -60,7 +60,7 @@ EXPORTS = [
     "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect", "sdrm_batch_reset_channel",
     "sdrm_dsp_worker_create", "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt", "sdrm_batcher_abandon", "sdrm_fsk_demod_error", "sdrm_last_error", "sdrm_batch_wait_input", "sdrm_wire_write_response",
     "sdrm_wire_read_header", "sdrm_wire_decode_rx_request",
-    "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_error", "sdrm_batcher_destroy",
+    "sdrm_batcher_set_doppler", "sdrm_batcher_reset_channel", "sdrm_batcher_reset_channel_offset", "sdrm_batch_set_pre_offset", "sdrm_batcher_channels", "sdrm_batcher_rounds", "sdrm_batcher_error", "sdrm_batcher_destroy",
     "sdrm_node_create", "sdrm_node_attach", "sdrm_node_detach", "sdrm_node_batchers", "sdrm_node_stat_read",
     "sdrm_node_destroy", "sdrm_channel_cost",
     "sdrm_doppler_create", "sdrm_doppler_plan", "sdrm_doppler_destroy",

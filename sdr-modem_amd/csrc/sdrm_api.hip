@@ -70,6 +70,13 @@ struct sdrm_batch_t {
     int n_gen = 0;
     // NCO pre-mix (allocated on first use)
     sdrm_nco_seg *d_nco_segs = nullptr, *h_nco_segs = nullptr;  // [SLOTS][nco_seg_cap]
+    // constant-frequency oscillator in front of everything else, per channel (sdrm_batch_set_pre_offset: the file source's rx_offset)
+    std::vector<int64_t> pre_offset;   // [C] Hz, 0 = none
+    bool any_pre = false;
+    float *d_pre_state = nullptr;      // [C] its fp32 phase, carried across calls
+    float *d_pre_phase = nullptr;      // [C][phase stride] phase of every sample of the call
+    sdrm_nco_seg *d_pre_segs = nullptr, *h_pre_segs = nullptr;    // [SLOTS][C] one batch per channel and call
+    sdrm_chunk_ctl *d_ctl_pre = nullptr, *h_ctl_pre = nullptr;    // [SLOTS][C] the control block as that pass sees it
     size_t nco_seg_cap = 0;
     float *d_nco_state = nullptr, *d_nco_phase = nullptr, *d_nco_phase2 = nullptr;  // phases: one buffer per call parity
     hipStream_t s_nco = nullptr;                 // phase accumulator of the next call runs beside this call's stages
@@ -342,6 +349,16 @@ static void batch_free(sdrm_batch_t *b) {
     }
     if (b->h_out8) {
         (void) hipHostFree(b->h_out8);
+    }
+    (void) hipFree(b->d_pre_state);
+    (void) hipFree(b->d_pre_phase);
+    (void) hipFree(b->d_pre_segs);
+    (void) hipFree(b->d_ctl_pre);
+    if (b->h_pre_segs) {
+        (void) hipHostFree(b->h_pre_segs);
+    }
+    if (b->h_ctl_pre) {
+        (void) hipHostFree(b->h_ctl_pre);
     }
     if (b->h_nco_segs) {
         (void) hipHostFree(b->h_nco_segs);
@@ -1066,6 +1083,16 @@ extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_
     for (int s = 0; s < SDRM_CTL_SLOTS; s++) {
         HIP_TRY(hipMemset(b->d_flags + (size_t) s * pl.design.size() + c, 0, sizeof(uint32_t)));
     }
+    if (b->d_pre_state != nullptr) {  // the new stream has no oscillator in front until it asks for one
+        HIP_TRY(hipMemset(b->d_pre_state + c, 0, sizeof(float)));
+    }
+    if (c < b->pre_offset.size() && b->pre_offset[c] != 0) {
+        b->pre_offset[c] = 0;
+        b->any_pre = false;
+        for (int64_t f : b->pre_offset) {
+            b->any_pre = b->any_pre || f != 0;
+        }
+    }
     if (b->d_nco_state != nullptr) {
         HIP_TRY(hipMemset(b->d_nco_state + c, 0, sizeof(float)));
     }
@@ -1209,6 +1236,61 @@ static int ensure_nco(sdrm_batch_t *b) {
         code = -ENOMEM;
     }
     return code;
+}
+
+// buffers of the constant-frequency oscillator in front of the path (allocated when the first channel asks for one)
+static int ensure_pre(sdrm_batch_t *b) {
+    int code = ensure_nco(b);
+    if (code != 0 || b->d_pre_state != nullptr) {
+        return code;
+    }
+    const size_t C = b->plan.design.size();
+    code = code ? code : dev_alloc_zero(&b->d_pre_state, C);
+    code = code ? code : dev_alloc_zero(&b->d_pre_phase, C * (size_t) SDRM_PHASE_STRIDE(b->in_stride));
+    code = code ? code : dev_alloc_zero(&b->d_pre_segs, C * SDRM_CTL_SLOTS);
+    code = code ? code : dev_alloc_zero(&b->d_ctl_pre, C * SDRM_CTL_SLOTS);
+    if (code == 0 && (hipHostMalloc((void **) &b->h_pre_segs, sizeof(sdrm_nco_seg) * C * SDRM_CTL_SLOTS) != hipSuccess ||
+                      hipHostMalloc((void **) &b->h_ctl_pre, sizeof(sdrm_chunk_ctl) * C * SDRM_CTL_SLOTS) != hipSuccess)) {
+        code = -ENOMEM;
+    }
+    return code;
+}
+
+// From the next call on, the channel's input is mixed with ONE oscillator at the integer frequency freq_hz (fp32 phase carried
+// across calls, started at 0 now) in front of everything else -- what the reference's file source does with RxRequest.rx_offset
+// (src/sdr/file_source.c:120-128, sig_source_multiply) before the samples reach dsp_worker_put.  NCO batches of the same call
+// (the Doppler correction, src/dsp_worker.c:65-71) then run BEHIND it: two oscillators in series, every sample rounded to fp32
+// in between, as in the reference.  freq_hz == 0 switches it off.  Waits for enqueued calls.
+extern "C" int sdrm_batch_set_pre_offset(sdrm_batch *b, size_t channel, int64_t freq_hz) {
+    if (b == nullptr || channel >= b->plan.design.size()) {
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    int code = wait_for_all_calls(b);
+    if (code != 0) {
+        return code;
+    }
+    if (freq_hz != 0) {
+        code = ensure_pre(b);
+        if (code != 0) {
+            return code;
+        }
+    }
+    b->pre_offset.resize(b->plan.design.size(), 0);
+    b->pre_offset[channel] = freq_hz;
+    b->any_pre = false;
+    for (int64_t f : b->pre_offset) {
+        b->any_pre = b->any_pre || f != 0;
+    }
+    if (b->d_pre_state != nullptr) {
+        HIP_TRY(hipMemset(b->d_pre_state + channel, 0, sizeof(float)));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    if (b->sg_exec != nullptr) {  // the one-channel graph has no such pass: calls take the plain path from here on
+        (void) hipGraphExecDestroy(b->sg_exec);
+        b->sg_exec = nullptr;
+    }
+    return 0;
 }
 
 // ---- online refinement of the schedule for calls the calibration did not cover ---------------------------------------
@@ -1495,12 +1577,35 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
             }
         }
     }
+    // the oscillator in front (sdrm_batch_set_pre_offset): one batch per channel and call, a control block of its own
+    bool with_pre = false;
+    uint32_t pre_max_len = 0;
+    if (b->any_pre) {
+        sdrm_chunk_ctl *hp = b->h_ctl_pre + (size_t) slot * C;
+        sdrm_nco_seg *sp = b->h_pre_segs + (size_t) slot * C;
+        for (size_t c = 0; c < C; c++) {
+            hp[c] = h[c];
+            hp[c].nco_off = (uint32_t) c;
+            hp[c].nco_cnt = 0;
+            sp[c].len = 0;
+            sp[c].step = 0.0f;
+            if (b->pre_offset[c] != 0 && h[c].n_in > 0 && h[c].absent == 0) {
+                hp[c].nco_cnt = 1;
+                sp[c].len = h[c].n_in;
+                const float two_pi = (float) (2 * 3.14159265358979323846);  // as plan_nco: sig_source.c:44 in fp32
+                sp[c].step = two_pi * (float) b->pre_offset[c] / b->plan.design[c].cfg.sampling_freq;
+                h[c].pre = 1;
+                with_pre = true;
+                pre_max_len = std::max(pre_max_len, h[c].n_in);
+            }
+        }
+    }
     {
         uint64_t sig = 0;
         for (size_t c = 0; c < C; c++) {
             sig += h[c].n_in;
         }
-        online_tune_before(b, with_nco, sig);
+        online_tune_before(b, with_nco || with_pre, sig);
     }
     d.nco_segs = with_nco ? b->d_nco_segs + (size_t) slot * b->nco_seg_cap : nullptr;
     d.nco_phase_state = b->d_nco_state;
@@ -1641,6 +1746,19 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         if (b->d_placed != nullptr) {
             sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_target + sdrm::clock_workgroups(d), 400, b->s_front);
         }
+    }
+    if (with_pre) {
+        sdrm::DeviceBatch dp = d;
+        dp.ctl = b->d_ctl_pre + (size_t) slot * C;
+        dp.nco_segs = b->d_pre_segs + (size_t) slot * C;
+        dp.nco_phase_state = b->d_pre_state;
+        dp.nco_phase = b->d_pre_phase;
+        HIP_TRY(hipMemcpyAsync(b->d_ctl_pre + (size_t) slot * C, b->h_ctl_pre + (size_t) slot * C, sizeof(sdrm_chunk_ctl) * C,
+                               hipMemcpyHostToDevice, b->s_front));
+        HIP_TRY(hipMemcpyAsync(b->d_pre_segs + (size_t) slot * C, b->h_pre_segs + (size_t) slot * C, sizeof(sdrm_nco_seg) * C,
+                               hipMemcpyHostToDevice, b->s_front));
+        sdrm::launch_nco_phase(dp, b->s_front);
+        sdrm::launch_nco_mix(dp, d_in, in_stride, pre_max_len, b->s_front);
     }
     if (with_nco) {
         if (!nco_aside) {
@@ -1987,7 +2105,7 @@ static bool serial_call_hands_off(const sdrm_batch_t *b, size_t n) {
 
 static bool serial_graph_usable(const sdrm_batch_t *b, size_t n, const sdrm_nco_segment *segs) {
     return getenv("SDRM_NO_GRAPH") == nullptr &&  // escape hatch for measurements
-           !serial_call_hands_off(b, n) &&
+           !serial_call_hands_off(b, n) && !b->any_pre &&
            !b->sg_broken && b->serial && b->plan.design.size() == 1 && b->n_gen == 0 && segs == nullptr && !b->timing &&
            b->d_timeline == nullptr && b->dev.k3_stamps == nullptr && b->d_out8_b == nullptr && b->calls > 0 && n > 0 &&
            n <= SDRM_GRAPH_MAX_SAMPLES && n <= b->plan.params[0].max_len;

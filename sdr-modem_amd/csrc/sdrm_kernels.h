@@ -183,6 +183,8 @@ struct sdrm_chunk_ctl {
     uint32_t nco_off, nco_cnt;  // this call's NCO segments of the channel in the segment table (cnt 0: no NCO)
     uint32_t absent;  // the channel takes no part in this call (SDRM_LEN_ABSENT): no output, stream state untouched --
                       // unlike an EMPTY call, which the reference's clock stage answers from its carried samples
+    uint32_t pre;     // the channel's input of this call has been through its constant-frequency oscillator (the file source's
+                      // rx_offset, reference src/sdr/file_source.c:120-128) and lies in nco_out: what follows reads it there
 };
 
 // one batch of the Doppler pre-correction: `len` samples mixed with an oscillator advancing `step` radians per sample

@@ -230,7 +230,9 @@ __global__ __launch_bounds__(256) void k0_nco_mix(DeviceBatch b, const sdrm_f2 *
     if (ctl.nco_cnt == 0) {
         return;
     }
-    const sdrm_f2 *in = d_in + (size_t) c * in_stride;
+    // (a second oscillator in series -- the Doppler correction behind the file source's offset, src/dsp_worker.c:65-71 behind
+    // src/sdr/file_source.c:120-128 -- mixes in place what the first one left: every sample is rounded to fp32 in between)
+    const sdrm_f2 *in = ctl.pre ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
     const float *ph = b.nco_phase + (size_t) c * b.nco_phase_stride;
     sdrm_f2 *out = b.nco_out + (size_t) c * b.nco_stride;
     for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < ctl.n_in; n += gridDim.x * blockDim.x) {
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
         // Every channel gets this workgroup, also one without a tile this call (an empty or absent input still rolls).
         const sdrm_f2 *cur = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
         sdrm_f2 *next = b.raw_hist + ((size_t) c * 2 + (ctl.parity ^ 1u)) * b.hist_stride;
-        const sdrm_f2 *src = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
+        const sdrm_f2 *src = (ctl.nco_cnt | ctl.pre) ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
         sdrm_hist_roll((int) threadIdx.x, SDRM_K1_THREADS, p, ctl, src, cur, next);
     }
     if (tile_id >= ctl.tiles) {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
 
     const int tid = threadIdx.x;
     const sdrm_k1_tile t = sdrm_k1_tile_setup(p, ctl, (int) tile_id);
-    const sdrm_f2 *in = ctl.nco_cnt ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
+    const sdrm_f2 *in = (ctl.nco_cnt | ctl.pre) ? b.nco_out + (size_t) c * b.nco_stride : d_in + (size_t) c * in_stride;
     const sdrm_f2 *hist = b.raw_hist + ((size_t) c * 2 + ctl.parity) * b.hist_stride;
 
     const bool stamp = b.k3_stamps != nullptr;  // diagnostics: per-phase cycles, summed over workgroups

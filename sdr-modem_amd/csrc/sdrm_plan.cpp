@@ -289,6 +289,7 @@ uint32_t plan_call(BatchPlan &plan, const size_t *lens, sdrm_chunk_ctl *ctl) {
         k.nco_off = 0;
         k.nco_cnt = 0;
         k.absent = absent ? 1u : 0u;
+        k.pre = 0;
         plan.phase[c] = k.i0 + k.nz * p.decim - k.n_in;
         plan.parity[c] ^= 1u;
         plan.zbase[c] += k.nz;

@@ -262,7 +262,7 @@ void Batcher::abandon(size_t c) {
     cv_result_.notify_all();
 }
 
-int Batcher::reset_channel(size_t c, const sdrm_fsk_config *cfg) {
+int Batcher::reset_channel(size_t c, const sdrm_fsk_config *cfg, int64_t pre_offset_hz) {
     if (c >= n_) {
         return -1;
     }
@@ -272,6 +272,7 @@ int Batcher::reset_channel(size_t c, const sdrm_fsk_config *cfg) {
     if (cfg != nullptr) {
         req.cfg = *cfg;
     }
+    req.pre_offset_hz = pre_offset_hz;
     req.done = false;
     req.code = 0;
     std::unique_lock<std::mutex> lk(m_);
@@ -331,7 +332,7 @@ void Batcher::run() {
             Reset *req = resets_.front();
             resets_.pop_front();
             lk.unlock();
-            const int code = be_->reset_channel(req->channel, req->has_cfg ? &req->cfg : nullptr);
+            const int code = be_->reset_channel(req->channel, req->has_cfg ? &req->cfg : nullptr, req->pre_offset_hz);
             lk.lock();
             if (code == 0 && error_ == 0 && closed_[req->channel]) {
                 closed_[req->channel] = 0;  // the slot serves a new client
@@ -447,6 +448,9 @@ extern "C" void sdrm_batcher_complete(sdrm_batcher *b, size_t channel) {
 
 extern "C" int sdrm_batcher_reset_channel(sdrm_batcher *b, size_t channel, const sdrm_fsk_config *config) {
     return b != nullptr ? reinterpret_cast<sdrm::Batcher *>(b)->reset_channel(channel, config) : -1;
+}
+extern "C" int sdrm_batcher_reset_channel_offset(sdrm_batcher *b, size_t channel, const sdrm_fsk_config *config, int64_t rx_offset_hz) {
+    return b != nullptr ? reinterpret_cast<sdrm::Batcher *>(b)->reset_channel(channel, config, rx_offset_hz) : -1;
 }
 
 extern "C" void sdrm_batcher_interrupt(sdrm_batcher *b, size_t channel) {

@@ -37,8 +37,9 @@ struct BatchBackend {
     virtual int arena(size_t slots, sdrm_cf32 **base, size_t *chan_stride, size_t *slot_stride) = 0;
     virtual int submit(size_t slot, const size_t *lens, const sdrm_nco_segment *segs, size_t n_segs) = 0;
     virtual int collect(int8_t **outputs, size_t *lens) = 0;
-    // same contract as sdrm_batch_reset_channel (nothing is in flight when the batcher calls it)
-    virtual int reset_channel(size_t channel, const sdrm_fsk_config *cfg) = 0;
+    // same contract as sdrm_batch_reset_channel (nothing is in flight when the batcher calls it), then sdrm_batch_set_pre_offset
+    // when pre_offset_hz != 0 (the new client's file-source offset)
+    virtual int reset_channel(size_t channel, const sdrm_fsk_config *cfg, int64_t pre_offset_hz) = 0;
 };
 
 typedef size_t (*doppler_plan_fn)(void *planner, uint32_t channel, size_t input_len, sdrm_nco_segment *segments, size_t cap);
@@ -60,7 +61,7 @@ public:
     void set_doppler(size_t channel, doppler_plan_fn fn, void *planner);
     // hand the channel to a new client: waits until everything put on it has been consumed, drains the device, resets
     // the channel (cfg may be NULL = same configuration) and reopens it after a poison pill
-    int reset_channel(size_t channel, const sdrm_fsk_config *cfg);
+    int reset_channel(size_t channel, const sdrm_fsk_config *cfg, int64_t pre_offset_hz = 0);
     // first device failure (submit or collect), 0 while the device answers.  Sticky: from then on nothing is delivered any
     // more -- take() returns NULL like after a poison pill, put() drops -- and the owners of the channels read the code
     // here (sdrm_batcher_error) to tell a dead device from a client that left.
@@ -112,6 +113,7 @@ private:
         size_t channel;
         bool has_cfg;
         sdrm_fsk_config cfg;
+        int64_t pre_offset_hz;
         bool done;
         int code;
     };

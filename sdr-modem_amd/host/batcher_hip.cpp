@@ -22,10 +22,13 @@ struct HipBackend : sdrm::BatchBackend {
         return sdrm_batch_submit(batch, slot, lens, segs, n);
     }
     int collect(int8_t **outs, size_t *lens) override { return sdrm_batch_collect(batch, outs, lens); }
-    int reset_channel(size_t c, const sdrm_fsk_config *cfg) override {
+    int reset_channel(size_t c, const sdrm_fsk_config *cfg, int64_t pre_offset_hz) override {
         int code = sdrm_batch_reset_channel(batch, c, cfg);
         if (code == 0 && cfg != nullptr) {
             maxlen[c] = cfg->max_input_buffer_length;
+        }
+        if (code == 0 && pre_offset_hz != 0) {
+            code = sdrm_batch_set_pre_offset(batch, c, pre_offset_hz);
         }
         return code;
     }

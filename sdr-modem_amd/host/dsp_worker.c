@@ -155,14 +155,17 @@ static void *worker_main(void *arg) {
         int8_t *soft = NULL;
         size_t soft_len = 0;
         if (w->corrected != NULL) {
-            /* reference order: doppler_process_rx, then fsk_demod_process (src/dsp_worker.c:65-76); here one call */
+            /* reference order: [the file source's offset oscillator, file_source.c:120-128 -- the batch's pre-offset,] then
+             * doppler_process_rx, then fsk_demod_process (src/dsp_worker.c:65-76); here one call */
             sdrm_nco_segment segs[64];
-            size_t n_segs = sdrm_doppler_plan(w->doppler, 0, iq_len, segs, 64);
+            size_t n_segs = w->doppler != NULL ? sdrm_doppler_plan(w->doppler, 0, iq_len, segs, 64) : 0;
             const sdrm_cf32 *ins[1] = {iq};
             size_t lens[1] = {iq_len};
             int8_t *outs[1] = {NULL};
             size_t olens[1] = {0};
-            if (sdrm_batch_process_nco(w->corrected, ins, lens, segs, n_segs, outs, olens) != 0) {
+            const int failed = n_segs > 0 ? sdrm_batch_process_nco(w->corrected, ins, lens, segs, n_segs, outs, olens)
+                                          : sdrm_batch_process(w->corrected, ins, lens, outs, olens);
+            if (failed != 0) {
                 complete_buffer_processing(w->inbox);
                 fprintf(stderr, "<3>[%d] demodulation failed on the device\n", w->id);
                 break;
@@ -205,14 +208,6 @@ int dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_config *
     return sdrm_dsp_worker_create(id, client_socket, cfg, result);
 }
 
-/* the file source's offset as a "Doppler" that never changes: the planner (doppler.c:128-180) interpolates between equal
- * per-second values and truncates to the same integer, and batches of equal frequency are one oscillator run
- * (sig_source.c:43-75 keeps its phase across calls) -- file_source.c:120-128's sig_source_multiply(freq_offset, ...) */
-static double constant_offset(void *user, uint64_t second) {
-    (void) second;
-    return (double) *(const int64_t *) user;
-}
-
 /* a worker that never started: what dsp_worker_destroy would free of it */
 static void discard(dsp_worker *w) {
     if (w->doppler_release != NULL) {
@@ -232,18 +227,11 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
     w->doppler_release = cfg->doppler_release;
     w->doppler_user = cfg->doppler_user;
     int code = 0;
+    /* The file source's offset (file_source.c:120-128: sig_source_multiply(freq_offset, ...), one oscillator for the life of the
+     * stream) is the batch's pre-offset; the Doppler correction (src/dsp_worker.c:65-71) runs behind it with an oscillator of
+     * its own -- in series, every sample rounded to fp32 in between, as the reference has them. */
     sdrm_doppler_shift_fn shift_fn = cfg->doppler_shift;
     void *shift_user = cfg->doppler_user;
-    if (cfg->rx_offset_hz != 0) {
-        if (cfg->doppler_shift != NULL) {
-            /* the reference runs the file source's oscillator and the Doppler one in series (two roundings per sample) */
-            fprintf(stderr, "<3>[%d] rx offset and doppler correction together are not supported\n", w->id);
-            discard(w);
-            return -ENOTSUP;
-        }
-        shift_fn = constant_offset;
-        shift_user = &w->rx_offset_hz;
-    }
     sdrm_fsk_config fc = {cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
                           (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,
                           cfg->demod_fsk_use_dc_block, cfg->buffer_size};
@@ -257,7 +245,7 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
             w->batcher = cfg->batcher;
             w->channel = cfg->batcher_channel;
             /* the slot starts a new stream with this client's parameters (fsk_demod_create's part, src/dsp_worker.c:138-144) */
-            code = sdrm_batcher_reset_channel(w->batcher, w->channel, &fc);
+            code = sdrm_batcher_reset_channel_offset(w->batcher, w->channel, &fc, cfg->rx_offset_hz);
         } else {
             /* the node places the client (least-loaded healthy device); a device that fails between the placement and the
              * slot's reset is skipped next time round, so at most one attempt per batcher */
@@ -268,7 +256,7 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
                 if (code != 0) {
                     break;
                 }
-                code = sdrm_batcher_reset_channel(w->slot.batcher, w->slot.channel, &fc);
+                code = sdrm_batcher_reset_channel_offset(w->slot.batcher, w->slot.channel, &fc, cfg->rx_offset_hz);
                 if (code == 0) {
                     w->node = cfg->node;
                     w->batcher = w->slot.batcher;
@@ -293,14 +281,19 @@ int sdrm_dsp_worker_create(uint32_t id, int client_socket, const sdrm_worker_con
                 code = sdrm_batcher_set_doppler(w->batcher, w->channel, w->doppler);
             }
         }
-    } else if (shift_fn != NULL) {
-        code = sdrm_doppler_create(cfg->rx_sampling_freq, shift_fn, shift_user, &w->doppler);
-        if (code != 0) {
-            fprintf(stderr, "<3>[%d] unable to create doppler correction block\n", w->id);
-            dsp_worker_destroy(w);
-            return code;
+    } else if (shift_fn != NULL || cfg->rx_offset_hz != 0) {
+        if (shift_fn != NULL) {
+            code = sdrm_doppler_create(cfg->rx_sampling_freq, shift_fn, shift_user, &w->doppler);
+            if (code != 0) {
+                fprintf(stderr, "<3>[%d] unable to create doppler correction block\n", w->id);
+                dsp_worker_destroy(w);
+                return code;
+            }
         }
         code = sdrm_batch_create(&fc, 1, -1, 0, &w->corrected);
+        if (code == 0 && cfg->rx_offset_hz != 0) {
+            code = sdrm_batch_set_pre_offset(w->corrected, 0, cfg->rx_offset_hz);
+        }
     } else {
         code = fsk_demod_create(cfg->rx_sampling_freq, cfg->demod_baud_rate, cfg->demod_fsk_deviation,
                                 (uint8_t) cfg->demod_decimation, cfg->demod_fsk_transition_width,

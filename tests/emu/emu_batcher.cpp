@@ -15,6 +15,7 @@ struct EmuBatch;
 extern "C" int emu_create(const sdrm_fsk_config *cfgs, size_t n, EmuBatch **out);
 extern "C" void emu_destroy(EmuBatch *b);
 extern "C" int emu_reset_channel(EmuBatch *b, size_t c, const sdrm_fsk_config *cfg);
+extern "C" int emu_set_pre_offset(EmuBatch *b, size_t c, int64_t freq_hz);
 extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t *lens, const int8_t **out8,
                            const float **outf, size_t *outlens);
 extern "C" int emu_process_nco(EmuBatch *b, const float *const *inputs, const size_t *lens, const sdrm_nco_segment *segs,
@@ -69,8 +70,7 @@ struct EmuBackend : sdrm::BatchBackend {
         std::vector<const int8_t *> o8(C);
         std::vector<const float *> of(C);
         std::vector<size_t> ol(C);
-        int code = n_segs ? emu_process_nco(emu, ins.data(), lens, segs, n_segs, o8.data(), of.data(), ol.data())
-                          : emu_process(emu, ins.data(), lens, o8.data(), of.data(), ol.data());
+        int code = emu_process_nco(emu, ins.data(), lens, segs, n_segs, o8.data(), of.data(), ol.data());
         if (code != 0) return code;
         Result r;
         r.out.resize(C);
@@ -78,9 +78,10 @@ struct EmuBackend : sdrm::BatchBackend {
         done.push_back(std::move(r));
         return 0;
     }
-    int reset_channel(size_t c, const sdrm_fsk_config *cfg) override {
+    int reset_channel(size_t c, const sdrm_fsk_config *cfg, int64_t pre_offset_hz) override {
         int code = emu_reset_channel(emu, c, cfg);
         if (code == 0 && cfg != nullptr) maxlen[c] = cfg->max_input_buffer_length;
+        if (code == 0 && pre_offset_hz != 0) code = emu_set_pre_offset(emu, c, pre_offset_hz);
         return code;
     }
     std::vector<std::vector<int8_t>> last;

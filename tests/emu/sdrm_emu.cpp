@@ -28,6 +28,9 @@ struct EmuBatch {
     std::vector<sdrm_chunk_ctl> ctl;
     std::vector<uint32_t> nonfinite;
     uint64_t wild_calls = 0;
+    std::vector<int64_t> pre_offset;  // the oscillator in front (sdrm_batch_set_pre_offset), Hz per channel, 0 = none
+    std::vector<float> pre_state;
+    std::vector<std::vector<sdrm_f2>> pre_mixed;
     std::vector<float> nco_state;
     std::vector<std::vector<sdrm_f2>> mixed;
     std::vector<sdrm_nco_seg> nco_table;
@@ -127,6 +130,10 @@ extern "C" int emu_reset_channel(EmuBatch *b, size_t c, const sdrm_fsk_config *c
     b->clock[c].omega = pl.design[c].sps;
     b->nonfinite[c] = 0;
     b->nco_state[c] = 0.0f;
+    if (c < b->pre_offset.size()) {
+        b->pre_offset[c] = 0;
+        b->pre_state[c] = 0.0f;
+    }
     emu_sync_generic(b, (long) c);
     return 0;
 }
@@ -515,13 +522,40 @@ static void emu_clock_generic(EmuBatch *b) {
 
 extern "C" uint64_t emu_wild_calls(const EmuBatch *b) { return b->wild_calls; }
 
+extern "C" int emu_set_pre_offset(EmuBatch *b, size_t c, int64_t freq_hz) {
+    const size_t C = b->plan.params.size();
+    if (c >= C) return -1;
+    b->pre_offset.resize(C, 0);
+    b->pre_state.resize(C, 0.0f);
+    b->pre_mixed.resize(C);
+    b->pre_offset[c] = freq_hz;
+    b->pre_state[c] = 0.0f;
+    return 0;
+}
+
+// the oscillator in front of everything else: one batch over the channel's whole input of the call (as the device plans it)
+static const sdrm_f2 *emu_pre_mix(EmuBatch *b, size_t c, const sdrm_f2 *in) {
+    if (c >= b->pre_offset.size() || b->pre_offset[c] == 0 || b->ctl[c].n_in == 0 || b->ctl[c].absent) return in;
+    const float two_pi = (float) (2 * 3.14159265358979323846);
+    const float step = two_pi * (float) b->pre_offset[c] / b->plan.design[c].cfg.sampling_freq;
+    std::vector<sdrm_f2> &m = b->pre_mixed[c];
+    m.resize(b->ctl[c].n_in);
+    float phase = b->pre_state[c];
+    for (uint32_t n = 0; n < b->ctl[c].n_in; n++) {
+        m[n] = sdrm_nco_mix(in[n], sdrm_nco_sample(phase));
+        phase = sdrm_nco_advance(phase, step);
+    }
+    b->pre_state[c] = phase;
+    return m.data();
+}
+
 // inputs[c]: interleaved cf32, lens[c] samples.  Outputs: per channel pointers into emu-owned memory.
 extern "C" int emu_process(EmuBatch *b, const float *const *inputs, const size_t *lens, const int8_t **out8,
                            const float **outf, size_t *outlens) {
     const size_t C = b->plan.params.size();
     plan_call(b->plan, lens, b->ctl.data());
     std::vector<const sdrm_f2 *> ins(C);
-    for (size_t c = 0; c < C; c++) ins[c] = reinterpret_cast<const sdrm_f2 *>(inputs[c]);
+    for (size_t c = 0; c < C; c++) ins[c] = emu_pre_mix(b, c, reinterpret_cast<const sdrm_f2 *>(inputs[c]));
     emu_front_any(b, ins.data());
     emu_dc(b);
     emu_dc_generic(b);
@@ -546,7 +580,7 @@ extern "C" int emu_process_nco(EmuBatch *b, const float *const *inputs, const si
     std::vector<const sdrm_f2 *> ins(C);
     for (size_t c = 0; c < C; c++) {
         const sdrm_chunk_ctl &k = b->ctl[c];
-        const sdrm_f2 *in = reinterpret_cast<const sdrm_f2 *>(inputs[c]);
+        const sdrm_f2 *in = emu_pre_mix(b, c, reinterpret_cast<const sdrm_f2 *>(inputs[c]));
         if (k.nco_cnt == 0) {
             ins[c] = in;
             continue;

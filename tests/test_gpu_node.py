@@ -237,3 +237,44 @@ def test_reference_signature_adapter_on_the_device(tmp_path):
     want = np.concatenate([o.process(d.process(iq[off:off + 4096].view(np.float32)))[0] for off in range(0, len(iq), 4096)])
     assert np.array_equal(got[0], want)
     A.sdrm_ref_set_doppler_factory(None)
+
+
+@pytest.mark.parametrize("placed", ["private", "node"])
+def test_file_source_offset_and_doppler_correction_in_series_on_the_device(placed):
+    """RxRequest.rx_offset AND RxRequest.doppler: the reference runs two oscillators in series, each with a phase of its own and
+    every sample rounded to fp32 in between -- the file source's (src/sdr/file_source.c:120-128), then the Doppler correction's
+    (src/dsp_worker.c:65-71, src/dsp/doppler.c:116-190).  -ENOTSUP until round 5; now the batch's pre-offset oscillator in front
+    of the NCO batches (sdrm_batch_set_pre_offset).  Bit for bit orc.Nco -> orc.Doppler -> orc.Fsk over the reference's
+    recording, across one-second boundaries, as a private worker and on a node slot beside a plain client."""
+    L = binding.load()
+    L.dsp_worker_put.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.dsp_worker_destroy.argtypes = [C.c_void_p]
+    import json
+    shifts = json.load(open(os.path.join(GOLDEN, "doppler_shifts_lucky7.json")))["shifts_hz"]
+    cb = binding.SHIFT_FN(lambda user, k: float(shifts[min(int(k), len(shifts) - 1)]))
+    iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.complex64)
+    cfg = (48000, 4800, 5000, 2, 2000, True, 4096)
+    node = binding.Node(cfg, 4, n_batchers=2, devices=[0, 0], batcher=(4, 50000, True)) if placed == "node" else None
+    with tempfile.TemporaryDirectory() as tmp:
+        def worker(i, offset, doppler):
+            wc = binding.WorkerConfig(48000, 4800, 5000, 2, 2000, True, False, 0, 4096, 4, True, tmp.encode(),
+                                      C.cast(cb, C.c_void_p) if doppler else None, None, None, 0, node.h if node else None, 1, offset)
+            w = C.c_void_p()
+            assert L.dsp_worker_create(i, -1, C.byref(wc), C.byref(w)) == 0
+            return w
+        ws = [worker(41, -1200, True), worker(42, 0, False), worker(43, 700, False)]
+        for off in range(0, len(iq), 4096):
+            part = np.ascontiguousarray(iq[off:off + 4096]).view(np.float32)
+            for w in ws:
+                L.dsp_worker_put(part.ctypes.data, len(part) // 2, w)
+        for w in ws:
+            L.dsp_worker_destroy(w)
+        got = [np.fromfile(os.path.join(tmp, "rx.demod2client.%d.s8" % i), dtype=np.int8) for i in (41, 42, 43)]
+    parts = [iq[off:off + 4096].view(np.float32) for off in range(0, len(iq), 4096)]
+    osc, dop, o = orc.Nco(1.0, 48000, 4096), orc.Doppler(48000, shifts, 4096), orc.Fsk(*cfg)
+    assert np.array_equal(got[0], np.concatenate([o.process(dop.process(osc.multiply(-1200, p)))[0] for p in parts]))
+    assert np.array_equal(got[1], orc.demod_stream(cfg[:6], iq, 4096)[0])
+    osc, o = orc.Nco(1.0, 48000, 4096), orc.Fsk(*cfg)
+    assert np.array_equal(got[2], np.concatenate([o.process(osc.multiply(700, p))[0] for p in parts]))
+    if node:
+        node.close()

@@ -202,9 +202,21 @@ def test_worker_with_the_file_sources_rx_offset_matches_the_reference_vector(tmp
     want = np.concatenate([o.process(osc.multiply(1000, sig[k * chunk:(k + 1) * chunk].view(np.float32)))[0] for k in range(14)])
     got = np.fromfile(os.path.join(str(tmp_path), "rx.demod2client.7.s8"), dtype=np.int8)
     assert np.array_equal(got, want)
-    # offset and Doppler together: refused, as documented
-    cb = binding.SHIFT_FN(lambda user, k: 0.0)
+    # offset and Doppler together (-ENOTSUP until round 5): two oscillators in series with separate phases, every sample rounded
+    # to fp32 in between -- the file source's (file_source.c:122), then the Doppler correction's (src/dsp_worker.c:65-71)
+    shifts = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "doppler_shifts_lucky7.json")))["shifts_hz"]
+    cb = binding.SHIFT_FN(lambda user, k: float(shifts[min(int(k), len(shifts) - 1)]))
     wc2 = _worker_cfg(node, tmp_path, GEOM, offset=1000)
     wc2.doppler_shift = C.cast(cb, C.c_void_p)
-    assert L.dsp_worker_create(8, -1, C.byref(wc2), C.byref(w)) == -95  # -ENOTSUP
+    assert L.dsp_worker_create(8, -1, C.byref(wc2), C.byref(w)) == 0
+    for k in range(14):
+        part = np.ascontiguousarray(sig[k * chunk:(k + 1) * chunk]).view(np.float32)
+        L.dsp_worker_put(part.ctypes.data, chunk, w)
+    L.dsp_worker_destroy(w)
+    osc = orc.Nco(1.0, 48000, chunk)
+    dop = orc.Doppler(48000, shifts, chunk)
+    o = orc.Fsk(*GEOM)
+    want = np.concatenate([o.process(dop.process(osc.multiply(1000, sig[k * chunk:(k + 1) * chunk].view(np.float32))))[0] for k in range(14)])
+    got = np.fromfile(os.path.join(str(tmp_path), "rx.demod2client.8.s8"), dtype=np.int8)
+    assert np.array_equal(got, want)
     node.close()
