@@ -108,6 +108,84 @@ def test_two_rank_sharding_and_config_fanout():
     assert all(r[2] for r in ranges)
 
 
+def _worker_node(rank, world, port, ret):
+    """BASELINE configs[3] (4096 channels) and configs[4] (2048 mixed-rate channels, cost-balanced) fanned out over `world` ranks"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sdrm_pkg
+    sdrm_pkg.load()
+    from sdr_modem_amd import shard, siggen
+    import emu_api
+    import orc
+    ok = True
+    report = {}
+    n = 2048  # samples per call here: the tables are the node's, the calls are short (CPU emulation)
+    for name, total, balance, make in (
+            ("configs3", 4096, "count", lambda: [(48000, 9600, 5000, 1, 2000, True, n)] * 4096),
+            ("configs4", 2048, "cost", lambda: [(240000, 19200, 5000, 5, 2000, True, n)] * 1024 + [(48000, 1200, 5000, 8, 2000, True, n)] * 1024)):
+        part = shard.fanout_configs(make() if rank == 0 else None, total, balance=balance)
+        cfgs, lo, hi = part
+        ok = ok and len(cfgs) == hi - lo
+        # this rank demodulates the first and the last channel of its shard (its whole shard on a GPU)
+        spots = sorted(set([0, len(cfgs) - 1])) if cfgs else []
+        if spots:
+            e = emu_api.EmuBatch([cfgs[i] for i in spots])
+            sigs = [siggen.gmsk_channel(lo + i, n, fs=cfgs[i][0], baud=cfgs[i][1]) for i in spots]
+            got8, _ = e.process(sigs)
+            for k, i in enumerate(spots):
+                ok = ok and np.array_equal(orc.demod_stream(cfgs[i][:6], sigs[k], n)[0], got8[k])
+        # the call's Doppler batches: three per channel, planned on rank 0 for the node, one fixed-size collective
+        segs = np.array([(c, ln, -10000 + 7 * c + 100 * k) for c in range(total) for k, ln in enumerate((700, 700, n - 1400))],
+                        dtype=np.int64) if rank == 0 else None
+        mine = shard.fanout_nco_segments(segs, part, as_array=True, capacity=3 * total)
+        ok = ok and len(mine) == 3 * (hi - lo) and (len(mine) == 0 or (mine[0, 0] == 0 and mine[-1, 0] == hi - lo - 1))
+        ok = ok and all(int(f) == -10000 + 7 * (int(c) + lo) + 100 * (j % 3) for j, (c, _, f) in enumerate(mine.tolist()))
+        try:  # more batches than agreed: every rank raises, behind the collective
+            shard.fanout_nco_segments(segs, part, as_array=True, capacity=total)
+            ok = False
+        except ValueError as exc:
+            ok = ok and "exceed the agreed capacity" in str(exc)
+        again = shard.fanout_nco_segments(segs, part, as_array=True, capacity=3 * total)  # ... and the next one lines up
+        ok = ok and np.array_equal(again, mine)
+        spans = [None] * world
+        dist.all_gather_object(spans, (lo, hi, sum(shard.channel_cost(c) for c in cfgs)))
+        report[name] = spans
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        ret["report"] = report
+        ret["ok"] = flags
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_node_sized_tables_over_four_and_eight_ranks(world):
+    """SURVEY 8e at the node's size, on CPU over gloo (the RCCL leg needs the 8-GPU node): BASELINE configs[3]'s 4096 channels in
+    equal blocks and configs[4]'s 2048 mixed-rate channels in cost-balanced blocks, the channel table broadcast from rank 0,
+    per-call Doppler batches fanned out with the same partition through one fixed-size collective (and its overflow raised on
+    every rank).  Blocks tile the table, the cost per rank is within 15 %, spot channels of every rank match the oracle."""
+    port = 31500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_node, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret["ok"]), ret["ok"]
+    for name, total in (("configs3", 4096), ("configs4", 2048)):
+        spans = ret["report"][name]
+        assert spans[0][0] == 0 and spans[-1][1] == total and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        costs = [s[2] for s in spans]
+        assert max(costs) / min(costs) <= 1.15, (name, world, costs)
+    assert [s[1] - s[0] for s in ret["report"]["configs3"]] == [4096 // world] * world
+    counts4 = [s[1] - s[0] for s in ret["report"]["configs4"]]
+    assert counts4[0] < 2048 // world < counts4[-1]  # the heavy channels come first: fewer of them per rank
+
+
 def test_shard_range_tiles_everything():
     sys.path.insert(0, ROOT)
     import sdrm_pkg
