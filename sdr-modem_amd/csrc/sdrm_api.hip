@@ -19,191 +19,7 @@
 #include "sdrm_tables.h"
 
 
-#define SDRM_CTL_SLOTS 8
-#define SDRM_RES_SETS 4    // pinned result sets of the pipelined host path
-// row pitch of the NCO phase buffers: every channel's generator writes the same column at the same time, and a pitch that
-// is a power of two would put all of those writes on one memory channel; 4 KiB + 256 B more per row spreads them
-#define SDRM_PHASE_STRIDE(in_stride) ((in_stride) + 1088u)
-#define SDRM_MAX_FLIGHT 3  // uncollected calls it allows (copy-in, kernels and copy-back of different calls overlap)
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) {                                                                         \
-            fprintf(stderr, "<3>sdrmodem_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_),   \
-                    __FILE__, __LINE__);                                                                \
-            return -EIO;                                                                                \
-        }                                                                                               \
-    } while (0)
-
-struct TimingLane {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
-    double total_ms = 0.0;
-    uint64_t launches = 0;
-    // a stage whose consecutive launches overlap (the clock stage resident early): a launch's time counts from the end of
-    // the launch before it, if that came later than its own start
-    bool overlapped = false;
-    bool has_prev = false;
-    std::pair<hipEvent_t, hipEvent_t> prev;
-};
-
-struct sdrm_batch_t {
-    int device = 0;
-    uint32_t flags = 0;
-    sdrm::BatchPlan plan;  // designs, packed parameters, host-side streaming bookkeeping
-    // device memory
-    sdrm_chan_params *d_params = nullptr;
-    sdrm_chunk_ctl *d_ctl = nullptr;  // [SLOTS][C]
-    float *d_taps = nullptr, *d_atan = nullptr, *d_bank = nullptr;
-    sdrm_f2 *d_hist = nullptr;
-    float *d_z = nullptr, *d_dcout = nullptr, *d_dcstate = nullptr;
-    sdrm_clock_state *d_clock = nullptr;
-    int8_t *d_out8 = nullptr;
-    float *d_outf = nullptr;
-    uint32_t *d_outlen = nullptr;
-    uint32_t *d_flags = nullptr;  // [SLOTS][C] non-finite flags, one set per control slot
-    // generic channels (sdrm_kernels.h): per-channel state in global memory, the list of such channels and the pointer table
-    std::vector<float *> gen_ptr;  // [C] device allocations (null for the others)
-    float **d_gen_state = nullptr;
-    int *d_gen_list = nullptr;
-    int n_gen = 0;
-    // NCO pre-mix (allocated on first use)
-    sdrm_nco_seg *d_nco_segs = nullptr, *h_nco_segs = nullptr;  // [SLOTS][nco_seg_cap]
-    // constant-frequency oscillator in front of everything else, per channel (sdrm_batch_set_pre_offset: the file source's rx_offset)
-    std::vector<int64_t> pre_offset;   // [C] Hz, 0 = none
-    bool any_pre = false;
-    float *d_pre_state = nullptr;      // [C] its fp32 phase, carried across calls
-    float *d_pre_phase = nullptr;      // [C][phase stride] phase of every sample of the call
-    sdrm_nco_seg *d_pre_segs = nullptr, *h_pre_segs = nullptr;    // [SLOTS][C] one batch per channel and call
-    sdrm_chunk_ctl *d_ctl_pre = nullptr, *h_ctl_pre = nullptr;    // [SLOTS][C] the control block as that pass sees it
-    size_t nco_seg_cap = 0;
-    float *d_nco_state = nullptr, *d_nco_phase = nullptr, *d_nco_phase2 = nullptr;  // phases: one buffer per call parity
-    hipStream_t s_nco = nullptr;                 // phase accumulator of the next call runs beside this call's stages
-    hipEvent_t ev_phase[SDRM_CTL_SLOTS] = {};    // phases (and control block) of the call are on the device
-    sdrm_f2 *d_nco_out = nullptr;
-    std::vector<sdrm_nco_seg> nco_table;
-    sdrm_f2 *d_in = nullptr;  // staging for the host-buffer API (lazy)
-    // host (pinned) mirrors
-    sdrm_chunk_ctl *h_ctl = nullptr;  // [SLOTS][C]
-    uint32_t *h_outlen = nullptr;
-    int8_t *h_out8 = nullptr;  // lazy
-    hipEvent_t slot_done[SDRM_CTL_SLOTS] = {};   // clock stage of the call that used the slot has finished
-    hipEvent_t ev_in[SDRM_CTL_SLOTS] = {};       // caller's stream position when the call was made (input ready)
-    hipEvent_t ev_front[SDRM_CTL_SLOTS] = {};    // front-end (K1 + history roll) finished
-    hipEvent_t ev_dc[SDRM_CTL_SLOTS] = {};       // DC blocker finished
-    bool slot_used[SDRM_CTL_SLOTS] = {};
-    // The three stages of consecutive calls overlap: each stage has its own stream, the stage-to-stage buffers
-    // (z, dcout) are double buffered, and events order producer -> consumer and buffer reuse.
-    hipStream_t s_front = nullptr, s_dc = nullptr, s_clock = nullptr;
-    // Opt-in (SDRM_K3_EARLY, see sdrm_batch_create): the clock stage of call i+1 is launched on a second stream as soon as
-    // ITS inputs are ready and takes its CUs while call i's is still running; its workgroups wait inside the kernel for the
-    // finished-workgroups counter (DeviceBatch::k3_wait_for).  The hand-over from one call's clock stage to the next then
-    // costs a counter look instead of a kernel boundary plus the hunt for CUs with 141 KB of free LDS.
-    hipStream_t s_clock_alt = nullptr;
-    bool clock_early = false;
-    bool clock_prev_alt = false;       // the previous call's clock stage went to s_clock_alt
-    bool clock_same_stream = false;    // this call's goes to the same stream as the previous call's
-    bool clock_prev_converts = false;  // ... and had k3_quantize behind it
-    // Small batches: a grid of idle-spinning waves beside every clock-stage launch (sdrm_kernels.hip, k3_company)
-    hipStream_t s_company = nullptr;
-    hipEvent_t ev_company = nullptr;
-    uint32_t *d_k3_done = nullptr;   // clock-stage workgroups finished, all launches
-    uint32_t *d_counters = nullptr;  // [16] batch-lifetime device counters (DeviceBatch::counters)
-    // in-call hand-off (DESIGN.md "stages of one call overlap"): tile stamps [C][hand_tiles_cap], DC-blocker counts [C]
-    uint32_t *d_hand_tiles = nullptr;
-    uint32_t hand_tiles_cap = 0;
-    unsigned long long *d_hand_prog = nullptr;
-    hipEvent_t ev_ctl[SDRM_CTL_SLOTS] = {};  // the call's control block is on the device
-    bool hand_allowed = true;        // SDRM_HANDOFF=0 switches it off
-    bool hand_used = false;          // a hand-off call has been enqueued since the device error word was last looked at
-    hipStream_t s_hand_dc = nullptr, s_hand_clock = nullptr;  // a one-stream (serial) batch: side streams for a hand-off call's DC and clock stages, created on first use
-    bool hand_side_last = false;     // the call enqueued last ran on them: the next call's first stream waits for its end
-    uint64_t hand_calls = 0;         // diagnostics: calls enqueued with the hand-off
-    uint32_t *d_placed = nullptr;    // [2] DC / clock-stage workgroups started, all launches (what the stream holds wait for)
-    uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started
-    uint32_t k3_placed_after[SDRM_CTL_SLOTS] = {};        // ... once the clock stage of the call in that slot has
-    uint32_t k3_done_target = 0;     // what the counter reads when the launch enqueued last has finished
-    int device_error = 0;            // sticky: a kernel reported through d_k3_done[2] that it gave up a bounded wait
-    int company_blocks = 0;
-    int company_rounds = 120;        // bound on the companion grid's life, in ~50 us looks at the counter
-    int company_nops = 1;            // s_nop 7 between two vector instructions of a companion wave (1 / 4 / 16 / 64)
-    int company_grid = 4096;         // the grid the companion stage takes when it is on
-    bool hold_front = false;         // the front-end waits for the clock stage of call i-2 to have its workgroups placed
-    // what the batch's self-calibration decided (sdrm_batch_create -> calibrate), for inspection: sdrm_batch_schedule
-    bool calibrated = false;
-    float calib_ms[3] = {0.0f, 0.0f, 0.0f};  // ms per full-length call: before, after, and what the calibration itself took
-    // Online refinement (online_tune_*): the calibration at creation times calls WITHOUT Doppler correction; the first
-    // stretch of calls that carry NCO batches re-decides the two settings that may change between any two calls (front
-    // hold, companion grid) on the caller's own workload, from the device-side spacing of the clock stages' completions.
-    struct OnlineTune {
-        int state = 0;            // 0 not started, 1 measuring, 2 settled
-        int phase = 0;            // while measuring: 1 the starting point's steady state, 2 the blocks, 3 the winner's probation
-        int cand = 0, n = 0;      // block being run (0-3: bit 0 hold toggled, bit 1 companion grid toggled; 4 as is again; 5 the winner again), calls of the phase / block so far
-        hipEvent_t ev[6][6] = {};     // per block: the clock stage's completion of the calls SKIP .. SKIP + TIMED of the block
-        hipEvent_t watch[2][33] = {};  // the same over 32 intervals: [0] the starting point before the blocks, [1] the winner after them
-        // ms per call: the four settings, as is / the winner again, the starting point's and the winner's steady state
-        float ms[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        int best = -1;            // the first round's winner
-        bool idle = false;        // this call is not part of a block (waiting for completions)
-        bool base_hold = false;
-        int base_company = 0;
-        uint64_t sig = 0;         // the class of calls being refined: total samples (calls within a factor of two count as alike
-        bool nco = false;         // once settled) and whether they carry NCO batches
-        int chosen = -1;
-        // after a winner has been kept: every 64th call of its class starts a sample of five intervals; two bad samples in a row
-        // (more than 5 % behind the starting point's steady state) give the starting point back for good
-        int guard_n = 0, guard_bad = 0;
-        bool guard_pending = false, guard_alike = false;
-    } tune;
-    float *d_z2 = nullptr, *d_dcout2 = nullptr;
-    bool any_nodc = false;
-    bool serial = false;
-    uint64_t calls = 0;
-    uint32_t last_max_symbols = 0;  // upper bound of any channel's symbol count in the call enqueued last
-    // Blocking calls of a one-channel batch (a plain fsk_demod handle) replay a graph: staged input -> control
-    // record -> kernels -> counts and soft bits back, one launch and one wait per call.  One graph per input length.
-    hipGraphExec_t sg_exec = nullptr;
-    size_t sg_len = 0;            // input length the graph was built for
-    uint32_t sg_width = 0;        // soft-bit bytes it copies back
-    sdrm_f2 *h_in_stage = nullptr;  // pinned staging for the caller's (pageable) buffer
-    bool sg_broken = false;       // building or instantiating the graph failed once: stay on the plain path
-    size_t sg_prev_len = 0;       // length of the previous blocking call: a graph is built when a length repeats
-    int last_slot = -1;
-    hipStream_t stream = nullptr;  // private stream of the host-buffer API
-    sdrm::DeviceBatch dev = {};
-    uint32_t in_stride = 0;  // staging stride (samples)
-    bool timing = false;
-    TimingLane lanes[3];
-    std::vector<uint32_t> last_lens;
-    // pipelined host-buffer path (sdrm_batch_arena / _submit / _collect): the caller fills pinned arena slots, the
-    // copy of call k+1 runs while call k computes, results come back through two pinned result sets
-    sdrm_f2 *h_arena = nullptr;
-    size_t arena_slots = 0;
-    sdrm_f2 *d_in_ring[2] = {nullptr, nullptr};
-    int8_t *d_out8_b = nullptr;      // second output set: calls alternate between the two once the arena exists
-    uint32_t *d_outlen_b = nullptr;
-    int8_t *h_res8[SDRM_RES_SETS] = {};
-    uint32_t *h_reslen[SDRM_RES_SETS] = {};
-    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
-    hipEvent_t ev_res[SDRM_RES_SETS] = {};  // results of call k are in h_res8 / h_reslen [k % SDRM_RES_SETS]
-    hipEvent_t ev_out_free[2] = {};         // the device output set of that parity has been copied back
-    bool out_busy[2] = {false, false};
-    uint32_t res_width[SDRM_RES_SETS] = {};  // bytes per channel copied back for that call
-    uint32_t back_width[SDRM_RES_SETS] = {};
-    int back_slot[SDRM_RES_SETS] = {};
-    bool back_pending = false;               // the newest submitted call's copy-back is not enqueued yet
-    uint64_t submitted = 0, collected = 0;
-    uint64_t first_pipelined_call = 0;
-    uint64_t stamp_only_call = 0;  // diagnostics: 0 = every call writes the cycle stamps, else only that call
-    unsigned long long *d_timeline = nullptr;  // diagnostics: see sdrm_batch_timeline
-    uint64_t timeline_first_call = 0;
-};
-
-static int8_t *out8_of(const sdrm_batch_t *b, uint64_t call) { return (b->d_out8_b && (call & 1)) ? b->d_out8_b : b->d_out8; }
-static uint32_t *outlen_of(const sdrm_batch_t *b, uint64_t call) {
-    return (b->d_outlen_b && (call & 1)) ? b->d_outlen_b : b->d_outlen;
-}
+#include "sdrm_batch_impl.h"
 
 extern "C" int sdrm_device_count(void) {
     int n = 0;
@@ -467,18 +283,17 @@ static int sync_generic(sdrm_batch_t *b, long only_channel) {
     return 0;
 }
 
-// ---- self-calibration of the schedule ------------------------------------------------------------------------------
-// Which clock-stage shape, whether the front-end holds back for the clock stage's placement and whether the clock stage gets
-// a companion grid used to be decided by constants fitted on one box at one power state (channel-count thresholds, 18.4e12
-// multiply-adds per second, 97 ns per symbol).  Those constants now only give the STARTING point: a batch of at least 32
-// channels times its own pipeline at creation -- full-length calls on a synthetic row that every channel reads (input
-// stride 0: no buffer of the batch's size is needed), a few calls per candidate setting (at least ~4 ms of them: short calls are launch-bound and noisy), one dimension after the other --
-// keeps what was fastest by more than the noise, and then puts every stream back to its initial state.  Costs a few dozen
-// calls (tens of milliseconds for 256 channels, a few hundred for 4096) once per batch.
-// SDRM_AUTOTUNE=0 switches it off; SDRM_K3_LANES / SDRM_FRONT_HOLD / SDRM_K3_COMPANY pin their dimension as before.
 static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
                         const sdrm_nco_segment *segs, size_t n_segs);
 static int wait_for_all_calls(sdrm_batch_t *b);
+
+static int reset_all_streams(sdrm_batch_t *b);
+int sdrm_enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
+                      const sdrm_nco_segment *segs, size_t n_segs) {
+    return enqueue_call(b, d_in, in_stride, lens, caller, segs, n_segs);
+}
+int sdrm_wait_for_all_calls(sdrm_batch_t *b) { return wait_for_all_calls(b); }
+int sdrm_reset_all_streams(sdrm_batch_t *b) { return reset_all_streams(b); }
 
 static int reset_all_streams(sdrm_batch_t *b) {
     const sdrm::BatchPlan &pl = b->plan;
@@ -510,140 +325,6 @@ static int reset_all_streams(sdrm_batch_t *b) {
     b->hand_calls = 0;
     b->last_slot = -1;
     return 0;
-}
-
-static int calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
-    const size_t C = b->plan.design.size();
-    const char *env = getenv("SDRM_AUTOTUNE");
-    if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->clock_early || b->n_gen > 0) {
-        return 0;
-    }
-    uint32_t longest = 0;
-    std::vector<size_t> lens(C);
-    for (size_t c = 0; c < C; c++) {
-        lens[c] = cfgs[c].max_input_buffer_length;
-        longest = std::max(longest, cfgs[c].max_input_buffer_length);
-    }
-    if (longest < 1024) {
-        return 0;  // calls this short are launch-bound whatever the schedule
-    }
-    // one row of plausible IQ: unit-amplitude FM of a slow square wave plus a little deterministic noise (finite, no zeros:
-    // the discriminator stays on its short form, the clock loop on its finite one, as with real signals)
-    std::vector<sdrm_f2> row(longest);
-    uint32_t lcg = 12345u;
-    double ph = 0.0;
-    for (uint32_t i = 0; i < longest; i++) {
-        ph += ((i / 5) % 7 < 3 ? 0.16 : -0.16);
-        lcg = lcg * 1664525u + 1013904223u;
-        const float n1 = (float) ((lcg >> 8) & 0xffff) / 65536.0f - 0.5f;
-        lcg = lcg * 1664525u + 1013904223u;
-        const float n2 = (float) ((lcg >> 8) & 0xffff) / 65536.0f - 0.5f;
-        row[i].x = (float) cos(ph) + 0.1f * n1;
-        row[i].y = (float) sin(ph) + 0.1f * n2;
-    }
-    sdrm_f2 *d_row = nullptr;
-    if (hipMalloc((void **) &d_row, sizeof(sdrm_f2) * longest) != hipSuccess) {
-        return 0;  // no room for the row: keep the starting point
-    }
-    int code = 0;
-    auto t_start = std::chrono::steady_clock::now();
-    if (hipMemcpy(d_row, row.data(), sizeof(sdrm_f2) * longest, hipMemcpyHostToDevice) != hipSuccess) {
-        code = -EIO;
-    }
-    // ms per call of the batch as it is set up now: `warm` calls to fill the pipeline, then `timed` calls between two waits
-    int timed = 5;  // raised below so that a measurement lasts >= ~4 ms: short calls are launch-bound and noisy
-    auto measure = [&](double *ms) -> int {
-        const int warm = 3;
-        for (int k = 0; k < warm; k++) {
-            int c2 = enqueue_call(b, d_row, 0, lens.data(), b->stream, nullptr, 0);
-            if (c2 != 0) return c2;
-        }
-        int c2 = wait_for_all_calls(b);
-        if (c2 != 0) return c2;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int k = 0; k < timed; k++) {
-            c2 = enqueue_call(b, d_row, 0, lens.data(), b->stream, nullptr, 0);
-            if (c2 != 0) return c2;
-        }
-        c2 = wait_for_all_calls(b);
-        *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
-        return c2;
-    };
-    double best = 0.0;
-    code = code ? code : measure(&best);  // first pass: also pays the kernels' first-launch costs
-    if (code == 0 && best > 0.0 && best * timed < 4.0) {
-        timed = std::min(64, (int) ceil(4.0 / best));
-    }
-    code = code ? code : measure(&best);
-    const double before = best;
-    const double margin = 0.97;  // a candidate replaces the incumbent only when it is more than 3 % faster
-    // (1) the clock stage's workgroup shape
-    if (code == 0 && !sdrm::k3_shape_is_forced() && b->plan.clock_carried_max <= 128 && C >= 512) {
-        const int shapes[3][3] = {{16, 1024, 0}, {32, 512, 0}, {64, 256, 1}};
-        const sdrm_k3_shape cur = sdrm_k3_shape_for((int) C, 0, 0, 0, (int) b->plan.clock_carried_max);
-        int keep[3] = {cur.lanes, cur.ring, cur.plain};
-        for (const auto &sh : shapes) {
-            if (sh[0] == cur.lanes && sh[1] == cur.ring && sh[2] == cur.plain) {
-                continue;
-            }
-            b->dev.k3_lanes = sh[0];
-            b->dev.k3_ring = sh[1];
-            b->dev.k3_plain = sh[2];
-            double ms = 0.0;
-            code = measure(&ms);
-            if (code != 0) {
-                break;
-            }
-            if (ms < best * margin) {
-                best = ms;
-                keep[0] = sh[0];
-                keep[1] = sh[1];
-                keep[2] = sh[2];
-            }
-        }
-        b->dev.k3_lanes = keep[0];
-        b->dev.k3_ring = keep[1];
-        b->dev.k3_plain = keep[2];
-    }
-    // (2) the front-end's hold for the clock stage's placement
-    if (code == 0 && !sdrm::front_hold_is_forced() && C >= 256) {
-        const bool was = b->hold_front;
-        b->hold_front = !was;
-        double ms = 0.0;
-        code = measure(&ms);
-        if (code == 0 && ms < best * margin) {
-            best = ms;
-        } else {
-            b->hold_front = was;
-        }
-    }
-    // (3) the companion grid beside the clock stage
-    if (code == 0 && getenv("SDRM_K3_COMPANY") == nullptr && C <= 2048) {
-        const int was = b->company_blocks;
-        b->company_blocks = was > 0 ? 0 : b->company_grid;
-        double ms = 0.0;
-        code = measure(&ms);
-        if (code == 0 && ms < best * margin) {
-            best = ms;
-        } else {
-            b->company_blocks = was;
-        }
-    }
-    if (code == 0) {
-        code = reset_all_streams(b);
-    }
-    (void) hipFree(d_row);
-    b->calibrated = code == 0;
-    b->calib_ms[0] = (float) before;
-    b->calib_ms[1] = (float) best;
-    b->calib_ms[2] = (float) std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    if (getenv("SDRM_AUTOTUNE_LOG") != nullptr) {
-        const sdrm_k3_shape sh = sdrm_k3_shape_for((int) C, b->dev.k3_lanes, b->dev.k3_ring, b->dev.k3_plain, (int) b->plan.clock_carried_max);
-        fprintf(stderr, "sdrmodem_hip: calibrated %zu channels in %.0f ms: %.3f -> %.3f ms per call; clock stage %dx%d%s, front hold %s, "
-                        "companion grid %d\n", C, b->calib_ms[2], before, best, sh.lanes, sh.ring, sh.plain ? "p" : "",
-                b->hold_front ? "on" : "off", b->company_blocks);
-    }
-    return code;
 }
 
 extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels, int device, uint32_t flags,
@@ -874,7 +555,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         batch_free(b);
         return code;
     }
-    code = calibrate(b, cfgs);
+    code = sdrm_calibrate(b, cfgs);
     if (code != 0) {
         batch_free(b);
         return code;
@@ -1293,249 +974,6 @@ extern "C" int sdrm_batch_set_pre_offset(sdrm_batch *b, size_t channel, int64_t 
     return 0;
 }
 
-// ---- online refinement of the schedule for calls the calibration did not cover ---------------------------------------
-// Why: the NCO stages are a fourth pipeline stage (a dependent chain as long as the clock stage's in BASELINE configs[4]'s mix);
-// what the creation-time calibration found best without them (there: front hold on, companion grid on, -14 %) cost that
-// workload 9 % (profiles/r04_config5_schedule.txt).  Calls of less than half the calibrated length are the second class it does
-// not cover (the companion grid cost 4096-sample calls 14 % at 256 channels in round 3).  The streams hold the caller's state by
-// then, so nothing can be replayed -- but front hold and companion grid may change between any two calls without touching a
-// result.  So, on the caller's own calls, from the 17th call of such a class on:
-//   1. the starting point's steady state: 40 calls, the median of the last 32 completion-to-completion intervals of the clock stage;
-//   2. four settings for eight calls each (the median of the last five intervals), then the starting point and the winner again:
-//      a winner must win both rounds by more than 3 %;
-//   3. the winner's probation: 40 calls like (1); it stays only if its steady state beats (1) by more than 3 % -- a block of
-//      eight calls can flatter a setting whose cost builds up over tens of calls (seen: 1.05 ms per call in its blocks, 2.9 in
-//      the steady state, profiles/r04_online_refinement.txt);
-//   4. a standing guard: every 64th call of the class starts a five-interval sample; two bad samples in a row (5 % behind (1)) give
-//      the starting point back for good.
-// Medians, because the host may stall between two calls (the HIP runtime grows its pools 6 ms at a time during a process's first
-// dozens of calls) and the device then idles for reasons no setting is to blame for.  The winner serves calls of its class (same
-// NCO flag, total length within a factor of two), other calls keep the calibrated setting.  Results do not depend on any of it.
-#define SDRM_TUNE_SKIP 3   // calls of a block before its first timed completion (the pipeline holds three calls)
-#define SDRM_TUNE_TIMED 5  // completion-to-completion intervals per block (ev[][TIMED + 1])
-#define SDRM_WATCH_SKIP 8
-#define SDRM_WATCH_TIMED 32
-static void online_tune_apply(sdrm_batch_t *b, int cand) {
-    b->hold_front = (cand & 1) ? !b->tune.base_hold : b->tune.base_hold;
-    b->company_blocks = (cand & 2) ? (b->tune.base_company > 0 ? 0 : b->company_grid) : b->tune.base_company;
-}
-static void online_tune_settle(sdrm_batch_t *b, int cand) {
-    online_tune_apply(b, cand);
-    b->tune.chosen = cand;
-    b->tune.state = 2;
-    if (getenv("SDRM_AUTOTUNE_LOG") != nullptr) {
-        const float *ms = b->tune.ms;
-        fprintf(stderr, "sdrmodem_hip: refined online for calls %s NCO batches, %llu samples per call: steady %.3f ms per call; %.3f / %.3f / "
-                        "%.3f / %.3f (as is, hold toggled, companion grid toggled, both), again %.3f as is / %.3f the winner, the winner's "
-                        "steady state %.3f; front hold %s, companion grid %d\n",
-                b->tune.nco ? "with" : "without", (unsigned long long) b->tune.sig, ms[6], ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[7],
-                b->hold_front ? "on" : "off", b->company_blocks);
-    }
-}
-// what the creation-time calibration measured: full-length calls without NCO batches
-static uint64_t full_length_samples(const sdrm_batch_t *b) {
-    uint64_t n = 0;
-    for (const sdrm_chan_params &p : b->plan.params) {
-        n += p.max_len;
-    }
-    return n;
-}
-// median of the intervals between n + 1 consecutive completion events
-static bool median_interval(const hipEvent_t *ev, int n, float *out) {
-    float iv[SDRM_WATCH_TIMED];
-    for (int j = 0; j < n; j++) {
-        if (hipEventElapsedTime(&iv[j], ev[j], ev[j + 1]) != hipSuccess) {
-            return false;
-        }
-    }
-    std::sort(iv, iv + n);
-    *out = iv[n / 2];
-    return true;
-}
-static void online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
-    sdrm_batch_t::OnlineTune &t = b->tune;
-    if (t.state == 2) {
-        if (t.chosen < 0) {
-            return;  // never measured (switched off, forced, small batch): the batch's settings stand
-        }
-        // settled: the refined setting serves the class of calls it was measured on, the calibrated one everything else
-        const bool alike = t.chosen > 0 && with_nco == t.nco && sig * 2 >= t.sig && sig <= t.sig * 2;
-        if (t.guard_pending && hipEventQuery(t.ev[0][SDRM_TUNE_TIMED]) == hipSuccess) {
-            t.guard_pending = false;
-            float ms = 0.0f;
-            if (t.chosen > 0 && median_interval(t.ev[0], SDRM_TUNE_TIMED, &ms) && ms > t.ms[6] * 1.05f) {
-                if (++t.guard_bad >= 2) {
-                    if (getenv("SDRM_AUTOTUNE_LOG") != nullptr) {
-                        fprintf(stderr, "sdrmodem_hip: the refined setting fell behind (%.3f ms per call, the starting point's steady state was "
-                                        "%.3f): the starting point is back\n", ms, t.ms[6]);
-                    }
-                    t.chosen = 0;
-                }
-            } else {
-                t.guard_bad = 0;
-            }
-        }
-        t.guard_alike = alike && sig == t.sig;
-        online_tune_apply(b, alike ? t.chosen : 0);
-        return;
-    }
-    if (t.state == 0) {
-        // calls the calibration did not cover: Doppler correction (a fourth stage), or less than half its length
-        if (!with_nco && sig * 2 > full_length_samples(b)) {
-            return;
-        }
-        const char *env = getenv("SDRM_AUTOTUNE");  // read per batch, like the calibration does
-        if (b->serial || b->clock_early || b->plan.design.size() < 32 || (env != nullptr && atoi(env) == 0) || b->n_gen > 0 ||
-            sdrm::front_hold_is_forced() || getenv("SDRM_K3_COMPANY") != nullptr) {
-            t.state = 2;
-            return;
-        }
-        if (b->calls < 16 || sig == 0) {
-            return;
-        }
-        bool ok = true;
-        for (auto &row : t.ev) {
-            for (hipEvent_t &e : row) {
-                ok = ok && hipEventCreate(&e) == hipSuccess;
-            }
-        }
-        for (auto &row : t.watch) {
-            for (hipEvent_t &e : row) {
-                ok = ok && hipEventCreate(&e) == hipSuccess;
-            }
-        }
-        if (!ok) {
-            t.state = 2;
-            return;
-        }
-        t.base_hold = b->hold_front;
-        t.base_company = b->company_blocks;
-        t.sig = sig;
-        t.nco = with_nco;
-        t.phase = 1;
-        t.cand = 0;
-        t.n = 0;
-        t.state = 1;
-    }
-    if (with_nco != t.nco || sig != t.sig) {
-        online_tune_settle(b, 0);  // the calls stopped looking alike: nothing to compare, the starting point stays
-        return;
-    }
-    t.idle = false;
-    if (t.phase == 1) {
-        online_tune_apply(b, 0);
-        return;
-    }
-    if (t.phase == 3) {
-        online_tune_apply(b, t.best);
-        if (t.n < SDRM_WATCH_SKIP + SDRM_WATCH_TIMED) {
-            return;
-        }
-        t.idle = true;  // every call of the probation is enqueued: the winner stays on until their completions are in
-        if (hipEventQuery(t.watch[1][SDRM_WATCH_TIMED]) != hipSuccess) {
-            return;
-        }
-        const bool ok = median_interval(t.watch[1], SDRM_WATCH_TIMED, &t.ms[7]);
-        online_tune_settle(b, ok && t.ms[7] < t.ms[6] * 0.97f ? t.best : 0);
-        return;
-    }
-    // phase 2: the blocks
-    if (t.cand == 5 && t.best < 0) {
-        // the first round is enqueued (blocks 0-3, then the starting point again as block 4): its winner runs again as block 5
-        if (hipEventQuery(t.ev[3][SDRM_TUNE_TIMED]) != hipSuccess) {
-            online_tune_apply(b, 0);
-            t.idle = true;
-            return;
-        }
-        int best = 0;
-        for (int k = 0; k < 4; k++) {
-            if (!median_interval(t.ev[k], SDRM_TUNE_TIMED, &t.ms[k])) {
-                online_tune_settle(b, 0);
-                return;
-            }
-            best = t.ms[k] < t.ms[best] ? k : best;
-        }
-        if (!median_interval(t.watch[0], SDRM_WATCH_TIMED, &t.ms[6]) || best == 0 || t.ms[best] >= t.ms[0] * 0.97f) {
-            online_tune_settle(b, 0);
-            return;
-        }
-        t.best = best;
-    }
-    if (t.cand < 4) {
-        online_tune_apply(b, t.cand);
-    } else if (t.cand == 4) {
-        online_tune_apply(b, 0);
-    } else if (t.cand == 5) {
-        online_tune_apply(b, t.best);
-    } else {
-        // both rounds are enqueued: the starting point until the second round's completions are in
-        online_tune_apply(b, 0);
-        t.idle = true;
-        if (hipEventQuery(t.ev[5][SDRM_TUNE_TIMED]) != hipSuccess) {
-            return;
-        }
-        const bool ok = median_interval(t.ev[4], SDRM_TUNE_TIMED, &t.ms[4]) && median_interval(t.ev[5], SDRM_TUNE_TIMED, &t.ms[5]);
-        if (!ok || t.ms[5] >= t.ms[4] * 0.97f) {
-            online_tune_settle(b, 0);
-            return;
-        }
-        t.phase = 3;  // the winner's probation starts with this call
-        t.n = 0;
-        t.idle = false;
-        online_tune_apply(b, t.best);
-    }
-}
-static void online_tune_after(sdrm_batch_t *b, hipStream_t s_clock) {
-    sdrm_batch_t::OnlineTune &t = b->tune;
-    if (t.state == 2 && t.chosen > 0) {
-        // the guard's samples (see OnlineTune): calls 64 + SKIP .. 64 + SKIP + TIMED of a run of like calls
-        if (!t.guard_alike) {
-            t.guard_n = 0;
-            return;
-        }
-        t.guard_n++;
-        const int k = t.guard_n - 64;
-        if (k >= SDRM_TUNE_SKIP && k <= SDRM_TUNE_SKIP + SDRM_TUNE_TIMED && !t.guard_pending) {
-            (void) hipEventRecord(t.ev[0][k - SDRM_TUNE_SKIP], s_clock);
-        }
-        if (k == SDRM_TUNE_SKIP + SDRM_TUNE_TIMED) {
-            t.guard_pending = true;
-            t.guard_n = 0;
-        }
-        return;
-    }
-    if (t.state != 1 || t.idle) {
-        return;
-    }
-    if (t.phase == 1 || t.phase == 3) {
-        hipEvent_t *w = t.watch[t.phase == 1 ? 0 : 1];
-        if (t.n >= SDRM_WATCH_SKIP + SDRM_WATCH_TIMED) {
-            return;
-        }
-        t.n++;
-        if (t.n >= SDRM_WATCH_SKIP) {
-            (void) hipEventRecord(w[t.n - SDRM_WATCH_SKIP], s_clock);
-        }
-        if (t.n == SDRM_WATCH_SKIP + SDRM_WATCH_TIMED && t.phase == 1) {
-            t.phase = 2;
-            t.cand = 0;
-            t.n = 0;
-        }
-        return;
-    }
-    if (t.cand >= 6) {
-        return;
-    }
-    t.n++;
-    if (t.n >= SDRM_TUNE_SKIP) {
-        (void) hipEventRecord(t.ev[t.cand][t.n - SDRM_TUNE_SKIP], s_clock);
-    }
-    if (t.n == SDRM_TUNE_SKIP + SDRM_TUNE_TIMED) {
-        t.cand++;
-        t.n = 0;
-    }
-}
-
 static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
                         const sdrm_nco_segment *segs, size_t n_segs) {
     const size_t C = b->plan.design.size();
@@ -1605,7 +1043,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         for (size_t c = 0; c < C; c++) {
             sig += h[c].n_in;
         }
-        online_tune_before(b, with_nco || with_pre, sig);
+        sdrm_online_tune_before(b, with_nco || with_pre, sig);
     }
     d.nco_segs = with_nco ? b->d_nco_segs + (size_t) slot * b->nco_seg_cap : nullptr;
     d.nco_phase_state = b->d_nco_state;
@@ -1719,11 +1157,6 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         }
     }
     d.placed = b->d_placed;
-    int dc_first_us = 0;
-    if (!b->serial && i >= 1 && d.any_dc && sdrm::front_waits_for_dc_start((int) C, &dc_first_us)) {
-        // the previous call's DC stage (released by the end of its front-end, i.e. now) places its workgroups first
-        sdrm::launch_hold_until(b->d_placed + 0, b->k2_placed_target, dc_first_us, b->s_front);
-    }
     if (!b->serial && i >= 3 && b->hold_front) {
         // let the clock stage of call i-2 (released by the end of call i-3's) take its CUs before this grid floods the chip
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[(i + SDRM_CTL_SLOTS - 3) % SDRM_CTL_SLOTS], 0));
@@ -1783,10 +1216,6 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         HIP_TRY(hipStreamWaitEvent(s_dc, hand ? b->ev_ctl[slot] : b->ev_front[slot], 0));
         if (have_prev2) {
             HIP_TRY(hipStreamWaitEvent(s_dc, b->slot_done[prev2], 0));
-        }
-        if (!b->serial && have_prev2 && sdrm::dc_waits_for_clock_start(d)) {
-            // many channels: the clock stage of call i-1, released by the same event (the end of call i-2's), takes its CUs first
-            sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_after[(i + SDRM_CTL_SLOTS - 1) % SDRM_CTL_SLOTS], 200, s_dc);
         }
         b->k2_placed_target += sdrm::dc_workgroups(d);
         if (b->timing) {
@@ -1866,7 +1295,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         }
     }
     HIP_TRY(hipEventRecord(b->slot_done[slot], s_clock));
-    online_tune_after(b, s_clock);
+    sdrm_online_tune_after(b, s_clock);
     b->slot_used[slot] = true;
     b->last_slot = slot;
     b->calls++;

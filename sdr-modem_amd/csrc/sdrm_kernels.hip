@@ -495,28 +495,9 @@ bool front_waits_for_clock_start(int n_channels) {
     }
     return n_channels >= lo && n_channels <= hi;
 }
-// The next front-end can wait for the DC stage's placement.  Rounds 1-2 needed that from 1536 channels on (4096 channels:
-// 9.7 -> 8.9 ms per call); since the clock stage of large batches takes the plain ring (75 KB: its workgroups no longer
-// wait for whole CUs, and the DC grid finds room beside them) it changes nothing between 1536 and 4096 channels at 32768-
-// and 131072-sample calls (profiles/r03_dcfirst.txt) and costs up to 8 % when the DC stage is not yet released and the
-// wait runs into its bound.  Off by default; SDRM_DC_FIRST="channels,max_us" switches it on from that many channels.
-bool front_waits_for_dc_start(int n_channels, int *max_us) {
-    static const char *e = getenv("SDRM_DC_FIRST");
-    int lo = 0, n = 100;
-    if (e != nullptr) {
-        sscanf(e, "%d,%d", &lo, &n);
-    }
-    *max_us = n;
-    return lo > 0 && n_channels >= lo;
-}
-// The DC stage can wait for the clock stage's placement (rounds 1-2: from 2048 channels on, so that the clock stage released
-// by the same event got its CUs first).  With the plain-ring clock stage it makes no measurable difference between 1536
-// and 4096 channels (profiles/r03_dchold.txt): off by default, SDRM_DC_HOLD=<channels> switches it on from there.
-bool dc_waits_for_clock_start(const DeviceBatch &b) {
-    static const char *e = getenv("SDRM_DC_HOLD");
-    const int lo = e != nullptr ? atoi(e) : 0;
-    return b.any_dc && lo > 0 && b.n_channels >= lo;
-}
+// (Rounds 1-3 also had the front-end wait for the DC stage's placement and the DC stage for the clock stage's -- SDRM_DC_FIRST,
+// SDRM_DC_HOLD.  Measured useless since the clock stage of large batches takes the plain ring, profiles/r03_dcfirst.txt and
+// r03_dchold.txt; removed in round 5.)
 
 // DC blocker: design in sdrm_kernels.h (K2).  Workgroup = dc_group channels (16 unless long boxcars need the LDS), six
 // waves: 0 chain, 1 feeder, 2..4 stage s -> s+1, 5 output.  Iteration `it` (one barrier each): the chain wave sums block

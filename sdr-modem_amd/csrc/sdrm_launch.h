@@ -92,8 +92,6 @@ bool front_waits_for_clock_start(int n_channels);
 sdrm_k3_shape describe_shape(const DeviceBatch &b);  // the clock-stage shape the next launch takes
 bool front_hold_is_forced();      // SDRM_FRONT_HOLD is set: measurements, not to be re-decided by the batch's calibration
 bool k3_shape_is_forced();        // SDRM_K3_LANES likewise
-bool front_waits_for_dc_start(int n_channels, int *max_us);
-bool dc_waits_for_clock_start(const DeviceBatch &b);
 void launch_hold_until(const uint32_t *counter, uint32_t target, int max_us, hipStream_t s);
 unsigned dc_workgroups(const DeviceBatch &b);
 
