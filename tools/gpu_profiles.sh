@@ -21,9 +21,9 @@ for ch in 1024 4096; do
 done
 echo "== config5 under rocprofv3"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/config5_stats -- python3 $R/tools/config5.py 256 > $OUT/config5.txt 2>&1; echo "exit $?"
-pmc() { # tag channels name counters...
+pmc() { # tag channels name counters...   (stage_times.py waits for every call: without the in-call hand-off the stages run one after the other)
   tag=$1; ch=$2; name=$3; shift 3
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${tag}_$name -- python3 $R/tools/stage_times.py $ch > $OUT/pmc_${tag}_$name.log 2>&1
+  SDRM_HANDOFF=0 timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${tag}_$name -- python3 $R/tools/stage_times.py $ch > $OUT/pmc_${tag}_$name.log 2>&1
   echo "pmc $tag $name exit $?"
 }
 for ch in 256 4096; do
