@@ -472,7 +472,22 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
             b->company_grid = blocks;
         }
         // the side stream and its event exist whether the grid starts switched on or not: the calibration may switch it
-        e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
+        // SDRM_K3_COMPANY_CUMASK=<hex words, low first, comma separated> (measurements: profiles/r05_company_mechanism.txt) confines the
+        // companion grid to a set of CUs -- bit i = CU i / 8 of XCD i % 8 (tools/cumask_probe.hip)
+        if (const char *mask_env = getenv("SDRM_K3_COMPANY_CUMASK")) {
+            std::vector<uint32_t> words;
+            for (const char *p = mask_env; *p;) {
+                char *end = nullptr;
+                words.push_back((uint32_t) strtoul(p, &end, 16));
+                p = (*end == ',') ? end + 1 : end;
+                if (end == p && *end != ',') {
+                    break;
+                }
+            }
+            e = e ? e : hipExtStreamCreateWithCUMask(&b->s_company, (uint32_t) words.size(), words.data());
+        } else {
+            e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
+        }
         e = e ? e : hipEventCreateWithFlags(&b->ev_company, hipEventDisableTiming);
         b->hold_front = sdrm::front_waits_for_clock_start((int) n_channels);
         // The next call's clock stage resident early -- OPT-IN: SDRM_K3_EARLY=<channels> switches it on for batches of up
