@@ -1773,8 +1773,11 @@ static int issue_copy_back(sdrm_batch_t *b, uint64_t k) {
     hipStream_t back = b->s_dc;
     HIP_TRY(hipStreamWaitEvent(back, b->slot_done[b->back_slot[set]], 0));
     HIP_TRY(hipMemcpyAsync(b->h_reslen[set], outlen_of(b, k), sizeof(uint32_t) * C, hipMemcpyDeviceToHost, back));
-    HIP_TRY(hipMemcpy2DAsync(b->h_res8[set], b->dev.out_stride, out8_of(b, k), b->dev.out_stride, b->back_width[set], C,
-                             hipMemcpyDeviceToHost, back));
+    if (b->back_rows[set] > 0 && b->back_width[set] > 0) {
+        const size_t at = (size_t) b->back_first[set] * b->dev.out_stride;
+        HIP_TRY(hipMemcpy2DAsync(b->h_res8[set] + at, b->dev.out_stride, out8_of(b, k) + at, b->dev.out_stride, b->back_width[set],
+                                 b->back_rows[set], hipMemcpyDeviceToHost, back));
+    }
     HIP_TRY(hipEventRecord(b->ev_res[set], back));
     HIP_TRY(hipEventRecord(b->ev_out_free[par], back));
     b->out_busy[par] = true;
@@ -1792,6 +1795,15 @@ extern "C" int sdrm_batch_arena(sdrm_batch *b, size_t slots, sdrm_cf32 **base, s
     const size_t slot_samples = C * (size_t) b->in_stride;
     if (b->h_arena == nullptr) {
         HIP_TRY(hipDeviceSynchronize());  // the output-set switch below must not race a running call
+        // No companion grid on the pipelined host path (unless SDRM_K3_COMPANY asks for one): with a copy stream and a copy-back
+        // among the batch's streams the hardware queues are shared, and a grid that lives as long as the clock stage holds back
+        // whatever lands on its queue -- a sparse 512-slot batcher ran 4.3 instead of 3.0 ms per round with it (3 live clients;
+        // 5.5 instead of 3.5 with BASELINE configs[4]'s mix), a full one is bound by the host link either way
+        // (profiles/r05_node_schedule.txt).  The calibration at creation timed device-resident calls: it cannot see this.
+        if (getenv("SDRM_K3_COMPANY") == nullptr) {
+            b->company_blocks = 0;
+            b->company_grid = 0;
+        }
         int code = 0;
         for (int i = 0; i < 2 && code == 0; i++) {
             code = dev_alloc_zero(&b->d_in_ring[i], slot_samples);
@@ -1847,20 +1859,37 @@ extern "C" int sdrm_batch_submit(sdrm_batch *b, size_t slot, const size_t *input
     if (k >= 2 && b->slot_used[(k - 2) % SDRM_CTL_SLOTS]) {
         HIP_TRY(hipStreamWaitEvent(b->s_h2d, b->ev_front[(k - 2) % SDRM_CTL_SLOTS], 0));
     }
-    size_t longest = 0;
-    for (size_t c = 0; c < C; c++) {
-        if (input_lens[c] <= b->plan.params[c].max_len) {
-            longest = std::max(longest, input_lens[c]);
-        }
-    }
+    // Only the rows of channels that take part travel: a server's batcher is sized for its busiest hour, and a call of 3 live
+    // clients on 512 slots used to copy all 512 rows (537 MB, 10 ms per round -- profiles/r05_node_schedule.txt).  Runs of rows
+    // (gaps of up to 7 absent channels stay inside a run: one copy costs ~5 us to issue), at most 16 copies per call.
     const sdrm_f2 *src = b->h_arena + slot * C * (size_t) b->in_stride;
-    if (longest == b->in_stride) {
-        HIP_TRY(hipMemcpyAsync(b->d_in_ring[par], src, C * (size_t) b->in_stride * sizeof(sdrm_f2), hipMemcpyHostToDevice,
-                               b->s_h2d));
-    } else if (longest > 0) {
-        HIP_TRY(hipMemcpy2DAsync(b->d_in_ring[par], (size_t) b->in_stride * sizeof(sdrm_f2), src,
-                                 (size_t) b->in_stride * sizeof(sdrm_f2), longest * sizeof(sdrm_f2), C, hipMemcpyHostToDevice,
-                                 b->s_h2d));
+    auto takes_part = [&](size_t c) { return input_lens[c] != SDRM_LEN_ABSENT && input_lens[c] > 0 && input_lens[c] <= b->plan.params[c].max_len; };
+    size_t first_present = C, last_present = 0, runs = 0;
+    for (size_t c = 0; c < C;) {
+        if (!takes_part(c)) {
+            c++;
+            continue;
+        }
+        size_t end = c + 1, last = c, longest = input_lens[c];
+        while (end < C && (end - last <= 8 || runs >= 15)) {
+            if (takes_part(end)) {
+                last = end;
+                longest = std::max(longest, input_lens[end]);
+            }
+            end++;
+        }
+        const size_t rows = last - c + 1;
+        const size_t at = c * (size_t) b->in_stride;
+        if (longest == b->in_stride) {
+            HIP_TRY(hipMemcpyAsync(b->d_in_ring[par] + at, src + at, rows * (size_t) b->in_stride * sizeof(sdrm_f2), hipMemcpyHostToDevice, b->s_h2d));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(b->d_in_ring[par] + at, (size_t) b->in_stride * sizeof(sdrm_f2), src + at,
+                                     (size_t) b->in_stride * sizeof(sdrm_f2), longest * sizeof(sdrm_f2), rows, hipMemcpyHostToDevice, b->s_h2d));
+        }
+        first_present = std::min(first_present, c);
+        last_present = std::max(last_present, last);
+        runs++;
+        c = last + 1;
     }
     int code = enqueue_call(b, b->d_in_ring[par], b->in_stride, input_lens, b->s_h2d, segments, n_segments);
     if (code != 0) {
@@ -1879,6 +1908,17 @@ extern "C" int sdrm_batch_submit(sdrm_batch *b, size_t slot, const size_t *input
     width = std::min<uint32_t>((width + 63u) & ~63u, b->dev.out_stride);
     b->back_width[k % SDRM_RES_SETS] = width;
     b->back_slot[k % SDRM_RES_SETS] = b->last_slot;
+    // soft bits come back for the span of channels that may have produced some: those that took part, and -- an empty call is
+    // answered from the carried samples (at >= 8 samples per symbol) -- those with a length of 0
+    size_t lo = first_present, hi = last_present;
+    for (size_t c = 0; c < C; c++) {
+        if (input_lens[c] == 0) {
+            lo = std::min(lo, c);
+            hi = std::max(hi, c);
+        }
+    }
+    b->back_first[k % SDRM_RES_SETS] = (uint32_t) (lo < C ? lo : 0);
+    b->back_rows[k % SDRM_RES_SETS] = (uint32_t) (lo < C ? hi - lo + 1 : 0);
     // the previous call's copy-back goes in now, BEHIND this call's DC stage (see issue_copy_back)
     if (b->back_pending) {
         code = issue_copy_back(b, k - 1);

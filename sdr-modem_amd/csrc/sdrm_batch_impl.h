@@ -190,6 +190,7 @@ struct sdrm_batch_t {
     bool out_busy[2] = {false, false};
     uint32_t res_width[SDRM_RES_SETS] = {};  // bytes per channel copied back for that call
     uint32_t back_width[SDRM_RES_SETS] = {};
+    uint32_t back_first[SDRM_RES_SETS] = {}, back_rows[SDRM_RES_SETS] = {};  // the span of channels that took part in that call
     int back_slot[SDRM_RES_SETS] = {};
     bool back_pending = false;               // the newest submitted call's copy-back is not enqueued yet
     uint64_t submitted = 0, collected = 0;

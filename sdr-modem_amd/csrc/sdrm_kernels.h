@@ -883,7 +883,29 @@ struct sdrm_k2_slot {
     uint32_t nz;         // samples of this call
     uint32_t HX;         // 2 (L - 1): samples of x carried between calls
     float Lf, invL;
+    int alias;           // 1: a REPLICA of another slot of the group (sdrm_k2_fill_aliases): computes the same, saves nothing
 };
+
+// A slot of the group without a channel in this call (a batcher slot without a buffer this round, or waiting for a client)
+// becomes a replica of the group's longest live slot: it computes exactly what that slot computes -- same channel, same state
+// read at the start, same stores of the same values -- so that the group's waves keep their straight-line code, which needs
+// every lane to have a channel (a 512-slot batcher with 3 live clients ran its DC stage in 2.6 ms instead of 1.16:
+// profiles/r05_node_schedule.txt).  What a replica must NOT do is save state that its original reads while saving (the carried
+// samples of x): the savers skip replicas.  Slots at or beyond n_use (the group's ring space) stay empty.
+SDRM_HD void sdrm_k2_fill_aliases(sdrm_k2_slot *slots, int n_use) {
+    int best = -1;
+    for (int i = 0; i < n_use; i++) {
+        if (slots[i].chan >= 0 && (best < 0 || slots[i].nz > slots[best].nz)) {
+            best = i;
+        }
+    }
+    for (int i = 0; i < n_use && best >= 0; i++) {
+        if (slots[i].chan < 0) {
+            slots[i] = slots[best];
+            slots[i].alias = 1;
+        }
+    }
+}
 
 // DC state of a channel in global memory: hx[hx_cap] (the last 2(L-1) samples of x, oldest first, at the FRONT of the
 // array), three tails of l_cap floats (the last L quotients of stages 0..2, oldest first), four running sums
@@ -895,6 +917,7 @@ SDRM_HD size_t sdrm_k2_state_floats(uint32_t hx_cap, uint32_t l_cap) { return (s
 SDRM_HD uint32_t sdrm_k2_ring_pitch(uint32_t rcap_max) { return rcap_max + SDRM_K2_MIRROR + 4; }
 
 SDRM_HD void sdrm_k2_slot_setup(sdrm_k2_slot &s, int chan, const sdrm_chan_params &p, uint32_t nz) {
+    s.alias = 0;
     s.chan = chan;
     s.L = p.dc_len;
     s.A = (p.dc_len + SDRM_K2_BLK - 1) / SDRM_K2_BLK * SDRM_K2_BLK;

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     if (tid < SDRM_K2_SLOTS) {
         sdrm_k2_slot s;
         s.chan = -1;
-        s.L = 1; s.A = 64; s.rcap = 128; s.nz = 0; s.HX = 0; s.Lf = 1.0f; s.invL = 1.0f;
+        s.L = 1; s.A = 64; s.rcap = 128; s.nz = 0; s.HX = 0; s.Lf = 1.0f; s.invL = 1.0f; s.alias = 0;
         const int c = c0 + tid;
         if (tid < b.dc_group && c < b.n_channels) {
             const sdrm_chan_params p = b.params[c];
@@ -692,6 +692,10 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     if (nb == 0) {
         return;  // nothing to do for any channel of the group: states stay as they are
     }
+    if (tid == 0) {
+        sdrm_k2_fill_aliases(slots, (int) b.dc_group);  // empty slots beside live ones: replicas, so that every lane has a channel
+    }
+    __syncthreads();
     // roles: wave 0 = chain; then WPR waves each of feeder, stage 0, 1, 2, output; a helper wave covers P slots
     const int role = wave == 0 ? 0 : 1 + (wave - 1) / SDRM_K2_WPR;      // 0 chain, 1 feeder, 2..4 stage (role - 2), 5 output
     const int sub = wave == 0 ? 0 : (wave - 1) % SDRM_K2_WPR;
@@ -1296,14 +1300,14 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     // ---- state back: running sums, ring tails, carried samples of x
     if (role == 0) {
         const sdrm_k2_slot s = slots[lane & (SDRM_K2_SLOTS - 1)];
-        if (s.chan >= 0) {
+        if (s.chan >= 0 && !s.alias) {
             sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4] = acc;
         }
     } else if (role >= 2 && role <= 4) {
         for (int i = 0; i < SDRM_K2_P; i++) {
             const int sl = sub * SDRM_K2_P + i;
             const sdrm_k2_slot s = slots[sl];
-            if (sl < b.dc_group && s.chan >= 0) {
+            if (sl < b.dc_group && s.chan >= 0 && !s.alias) {
                 float *st = b.dc_state + b.params[s.chan].dc_state_off;
                 sdrm_k2_ring_save(rings + ((size_t) (role - 2) * b.dc_group + sl) * rpitch, s,
                                   sdrm_k2_state_tail(st, role - 2, b.dc_hx_cap, b.dc_l_cap), lane, 64);
@@ -1314,7 +1318,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         // NaN/Inf: the clock stage takes its general (NaN-aware) symbol for this channel; beyond the tame amplitude
         // (sdrm_kernels.h "wild channels"; an Inf raises both): it runs the channel's call from global memory
         const uint32_t bits = (odd ? SDRM_FLAG_NONFINITE : 0u) | (!(amax < sdrm_tame_level(b.params[L.s.chan], true)) ? SDRM_FLAG_WILD : 0u);
-        if (bits) {
+        if (bits && !HAND) {  // (with the hand-off every block has raised its own, and the clock stage may have consumed and cleared them)
             atomicOr(b.nonfinite + L.s.chan, bits);
         }
         if (HAND) {  // the last block (and those flags) are out: the channel's count reaches its end
@@ -1331,7 +1335,7 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     // overlaps the old one shifted by nz, so every round reads before anybody writes (and later rounds read further up)
     for (int sl = 0; sl < b.dc_group; sl++) {
         const sdrm_k2_slot s = slots[sl];
-        if (s.chan < 0 || s.nz == 0) {
+        if (s.chan < 0 || s.nz == 0 || s.alias) {
             continue;
         }
         float *hx = b.dc_state + b.params[s.chan].dc_state_off;
@@ -1711,8 +1715,13 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
                 }
             }
         }
-        nz_sh[lane] = L.nz;
-        dc_sh[lane] = uses_dc;
+        // A channel that takes no part in the call (absent: a batcher slot without a buffer this round, or waiting for a client;
+        // generic) says -1: it does not decide how the workgroup's blocks are staged -- its row is staged along with the others
+        // (allocated memory, whatever it holds, into the ring of a lane that never steps) so that the live channels beside it keep
+        // the unpredicated path (a 512-slot batcher with 3 live clients ran its clock stage in 3.8 ms instead of 2.5:
+        // profiles/r05_node_schedule.txt)
+        nz_sh[lane] = absent ? -1 : L.nz;
+        dc_sh[lane] = (active && absent) ? (int) (b.params[c].dc_len != 0) : uses_dc;
         flag_sh[lane] = 0;
     }
     __shared__ unsigned hw_sh;  // diagnostics: where the producer wave runs (HW_ID: SIMD in bits 5:4, CU 11:8, SE 15:13)
@@ -1729,9 +1738,13 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     for (int r = 0; r < nrows; r++) {
         int v = __builtin_amdgcn_readlane(my_nz, r);
         max_nz = v > max_nz ? v : max_nz;
-        min_nz = v < min_nz ? v : min_nz;
+        min_nz = (v >= 0 && v < min_nz) ? v : min_nz;  // (-1: the row takes no part)
     }
+    // ... up to the end of the LONGEST row: a row that has ended (a mixed-rate batch: 131072 / 26214 / 16384 samples per call side by
+    // side) is staged on with whatever its memory holds -- the rows are z_stride long -- into a ring whose lane has finished: its
+    // consumer lane wrote its state back when its own samples ended (below), before those slots are overwritten
     const bool uniform = same_src && nrows == G::lanes;
+    (void) min_nz;
     const int nblocks = (max_nz + G::block - 1) / G::block;
 
 
@@ -1746,7 +1759,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 #define K3_ISSUE_AS(k, LOAD)                                                                                 \
     {                                                                                                        \
         const int n_ = (k) * G::block + lane;                                                            \
-        if (uniform && ((k) + 1) * G::block <= min_nz) {                                                 \
+        if (uniform && ((k) + 1) * G::block <= max_nz) {                                                 \
             const float *p_ = row0 + n_;                                                                      \
             _Pragma("unroll") for (int r = 0; r < G::lanes; r++) {                                       \
                 _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                    \
@@ -1818,7 +1831,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 #define K3_COMMIT(k)                                                                                         \
     {                                                                                                        \
         const int n_ = (k) * G::block + lane;                                                            \
-        if (uniform && ((k) + 1) * G::block <= min_nz) {                                                 \
+        if (uniform && ((k) + 1) * G::block <= max_nz) {                                                 \
             if (G::plain) {                                                                                   \
                 _Pragma("unroll") for (int h = 0; h < G::segs; h++) {                                         \
                     float *dst_ = ring + (((n_ + h * SDRM_K3_WAVE) & (G::ring - 1)) + SDRM_K3_PRE);           \
@@ -2051,6 +2064,27 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     // the next call's clock stage is let onto the chip when every workgroup of this one is within K3_NEAR_BLOCKS staging
     // steps of its end (sdrm_api.hip, clock_early): k3_done[1] counts the workgroups that are
     const int near_at = nblocks > K3_NEAR_BLOCKS ? nblocks - K3_NEAR_BLOCKS : 0;
+    // what a call leaves behind for the next (reference clock_recovery_mm.c:127-135) -- written when the LANE's samples end, which
+    // in a workgroup of unequal rows is before the workgroup's last block: the ring slots that hold the carried samples are
+    // intact then (the block being staged meanwhile goes elsewhere) and are not later
+    bool finished = false;
+    auto finish_lane = [&]() {
+        int from_n, new_kept;
+        sdrm_k3_finish(L, &from_n, &new_kept);
+        for (int j = 0; j < new_kept; j++) {
+            cs->hist[j] = sdrm_k3_ring_get<G>(my_col, from_n + j);
+        }
+        cs->kept = (uint32_t) new_kept;
+        cs->mu = L.st.mu;
+        cs->omega = L.st.omega;
+        cs->last = L.st.last;
+        // the carried samples come from this call's stream; a loop state that is no longer finite (an Inf sample makes
+        // omega and mu NaN two symbols later) keeps the channel off the finite-only fast path until it is reset
+        cs->poison = (flagged != 0 || !(fabsf(L.st.mu) < INFINITY) || !(fabsf(L.st.omega) < INFINITY) || !(fabsf(L.st.last) < INFINITY)) ? SDRM_FLAG_NONFINITE : 0u;
+        b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
+        b.out_len[c] = L.oo;
+        finished = true;
+    };
     for (int k = 0; k <= nblocks; k++) {
         // k == nblocks: nothing new, only drains what the carried history alone allows (nz == 0 case)
         if (k == near_at && b.k3_done != nullptr && lane == 0) {
@@ -2099,6 +2133,9 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         } else {
             K3_DRAIN(false)
         }
+        if (active && !absent && !wild && !finished && (k + 1) * G::block >= L.nz) {
+            finish_lane();  // this lane's samples are all staged and drained
+        }
         if (b.k3_stamps) {
             unsigned long long t2 = __builtin_amdgcn_s_memtime();
             t_wait += t1 - t0;
@@ -2137,21 +2174,8 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
         b.out_len[c] = sdrm_k3_rescue(p, cs, src, L.nz, (const float *) bank_rev, of, b.out_i8 + (size_t) c * b.out_stride, flagged);
         b.nonfinite[c] = 0;
         atomicAdd(b.counters + 0, 1u);  // sdrm_batch_wild_calls
-    } else if (active) {
-        int from_n, new_kept;
-        sdrm_k3_finish(L, &from_n, &new_kept);
-        for (int j = 0; j < new_kept; j++) {
-            cs->hist[j] = sdrm_k3_ring_get<G>(my_col, from_n + j);
-        }
-        cs->kept = (uint32_t) new_kept;
-        cs->mu = L.st.mu;
-        cs->omega = L.st.omega;
-        cs->last = L.st.last;
-        // the carried samples come from this call's stream; a loop state that is no longer finite (an Inf sample makes
-        // omega and mu NaN two symbols later) keeps the channel off the finite-only fast path until it is reset
-        cs->poison = (flagged != 0 || !(fabsf(L.st.mu) < INFINITY) || !(fabsf(L.st.omega) < INFINITY) || !(fabsf(L.st.last) < INFINITY)) ? SDRM_FLAG_NONFINITE : 0u;
-        b.nonfinite[c] = 0;        // consumed: the slot is clean for its next use
-        b.out_len[c] = L.oo;
+    } else if (active && !finished) {
+        finish_lane();
     }
     if (HAND && active && __hip_atomic_load(b.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         b.out_len[c] = SDRM_OUT_LEN_FAILED;  // a hand-off wait of this batch ran into its bound: no result of this call can be trusted

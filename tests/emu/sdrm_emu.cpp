@@ -192,7 +192,7 @@ static void emu_dc(EmuBatch *b) {
         for (int sl = 0; sl < SDRM_K2_SLOTS; sl++) {
             sdrm_k2_slot &s = slots[sl];
             s.chan = -1;
-            s.L = 1; s.A = 64; s.rcap = 128; s.nz = 0; s.HX = 0; s.Lf = 1.0f; s.invL = 1.0f;
+            s.L = 1; s.A = 64; s.rcap = 128; s.nz = 0; s.HX = 0; s.Lf = 1.0f; s.invL = 1.0f; s.alias = 0;
             const int c = c0 + sl;
             if (sl < G && c < C && pl.params[c].dc_len != 0 && b->ctl[c].absent == 0 && pl.params[c].generic == 0) {
                 sdrm_k2_slot_setup(s, c, pl.params[c], b->ctl[c].nz);
@@ -200,6 +200,7 @@ static void emu_dc(EmuBatch *b) {
             }
         }
         if (nb == 0) continue;
+        sdrm_k2_fill_aliases(slots, G);  // as the kernel: empty slots beside live ones become replicas
         float acc[SDRM_K2_ROWS];
         for (int r = 0; r < SDRM_K2_ROWS; r++) {
             const sdrm_k2_slot &s = slots[r & (SDRM_K2_SLOTS - 1)];
@@ -259,18 +260,18 @@ static void emu_dc(EmuBatch *b) {
         }
         for (int r = 0; r < SDRM_K2_ROWS; r++) {
             const sdrm_k2_slot &s = slots[r & (SDRM_K2_SLOTS - 1)];
-            if (s.chan >= 0) sdrm_k2_state_acc(b->dcstate.data() + pl.params[s.chan].dc_state_off, pl.dc_hx_cap, pl.dc_l_cap)[r >> 4] = acc[r];
+            if (s.chan >= 0 && !s.alias) sdrm_k2_state_acc(b->dcstate.data() + pl.params[s.chan].dc_state_off, pl.dc_hx_cap, pl.dc_l_cap)[r >> 4] = acc[r];
         }
         for (int ring = 0; ring < 3; ring++)
             for (int sl = 0; sl < G; sl++)
-                if (slots[sl].chan >= 0)
+                if (slots[sl].chan >= 0 && !slots[sl].alias)
                     for (int lane = 0; lane < 64; lane++)
                         sdrm_k2_ring_save(rings.data() + ((size_t) ring * G + sl) * rpitch, slots[sl],
                                           sdrm_k2_state_tail(b->dcstate.data() + pl.params[slots[sl].chan].dc_state_off, ring, pl.dc_hx_cap, pl.dc_l_cap), lane, 64);
         const uint32_t T = 64 * SDRM_K2_WAVES;
         for (int sl = 0; sl < G; sl++) {
             const sdrm_k2_slot &s = slots[sl];
-            if (s.chan < 0 || s.nz == 0) continue;
+            if (s.chan < 0 || s.nz == 0 || s.alias) continue;
             float *hx = b->dcstate.data() + pl.params[s.chan].dc_state_off;
             std::vector<float> v(T);
             for (uint32_t j0 = 0; j0 < s.HX; j0 += T) {  // a round: every thread reads, barrier, every thread writes

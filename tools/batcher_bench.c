@@ -5,7 +5,10 @@
  * Build: gcc -O2 -pthread tools/batcher_bench.c -Iinclude -Lsdr-modem_amd/csrc -lsdrmodem_hip -Wl,-rpath,'$ORIGIN/../sdr-modem_amd/csrc' -lm -o tools/batcher_bench
  * Run:   tools/batcher_bench [channels] [chunk] [rounds] [producer threads] [consumer threads] [batchers]
  * batchers > 0: the clients are placed by a node front door (sdrm_node_*) over that many batchers -- one per visible GPU,
- * wrapping round on a box with fewer: the one-process, many-GPU layout of INTEGRATION.md section 3c. */
+ * wrapping round on a box with fewer: the one-process, many-GPU layout of INTEGRATION.md section 3c.
+ * Environment (node mode): BB_SLOTS=<slots per batcher> (default: just enough for the clients) -- a server's batcher is sized for
+ * its busiest hour, most slots wait for a client; BB_KINDS=3 -- the clients are BASELINE configs[4]'s three kinds in turn
+ * (48 kHz / 9600 baud, 240 kHz / 19200 baud / decimation 5, 48 kHz / 1200 baud / decimation 8) instead of the first alone. */
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -101,6 +104,14 @@ int main(int argc, char **argv) {
         cfg[c].transition_width = 2000;
         cfg[c].use_dc_block = true;
         cfg[c].max_input_buffer_length = (uint32_t) chunk;
+        if (getenv("BB_KINDS") != NULL && atoi(getenv("BB_KINDS")) == 3 && c % 3 == 1) {
+            cfg[c].sampling_freq = 240000;
+            cfg[c].baud_rate = 19200;
+            cfg[c].decimation = 5;
+        } else if (getenv("BB_KINDS") != NULL && atoi(getenv("BB_KINDS")) == 3 && c % 3 == 2) {
+            cfg[c].baud_rate = 1200;
+            cfg[c].decimation = 8;
+        }
     }
     sdrm_batcher_config bc = {6, 100000, true};
     int code = 0;
@@ -109,6 +120,9 @@ int main(int argc, char **argv) {
         memset(&nc, 0, sizeof(nc));
         nc.n_batchers = (size_t) n_batchers;
         nc.slots_per_batcher = (n_ch + (size_t) n_batchers - 1) / (size_t) n_batchers;
+        if (getenv("BB_SLOTS") != NULL && (size_t) atol(getenv("BB_SLOTS")) > nc.slots_per_batcher) {
+            nc.slots_per_batcher = (size_t) atol(getenv("BB_SLOTS"));
+        }
         nc.geometry = cfg[0];
         nc.batcher = bc;
         code = sdrm_node_create(&nc, &node);
