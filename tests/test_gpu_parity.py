@@ -1423,3 +1423,45 @@ def test_a_plain_handle_takes_the_hand_off_for_long_calls_and_the_graph_replay_f
         got = d.process(part)
         assert np.array_equal(got, want), (n, pos, len(got), len(want))
     d.close()
+
+
+@pytest.mark.parametrize("keep_soft", [False, True])
+def test_few_live_channels_in_a_large_batch_keep_their_streams_on_the_device(keep_soft):
+    """A 96-slot batch of four kinds of channels with few of them live per call, presence and lengths changing from call to call --
+    what a server's batcher sees off-peak.  Since round 5 absent channels no longer send their workgroup's live neighbours to the
+    predicated code (DC stage: empty slots become replicas of a live one; clock stage: absent rows and rows that have ended are
+    staged along, a lane writes its state back when ITS samples end, before its ring slots are overwritten by the longer rows'
+    blocks): profiles/r05_node_schedule.txt.  Every live channel's stream equals the oracle's, across calls it sat out."""
+    kinds = [(48000, 9600, 5000, 1, 2000, True), (240000, 19200, 5000, 5, 2000, True), (48000, 1200, 5000, 8, 2000, True),
+             (48000, 9600, 5000, 1, 2000, False), (240000, 9600, 5000, 1, 2000, True)]
+    maxlen = 20000
+    n_ch = 96
+    cfgs = [kinds[i % 5] + (maxlen,) for i in range(n_ch)]
+    g = binding.Batch(cfgs, keep_soft=keep_soft)
+    assert g.code == 0
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    sigs = {}
+    pos = [0] * n_ch
+    rng = np.random.default_rng(23)
+    patterns = [[0], [0, 1, 2], [95], [3, 4, 19, 40, 41], list(range(n_ch)), [16, 18, 80], [5], [0, 95], list(range(10, 58)), [1, 17, 33, 49, 65, 81]]
+    for call, live in enumerate(patterns):
+        parts = []
+        for i in range(n_ch):
+            if i in live:
+                if i not in sigs:
+                    sigs[i] = siggen.gmsk_channel(1000 + i, 6 * maxlen, fs=cfgs[i][0], baud=cfgs[i][1])
+                n = int(rng.choice([maxlen, maxlen, 16384, 4097, 300, 0]))
+                parts.append(sigs[i][pos[i]:pos[i] + n])
+                pos[i] += n
+            else:
+                parts.append(binding.ABSENT)
+        g8 = g.process(parts)
+        for i in range(n_ch):
+            if i in live:
+                o8, of = oracles[i].process(parts[i])
+                assert np.array_equal(o8, g8[i]), (call, i, len(o8), len(g8[i]))
+                if keep_soft:
+                    assert np.array_equal(of.view(np.uint32), g.last_soft(i).view(np.uint32)), (call, i)
+            else:
+                assert len(g8[i]) == 0
+    g.close()

@@ -609,3 +609,37 @@ def test_batch_geometry_grows_with_a_new_clients_configuration():
     calls(2)
     assert e.reset_channel(2, (48000, 9600, 5000, 1, 2000, True, 2 * n)) != 0
     calls(1)
+
+
+def test_few_live_channels_in_a_large_batch_keep_their_streams():
+    """A server's batcher is sized for its busiest hour: most slots have no buffer in a round (ABSENT).  Since round 5 an empty slot
+    of a DC workgroup is a REPLICA of the group's longest live slot (it computes the same and saves nothing: sdrm_k2_fill_aliases),
+    so that the live channels keep the stage's straight-line code.  20 channels of three kinds, presence changing from call to call
+    (a channel that sits out a call continues where it left off), lengths ragged: every live channel's stream equals the oracle's."""
+    kinds = [(48000, 9600, 5000, 1, 2000, True), (240000, 19200, 5000, 5, 2000, True), (48000, 1200, 5000, 8, 2000, True),
+             (48000, 9600, 5000, 1, 2000, False)]
+    maxlen = 6000
+    cfgs = [kinds[i % 4] + (maxlen,) for i in range(20)]
+    e = emu_api.EmuBatch(cfgs)
+    assert e.code == 0
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    sigs = [siggen.gmsk_channel(900 + i, 8 * maxlen, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    pos = [0] * 20
+    rng = np.random.default_rng(17)
+    patterns = [[0], [0, 1, 2], [17], [3, 4, 19], list(range(20)), [16, 18], [5], [0, 19], [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]]
+    for live in patterns:
+        parts = []
+        for i in range(20):
+            if i in live:
+                n = int(rng.choice([maxlen, maxlen, 4097, 300, 0]))
+                parts.append(sigs[i][pos[i]:pos[i] + n])
+                pos[i] += n
+            else:
+                parts.append(emu_api.ABSENT)
+        e8, ef = e.process(parts)
+        for i in range(20):
+            if i in live:
+                o8, of = oracles[i].process(parts[i])
+                assert np.array_equal(o8, e8[i]) and np.array_equal(of.view(np.uint32), ef[i].view(np.uint32)), (i, live)
+            else:
+                assert len(e8[i]) == 0

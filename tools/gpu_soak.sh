@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 soak session (each soak under its own timeout): differential, bit-exact against the oracle or they stop.
+# Soak session (round 5: its fuzz draws low deviations every second round, blocking calls take the in-call hand-off) (each soak under its own timeout): differential, bit-exact against the oracle or they stop.
 # Arguments: seconds scale (1 = the full session of ~35 minutes), first seed offset
 set +e
 export TMPDIR=/tmp
@@ -8,10 +8,10 @@ cd "$R"
 mkdir -p gpurun_out
 S=${1:-1}
 F=${2:-0}
-O=gpurun_out/r04_soak_$F.log
+O=gpurun_out/r05_soak_$F.log
 : > $O
 git_rev=$(cat .git_rev 2>/dev/null)
-echo "round-4 soak session (scale $S, seeds +$F), commit ${git_rev:-unknown}" >> $O
+echo "round-5 soak session (scale $S, seeds +$F), commit ${git_rev:-unknown}" >> $O
 run() { echo "\$ $*" >> $O; timeout $1 "${@:2}" 2>&1 | tr "\r" "\n" | grep -a -o "[a-z ]*soak ok:.*\|MISMATCH.*\|HANG.*\|Traceback.*\|Error.*\|failed.*" | tail -3 >> $O; echo "exit ${PIPESTATUS[0]}" >> $O; }
 t() { python3 -c "print(int($1 * $S))"; }
 run $(t 700) python tools/soak_fuzz.py $(t 600) $((110000 + F))
