@@ -89,6 +89,11 @@ typedef struct {
                                     * lucky7 without DC blocker (a burst of ~30 symbols up to 19 LSB off after a flipped
                                     * interpolator-filter choice).  Never the default; for throughput experiments. */
 
+#define SDRM_FLAG_NO_CALIBRATION 4u /* skip the creation-time timing of the batch's own pipeline (0.1 - 0.4 s for large batches): the
+                                     * schedule starts from its rules and is refined online on the caller's own calls, whatever
+                                     * their class.  What a batcher passes for its batch: its slots are placeholders when it is
+                                     * created, its real clients arrive later.  Results never depend on the schedule. */
+
 /* device < 0: current HIP device.  Returns 0, -ENOMEM, -1 (bad parameters), -ENODEV (no usable GPU), -ENOTSUP (a filter too long
  * for a tile's LDS -- about ten thousand taps --, fewer than one or more than 16384 samples per symbol, decimation beyond the
  * filter length).  Any samples per symbol the reference accepts (src/dsp/fsk_demod.c:53-63) is accepted: up to ~244 a channel

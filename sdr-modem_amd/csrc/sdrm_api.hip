@@ -295,10 +295,32 @@ int sdrm_enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, co
 int sdrm_wait_for_all_calls(sdrm_batch_t *b) { return wait_for_all_calls(b); }
 int sdrm_reset_all_streams(sdrm_batch_t *b) { return reset_all_streams(b); }
 
+// Waits for everything this batch has put on the device -- its own streams only: another batch on the same device (a node with
+// several batchers per GPU, a server with a handle per client) is not made to drain because this one resets a channel.
+static int quiesce(sdrm_batch_t *b) {
+    hipStream_t all[11] = {b->stream, b->s_h2d, b->s_d2h, b->s_front, b->s_dc, b->s_clock, b->s_clock_alt, b->s_nco, b->s_company,
+                           b->s_hand_dc, b->s_hand_clock};
+    for (int i = 0; i < 11; i++) {
+        bool seen = all[i] == nullptr;
+        for (int j = 0; j < i && !seen; j++) {
+            seen = all[j] == all[i];
+        }
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(all[i]));
+        }
+    }
+    return 0;
+}
+
 static int reset_all_streams(sdrm_batch_t *b) {
     const sdrm::BatchPlan &pl = b->plan;
     const size_t C = pl.design.size();
-    HIP_TRY(hipDeviceSynchronize());
+    if (b->n_gen > 0 || b->d_nco_state != nullptr || b->d_pre_state != nullptr) {
+        return -1;  // generic channels and oscillators keep state this does not clear: the calibration never runs with them
+    }
+    if (int code = quiesce(b)) {
+        return code;
+    }
     HIP_TRY(hipMemset(b->d_hist, 0, sizeof(sdrm_f2) * C * 2 * (size_t) pl.hist_stride));
     if (b->d_dcstate != nullptr) {
         HIP_TRY(hipMemset(b->d_dcstate, 0, sizeof(float) * pl.dc_state_floats));
@@ -313,7 +335,7 @@ static int reset_all_streams(sdrm_batch_t *b) {
     HIP_TRY(hipMemset(b->d_flags, 0, sizeof(uint32_t) * C * SDRM_CTL_SLOTS));
     HIP_TRY(hipMemset(b->d_outlen, 0, sizeof(uint32_t) * C));
     HIP_TRY(hipMemset(b->d_counters, 0, 64));  // sdrm_batch_wild_calls counts the caller's calls, not the calibration's
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(nullptr));
     std::fill(b->plan.phase.begin(), b->plan.phase.end(), 0u);
     std::fill(b->plan.parity.begin(), b->plan.parity.end(), 0u);
     std::fill(b->plan.zbase.begin(), b->plan.zbase.end(), 0u);
@@ -421,7 +443,25 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     int prio_low = 0, prio_high = 0;
     e = e ? e : hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     const int prio_mid = (prio_low + prio_high) / 2;
-    e = e ? e : hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, prio_low);
+    // SDRM_STAGE_CUS="a,b" (measurements): the chain stages (DC blocker, clock recovery) on the first a CUs of every XCD, the
+    // front-end on the CUs from b on -- bit i of the mask = CU i / 8 of XCD i % 8 (tools/cumask_probe.hip)
+    int split_a = 0, split_b = 0;
+    if (const char *env = getenv("SDRM_STAGE_CUS")) {
+        sscanf(env, "%d,%d", &split_a, &split_b);
+    }
+    auto masked_stream = [](hipStream_t *s, int first, int last) {  // CUs first .. last - 1 of every XCD
+        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = first; j < last && j < 32; j++) {
+            words[j / 4] |= 0xffu << (8 * (j % 4));
+        }
+        return hipExtStreamCreateWithCUMask(s, 8, words);
+    };
+    const bool split = split_a > 0 && n_channels > 1 && getenv("SDRM_SERIAL_STAGES") == nullptr;
+    if (split) {
+        e = e ? e : masked_stream(&b->s_front, split_b, 32);
+    } else {
+        e = e ? e : hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, prio_low);
+    }
     if (getenv("SDRM_SERIAL_STAGES") != nullptr || n_channels == 1) {
         // A batch of one channel (a plain fsk_demod handle) gains nothing from overlapping its stages across calls --
         // the caller waits for every call -- and a server with one handle per client would otherwise hold four streams
@@ -431,8 +471,13 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         b->s_clock = b->s_front;
         b->serial = true;
     } else {
-        e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
-        e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
+        if (split) {
+            e = e ? e : masked_stream(&b->s_dc, 0, split_a);
+            e = e ? e : masked_stream(&b->s_clock, 0, split_a);
+        } else {
+            e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
+            e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
+        }
         e = e ? e : hipMalloc((void **) &b->d_placed, 64);
         e = e ? e : hipMemset(b->d_placed, 0, 64);
         // company for the clock stage while the batch is too small to keep the chip busy by itself: the front-end of a
@@ -745,7 +790,9 @@ extern "C" int sdrm_batch_reset_channel(sdrm_batch *b, size_t c, const sdrm_fsk_
         return -1;
     }
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipDeviceSynchronize());
+    if (int code = quiesce(b)) {
+        return code;
+    }
     sdrm::BatchPlan &pl = b->plan;
     const sdrm_fsk_config use = cfg ? *cfg : pl.design[c].cfg;
     sdrm::GeometryGrowth growth;
@@ -980,7 +1027,7 @@ extern "C" int sdrm_batch_set_pre_offset(sdrm_batch *b, size_t channel, int64_t 
     }
     if (b->d_pre_state != nullptr) {
         HIP_TRY(hipMemset(b->d_pre_state + channel, 0, sizeof(float)));
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(nullptr));
     }
     if (b->sg_exec != nullptr) {  // the one-channel graph has no such pass: calls take the plain path from here on
         (void) hipGraphExecDestroy(b->sg_exec);
@@ -1977,7 +2024,9 @@ extern "C" int sdrm_batch_fetch(sdrm_batch *b, int8_t *data, size_t stride, size
     }
     HIP_TRY(hipSetDevice(b->device));
     const size_t C = b->plan.design.size();
-    HIP_TRY(hipDeviceSynchronize());
+    if (int code = quiesce(b)) {
+        return code;
+    }
     if (int code = wait_for_all_calls(b)) {
         return code;  // sticky device error (a bounded in-kernel wait expired)
     }
@@ -2000,7 +2049,9 @@ extern "C" int sdrm_batch_last_soft(sdrm_batch *b, size_t c, float *dst, size_t 
         return -1;
     }
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipDeviceSynchronize());
+    if (int code = quiesce(b)) {
+        return code;
+    }
     if (int code = wait_for_all_calls(b)) {
         return code;  // sticky device error (a bounded in-kernel wait expired)
     }

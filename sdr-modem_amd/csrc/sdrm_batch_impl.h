@@ -150,6 +150,7 @@ struct sdrm_batch_t {
         uint64_t sig = 0;         // the class of calls being refined: total samples (calls within a factor of two count as alike
         bool nco = false;         // once settled) and whether they carry NCO batches
         int chosen = -1;
+        int restarts = 0;         // measurements given up because the calls stopped looking alike
         // after a winner has been kept: every 64th call of its class starts a sample of five intervals; two bad samples in a row
         // (more than 5 % behind the starting point's steady state) give the starting point back for good
         int guard_n = 0, guard_bad = 0;

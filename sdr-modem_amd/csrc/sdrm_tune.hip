@@ -15,7 +15,8 @@
 int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
     const size_t C = b->plan.design.size();
     const char *env = getenv("SDRM_AUTOTUNE");
-    if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->clock_early || b->n_gen > 0) {
+    if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->clock_early || b->n_gen > 0 ||
+        (b->flags & SDRM_FLAG_NO_CALIBRATION) != 0) {
         return 0;
     }
     uint32_t longest = 0;
@@ -233,8 +234,9 @@ void sdrm_online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
         return;
     }
     if (t.state == 0) {
-        // calls the calibration did not cover: Doppler correction (a fourth stage), or less than half its length
-        if (!with_nco && sig * 2 > full_length_samples(b)) {
+        // calls the calibration did not cover: Doppler correction (a fourth stage), or less than half its length -- or any call
+        // of a batch that was created without calibration
+        if (!with_nco && sig * 2 > full_length_samples(b) && (b->flags & SDRM_FLAG_NO_CALIBRATION) == 0) {
             return;
         }
         const char *env = getenv("SDRM_AUTOTUNE");  // read per batch, like the calibration does
@@ -249,12 +251,12 @@ void sdrm_online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
         bool ok = true;
         for (auto &row : t.ev) {
             for (hipEvent_t &e : row) {
-                ok = ok && hipEventCreate(&e) == hipSuccess;
+                ok = ok && (e != nullptr || hipEventCreate(&e) == hipSuccess);  // (a restarted measurement has them)
             }
         }
         for (auto &row : t.watch) {
             for (hipEvent_t &e : row) {
-                ok = ok && hipEventCreate(&e) == hipSuccess;
+                ok = ok && (e != nullptr || hipEventCreate(&e) == hipSuccess);
             }
         }
         if (!ok) {
@@ -268,10 +270,21 @@ void sdrm_online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
         t.phase = 1;
         t.cand = 0;
         t.n = 0;
+        t.best = -1;
+        t.idle = false;
         t.state = 1;
     }
-    if (with_nco != t.nco || sig != t.sig) {
-        online_tune_settle(b, 0);  // the calls stopped looking alike: nothing to compare, the starting point stays
+    // a batcher's rounds differ by a client's buffer or two: calls within an eighth of the first one's length are one class
+    const uint64_t apart = sig > t.sig ? sig - t.sig : t.sig - sig;
+    if (with_nco != t.nco || apart * 8 > t.sig) {
+        // the calls stopped looking alike: nothing to compare.  The starting point is back, and the measurement starts over on
+        // the class that follows -- three times; a caller whose calls never settle keeps the starting point for good
+        if (++t.restarts > 3) {
+            online_tune_settle(b, 0);
+        } else {
+            online_tune_apply(b, 0);
+            t.state = 0;
+        }
         return;
     }
     t.idle = false;

@@ -46,7 +46,9 @@ extern "C" int sdrm_batcher_create(const sdrm_fsk_config *cfgs, size_t n_channel
         return -1;
     }
     std::unique_ptr<HipBackend> be(new HipBackend());
-    int code = sdrm_batch_create(cfgs, n_channels, device, 0, &be->batch);
+    // no creation-time calibration: the slots are placeholders, the real clients arrive one at a time with parameters of their own
+    // (profiles/r05_node_schedule.txt: rules + online refinement tie with the calibrated schedule on a server's load)
+    int code = sdrm_batch_create(cfgs, n_channels, device, SDRM_FLAG_NO_CALIBRATION, &be->batch);
     if (code != 0) {
         return code;  // -ENODEV without a HIP device: there is no CPU path
     }

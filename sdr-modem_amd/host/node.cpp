@@ -28,6 +28,17 @@ double channel_cost(const sdrm_fsk_config &cfg) {
     return (double) cfg.sampling_freq * (4.0 * t1 + 2.0 * t2 / d);
 }
 
+// A client beyond the fast stages' range (more than ~228 samples per symbol, or a DC boxcar beyond 7712 samples: sdrm_design.cpp,
+// "generic") runs the generic DC and clock stages: milliseconds per call on the DC stream, which every other client of the same
+// batch then waits for.  Such clients are kept together, and away from the others while another batcher has room.
+bool channel_is_slow(const sdrm_fsk_config &cfg) {
+    if (cfg.baud_rate == 0 || cfg.decimation == 0) {
+        return false;
+    }
+    const float sps = (float) ((double) cfg.sampling_freq / cfg.baud_rate / cfg.decimation);
+    return sps * 1.01f + 24.0f > 255.0f || (cfg.use_dc_block && ceilf(sps * 32) > 7712.0f);
+}
+
 // how far above the least-loaded device's load (after placing the client) a device may be and still be preferred because
 // it already serves the client's source
 static const double SOURCE_AFFINITY_SLACK = 1.08;
@@ -71,6 +82,7 @@ int Node::init(const sdrm_node_config &cfg, int visible_devices) {
         }
         d.used.assign(table.size(), 0);
         d.cost.assign(table.size(), 0.0);
+        d.is_slow.assign(table.size(), 0);
         d.source.assign(table.size(), 0);
         // a round waits for every OPEN channel: slots without a client stay closed until the client's worker resets its
         // slot (sdrm_batcher_reset_channel reopens it), so a round goes as soon as the live clients have delivered
@@ -87,6 +99,7 @@ int Node::attach(const sdrm_fsk_config &client, uint64_t source_id, sdrm_node_sl
         return -1;
     }
     const double cost = channel_cost(client);
+    const bool slow = channel_is_slow(client);
     std::lock_guard<std::mutex> g(m_);
     int best = -1, fellow = -1, first_error = 0;
     bool any_alive = false;
@@ -101,7 +114,10 @@ int Node::attach(const sdrm_fsk_config &client, uint64_t source_id, sdrm_node_sl
         if (d.clients >= d.used.size()) {
             continue;  // full
         }
-        if (best < 0 || d.load < dev_[(size_t) best].load) {
+        // least loaded -- among the batchers of the client's kind (slow with slow, fast away from slow) while there is one
+        const bool kind = slow ? d.slow > 0 : d.slow == 0;
+        const bool best_kind = best >= 0 && (slow ? dev_[(size_t) best].slow > 0 : dev_[(size_t) best].slow == 0);
+        if (best < 0 || (kind && !best_kind) || (kind == best_kind && d.load < dev_[(size_t) best].load)) {
             best = (int) i;
         }
         if (source_id != 0) {
@@ -121,7 +137,8 @@ int Node::attach(const sdrm_fsk_config &client, uint64_t source_id, sdrm_node_sl
         return -EBUSY;  // every slot of every healthy device is taken
     }
     int pick = best;
-    if (fellow >= 0 && dev_[(size_t) fellow].load + cost <= (dev_[(size_t) best].load + cost) * SOURCE_AFFINITY_SLACK) {
+    if (fellow >= 0 && dev_[(size_t) fellow].load + cost <= (dev_[(size_t) best].load + cost) * SOURCE_AFFINITY_SLACK &&
+        (dev_[(size_t) fellow].slow > 0) == (dev_[(size_t) best].slow > 0)) {
         pick = fellow;
     }
     Device &d = dev_[(size_t) pick];
@@ -131,6 +148,8 @@ int Node::attach(const sdrm_fsk_config &client, uint64_t source_id, sdrm_node_sl
     }
     d.used[s] = 1;
     d.cost[s] = cost;
+    d.is_slow[s] = slow ? 1 : 0;
+    d.slow += slow ? 1 : 0;
     d.source[s] = source_id;
     d.load += cost;
     d.clients++;
@@ -157,6 +176,8 @@ int Node::detach(const sdrm_node_slot &slot) {
     d.used[slot.channel] = 0;
     d.load -= d.cost[slot.channel];
     d.cost[slot.channel] = 0.0;
+    d.slow -= d.is_slow[slot.channel];
+    d.is_slow[slot.channel] = 0;
     d.source[slot.channel] = 0;
     d.clients--;
     if (d.clients == 0) {

@@ -53,6 +53,8 @@ private:
         std::vector<uint8_t> used;
         std::vector<double> cost;      // cost of the client in each used slot
         std::vector<uint64_t> source;  // its source id
+        std::vector<uint8_t> is_slow;  // it runs the generic DC / clock stages (channel_is_slow)
+        size_t slow = 0;               // such clients here
         double load = 0.0;
         size_t clients = 0;
         uint64_t attached = 0;         // clients placed here since the node was created

@@ -106,6 +106,44 @@ def test_a_full_node_says_so_and_takes_clients_again_after_a_detach():
     node.close()
 
 
+def test_clients_of_the_generic_stages_are_kept_together_and_away_from_the_others():
+    """A client beyond the fast stages' range (48 kHz / 150 baud: 320 samples per symbol) runs the generic DC and clock stages,
+    milliseconds per call that every client of the same batch waits for: such clients share a batcher, the others avoid it
+    while another batcher has room (and use it when there is none)"""
+    slow = (48000, 150, 5000, 1, 2000, True, 4096)
+    node = emu_api.emu_node(GEOM, 8, 3)
+    where = []
+    for cfg in (GEOM, slow, GEOM, GEOM, slow, GEOM, slow, GEOM):
+        code, s = node.attach(cfg)
+        assert code == 0
+        where.append((cfg, s))
+    slow_on = {s.batcher_index for cfg, s in where if cfg == slow}
+    fast_on = {s.batcher_index for cfg, s in where if cfg == GEOM}
+    assert len(slow_on) == 1, where
+    # the first slow client went to the least-loaded batcher (one that had a fast client by then: three batchers, one client
+    # before it); fast clients that came later stay away from it
+    later_fast = [s.batcher_index for cfg, s in where[2:] if cfg == GEOM]
+    assert not (set(later_fast) & slow_on), where
+    assert len(fast_on - slow_on) == 2
+    # no room elsewhere: the fast clients take the slow batcher's free slots
+    extra = []
+    while True:
+        code, s = node.attach(GEOM)
+        if code != 0:
+            assert code == -16
+            break
+        extra.append(s)
+    assert sum(node.stat(i).clients for i in range(3)) == 24
+    assert any(s.batcher_index in slow_on for s in extra)
+    # the slow clients leave: the batcher is an ordinary one again
+    for cfg, s in where:
+        if cfg == slow:
+            assert node.detach(s) == 0
+    code, s = node.attach(slow)
+    assert code == 0 and s.batcher_index in slow_on  # (the only batcher with free slots)
+    node.close()
+
+
 def _worker_cfg(node, tmp, cfg, source_id=0, offset=0):
     return binding.WorkerConfig(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], False, 0, cfg[6], 8, True, str(tmp).encode(),
                                 None, None, None, 0, node.h, source_id, offset)
