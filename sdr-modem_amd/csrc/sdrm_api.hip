@@ -335,6 +335,12 @@ static int reset_all_streams(sdrm_batch_t *b) {
     HIP_TRY(hipMemset(b->d_flags, 0, sizeof(uint32_t) * C * SDRM_CTL_SLOTS));
     HIP_TRY(hipMemset(b->d_outlen, 0, sizeof(uint32_t) * C));
     HIP_TRY(hipMemset(b->d_counters, 0, 64));  // sdrm_batch_wild_calls counts the caller's calls, not the calibration's
+    if (b->d_hand_tiles != nullptr) {
+        HIP_TRY(hipMemset(b->d_hand_tiles, 0, sizeof(uint32_t) * C * (size_t) b->hand_tiles_cap));
+    }
+    if (b->d_hand_prog != nullptr) {
+        HIP_TRY(hipMemset(b->d_hand_prog, 0, sizeof(unsigned long long) * C));
+    }
     HIP_TRY(hipStreamSynchronize(nullptr));
     std::fill(b->plan.phase.begin(), b->plan.phase.end(), 0u);
     std::fill(b->plan.parity.begin(), b->plan.parity.end(), 0u);
@@ -1188,7 +1194,9 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     }
     if (hand) {
         d.handoff = 1;
-        d.epoch = (uint32_t) (i % 0xfffffff0ull) + 1u;
+        // (a count of its own, never reset: the stamps of earlier calls -- the calibration's, before reset_all_streams put the call
+        // count back to 0 -- must never look like this call's; found by the batcher soak, profiles/r05_soak.txt)
+        d.epoch = (uint32_t) (b->hand_epoch++ % 0xfffffff0ull) + 1u;
         d.hand_tiles = b->d_hand_tiles;
         d.hand_tiles_cap = b->hand_tiles_cap;
         d.hand_prog = b->d_hand_prog;

@@ -1,5 +1,6 @@
 // batcher_hip.cpp -- the one backend the shipped library has for the batcher: a sdrm_batch on a HIP device, driven
 // through its pipelined host-buffer calls (sdrm_batch_arena / _submit / _collect).  No device, no batcher.
+#include <stdlib.h>
 #include <errno.h>
 #include <stdio.h>
 
@@ -48,7 +49,9 @@ extern "C" int sdrm_batcher_create(const sdrm_fsk_config *cfgs, size_t n_channel
     std::unique_ptr<HipBackend> be(new HipBackend());
     // no creation-time calibration: the slots are placeholders, the real clients arrive one at a time with parameters of their own
     // (profiles/r05_node_schedule.txt: rules + online refinement tie with the calibrated schedule on a server's load)
-    int code = sdrm_batch_create(cfgs, n_channels, device, SDRM_FLAG_NO_CALIBRATION, &be->batch);
+    // (SDRM_BATCHER_CALIBRATE=1: measurements and the soak's regression -- the calibrated batch behind a batcher)
+    const char *cal = getenv("SDRM_BATCHER_CALIBRATE");
+    int code = sdrm_batch_create(cfgs, n_channels, device, cal != nullptr && atoi(cal) != 0 ? 0u : SDRM_FLAG_NO_CALIBRATION, &be->batch);
     if (code != 0) {
         return code;  // -ENODEV without a HIP device: there is no CPU path
     }

@@ -1407,6 +1407,54 @@ def test_blocking_calls_with_the_stages_of_one_call_resident_together(handoff, m
     g.close()
 
 
+def test_hand_off_after_the_creation_time_calibration_starts_from_fresh_stamps(monkeypatch):
+    """A batch of 32 channels or more times its own pipeline when it is created and then puts every stream back to its initial
+    state -- the call count too.  The hand-off's stamp value of a call used to be that count + 1, so the caller's calls found
+    the calibration's stamps of the same value in place: the DC and clock stages took tiles for finished that the front-end had
+    not written yet.  Found by the batcher soak of round 5 at seed 90173 (38 clients, filters of up to 932 taps, short buffers,
+    rounds launched 300 us after their first buffer): that round again, a dozen times, behind a batcher that calibrates
+    (SDRM_BATCHER_CALIBRATE=1; by default a batcher no longer does) -- before the fix one round in three had wrong clients."""
+    import threading
+    from test_gpu_fuzz import _cases
+    monkeypatch.setenv("SDRM_BATCHER_CALIBRATE", "1")
+    seed = 90173
+    for rep in range(12):
+        rng = np.random.default_rng(seed)
+        maxlen = int(rng.choice([4096, 8192]))
+        cfgs = [c + (maxlen,) for c in _cases(seed, int(rng.integers(2, 40)))]
+        cfgs = [c for c in cfgs if orc.Fsk(*c).code == 0]
+        K = int(rng.integers(2, 8))
+        sizes = [[int(rng.choice([1, 17, 500, 3000, maxlen])) for _ in range(K)] for _ in cfgs]
+        sigs = [siggen.gmsk_channel(int(rng.integers(0, 1 << 30)), sum(sz), fs=c[0], baud=c[1]) for c, sz in zip(cfgs, sizes)]
+        chunks = [[s[sum(sz[:k]):sum(sz[:k + 1])] for k in range(K)] for s, sz in zip(sigs, sizes)]
+        bt = binding.Batcher(cfgs, slots=int(rng.integers(3, 7)), max_wait_us=int(rng.choice([300, 2000, 50000])), blocking=True)
+        assert bt.code == 0 and len(cfgs) >= 32
+        got = [[] for _ in cfgs]
+
+        def producer(c):
+            for k in range(K):
+                bt.put(c, chunks[c][k])
+
+        def consumer(c):
+            for k in range(K):
+                got[c].append(bt.take(c))
+
+        th = [threading.Thread(target=f, args=(c,)) for c in range(len(cfgs)) for f in (producer, consumer)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(120)
+            assert not t.is_alive()
+        for c, cfg in enumerate(cfgs):
+            o = orc.Fsk(*cfg)
+            for k in range(K):
+                want = o.process(chunks[c][k])[0]
+                assert got[c][k] is not None and np.array_equal(got[c][k], want), (rep, c, k, cfg, sizes[c])
+        for c in range(len(cfgs)):
+            bt.interrupt(c)
+        bt.close()
+
+
 def test_a_plain_handle_takes_the_hand_off_for_long_calls_and_the_graph_replay_for_short_ones():
     """fsk_demod_process on one handle: repeated short calls are a replayed graph of the three stages, calls long enough for the
     overlap to pay run the in-call hand-off on the handle's stream plus two side streams -- every mix of the two, and ragged
