@@ -17,6 +17,9 @@ t() { python3 -c "print(int($1 * $S))"; }
 run $(t 700) python tools/soak_fuzz.py $(t 600) $((110000 + F))
 run $(t 300) python tools/soak_nco.py $(t 200) $((900 + F))
 run $(t 300) python tools/soak_batcher.py $(t 200) $((40000 + F))
+export SDRM_BATCHER_CALIBRATE=1  # the calibrated batch behind a batcher (what found the stale hand-off stamps in round 5)
+run $(t 200) python tools/soak_batcher.py $(t 120) $((90000 + F))
+unset SDRM_BATCHER_CALIBRATE
 run $(t 300) python tools/soak_misc.py $(t 200) $((40000 + F))
 run $(t 400) python tools/soak_workers.py $(t 300) $((40000 + F))
 run $(t 300) python tools/soak_live.py $(t 200) $((40000 + F))
