@@ -1196,6 +1196,12 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         d.handoff = 1;
         // (a count of its own, never reset: the stamps of earlier calls -- the calibration's, before reset_all_streams put the call
         // count back to 0 -- must never look like this call's; found by the batcher soak, profiles/r05_soak.txt)
+        if (b->hand_epoch != 0 && b->hand_epoch % 0xfffffff0ull == 0) {
+            // the 32-bit stamp values start over (weeks of calls): no stamp of the last time round may survive (the batch is idle)
+            HIP_TRY(hipMemset(b->d_hand_tiles, 0, sizeof(uint32_t) * C * (size_t) b->hand_tiles_cap));
+            HIP_TRY(hipMemset(b->d_hand_prog, 0, sizeof(unsigned long long) * C));
+            HIP_TRY(hipStreamSynchronize(nullptr));
+        }
         d.epoch = (uint32_t) (b->hand_epoch++ % 0xfffffff0ull) + 1u;
         d.hand_tiles = b->d_hand_tiles;
         d.hand_tiles_cap = b->hand_tiles_cap;
