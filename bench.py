@@ -386,7 +386,16 @@ def config5_single(torch, binding, siggen, dev, channels, chunk, steps=96, verif
     b.close()
     del x
     torch.cuda.empty_cache()
+    # the same workload on the schedule's starting point: the steady state the online refinement measured on these very calls
+    # before it tried anything (sdrm_batch_schedule_info.online_ms[6]), so that the figure is not tied to the warm-up's length
+    unrefined = None
+    online = (schedule or {}).get("online") or {}
+    if online.get("state") == 2 and len(online.get("ms_per_call", [])) == 8 and online["ms_per_call"][6] > 0:
+        ms0 = online["ms_per_call"][6]
+        unrefined = {"ms_per_step": ms0, "value": round(channels * chunk / ms0 / 1e3, 1), "unit": "Msamples/s",
+                     "kept": "refined" if online.get("choice", 0) > 0 else "starting point"}
     return {"value": round(channels * chunk / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+            "without_online_refinement": unrefined,
             "verified_vs_oracle": ok, "verify_mismatches": bad, "schedule": schedule,
             "channels": channels, "steps": steps, "kernel_ms": [round(m / max(n, 1), 3) for m, n in km],
             "workload": "half (240000,19200,5000,5,2000,dc) + half (48000,1200,5000,8,2000,dc), per-channel Doppler NCO "
