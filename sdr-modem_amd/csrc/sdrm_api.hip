@@ -449,25 +449,7 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     int prio_low = 0, prio_high = 0;
     e = e ? e : hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     const int prio_mid = (prio_low + prio_high) / 2;
-    // SDRM_STAGE_CUS="a,b" (measurements): the chain stages (DC blocker, clock recovery) on the first a CUs of every XCD, the
-    // front-end on the CUs from b on -- bit i of the mask = CU i / 8 of XCD i % 8 (tools/cumask_probe.hip)
-    int split_a = 0, split_b = 0;
-    if (const char *env = getenv("SDRM_STAGE_CUS")) {
-        sscanf(env, "%d,%d", &split_a, &split_b);
-    }
-    auto masked_stream = [](hipStream_t *s, int first, int last) {  // CUs first .. last - 1 of every XCD
-        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j = first; j < last && j < 32; j++) {
-            words[j / 4] |= 0xffu << (8 * (j % 4));
-        }
-        return hipExtStreamCreateWithCUMask(s, 8, words);
-    };
-    const bool split = split_a > 0 && n_channels > 1 && getenv("SDRM_SERIAL_STAGES") == nullptr;
-    if (split) {
-        e = e ? e : masked_stream(&b->s_front, split_b, 32);
-    } else {
-        e = e ? e : hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, prio_low);
-    }
+    e = e ? e : hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, prio_low);
     if (getenv("SDRM_SERIAL_STAGES") != nullptr || n_channels == 1) {
         // A batch of one channel (a plain fsk_demod handle) gains nothing from overlapping its stages across calls --
         // the caller waits for every call -- and a server with one handle per client would otherwise hold four streams
@@ -477,13 +459,8 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
         b->s_clock = b->s_front;
         b->serial = true;
     } else {
-        if (split) {
-            e = e ? e : masked_stream(&b->s_dc, 0, split_a);
-            e = e ? e : masked_stream(&b->s_clock, 0, split_a);
-        } else {
-            e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
-            e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
-        }
+        e = e ? e : hipStreamCreateWithPriority(&b->s_dc, hipStreamNonBlocking, prio_mid);
+        e = e ? e : hipStreamCreateWithPriority(&b->s_clock, hipStreamNonBlocking, prio_high);
         e = e ? e : hipMalloc((void **) &b->d_placed, 64);
         e = e ? e : hipMemset(b->d_placed, 0, 64);
         // company for the clock stage while the batch is too small to keep the chip busy by itself: the front-end of a

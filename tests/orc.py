@@ -258,7 +258,7 @@ class Fsk:
         return inf, _take(t1, inf.taps1_len), _take(t2, inf.taps2_len)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # (module globals are gone at interpreter shutdown)
             lib().orc_fsk_destroy(self.h)
 
 

@@ -14,17 +14,17 @@ O=gpurun_out/${RND}_handoff_raw.txt
 echo "commit $(cat .git_rev 2>/dev/null)" >> $O
 for h in 0 1; do
   echo "== blocking call, SDRM_HANDOFF=$h" >> $O
-  SDRM_HANDOFF=$h SDRM_TIMELINE=1 SDRM_VERIFY=1 timeout 300 python tools/blocking_call.py 256 131072 30 2>&1 | tail -14 >> $O
+  SDRM_HANDOFF=$h SDRM_TIMELINE=1 SDRM_VERIFY=1 timeout 300 python tools/blocking_call.py 256 131072 30 2>&1 | grep -a "^device\|^  [0-9]\|^blocking\|^channel" >> $O
   echo "== stage roles in a blocking call, SDRM_HANDOFF=$h" >> $O
-  SDRM_HANDOFF=$h BLOCKING=1 timeout 300 python tools/k3_probe.py 256 2>&1 | tail -5 >> $O
+  SDRM_HANDOFF=$h BLOCKING=1 timeout 300 python tools/k3_probe.py 256 2>&1 | grep -a "^wave 0\|^staging\|^K2\|^K1" >> $O
 done
 echo "== other blocking shapes" >> $O
 for shape in "64 131072" "256 32768" "1024 131072" "30 131072"; do
-  for h in 0 1; do SDRM_HANDOFF=$h timeout 300 python tools/blocking_call.py $shape 20 2>&1 | tail -1 >> $O; done
+  for h in 0 1; do SDRM_HANDOFF=$h timeout 300 python tools/blocking_call.py $shape 20 2>&1 | grep -a "^blocking" >> $O; done
 done
 echo "== one plain handle" >> $O
 for n in 4096 8192 16384 32768 65536 131072; do
-  for h in 0 1; do SDRM_HANDOFF=$h timeout 300 python tools/latency.py $n 100 2>&1 | tail -1 >> $O; done
+  for h in 0 1; do SDRM_HANDOFF=$h timeout 300 python tools/latency.py $n 100 2>&1 | grep -a "fsk_demod_process" >> $O; done
 done
 echo "== bench line (ms per step; per-stage kernel ms)" >> $O
 for h in 0 1; do for k in 20 256; do
