@@ -2383,12 +2383,14 @@ __global__ __launch_bounds__(64) void k2_dc_generic(DeviceBatch b) {
                 ring[idx] = u;
             }
             const float t = sdrm_boxcar_term(u, old);
-            float y = 0.0f, run = acc[s];
-            for (int i = 0; i < valid; i++) {  // y[n] = t[n] + y[n - 1], in order
-                run = __shfl(t, i) + run;
-                y = lane == i ? run : y;
-            }
-            acc[s] = run;
+            // y[n] = t[n] + y[n - 1], in order through the lanes: lane 0 adds the carried sum, then sixty-three additions with the
+            // DPP wave shift -- lane i takes lane i - 1's sum (lane 0, without a source lane, keeps its own), so after the k-th
+            // every lane up to k holds its final value and recomputes the same value from then on.  One instruction per sample
+            // where the shuffle form took four (the review's ~8 ms per 131072-sample call: profiles/r05_dc_generic.txt).
+            // (lanes beyond `valid` have t = 0 and carry the last sum along)
+            float y = t + (lane == 0 ? acc[s] : 0.0f);
+            asm volatile(".rept 63\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(y) : "v"(t));
+            acc[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), valid - 1));
             u = sdrm_boxcar_out(y, len_f);
         }
         uint32_t xi = xpos + (uint32_t) lane;
