@@ -2360,52 +2360,171 @@ __global__ __launch_bounds__(64) void k2_dc_generic(DeviceBatch b) {
         return;
     }
     const sdrm_gen_layout g = sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim);
-    float *st = b.gen_state[c];
+    // (global-address-space pointers, said so: through a pointer loaded from memory the compiler emits FLAT accesses, which count in
+    // two counters and made it wait for every single access -- 12 round trips per step)
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat *st = (gfloat *) b.gen_state[c];
     const int lane = threadIdx.x;
     float acc[4] = {st[0], st[1], st[2], st[3]};
     uint32_t pos = sdrm_bits(st[4]), xpos = sdrm_bits(st[5]);  // where u[n - L] / x[n - 2 (L - 1)] of the call's first sample sit
-    const float *z = b.z + (size_t) c * b.z_stride;
-    float *out = b.dcout + (size_t) c * b.z_stride;
+    const gfloat *z = (const gfloat *) (b.z + (size_t) c * b.z_stride);
+    gfloat *out = (gfloat *) (b.dcout + (size_t) c * b.z_stride);
     const float len_f = p.dc_len_f;
     const int nz = (int) ctl.nz;
-    for (int n0 = 0; n0 < nz; n0 += 64) {
-        const int valid = nz - n0 < 64 ? nz - n0 : 64;
-        const bool on = lane < valid;
-        const float x = on ? z[n0 + lane] : 0.0f;
-        float u = x;
-        uint32_t idx = pos + (uint32_t) lane;
-        idx = idx >= g.L ? idx - g.L : idx;
+    // The four boxcars are four in-order chains, each fed by the one in front -- but block by block: stage s can work on block
+    // k - s while stage 0 works on block k.  So a step runs the four stages on four consecutive blocks, and their chains --
+    // y[n] = t[n] + y[n - 1] through the lanes: lane 0 adds the carried sum, then sixty-three v_add_f32 whose first operand comes from the lane below (DPP:
+    // lane i takes lane i - 1's sum; a lane without a source lane keeps its own; after the k-th every lane up to k holds its final
+    // value and recomputes the same value from then on) -- are interleaved in one instruction stream: four independent
+    // additions per sample position, no wait states between them.  What a step reads from memory (the new block's samples, the
+    // delayed samples u_s[n - L] and x[n - 2 (L - 1)]) depends on nothing it computes -- a generic channel's boxcar is thousands of
+    // samples long, so everything a step reads was written long before -- and is fetched one step ahead.
+    // Same operations on the same values in the same order per sample as the shuffle form this replaces (24 ms per 131072-sample
+    // call, on the DC stream in front of everybody's clock stage; now ~1.5: profiles/r05_dc_generic.txt).
+    gfloat *xring = st + g.off_x;
+    const int nb = (nz + 63) / 64;
+    uint32_t pos_s[4] = {pos, pos, pos, pos};  // ring position of the block stage s works on next
+    float in_s[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // its input: the block's samples (stage 0) / the stage in front's output
+    float del_s[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // x[n - 2 (L - 1)] of that block, travelling with it to the output
+    auto ring_index = [&](uint32_t at, uint32_t len) {
+        const uint32_t i = at + (uint32_t) lane;
+        return i >= len ? i - len : i;
+    };
+    auto advance = [&](uint32_t at, int by, uint32_t len) {
+        const uint32_t i = at + (uint32_t) by;
+        return i >= len ? i - len : i;
+    };
+    auto block_valid = [&](int k) { return nz - 64 * k < 64 ? nz - 64 * k : 64; };
+    // operands of step `step` (stage s works on block step - s), fetched K2G_AHEAD steps before they are used -- one wave has
+    // nothing else to hide a memory round trip behind, and a step's arithmetic is a fraction of one
+#define K2G_AHEAD 4
+    float x_q[K2G_AHEAD], del_q[K2G_AHEAD], old_q[K2G_AHEAD][4];
+    uint32_t f_pos[4] = {pos, pos, pos, pos}, f_xpos = xpos;  // where the fetches stand (ahead of pos_s / xpos)
+    // ST (a compile-time flag): the step lies in the call's steady state -- all four stages at work on full blocks -- and every
+    // condition below is constant: no branch, no predicate, and the compiler can count the loads in flight instead of waiting
+    // for all of them at every join (which is what the general form costs: it serves the first three, the last few and ragged steps)
+    auto fetch = [&](int step, auto set_c, auto steady_c) {
+        constexpr int set = decltype(set_c)::value;
+        constexpr bool ST = decltype(steady_c)::value;
+        if (ST || step < nb) {
+            const bool on = ST || lane < block_valid(step);
+            x_q[set] = on ? z[64 * step + lane] : 0.0f;
+            del_q[set] = on ? xring[ring_index(f_xpos, g.XL)] : 0.0f;
+            f_xpos = advance(f_xpos, ST ? 64 : block_valid(step), g.XL);
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            float *ring = st + g.off_ring + (size_t) s * g.L;
-            const float old = on ? ring[idx] : 0.0f;
-            if (on) {
-                ring[idx] = u;
+            const int k = step - s;
+            if (ST || (k >= 0 && k < nb)) {
+                old_q[set][s] = (ST || lane < block_valid(k)) ? st[g.off_ring + (size_t) s * g.L + ring_index(f_pos[s], g.L)] : 0.0f;
+                f_pos[s] = advance(f_pos[s], ST ? 64 : block_valid(k), g.L);
             }
-            const float t = sdrm_boxcar_term(u, old);
-            // y[n] = t[n] + y[n - 1], in order through the lanes: lane 0 adds the carried sum, then sixty-three additions with the
-            // DPP wave shift -- lane i takes lane i - 1's sum (lane 0, without a source lane, keeps its own), so after the k-th
-            // every lane up to k holds its final value and recomputes the same value from then on.  One instruction per sample
-            // where the shuffle form took four (the review's ~8 ms per 131072-sample call: profiles/r05_dc_generic.txt).
-            // (lanes beyond `valid` have t = 0 and carry the last sum along)
-            float y = t + (lane == 0 ? acc[s] : 0.0f);
-            asm volatile(".rept 63\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+v"(y) : "v"(t));
-            acc[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), valid - 1));
-            u = sdrm_boxcar_out(y, len_f);
         }
-        uint32_t xi = xpos + (uint32_t) lane;
-        xi = xi >= g.XL ? xi - g.XL : xi;
-        float *xring = st + g.off_x;
-        if (on) {
-            const float delayed = xring[xi];
-            xring[xi] = x;
-            out[n0 + lane] = delayed - u;
+    };
+    auto do_step = [&](int step, auto set_c, auto steady_c) {
+        constexpr int j = decltype(set_c)::value;
+        constexpr bool ST = decltype(steady_c)::value;
+        if (!ST && step >= nb + 3) {
+            return;
         }
-        pos += (uint32_t) valid;
-        pos = pos >= g.L ? pos - g.L : pos;
-        xpos += (uint32_t) valid;
-        xpos = xpos >= g.XL ? xpos - g.XL : xpos;
+        const float old4[4] = {old_q[j][0], old_q[j][1], old_q[j][2], old_q[j][3]};
+        if (ST || step < nb) {
+            in_s[0] = x_q[j];
+            del_s[0] = del_q[j];
+            if (ST || lane < block_valid(step)) {
+                xring[ring_index(xpos, g.XL)] = x_q[j];
+            }
+            xpos = advance(xpos, ST ? 64 : block_valid(step), g.XL);
+        }
+        float t4[4], y4[4];
+        uint32_t next_pos[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int k = step - s;
+            const bool active = ST || (k >= 0 && k < nb);
+            const bool on = ST || (active && lane < block_valid(k));
+            if (on) {
+                st[g.off_ring + (size_t) s * g.L + ring_index(pos_s[s], g.L)] = in_s[s];
+            }
+            t4[s] = on ? sdrm_boxcar_term(in_s[s], old4[s]) : 0.0f;
+            y4[s] = t4[s] + (lane == 0 ? acc[s] : 0.0f);
+            next_pos[s] = active ? advance(pos_s[s], ST ? 64 : block_valid(k), g.L) : pos_s[s];
+        }
+        // (behind this step's stores in program order: they touch other addresses, thousands of samples apart)
+        fetch(step + K2G_AHEAD, set_c, steady_c);
+        // (the wave-wide shift wave_shr:1 costs ~20 cycles an instruction on this part; the shift inside a row of sixteen lanes runs at
+        // the full rate.  So: fifteen row shifts make row 0 final, one row_bcast:15 hands its last sum to row 1 -- to the whole row:
+        // lane 16 is then right, lanes 17 .. 31 are recomputed one after the other by the next fifteen shifts, as they would be
+        // from any value -- and so on through the four rows; rows that are final recompute their own values.)
+#define K2G_ROW_PHASE                                                                   \
+    ".rept 15\n\t"                                                                      \
+    "v_add_f32_dpp %0, %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                 \
+    "v_add_f32_dpp %1, %1, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                 \
+    "v_add_f32_dpp %2, %2, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                 \
+    "v_add_f32_dpp %3, %3, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                 \
+    ".endr\n\t"
+#define K2G_ROW_CARRY(MASK)                                                             \
+    "v_add_f32_dpp %0, %0, %4 row_bcast:15 row_mask:" MASK " bank_mask:0xf\n\t"         \
+    "v_add_f32_dpp %1, %1, %5 row_bcast:15 row_mask:" MASK " bank_mask:0xf\n\t"         \
+    "v_add_f32_dpp %2, %2, %6 row_bcast:15 row_mask:" MASK " bank_mask:0xf\n\t"         \
+    "v_add_f32_dpp %3, %3, %7 row_bcast:15 row_mask:" MASK " bank_mask:0xf\n\t"
+        asm volatile("s_nop 1\n\t"  // (a DPP operand written by the instruction in front needs two wait states; the compiler cannot see into this)
+                     K2G_ROW_PHASE K2G_ROW_CARRY("0x2") K2G_ROW_PHASE K2G_ROW_CARRY("0x4") K2G_ROW_PHASE K2G_ROW_CARRY("0x8") K2G_ROW_PHASE
+                     : "+v"(y4[0]), "+v"(y4[1]), "+v"(y4[2]), "+v"(y4[3])
+                     : "v"(t4[0]), "v"(t4[1]), "v"(t4[2]), "v"(t4[3]));
+#undef K2G_ROW_PHASE
+#undef K2G_ROW_CARRY
+        float out_u[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int k = step - s;
+            const bool active = ST || (k >= 0 && k < nb);
+            if (active) {
+                acc[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y4[s]), (ST ? 64 : block_valid(k)) - 1));
+            }
+            out_u[s] = sdrm_boxcar_out(y4[s], len_f);
+            pos_s[s] = next_pos[s];
+        }
+        if (ST || (step >= 3 && lane < block_valid(step - 3))) {
+            out[64 * (step - 3) + lane] = del_s[3] - out_u[3];
+        }
+#pragma unroll
+        for (int s = 3; s > 0; s--) {  // every block moves on to the next stage
+            in_s[s] = out_u[s - 1];
+            del_s[s] = del_s[s - 1];
+        }
+    };
+    typedef std::integral_constant<int, 0> set0;
+    typedef std::integral_constant<int, 1> set1;
+    typedef std::integral_constant<int, 2> set2;
+    typedef std::integral_constant<int, 3> set3;
+#pragma unroll
+    for (int j = 0; j < K2G_AHEAD; j++) {
+        x_q[j] = del_q[j] = 0.0f;
+        old_q[j][0] = old_q[j][1] = old_q[j][2] = old_q[j][3] = 0.0f;
     }
+    fetch(0, set0{}, std::false_type{});
+    fetch(1, set1{}, std::false_type{});
+    fetch(2, set2{}, std::false_type{});
+    fetch(3, set3{}, std::false_type{});
+    // a group of four steps is steady when its first step has all four stages at work (step >= 3) and the fetch its last step
+    // issues (four steps ahead) still lands on full blocks only
+    const int nb_full = nz / 64;
+    for (int base = 0; base < nb + 3; base += K2G_AHEAD) {
+        if (base >= K2G_AHEAD && base + 2 * K2G_AHEAD <= nb_full) {
+            do_step(base + 0, set0{}, std::true_type{});
+            do_step(base + 1, set1{}, std::true_type{});
+            do_step(base + 2, set2{}, std::true_type{});
+            do_step(base + 3, set3{}, std::true_type{});
+        } else {
+            do_step(base + 0, set0{}, std::false_type{});
+            do_step(base + 1, set1{}, std::false_type{});
+            do_step(base + 2, set2{}, std::false_type{});
+            do_step(base + 3, set3{}, std::false_type{});
+        }
+    }
+#undef K2G_AHEAD
+    pos = pos_s[3];
     __syncthreads();  // every lane's ring stores are issued before the state words say so
     if (lane == 0) {
         st[0] = acc[0];
