@@ -1130,7 +1130,11 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         const unsigned waiting = sdrm::clock_workgroups(d) + (d.any_dc ? sdrm::dc_workgroups(d) : 0u);
         const bool room = !d.any_dc || (size_t) d.dc_lds + sdrm::k1_lds_bytes(d.t1_max, d.t2_max) <= 160 * 1024;
         // (a DC workgroup that fills its CU -- long boxcars -- leaves the front-end no room beside it: then only a handful may wait)
-        hand = idle && waiting <= (room ? 64u : 16u) && sdrm::clock_shape_hands_off(d);
+        unsigned most = room ? 64u : 16u;
+        if (const char *env = getenv("SDRM_HAND_MAX_WAITING")) {  // measurements (profiles/r05_incall_handoff.txt)
+            most = (unsigned) atoi(env);
+        }
+        hand = idle && waiting <= most && sdrm::clock_shape_hands_off(d);
         if (hand && b->serial) {
             // a plain handle keeps its stages on one stream (a server holds one per client); a call long enough for the overlap
             // to pay (SDRM_HAND_SERIAL_MIN_NZ) gets two side streams, created when the first such call comes
