@@ -1119,8 +1119,10 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     // ---- in-call hand-off?  A call that meets an idle batch -- every blocking call, the first of a pipelined run -- cannot
     // hide its front-end and DC blocker behind an earlier call's clock stage: its three stages are made resident together
     // instead, each starting on the first finished pieces of the one in front (tile stamps / output counts, sdrm_launch.h).
-    // Waiting workgroups hold their CUs, so this is bounded: at most 64 of them (a quarter of the chip; a batch that fills it is
-    // front-end bound anyway) when a DC workgroup leaves room for a front-end workgroup beside it, 16 when it does not; the
+    // Waiting workgroups hold their CUs, so this is bounded: at most 192 of them (every batch of the 16 x 1024 clock-stage shape: 160 at
+    // 1280 channels, one per CU -- the front-end keeps the other CUs and the room beside the DC workgroups; measured 1024 channels
+    // 5.71 -> 3.07 ms per blocking call, the limit had been 64) when a DC workgroup leaves room for a front-end workgroup beside it
+    // (then the front-end can always be placed, whatever else waits on the chip), 16 when it does not; the
     // clock stage is launched only when the DC stage's workgroups are resident, the front-end only when both are -- then the
     // front-end, which waits for nobody, always finds a CU, the DC stage waits only for the front-end and the clock stage
     // only for the DC stage.  Every wait in the kernels is bounded besides (a void call, loudly, never a hung device).
@@ -1130,7 +1132,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         const unsigned waiting = sdrm::clock_workgroups(d) + (d.any_dc ? sdrm::dc_workgroups(d) : 0u);
         const bool room = !d.any_dc || (size_t) d.dc_lds + sdrm::k1_lds_bytes(d.t1_max, d.t2_max) <= 160 * 1024;
         // (a DC workgroup that fills its CU -- long boxcars -- leaves the front-end no room beside it: then only a handful may wait)
-        unsigned most = room ? 64u : 16u;
+        unsigned most = room ? 192u : 16u;
         if (const char *env = getenv("SDRM_HAND_MAX_WAITING")) {  // measurements (profiles/r05_incall_handoff.txt)
             most = (unsigned) atoi(env);
         }
