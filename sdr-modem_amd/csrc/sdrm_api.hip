@@ -547,6 +547,9 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     if (const char *env = getenv("SDRM_HANDOFF")) {
         b->hand_allowed = atoi(env) != 0;
     }
+    if (const char *env = getenv("SDRM_HAND_EPOCH0")) {  // tests: start the hand-off's call count near the end of its 32-bit stamp values
+        b->hand_epoch = strtoull(env, nullptr, 0);
+    }
     for (size_t c = 0; c < C; c++) {
         b->any_nodc = b->any_nodc || pl.params[c].dc_len == 0;
     }

@@ -1455,6 +1455,32 @@ def test_hand_off_after_the_creation_time_calibration_starts_from_fresh_stamps(m
         bt.close()
 
 
+def test_hand_off_stamp_values_start_over_cleanly(monkeypatch):
+    """the stamp value of a hand-off call is a 32-bit count (0xfffffff0 values, then over again -- weeks of calls): when it
+    starts over the tables are cleared, so that no stamp of the last time round can look like a new call's.  A batch whose count
+    starts ten calls before the end (SDRM_HAND_EPOCH0) makes twenty blocking calls across it, ragged, against the oracle."""
+    monkeypatch.setenv("SDRM_HAND_EPOCH0", str(0xfffffff0 - 10))
+    maxlen = 20000
+    cfgs = [(48000, 9600, 5000, 1, 2000, True, maxlen), (48000, 9600, 5000, 1, 2000, False, maxlen),
+            (240000, 9600, 5000, 1, 2000, True, maxlen), (48000, 4800, 5000, 2, 2000, True, maxlen)] * 3
+    g = binding.Batch(cfgs)
+    assert g.code == 0
+    oracles = [orc.Fsk(*c) for c in cfgs]
+    rng = np.random.default_rng(11)
+    sigs = [siggen.gmsk_channel(4000 + i, 20 * maxlen, fs=c[0], baud=c[1]) for i, c in enumerate(cfgs)]
+    pos = [0] * len(cfgs)
+    for call in range(20):
+        # long calls early (every tile stamped with the old values), short ones around the turn, long ones after it
+        lens = [maxlen if call < 6 or call > 12 else int(rng.choice([300, 5000])) for _ in cfgs]
+        parts = [s[p:p + n] for s, p, n in zip(sigs, pos, lens)]
+        g8 = g.process(parts)
+        for i, o in enumerate(oracles):
+            pos[i] += lens[i]
+            assert np.array_equal(o.process(parts[i])[0], g8[i]), (call, cfgs[i], lens[i])
+    assert g.handoff_calls() == 20
+    g.close()
+
+
 def test_a_plain_handle_takes_the_hand_off_for_long_calls_and_the_graph_replay_for_short_ones():
     """fsk_demod_process on one handle: repeated short calls are a replayed graph of the three stages, calls long enough for the
     overlap to pay run the in-call hand-off on the handle's stream plus two side streams -- every mix of the two, and ragged
