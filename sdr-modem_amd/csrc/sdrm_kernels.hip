@@ -2556,13 +2556,23 @@ __global__ __launch_bounds__(64) void k3_clock_generic(DeviceBatch b) {
         bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];
     }
     const sdrm_gen_layout g = sdrm_gen_layout_for(p.dc_len, p.omega_mid, p.max_len, p.decim);
-    float *work = b.gen_state[c] + g.off_work;  // work[3 + i] = position i of the reference's working buffer
+    // (global-address-space pointers, said so: see k2_dc_generic)
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat *work = (gfloat *) (b.gen_state[c] + g.off_work);  // work[3 + i] = position i of the reference's working buffer
     sdrm_clock_state *cs = b.clock_state + c;
     const int kept = (int) cs->kept;
     const int nz = (int) ctl.nz;
-    const float *src = (p.dc_len ? b.dcout : b.z) + (size_t) c * b.z_stride;
-    for (int i = lane; i < nz; i += 64) {
-        work[3 + kept + i] = src[i];
+    const gfloat *src = (const gfloat *) ((p.dc_len ? b.dcout : b.z) + (size_t) c * b.z_stride);
+    int i_copy = lane;
+    for (; i_copy + 192 < nz; i_copy += 256) {  // four loads in flight
+        const float v0 = src[i_copy], v1 = src[i_copy + 64], v2 = src[i_copy + 128], v3 = src[i_copy + 192];
+        work[3 + kept + i_copy] = v0;
+        work[3 + kept + i_copy + 64] = v1;
+        work[3 + kept + i_copy + 128] = v2;
+        work[3 + kept + i_copy + 192] = v3;
+    }
+    for (; i_copy < nz; i_copy += 64) {
+        work[3 + kept + i_copy] = src[i_copy];
     }
     __syncthreads();
     if (lane == 0) {
