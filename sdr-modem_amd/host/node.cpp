@@ -1,6 +1,8 @@
 // node.cpp -- client placement over the batchers of a multi-GPU node; design in node.h.
 #include "node.h"
 
+#include "../csrc/sdrm_core.h"  // SDRM_CLOCK_HCAP, SDRM_DC_MAX_LEN: the fast stages' range (sdrm_design.cpp, `generic`)
+
 #include <errno.h>
 #include <math.h>
 #include <stdio.h>
@@ -36,7 +38,7 @@ bool channel_is_slow(const sdrm_fsk_config &cfg) {
         return false;
     }
     const float sps = (float) ((double) cfg.sampling_freq / cfg.baud_rate / cfg.decimation);
-    return sps * 1.01f + 24.0f > 255.0f || (cfg.use_dc_block && ceilf(sps * 32) > 7712.0f);
+    return sps * 1.01f + 24.0f > (float) (SDRM_CLOCK_HCAP - 1) || (cfg.use_dc_block && ceilf(sps * 32) > (float) SDRM_DC_MAX_LEN);
 }
 
 // how far above the least-loaded device's load (after placing the client) a device may be and still be preferred because
