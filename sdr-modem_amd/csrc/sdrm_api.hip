@@ -547,6 +547,9 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     if (const char *env = getenv("SDRM_HANDOFF")) {
         b->hand_allowed = atoi(env) != 0;
     }
+    if (const char *env = getenv("SDRM_HAND_FOLLOW")) {  // measurements: 0 = no placement hold for the two calls behind a hand-off call
+        b->hand_follow = atoi(env) != 0;
+    }
     if (const char *env = getenv("SDRM_HAND_EPOCH0")) {  // tests: start the hand-off's call count near the end of its 32-bit stamp values
         b->hand_epoch = strtoull(env, nullptr, 0);
     }
@@ -1194,6 +1197,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         d.hand_prog = b->d_hand_prog;
         b->hand_used = true;
         b->hand_calls++;
+        b->last_hand_call = i;
     }
 
     // ---- NCO phases: need neither the input nor an earlier stage, only the phase buffer released by the mix of call i-2
@@ -1223,6 +1227,16 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
         // let the clock stage of call i-2 (released by the end of call i-3's) take its CUs before this grid floods the chip
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[(i + SDRM_CTL_SLOTS - 3) % SDRM_CTL_SLOTS], 0));
         sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_after[(i + SDRM_CTL_SLOTS - 2) % SDRM_CTL_SLOTS], 100, b->s_front);
+    }
+    if (!b->serial && !hand && d.any_dc && b->d_placed != nullptr && b->hand_calls > 0 && i - b->last_hand_call <= 2 &&
+        b->hand_follow) {
+        // The two calls behind a hand-off call: this front-end and the DC stage of the call before it are released by the same event
+        // (the hand-off call's DC stage ending), and the hand-off call's companion grid, started on an empty chip, sits on every
+        // CU until its clock stage ends.  If this grid covers the chip first, a DC workgroup (117 KB of LDS, 11 waves) may find
+        // no CU until the companion grid leaves -- seen in 20 of 240 20-call runs, in bursts (0 to 14 of a process's 40): the second
+        // call's DC stage 2.9 ms instead of 1.1, its clock stage 1.2 ms late, the run 2.3 % slower.  With the DC workgroups placed
+        // first: 3 of 240 (profiles/r05_incall_handoff.txt).  Bounded.
+        sdrm::launch_hold_until(b->d_placed + 0, b->k2_placed_target, 150, b->s_front);
     }
     if (nco_aside) {
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->ev_phase[slot], 0));

@@ -119,6 +119,8 @@ struct sdrm_batch_t {
     hipStream_t s_hand_dc = nullptr, s_hand_clock = nullptr;  // a one-stream (serial) batch: side streams for a hand-off call's DC and clock stages, created on first use
     bool hand_side_last = false;     // the call enqueued last ran on them: the next call's first stream waits for its end
     uint64_t hand_calls = 0;         // diagnostics: calls enqueued with the hand-off
+    uint64_t last_hand_call = 0;     // index of the last call that took the hand-off
+    bool hand_follow = true;         // the two calls behind it: their front-ends wait for the DC workgroups' placement
     uint64_t hand_epoch = 0;  // hand-off calls since the batch was created -- never reset: a call's stamp value must be new
     uint32_t *d_placed = nullptr;    // [2] DC / clock-stage workgroups started, all launches (what the stream holds wait for)
     uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started
