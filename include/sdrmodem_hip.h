@@ -95,10 +95,11 @@ typedef struct {
                                      * created, its real clients arrive later.  Results never depend on the schedule. */
 
 /* device < 0: current HIP device.  Returns 0, -ENOMEM, -1 (bad parameters), -ENODEV (no usable GPU), -ENOTSUP (a filter too long
- * for a tile's LDS -- about ten thousand taps --, fewer than one or more than 16384 samples per symbol, decimation beyond the
- * filter length).  Any samples per symbol the reference accepts (src/dsp/fsk_demod.c:53-63) is accepted: up to ~244 a channel
- * runs the fast LDS-resident DC and clock stages, beyond that (or with a DC boxcar longer than 7712 samples) their generic
- * forms with the state in global memory ("generic channels") -- same bits, a few milliseconds per call. */
+ * for a tile's LDS -- about ten thousand taps --, more than 16384 samples per symbol, decimation beyond the filter length).
+ * Any samples per symbol the reference accepts (src/dsp/fsk_demod.c:53-63) is accepted, fewer than one included (round 5: such a
+ * channel's calls run from global memory, sdrm_batch_wild_calls counts them): up to ~228 a channel runs the fast LDS-resident DC and
+ * clock stages, beyond that (or with a DC boxcar longer than 7712 samples) their generic forms with the state in global memory
+ * ("generic channels") -- same bits, ~2 ms per 131072-sample call. */
 int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels, int device, uint32_t flags, sdrm_batch **batch);
 void sdrm_batch_destroy(sdrm_batch *batch);
 size_t sdrm_batch_channels(const sdrm_batch *batch);
