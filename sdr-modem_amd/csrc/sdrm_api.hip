@@ -1126,7 +1126,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     // hide its front-end and DC blocker behind an earlier call's clock stage: its three stages are made resident together
     // instead, each starting on the first finished pieces of the one in front (tile stamps / output counts, sdrm_launch.h).
     // Waiting workgroups hold their CUs, so this is bounded: at most 192 of them (every batch of the 16 x 1024 clock-stage shape: 160 at
-    // 1280 channels, one per CU -- the front-end keeps the other CUs and the room beside the DC workgroups; measured 1024 channels
+    // 1280 channels, one per CU; batches of the 32 x 512 shape up to 2048 channels -- the front-end keeps the other CUs and the room beside the DC workgroups; measured 1024 channels
     // 5.71 -> 3.07 ms per blocking call, the limit had been 64) when a DC workgroup leaves room for a front-end workgroup beside it
     // (then the front-end can always be placed, whatever else waits on the chip), 16 when it does not; the
     // clock stage is launched only when the DC stage's workgroups are resident, the front-end only when both are -- then the

@@ -1616,8 +1616,8 @@ __device__ __forceinline__ void k3_drain_finite(sdrm_k3_lane &L, uint32_t lim, u
     L.st.inc = inc;
 }
 
-// HAND: the in-call hand-off (the stages in front are still running; DeviceBatch::handoff) -- a build of its own (one shape:
-// 16 x 1024, what a batch small enough for the hand-off takes), so that the ordinary builds carry none of its code
+// HAND: the in-call hand-off (the stages in front are still running; DeviceBatch::handoff) -- a build of its own (two shapes:
+// 16 x 1024 and 32 x 512, what batches small enough for the hand-off take), so that the ordinary builds carry none of its code
 template <int LANES, int RING, bool PLAIN, bool HAND = false>
 __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     typedef sdrm_k3_geom<LANES, RING, PLAIN> G;
@@ -2255,10 +2255,18 @@ static KernelLaunch describe_clock_hand(const DeviceBatch &b) {
     k.func = reinterpret_cast<const void *>(k3_clock<16, 1024, false, true>);
     return k;
 }
-// the in-call hand-off exists for this clock-stage shape only
+static KernelLaunch describe_clock_hand32(const DeviceBatch &b) {
+    KernelLaunch k = describe_clock_as<32, 512, false>(b);
+    static lds_grant granted;
+    allow_lds(k3_clock<32, 512, false, true>, k.lds, &granted);
+    k.func = reinterpret_cast<const void *>(k3_clock<32, 512, false, true>);
+    return k;
+}
+// the in-call hand-off exists for these two clock-stage shapes (batches of up to 2560 channels; the admission rule of
+// sdrm_api.hip, at most 192 waiting workgroups, ends at 2048): blocking 1536 x 131072 call 7.10 -> 4.10 ms, 2048: 7.83 -> 6.23
 bool clock_shape_hands_off(const DeviceBatch &b) {
     const sdrm_k3_shape sh = k3_shape(b);
-    return sh.lanes == 16 && sh.ring == 1024 && !sh.plain;
+    return !sh.plain && ((sh.lanes == 16 && sh.ring == 1024) || (sh.lanes == 32 && sh.ring == 512));
 }
 
 KernelLaunch describe_clock(const DeviceBatch &b) {
@@ -2267,7 +2275,7 @@ KernelLaunch describe_clock(const DeviceBatch &b) {
         case 16 * 10000 + 1024: return b.handoff ? describe_clock_hand(b) : describe_clock_as<16, 1024, false>(b);
         case 16 * 10000 + 512: return describe_clock_as<16, 512, false>(b);
         case 16 * 10000 + 256: return describe_clock_as<16, 256, false>(b);
-        case 32 * 10000 + 512: return describe_clock_as<32, 512, false>(b);
+        case 32 * 10000 + 512: return b.handoff ? describe_clock_hand32(b) : describe_clock_as<32, 512, false>(b);
         case 32 * 10000 + 256: return describe_clock_as<32, 256, false>(b);
         case -(64 * 10000 + 256): return describe_clock_as<64, 256, true>(b);
         case -(32 * 10000 + 256): return describe_clock_as<32, 256, true>(b);

@@ -1055,7 +1055,9 @@ def test_batcher_many_clients_on_the_device_match_oracle():
             want = o.process(d.process(x) if d else chunks[c][k])[0]
             # the Doppler-corrected client too: the device's oscillator is the correctly rounded one
             assert np.array_equal(got[c][k], want), (c, k)
-    assert bt.rounds() <= K + 3  # batched: about one device call per buffer index, not 24 * K
+    # batched: about one device call per buffer index, not 24 * K (a round also goes 50 ms after its first buffer: a loaded box's
+    # producer threads can miss that now and then -- 9 rounds seen once for K = 5)
+    assert bt.rounds() <= 2 * K + 4
     for c in range(len(cfgs)):
         bt.interrupt(c)
     assert bt.take(0) is None
