@@ -5,7 +5,7 @@ every fifth round adds channels of 267 to 400 samples per symbol (generic stages
 deviation of 1 .. 1000 Hz (timing loops outside their tame range: the clock stage's global-memory form);
 every third round also drives one plain fsk_demod handle with repeated lengths (the graph replay), every fourth the
 pinned-arena pipeline with three calls in flight, every fifth device-resident calls queued back to back, every 25th a batch
-of 400 to 2100 channels.  Bit-exact or it stops.
+of 400 to 2100 channels; every third round forces a clock-stage workgroup shape.  Bit-exact or it stops.
 python tools/soak_fuzz.py [seconds] [first seed]"""
 import os, sys, time
 import numpy as np
@@ -43,6 +43,12 @@ def signal(rng, cfg, n, i):
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     maxlen = int(rng.choice([6000, 20000]))
+    # every third round forces a clock-stage workgroup shape (read per launch): small batches then run the shapes of large ones --
+    # 32x512 takes the in-call hand-off like the default 16x1024
+    if seed % 3 == 0:
+        os.environ["SDRM_K3_LANES"] = str(np.random.default_rng(seed + 7).choice(["32x512", "32x512", "16x512", "64x256p", "32x256"]))
+    else:
+        os.environ.pop("SDRM_K3_LANES", None)
     cfgs = [c + (maxlen,) for c in _cases(seed, int(rng.integers(3, 40)))]
     if seed % 7 == 2:  # round 3: long symbols (up to 240 samples each, DC boxcars up to 7680) inside an ordinary batch
         cfgs += [c + (maxlen,) for c in [(240000, 1200, 5000, 1, 2000, True), (192000, 1200, 2400, 1, 4000, bool(rng.integers(0, 2))),
