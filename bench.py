@@ -165,7 +165,7 @@ def newest_kernels(channels, chunk):
 class Rig:
     """the device-resident workload of one rank: C channels x `resident` chunks of synthetic GMSK in HBM + a batch"""
 
-    def __init__(self, torch, binding, siggen, dev, local_rank, cfgs, first_channel, chunk, resident, base=None, fast_fma=False):
+    def __init__(self, torch, binding, siggen, dev, local_rank, cfgs, first_channel, chunk, resident, base=None):
         self.torch, self.C, self.N, self.R = torch, len(cfgs), chunk, resident
         n_total = resident * chunk
         k = min(self.C, DISTINCT)
@@ -179,7 +179,7 @@ class Rig:
             self.x[c] = torch.roll(base_t[c % k], shifts=2 * 977 * (c // k))
         del base_t
         torch.cuda.synchronize()
-        self.batch = binding.Batch(cfgs, device=local_rank, fast_fma=fast_fma)
+        self.batch = binding.Batch(cfgs, device=local_rank)
         if self.batch.code != 0:
             raise RuntimeError("sdrm_batch_create failed: %d" % self.batch.code)
         self.stream = torch.cuda.current_stream().cuda_stream

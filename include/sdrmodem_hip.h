@@ -81,13 +81,10 @@ typedef struct {
 #define SDRM_FLAG_KEEP_SOFT_F32 1u /* the caller reads the float soft bits (clock-recovery output) of a call; the stage
                                     * produces them in any case, the int8 output is converted from them */
 
-#define SDRM_FLAG_FAST_FMA 2u      /* OPT-IN fast mode: both low-pass filters accumulate with fused multiply-adds (half the
-                                    * vector instructions of the front-end).  NOT the reference's arithmetic and NO parity
-                                    * claim: the float soft bits are 2e-4 .. 3.4e-3 RMS off the CPU path (the north-star
-                                    * bar is 1e-4), and the int8 soft bits stay within the reference's own +-2 LSB test
-                                    * tolerance (test/test_fsk_demod.c:47) on three of its four golden fixtures but NOT on
-                                    * lucky7 without DC blocker (a burst of ~30 symbols up to 19 LSB off after a flipped
-                                    * interpolator-filter choice).  Never the default; for throughput experiments. */
+#define SDRM_FLAG_FAST_FMA 2u      /* REMOVED in round 6: sdrm_batch_create answers -ENOTSUP.  (Rounds 2-5: both low-pass filters
+                                    * with fused multiply-adds.  Not the reference's arithmetic: it failed the reference's own
+                                    * +-2 LSB tolerance, test/test_fsk_demod.c:47, on lucky7 without DC blocker -- 19 LSB,
+                                    * two hard-bit flips -- so nobody could ship it.  The value stays reserved.) */
 
 #define SDRM_FLAG_NO_CALIBRATION 4u /* skip the creation-time timing of the batch's own pipeline (0.1 - 0.4 s for large batches): the
                                      * schedule starts from its rules and is refined online on the caller's own calls, whatever
@@ -134,7 +131,12 @@ int sdrm_batch_sync(sdrm_batch *batch);
  * freeing the buffer on `stream` right away (a caching allocator reusing the block) would race it.  This makes `stream`
  * wait (on the device) until the latest call has consumed its input -- the front-end and the history roll, not the rest. */
 int sdrm_batch_wait_input(sdrm_batch *batch, void *stream);
-/* device pointers: int8 soft bits [C][out_stride], per-channel counts uint32[C], float soft bits or NULL */
+/* device pointers: int8 soft bits [C][out_stride], per-channel counts uint32[C], float soft bits or NULL.
+ * A count of 0xffffffff (SDRM_COUNT_VOID) is not a count: the call took the in-call hand-off and one of its stages gave up a
+ * bounded wait for the stage in front of it (a failed launch, a device in trouble) -- every result of that call is void and
+ * the batch is in error for good.  sdrm_batch_sync / _collect / _fetch / _process report it as -ETIMEDOUT; a consumer that
+ * reads the counts on its own stream (sdrm_batch_wait) must test for the value itself. */
+#define SDRM_COUNT_VOID 0xffffffffu
 int sdrm_batch_device_outputs(sdrm_batch *batch, void **d_out_i8, size_t *out_stride, void **d_out_len,
                               void **d_out_f32);
 /* after a synchronised call: copy channel c's float soft bits of the last call to host */

@@ -246,13 +246,13 @@ def _as_f32(iq):
 class Batch:
     """sdrm_batch_*: many channels per launch."""
 
-    def __init__(self, cfgs, device=-1, keep_soft=False, fast_fma=False, calibrate=True):
+    def __init__(self, cfgs, device=-1, keep_soft=False, calibrate=True):
         self.L = load()
         self.n = len(cfgs)
         self._cfgs = make_configs(list(cfgs))
         self.h = C.c_void_p()
-        # SDRM_FLAG_KEEP_SOFT_F32 | SDRM_FLAG_FAST_FMA | SDRM_FLAG_NO_CALIBRATION
-        flags = (1 if keep_soft else 0) | (2 if fast_fma else 0) | (0 if calibrate else 4)
+        # SDRM_FLAG_KEEP_SOFT_F32 | SDRM_FLAG_NO_CALIBRATION
+        flags = (1 if keep_soft else 0) | (0 if calibrate else 4)
         self.code = self.L.sdrm_batch_create(self._cfgs, self.n, device, flags, C.byref(self.h))
         if self.code != 0:
             self.h = C.c_void_p()

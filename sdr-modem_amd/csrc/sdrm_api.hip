@@ -83,8 +83,8 @@ static void batch_free(sdrm_batch_t *b) {
             }
         }
     }
-    hipStream_t streams[6] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock,
-                              b->s_nco != b->s_front ? b->s_nco : nullptr, b->s_company, b->s_clock_alt};
+    hipStream_t streams[5] = {b->s_front, b->serial ? nullptr : b->s_dc, b->serial ? nullptr : b->s_clock,
+                              b->s_nco != b->s_front ? b->s_nco : nullptr, b->s_company};
     if (b->ev_company) {
         (void) hipEventDestroy(b->ev_company);
     }
@@ -298,9 +298,9 @@ int sdrm_reset_all_streams(sdrm_batch_t *b) { return reset_all_streams(b); }
 // Waits for everything this batch has put on the device -- its own streams only: another batch on the same device (a node with
 // several batchers per GPU, a server with a handle per client) is not made to drain because this one resets a channel.
 static int quiesce(sdrm_batch_t *b) {
-    hipStream_t all[11] = {b->stream, b->s_h2d, b->s_d2h, b->s_front, b->s_dc, b->s_clock, b->s_clock_alt, b->s_nco, b->s_company,
+    hipStream_t all[10] = {b->stream, b->s_h2d, b->s_d2h, b->s_front, b->s_dc, b->s_clock, b->s_nco, b->s_company,
                            b->s_hand_dc, b->s_hand_clock};
-    for (int i = 0; i < 11; i++) {
+    for (int i = 0; i < 10; i++) {
         bool seen = all[i] == nullptr;
         for (int j = 0; j < i && !seen; j++) {
             seen = all[j] == all[i];
@@ -359,6 +359,10 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
                                  sdrm_batch **out) {
     if (cfgs == nullptr || n_channels == 0 || out == nullptr) {
         return -1;
+    }
+    if (flags & SDRM_FLAG_FAST_FMA) {
+        fprintf(stderr, "<3>sdrmodem_hip: SDRM_FLAG_FAST_FMA was removed (it did not hold the reference's own +-2 LSB tolerance)\n");
+        return -ENOTSUP;
     }
     // design + planning first: parameter errors are reported exactly like the reference, GPU or not
     sdrm_batch_t *b = new sdrm_batch_t();
@@ -500,40 +504,9 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
             b->company_grid = blocks;
         }
         // the side stream and its event exist whether the grid starts switched on or not: the calibration may switch it
-        // SDRM_K3_COMPANY_CUMASK=<hex words, low first, comma separated> (measurements: profiles/r05_company_mechanism.txt) confines the
-        // companion grid to a set of CUs -- bit i = CU i / 8 of XCD i % 8 (tools/cumask_probe.hip)
-        if (const char *mask_env = getenv("SDRM_K3_COMPANY_CUMASK")) {
-            std::vector<uint32_t> words;
-            for (const char *p = mask_env; *p;) {
-                char *end = nullptr;
-                words.push_back((uint32_t) strtoul(p, &end, 16));
-                p = (*end == ',') ? end + 1 : end;
-                if (end == p && *end != ',') {
-                    break;
-                }
-            }
-            e = e ? e : hipExtStreamCreateWithCUMask(&b->s_company, (uint32_t) words.size(), words.data());
-        } else {
-            e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
-        }
+        e = e ? e : hipStreamCreateWithFlags(&b->s_company, hipStreamNonBlocking);
         e = e ? e : hipEventCreateWithFlags(&b->ev_company, hipEventDisableTiming);
         b->hold_front = sdrm::front_waits_for_clock_start((int) n_channels);
-        // The next call's clock stage resident early -- OPT-IN: SDRM_K3_EARLY=<channels> switches it on for batches of up
-        // to that many channels.  Where the clock stage bounds the step and the front-end is short beside it (the companion
-        // grid's condition) the step gains 2-3 % (256 channels: 2.59 -> 2.52 ms per call, clock stages 1 us apart instead
-        // of 85), but the front-end then never meets a quiet chip: it takes 0.49 instead of 0.47 ms by the device's clock and
-        // 0.53 between its HIP events (more queues for the command processor to serve) -- and the front-end's time is what the
-        // roofline figure of this path is made of.  Elsewhere it loses outright: 1024 channels -2 %, BASELINE configs[4]'s mix
-        // (front-end as long as the clock stage) -12 % (profiles/r03_clock_early.txt).
-        bool early = false;
-        if (const char *env = getenv("SDRM_K3_EARLY")) {
-            early = (int) n_channels <= atoi(env);
-        }
-        if (early) {
-            b->clock_early = true;
-            e = e ? e : hipStreamCreateWithPriority(&b->s_clock_alt, hipStreamNonBlocking, prio_high);
-            b->lanes[2].overlapped = true;
-        }
         e = e ? e : hipMalloc((void **) &b->d_k3_done, 64);
         e = e ? e : hipMemset(b->d_k3_done, 0, 64);
     }
@@ -589,14 +562,9 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.dc_lds = (uint32_t) pl.dc_lds_bytes();
     d.any_dc = any_dc;
     d.k3_carried_max = (int) pl.clock_carried_max;
-    d.fast_fma = (flags & SDRM_FLAG_FAST_FMA) ? 1 : 0;
     {
         const char *q = getenv("SDRM_K1_QUAD");
         d.quad_flat = (q != nullptr && strcmp(q, "flat") == 0) ? 1 : 0;
-        const char *cp = getenv("SDRM_CHAIN_PRIO");
-        d.chain_prio = cp != nullptr ? atoi(cp) : 3;
-        const char *dp = getenv("SDRM_DC_PRIO");
-        d.dc_prio = dp != nullptr ? atoi(dp) : d.chain_prio;
     }
     b->in_stride = pl.in_stride;
     code = sync_generic(b, -1);
@@ -1133,7 +1101,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     // front-end, which waits for nobody, always finds a CU, the DC stage waits only for the front-end and the clock stage
     // only for the DC stage.  Every wait in the kernels is bounded besides (a void call, loudly, never a hung device).
     bool hand = false;
-    if (b->hand_allowed && b->n_gen == 0 && !b->clock_early && (b->serial || b->d_placed != nullptr) && max_tiles > 0) {
+    if (b->hand_allowed && b->n_gen == 0 && (b->serial || b->d_placed != nullptr) && max_tiles > 0) {
         const bool idle = b->last_slot < 0 || hipEventQuery(b->slot_done[b->last_slot]) == hipSuccess;
         const unsigned waiting = sdrm::clock_workgroups(d) + (d.any_dc ? sdrm::dc_workgroups(d) : 0u);
         const bool room = !d.any_dc || (size_t) d.dc_lds + sdrm::k1_lds_bytes(d.t1_max, d.t2_max) <= 160 * 1024;
@@ -1306,19 +1274,7 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     }
 
     // ---- clock recovery + int8
-    // consecutive calls' clock stages alternate between two streams when the next one is to be resident early: the order
-    // between them is then kept inside the kernel (k3_wait_for), the order two calls apart by the stream
-    // (a call whose int8 conversion is a kernel of its own behind the clock stage reads the float soft bits there: the
-    // next call's clock stage, which writes them, stays behind it on the same stream)
     hipStream_t s_clock = hand_side ? b->s_hand_clock : b->s_clock;
-    if (b->clock_early) {
-        hipStream_t prev = b->clock_prev_alt ? b->s_clock_alt : b->s_clock;
-        hipStream_t other = b->clock_prev_alt ? b->s_clock : b->s_clock_alt;
-        s_clock = (i == 0 || b->clock_prev_converts) ? prev : other;
-        b->clock_same_stream = s_clock == prev;
-        b->clock_prev_alt = s_clock == b->s_clock_alt;
-        b->clock_prev_converts = sdrm::describe_quantize(d).func != nullptr;
-    }
     if (hand) {
         HIP_TRY(hipStreamWaitEvent(s_clock, b->ev_ctl[slot], 0));
         if (d.any_dc && b->d_placed != nullptr) {
@@ -1341,14 +1297,6 @@ static int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, 
     }
     if (b->d_k3_done != nullptr) {
         d.k3_done = b->d_k3_done;
-        d.k3_wait = b->clock_early ? 1 : 0;
-        d.k3_wait_for = b->k3_done_target;  // every workgroup of the launches before this one has finished
-        if (b->clock_early && i > 0 && !b->clock_same_stream) {
-            // ... and it is let onto the chip only when they are all nearly done (k3_done[1]): workgroups that wait through
-            // most of the previous call's clock stage keep the front-end off their CUs for nothing (256 channels: the
-            // front-end took 0.54 instead of 0.47 ms beside two resident clock stages)
-            sdrm::launch_hold_until(b->d_k3_done + 1, b->k3_done_target, 50000, s_clock);
-        }
         b->k3_done_target += sdrm::clock_workgroups(d);
     }
     if (b->company_blocks > 0) {
@@ -1404,44 +1352,36 @@ extern "C" int sdrm_batch_wait_input(sdrm_batch *b, void *stream) {
     return 0;
 }
 
-// the host waits until every enqueued call has finished.  Consecutive calls' clock stages may sit on two streams
-// (clock_early): the later one cannot do its work before the earlier one has done all of its, but the earlier KERNEL may
-// still be retiring when the later one's event fires, so both events are waited for.
-// A clock stage that was resident early and gave up waiting for its predecessor (k3_clock, bounded look) raises the word
-// at d_k3_done[2]: its results cannot be trusted, and neither can any later call's -- the batch is in error for good.
+// A stage of a hand-off call that gave up waiting for the stage in front of it (bounded looks, ~2 s) raises the word at
+// d_counters[1]: that call's results cannot be trusted (its clock stage answers with the count SDRM_OUT_LEN_FAILED), and the
+// batch is in error for good.  The word is final only once the LAST hand-off call has finished: a look that comes earlier
+// (sdrm_batch_collect of an older call while a newer hand-off call is still running) keeps `hand_used` set, so that the look
+// behind that call is not skipped.
 static int check_device_error(sdrm_batch_t *b) {
     if (b->device_error == 0 && b->hand_used) {
-        // in-call hand-off: a stage that gave up waiting for the one in front (bounded looks, ~2 s) has said so
-        b->hand_used = false;
+        const int slot = (int) (b->last_hand_call % SDRM_CTL_SLOTS);
+        const bool over = b->calls > b->last_hand_call + SDRM_CTL_SLOTS - 1 /* its slot has been waited for and reused */ ||
+                          hipEventQuery(b->slot_done[slot]) == hipSuccess;
         uint32_t word = 0;
         HIP_TRY(hipMemcpy(&word, b->d_counters + 1, sizeof(word), hipMemcpyDeviceToHost));
         if (word != 0) {
             b->device_error = -ETIMEDOUT;
             fprintf(stderr, "<3>sdrmodem_hip: a stage timed out waiting for the stage in front of it inside a call; the batch is unusable\n");
         }
-    }
-    if (b->device_error == 0 && b->clock_early && b->d_k3_done != nullptr) {
-        uint32_t word = 0;
-        HIP_TRY(hipMemcpy(&word, b->d_k3_done + 2, sizeof(word), hipMemcpyDeviceToHost));
-        if (word != 0) {
-            b->device_error = -ETIMEDOUT;
-            fprintf(stderr, "<3>sdrmodem_hip: a clock stage launched early timed out waiting for the previous call's; "
-                            "the batch is unusable\n");
+        if (over) {
+            b->hand_used = false;
         }
     }
     return b->device_error;
 }
 
+// the host waits until every enqueued call has finished
 static int wait_for_all_calls(sdrm_batch_t *b) {
     if (b->device_error != 0) {
         return b->device_error;
     }
     if (b->last_slot >= 0) {
         HIP_TRY(hipEventSynchronize(b->slot_done[b->last_slot]));
-        const int before = (b->last_slot + SDRM_CTL_SLOTS - 1) % SDRM_CTL_SLOTS;
-        if (b->clock_early && b->slot_used[before]) {
-            HIP_TRY(hipEventSynchronize(b->slot_done[before]));
-        }
         return check_device_error(b);
     }
     return 0;
@@ -1605,7 +1545,7 @@ static const int SG_SLOT = SDRM_CTL_SLOTS - 1;
 
 static bool serial_call_hands_off(const sdrm_batch_t *b, size_t n) {
     const sdrm_chan_params &p = b->plan.params[0];
-    return b->hand_allowed && !b->clock_early && b->n_gen == 0 && n / p.decim >= SDRM_HAND_SERIAL_MIN_NZ;
+    return b->hand_allowed && b->n_gen == 0 && n / p.decim >= SDRM_HAND_SERIAL_MIN_NZ;
 }
 
 static bool serial_graph_usable(const sdrm_batch_t *b, size_t n, const sdrm_nco_segment *segs) {
@@ -2013,6 +1953,18 @@ extern "C" int sdrm_batch_collect(sdrm_batch *b, int8_t **outputs, size_t *outpu
     HIP_TRY(hipEventSynchronize(b->ev_res[set]));
     if (int code = check_device_error(b)) {
         return code;
+    }
+    for (size_t c = 0; c < C; c++) {
+        if (b->h_reslen[set][c] == SDRM_OUT_LEN_FAILED) {
+            // this call's clock stage says that a stage gave up waiting inside the call (the in-call hand-off's bounded looks):
+            // no count of the call is a count.  Sticky, like every device failure.
+            const int failed = check_device_error(b);
+            if (failed == 0) {
+                b->device_error = -ETIMEDOUT;
+                fprintf(stderr, "<3>sdrmodem_hip: a call came back void (a stage gave up waiting inside it); the batch is unusable\n");
+            }
+            return b->device_error;
+        }
     }
     for (size_t c = 0; c < C; c++) {
         const uint32_t n = b->h_reslen[set][c];

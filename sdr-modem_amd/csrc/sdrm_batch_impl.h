@@ -95,15 +95,6 @@ struct sdrm_batch_t {
     // The three stages of consecutive calls overlap: each stage has its own stream, the stage-to-stage buffers
     // (z, dcout) are double buffered, and events order producer -> consumer and buffer reuse.
     hipStream_t s_front = nullptr, s_dc = nullptr, s_clock = nullptr;
-    // Opt-in (SDRM_K3_EARLY, see sdrm_batch_create): the clock stage of call i+1 is launched on a second stream as soon as
-    // ITS inputs are ready and takes its CUs while call i's is still running; its workgroups wait inside the kernel for the
-    // finished-workgroups counter (DeviceBatch::k3_wait_for).  The hand-over from one call's clock stage to the next then
-    // costs a counter look instead of a kernel boundary plus the hunt for CUs with 141 KB of free LDS.
-    hipStream_t s_clock_alt = nullptr;
-    bool clock_early = false;
-    bool clock_prev_alt = false;       // the previous call's clock stage went to s_clock_alt
-    bool clock_same_stream = false;    // this call's goes to the same stream as the previous call's
-    bool clock_prev_converts = false;  // ... and had k3_quantize behind it
     // Small batches: a grid of idle-spinning waves beside every clock-stage launch (sdrm_kernels.hip, k3_company)
     hipStream_t s_company = nullptr;
     hipEvent_t ev_company = nullptr;
@@ -126,7 +117,7 @@ struct sdrm_batch_t {
     uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started
     uint32_t k3_placed_after[SDRM_CTL_SLOTS] = {};        // ... once the clock stage of the call in that slot has
     uint32_t k3_done_target = 0;     // what the counter reads when the launch enqueued last has finished
-    int device_error = 0;            // sticky: a kernel reported through d_k3_done[2] that it gave up a bounded wait
+    int device_error = 0;            // sticky: a kernel reported (d_counters[1]) that it gave up a bounded wait
     int company_blocks = 0;
     int company_rounds = 120;        // bound on the companion grid's life, in ~50 us looks at the counter
     int company_nops = 1;            // s_nop 7 between two vector instructions of a companion wave (1 / 4 / 16 / 64)

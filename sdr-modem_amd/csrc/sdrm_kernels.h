@@ -232,19 +232,18 @@ SDRM_HD sdrm_f2 sdrm_ext_sample(const sdrm_f2 *in, const sdrm_f2 *hist, int hist
     return *p;
 }
 
-// One tap of a dot product.  EXACT (the default, what every parity claim rests on): product and sum rounded separately, as
-// the reference's VOLK generic kernels do.  FUSED (opt-in, SDRM_FLAG_FAST_FMA): one fused multiply-add -- half the
-// vector instructions, and NOT the reference's bits: the soft bits then differ in the last place on a few per cent of
-// the symbols, which the reference's own tests tolerate at +-2 LSB of the int8 output (test/test_fsk_demod.c:47).
-template <bool FUSED>
+// One tap of a dot product: product and sum rounded separately, as the reference's VOLK generic kernels do (what every
+// parity claim rests on; built with -ffp-contract=off).  A fused multiply-add here is NOT the reference's bits: round 2-5's
+// opt-in SDRM_FLAG_FAST_FMA build failed the reference's own +-2 LSB tolerance on one of its four fixtures (19 LSB on
+// lucky7 without DC blocker) and was removed in round 6.
 SDRM_HD float sdrm_mac(float acc, float x, float t) {
-    return FUSED ? fmaf(x, t, acc) : acc + x * t;
+    return acc + x * t;
 }
 
 // K sequential taps on N adjacent outputs of a unit-stride FIR, register blocked: for every output the
 // taps are visited in increasing j, one fp32 multiply and one fp32 add each -- the reference's order
 // (fir_filter.c:100-105 / :130-135 with VOLK generic dot products).
-template <int N, int K, bool FUSED = false>
+template <int N, int K>
 SDRM_HD void sdrm_fir_block_c(const sdrm_f2 *xs, const float *taps, int ntaps, sdrm_f2 (&acc)[N]) {
     int j0 = 0;
     for (; j0 + K <= ntaps; j0 += K) {
@@ -258,8 +257,8 @@ SDRM_HD void sdrm_fir_block_c(const sdrm_f2 *xs, const float *taps, int ntaps, s
             const float tp = taps[j0 + u];
 #pragma unroll
             for (int r = 0; r < N; r++) {
-                acc[r].x = sdrm_mac<FUSED>(acc[r].x, w[r + u].x, tp);
-                acc[r].y = sdrm_mac<FUSED>(acc[r].y, w[r + u].y, tp);
+                acc[r].x = sdrm_mac(acc[r].x, w[r + u].x, tp);
+                acc[r].y = sdrm_mac(acc[r].y, w[r + u].y, tp);
             }
         }
     }
@@ -268,8 +267,8 @@ SDRM_HD void sdrm_fir_block_c(const sdrm_f2 *xs, const float *taps, int ntaps, s
 #pragma unroll
         for (int r = 0; r < N; r++) {
             sdrm_f2 v = xs[j0 + r];
-            acc[r].x = sdrm_mac<FUSED>(acc[r].x, v.x, tp);
-            acc[r].y = sdrm_mac<FUSED>(acc[r].y, v.y, tp);
+            acc[r].x = sdrm_mac(acc[r].x, v.x, tp);
+            acc[r].y = sdrm_mac(acc[r].y, v.y, tp);
         }
     }
 }
@@ -309,11 +308,7 @@ SDRM_HD sdrm_v2 sdrm_v2_make(float a, float b) {
     sdrm_v2 v = {a, b};
     return v;
 }
-template <bool FUSED = false>
 SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) {
-    if (FUSED) {
-        return sdrm_v2_make(fmaf(x.x, t, acc.x), fmaf(x.y, t, acc.y));
-    }
     return acc + x * t;
 }
 #else
@@ -324,17 +319,16 @@ SDRM_HD sdrm_v2 sdrm_v2_make(float a, float b) {
     sdrm_v2 v = {a, b};
     return v;
 }
-template <bool FUSED = false>
 SDRM_HD sdrm_v2 sdrm_v2_mac(sdrm_v2 acc, sdrm_v2 x, float t) {
     sdrm_v2 r;
-    r.x = sdrm_mac<FUSED>(acc.x, x.x, t);
-    r.y = sdrm_mac<FUSED>(acc.y, x.y, t);
+    r.x = sdrm_mac(acc.x, x.x, t);
+    r.y = sdrm_mac(acc.y, x.y, t);
     return r;
 }
 #endif
 
 // one step of K taps of sdrm_fir_block_rp (below): window of N + K - 1 samples from xs + j0, as even- and odd-aligned pairs
-template <int N, int K, bool FUSED>
+template <int N, int K>
 SDRM_HD void sdrm_fir_step_rp(const float *xs, const float *xo, const float *taps, int j0, sdrm_v2 (&pa)[N / 2], float &tail) {
     constexpr int P = N / 2;
     constexpr int W = N + K - 1;  // window floats per step
@@ -356,24 +350,24 @@ SDRM_HD void sdrm_fir_step_rp(const float *xs, const float *xo, const float *tap
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const int i = 2 * p + u;
-            pa[p] = sdrm_v2_mac<FUSED>(pa[p], (i & 1) ? wo[i / 2] : we[i / 2], tp);
+            pa[p] = sdrm_v2_mac(pa[p], (i & 1) ? wo[i / 2] : we[i / 2], tp);
         }
         if (N & 1) {
             const int i = N - 1 + u;
             const float x = (i & 1) ? we[i / 2].y : we[i / 2].x;
-            tail = sdrm_mac<FUSED>(tail, x, tp);
+            tail = sdrm_mac(tail, x, tp);
         }
     }
 }
 
 // the `rest` < K taps left after the last whole step: one step of exactly that many (REST counts down to the match)
-template <int N, int REST, bool FUSED>
+template <int N, int REST>
 SDRM_HD void sdrm_fir_rest_rp(const float *xs, const float *xo, const float *taps, int j0, int rest, sdrm_v2 (&pa)[N / 2], float &tail) {
     if constexpr (REST > 0) {
         if (rest == REST) {
-            sdrm_fir_step_rp<N, REST, FUSED>(xs, xo, taps, j0, pa, tail);
+            sdrm_fir_step_rp<N, REST>(xs, xo, taps, j0, pa, tail);
         } else {
-            sdrm_fir_rest_rp<N, REST - 1, FUSED>(xs, xo, taps, j0, rest, pa, tail);
+            sdrm_fir_rest_rp<N, REST - 1>(xs, xo, taps, j0, rest, pa, tail);
         }
     }
 }
@@ -384,7 +378,7 @@ SDRM_HD void sdrm_fir_rest_rp(const float *xs, const float *xo, const float *tap
 // odd-aligned pairs (x[2k+1], x[2k+2]), so that every pair operand is a register pair whatever the tap's parity.
 // The taps left over after the last whole step of K take one shorter step of the same form (round 2 ran them unpacked:
 // 3 of the 57 taps of the 9600-baud filter at two instructions per output instead of one).
-template <int N, int K, bool FUSED = false>
+template <int N, int K>
 SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, float (&acc)[N]) {
     constexpr int P = N / 2;
     sdrm_v2 pa[P];
@@ -403,9 +397,9 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
     const float *xo = xs + one;
     int j0 = 0;
     for (; j0 + K <= ntaps; j0 += K) {
-        sdrm_fir_step_rp<N, K, FUSED>(xs, xo, taps, j0, pa, tail);
+        sdrm_fir_step_rp<N, K>(xs, xo, taps, j0, pa, tail);
     }
-    sdrm_fir_rest_rp<N, K - 1, FUSED>(xs, xo, taps, j0, ntaps - j0, pa, tail);
+    sdrm_fir_rest_rp<N, K - 1>(xs, xo, taps, j0, ntaps - j0, pa, tail);
 #pragma unroll
     for (int p = 0; p < P; p++) {
         acc[2 * p] = pa[p].x;
@@ -422,7 +416,7 @@ SDRM_HD void sdrm_fir_block_rp(const float *xs, const float *taps, int ntaps, fl
 // same tap on samples `stride` apart); every operand is its own LDS read.  The kernel hands a thread the outputs tid,
 // tid + 256, ...: consecutive lanes then read addresses d floats apart (conflict-free for odd d) and all four waves share
 // the work -- round 2 gave each of the first few threads fifteen consecutive outputs and left three waves idle.
-template <int R, int K, bool FUSED = false>
+template <int R, int K>
 SDRM_HD void sdrm_fir_block_rd(const float *xs, int stride, int valid, const float *taps, int ntaps, float (&acc)[R]) {
     static_assert(R % 2 == 0, "outputs are processed in pairs");
     constexpr int P = R / 2;
@@ -443,7 +437,7 @@ SDRM_HD void sdrm_fir_block_rd(const float *xs, int stride, int valid, const flo
             const float tp = taps[j0 + u];
 #pragma unroll
             for (int q = 0; q < P; q++) {
-                pa[q] = sdrm_v2_mac<FUSED>(pa[q], sdrm_v2_make(p[2 * q][j0 + u], p[2 * q + 1][j0 + u]), tp);
+                pa[q] = sdrm_v2_mac(pa[q], sdrm_v2_make(p[2 * q][j0 + u], p[2 * q + 1][j0 + u]), tp);
             }
         }
     }
@@ -451,7 +445,7 @@ SDRM_HD void sdrm_fir_block_rd(const float *xs, int stride, int valid, const flo
         const float tp = taps[j0];
 #pragma unroll
         for (int q = 0; q < P; q++) {
-            pa[q] = sdrm_v2_mac<FUSED>(pa[q], sdrm_v2_make(p[2 * q][j0], p[2 * q + 1][j0]), tp);
+            pa[q] = sdrm_v2_mac(pa[q], sdrm_v2_make(p[2 * q][j0], p[2 * q + 1][j0]), tp);
         }
     }
 #pragma unroll
@@ -520,7 +514,6 @@ SDRM_HD void sdrm_k1_phase_load(int tid, const sdrm_k1_tile &t, const sdrm_f2 *i
 }
 
 // phase 1: LPF1 on R adjacent positions (reference src/dsp/fir_filter.c:123-144 via lpf.c:38-40)
-template <bool FUSED = false>
 SDRM_HD void sdrm_k1_phase_lpf1(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps1_rev,
                                 const sdrm_f2 *xs, sdrm_f2 *bnd, sdrm_k1_regs &regs) {
 #pragma unroll
@@ -529,7 +522,7 @@ SDRM_HD void sdrm_k1_phase_lpf1(int tid, const sdrm_k1_tile &t, const sdrm_chan_
         regs.y[r].y = 0.0f;
     }
     if (tid * SDRM_K1_R < t.ny) {
-        sdrm_fir_block_c<SDRM_K1_R, SDRM_K1_U, FUSED>(xs + tid * SDRM_K1_R, taps1_rev, (int) p.T1, regs.y);
+        sdrm_fir_block_c<SDRM_K1_R, SDRM_K1_U>(xs + tid * SDRM_K1_R, taps1_rev, (int) p.T1, regs.y);
     }
     bnd[tid] = regs.y[SDRM_K1_R - 1];
 }
@@ -703,7 +696,7 @@ SDRM_HD void sdrm_k1_phase_quad(int tid, const sdrm_k1_tile &t, const sdrm_chan_
 }
 
 // phase 3: LPF2 with decimation (reference src/dsp/fir_filter.c:93-114), results to the tile's staging area
-template <int R, bool FUSED>
+template <int R>
 SDRM_HD bool sdrm_k1_lpf2_decimated(int tid, const sdrm_k1_tile &t, int d, int ntaps, const float *taps2_rev, const float *qs, float *zs,
                                     float tame) {
     bool odd = false;
@@ -715,7 +708,7 @@ SDRM_HD bool sdrm_k1_lpf2_decimated(int tid, const sdrm_k1_tile &t, int d, int n
             acc[r] = 0.0f;
         }
         const int valid = (t.m - o0 + SDRM_K1_THREADS - 1) / SDRM_K1_THREADS;  // outputs o0 + r * THREADS below m
-        sdrm_fir_block_rd<R, SDRM_K1_U, FUSED>(qs + o0 * d, SDRM_K1_THREADS * d, valid, taps2_rev, ntaps, acc);
+        sdrm_fir_block_rd<R, SDRM_K1_U>(qs + o0 * d, SDRM_K1_THREADS * d, valid, taps2_rev, ntaps, acc);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int o = o0 + r * SDRM_K1_THREADS;
@@ -746,7 +739,6 @@ SDRM_HD void sdrm_flag_raise(uint32_t *flag, uint32_t bits) {
 #endif
 }
 
-template <bool FUSED = false>
 SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_params &p, const float *taps2_rev,
                                 const float *qs, float *zs, uint32_t *nonfinite_flag) {
     bool odd = false;
@@ -763,7 +755,7 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
         for (int r = 0; r < SDRM_K1_RZ; r++) {
             acc[r] = 0.0f;
         }
-        sdrm_fir_block_rp<SDRM_K1_RZ, SDRM_K1_U, FUSED>(qs + base, taps2_rev, (int) p.T2, acc);
+        sdrm_fir_block_rp<SDRM_K1_RZ, SDRM_K1_U>(qs + base, taps2_rev, (int) p.T2, acc);
         // results go to the tile's staging area (lane stride 15 floats: conflict-free) and leave in sdrm_k1_phase_store
 #pragma unroll
         for (int r = 0; r < SDRM_K1_RZ; r++) {
@@ -781,9 +773,9 @@ SDRM_HD void sdrm_k1_phase_lpf2(int tid, const sdrm_k1_tile &t, const sdrm_chan_
         }
         return;
     } else if (t.m <= 2 * SDRM_K1_THREADS) {
-        odd = sdrm_k1_lpf2_decimated<2, FUSED>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs, tame);
+        odd = sdrm_k1_lpf2_decimated<2>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs, tame);
     } else {
-        odd = sdrm_k1_lpf2_decimated<4, FUSED>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs, tame);
+        odd = sdrm_k1_lpf2_decimated<4>(tid, t, (int) p.decim, (int) p.T2, taps2_rev, qs, zs, tame);
     }
     if (odd) {
         uint32_t bits = 0;

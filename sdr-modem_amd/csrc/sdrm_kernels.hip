@@ -261,8 +261,7 @@ size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) { return sdrm_k1_lds_bytes
 
 // grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
 // per-thread boundary samples | arctan table.
-// FUSED: the opt-in fast mode (SDRM_FLAG_FAST_FMA): both filters' taps as fused multiply-adds.  Never the default.
-template <bool FUSED, bool HAND>
+template <bool HAND>
 __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
                                                             size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
@@ -358,13 +357,13 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     __syncthreads();
     unsigned long long t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_regs regs;
-    sdrm_k1_phase_lpf1<FUSED>(tid, t, p, taps1, xs, bnd, regs);
+    sdrm_k1_phase_lpf1(tid, t, p, taps1, xs, bnd, regs);
     __syncthreads();
     unsigned long long t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_quad(tid, t, p, tab, b.quad_flat ? nullptr : tab2, bnd, regs, qs);
     __syncthreads();
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    sdrm_k1_phase_lpf2<FUSED>(tid, t, p, taps2, qs, zs, b.nonfinite + c);
+    sdrm_k1_phase_lpf2(tid, t, p, taps2, qs, zs, b.nonfinite + c);
     __syncthreads();
     if (HAND) {
         // The tile is in memory (and any flag it raised, sdrm_k1_phase_lpf2) before its stamp says so: written THROUGH this
@@ -422,21 +421,14 @@ static void launch_described(const KernelLaunch &k, void **args, hipStream_t s) 
 
 KernelLaunch describe_front(const DeviceBatch &b) {
     KernelLaunch k;
-    static lds_grant granted, granted_fused;
+    static lds_grant granted, granted_hand;
     k.lds = k1_lds_bytes(b.t1_max, b.t2_max);
-    static lds_grant granted_hand, granted_fused_hand;
-    if (b.fast_fma && b.handoff) {
-        allow_lds(k1_front<true, true>, k.lds, &granted_fused_hand);
-        k.func = reinterpret_cast<const void *>(k1_front<true, true>);
-    } else if (b.fast_fma) {
-        allow_lds(k1_front<true, false>, k.lds, &granted_fused);
-        k.func = reinterpret_cast<const void *>(k1_front<true, false>);
-    } else if (b.handoff) {
-        allow_lds(k1_front<false, true>, k.lds, &granted_hand);
-        k.func = reinterpret_cast<const void *>(k1_front<false, true>);
+    if (b.handoff) {
+        allow_lds(k1_front<true>, k.lds, &granted_hand);
+        k.func = reinterpret_cast<const void *>(k1_front<true>);
     } else {
-        allow_lds(k1_front<false, false>, k.lds, &granted);
-        k.func = reinterpret_cast<const void *>(k1_front<false, false>);
+        allow_lds(k1_front<false>, k.lds, &granted);
+        k.func = reinterpret_cast<const void *>(k1_front<false>);
     }
     k.grid = dim3(b.max_tiles ? b.max_tiles : 1u, (unsigned) b.n_channels);  // tile 0 of every channel also rolls its history
     if (b.handoff) {
@@ -735,16 +727,8 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
         if (s.chan >= 0) {
             acc = sdrm_k2_state_acc(b.dc_state + b.params[s.chan].dc_state_off, b.dc_hx_cap, b.dc_l_cap)[lane >> 4];
         }
-        // one dependent chain: issue ahead of whatever shares the SIMD
-        if (b.dc_prio >= 3) {
-            __builtin_amdgcn_s_setprio(3);
-        } else if (b.dc_prio == 2) {
-            __builtin_amdgcn_s_setprio(2);
-        } else if (b.dc_prio == 1) {
-            __builtin_amdgcn_s_setprio(1);
-        } else {
-            __builtin_amdgcn_s_setprio(0);
-        }
+        // one dependent chain: issue ahead of whatever shares the SIMD (any level measured alike, profiles/r04_dc_prio.txt)
+        __builtin_amdgcn_s_setprio(3);
     } else {
         __builtin_amdgcn_s_setprio(1);  // the helpers: ahead of the clock stage's companion waves (priority 0)
     }
@@ -1507,7 +1491,6 @@ size_t k3_lds_bytes(int lanes, int ring, int plain) {
 #define SDRM_K3_LOOP_SKEW 0
 #endif
 #define K3_STORE_SLACK 32   // store instructions of the consumer that may still be in flight at a hand-over
-#define K3_NEAR_BLOCKS 32   // staging steps before its end at which a workgroup reports "nearly done" (~150 us at 5 samples per symbol)
 #ifdef SDRM_K3_NO_FUSED_INT8  // A/B builds only (profiles/r04_1024_ab.txt): every shape leaves the conversion to k3_quantize
 #define K3_FUSED_INT8(G) false
 #define K3_FUSED_INT8_RING(ring) false
@@ -1639,32 +1622,6 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     const int nrows = b.n_channels - c0 < G::lanes ? b.n_channels - c0 : G::lanes;
     for (int k = threadIdx.x; k < 129 * 8; k += 128) {
         bank_rev[(k >> 3) * SDRM_K3_BANKPITCH + (k & 7)] = b.mmse_bank[(k & ~7) + 7 - (k & 7)];  // rows reversed once: tap j meets window sample j
-    }
-    if (b.k3_wait) {
-        // Launched while the previous call's clock stage was still running (sdrm_api.hip, clock_early): this workgroup
-        // has its CU, and from here on it needs what that call leaves behind -- the channels' loop state and carried
-        // samples.  Every workgroup of every earlier launch bumps k3_done behind a release fence when its state is
-        // written; an acquire look that finds them all makes those writes visible here, whichever XCD wrote them.
-        // The look is bounded (~4 s): a launch that never finishes would otherwise hang the device instead of failing a test;
-        // an expired bound raises the batch's device error word.
-        if (threadIdx.x == 0) {
-            // relaxed looks (an acquire load invalidates this XCD's L2 every time, under the other stages' feet), one
-            // acquire fence when the count is there
-            bool there = false;
-            for (int looks = 0; looks < (1 << 22) && !there; looks++) {
-                there = (int32_t) (__hip_atomic_load(b.k3_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - b.k3_wait_for) >= 0;
-                if (!there) {
-                    __builtin_amdgcn_s_sleep(32);
-                }
-            }
-            if (!there) {
-                // the bound expired: what follows reads state the previous call may not have written.  Never silent: the
-                // batch's device error word (k3_done[2]) makes every later sync / collect / fetch of the batch fail
-                atomicOr(b.k3_done + 2, 1u);
-            }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        }
-        __syncthreads();
     }
     tl_mark(b, 2, 0);
     sdrm_k3_lane L;
@@ -2017,15 +1974,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 
     // ------------------------------------------------------------------ consumer wave
     // a long dependent chain on one wave: let it win issue arbitration against the throughput kernels sharing the SIMD
-    if (b.chain_prio >= 3) {
-        __builtin_amdgcn_s_setprio(3);
-    } else if (b.chain_prio == 2) {
-        __builtin_amdgcn_s_setprio(2);
-    } else if (b.chain_prio == 1) {
-        __builtin_amdgcn_s_setprio(1);
-    } else {
-        __builtin_amdgcn_s_setprio(0);
-    }
+    __builtin_amdgcn_s_setprio(3);
     // the stage writes the float soft bits; k3_quantize turns them into the int8 output behind it
     float *of = b.out_f32 + (size_t) (active ? c : 0) * b.out_stride;
     bool wave_clean = __all(clean);
@@ -2061,9 +2010,6 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     const uint32_t bank_addr = (uint32_t) (uintptr_t) (lds_cf) bank_rev;
     unsigned long long t_wait = 0, t_drain = 0, n_iter = 0;
     const unsigned long long real0 = b.k3_stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz reference clock
-    // the next call's clock stage is let onto the chip when every workgroup of this one is within K3_NEAR_BLOCKS staging
-    // steps of its end (sdrm_api.hip, clock_early): k3_done[1] counts the workgroups that are
-    const int near_at = nblocks > K3_NEAR_BLOCKS ? nblocks - K3_NEAR_BLOCKS : 0;
     // what a call leaves behind for the next (reference clock_recovery_mm.c:127-135) -- written when the LANE's samples end, which
     // in a workgroup of unequal rows is before the workgroup's last block: the ring slots that hold the carried samples are
     // intact then (the block being staged meanwhile goes elsewhere) and are not later
@@ -2087,9 +2033,6 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     };
     for (int k = 0; k <= nblocks; k++) {
         // k == nblocks: nothing new, only drains what the carried history alone allows (nz == 0 case)
-        if (k == near_at && b.k3_done != nullptr && lane == 0) {
-            __hip_atomic_fetch_add(b.k3_done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         unsigned long long t0 = b.k3_stamps ? __builtin_amdgcn_s_memtime() : 0;
         if (k < nblocks) {
             // float soft bits the staging wave may convert now: all but those of the newest stores (one store instruction
@@ -2180,14 +2123,10 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
     if (HAND && active && __hip_atomic_load(b.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         b.out_len[c] = SDRM_OUT_LEN_FAILED;  // a hand-off wait of this batch ran into its bound: no result of this call can be trusted
     }
-    if (b.k3_done != nullptr) {
-        // this wave's writes of the channels' state are out (and written back past this XCD's L2) before the count says so:
-        // the next call's clock stage may be waiting for it on another XCD; the companion grid (k3_company) leaves when
-        // every workgroup of this launch has counted
-        __threadfence();
-        if (lane == 0) {
-            __hip_atomic_fetch_add(b.k3_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    if (b.k3_done != nullptr && lane == 0) {
+        // the companion grid (k3_company) leaves when every workgroup of this launch has counted; nobody reads this launch's
+        // results on the strength of the count (the next call's clock stage is ordered by the stream), so no fence
+        __hip_atomic_fetch_add(b.k3_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     tl_mark(b, 2, 1);
 }

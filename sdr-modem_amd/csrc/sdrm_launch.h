@@ -49,18 +49,13 @@ struct DeviceBatch {
     uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
     int k3_carried_max;              // most samples a channel can carry between calls of the clock stage (sizes its ring)
-    int dc_prio;                     // measurements (SDRM_DC_PRIO): the DC chain wave's alone (default: chain_prio)
-    int chain_prio;                  // measurements (SDRM_CHAIN_PRIO): issue priority of the DC chain wave and the clock stage's consumer (default 3)
     int quad_flat;                   // measurements (SDRM_K1_QUAD=flat): the discriminator always takes its general form
-    int fast_fma;                    // SDRM_FLAG_FAST_FMA: fused multiply-adds in the two filters (not the reference's bits)
     uint32_t *placed;                // [2] DC / clock-stage workgroups that have started, cumulative over calls (k_hold_until)
-    uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches); nullptr: nobody is watching
+    uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches; the companion grid watches); nullptr: nobody is watching
     const int *gen_list;             // generic channels (sdrm_kernels.h): their indices, n_gen of them, and each one's state
     int n_gen;
     float *const *gen_state;         // [C] device pointers (null for the others)
     int k3_lanes, k3_ring, k3_plain; // clock-stage workgroup shape chosen for this batch (0: by channel count; SDRM_K3_LANES overrides both)
-    int k3_wait;                     // the clock stage's workgroups wait for k3_done to reach k3_wait_for before they touch any
-    uint32_t k3_wait_for;            //   state of the previous call (they were launched while that call's clock stage still ran)
     uint32_t *counters;              // [16] batch-lifetime device counters: [0] channel-calls run by sdrm_k3_rescue (sdrm_batch_wild_calls),
                                      //   [1] in-call hand-off waits that ran into their bound (the call's results are void: its clock stage answers
                                      //   with the count SDRM_OUT_LEN_FAILED)
@@ -72,7 +67,7 @@ struct DeviceBatch {
     uint32_t hand_tiles_cap;
     unsigned long long *hand_prog;   // [C]: epoch << 32 | DC-blocker outputs of this call that are in memory
 };
-#define SDRM_OUT_LEN_FAILED 0xffffffffu
+#define SDRM_OUT_LEN_FAILED 0xffffffffu  // == SDRM_COUNT_VOID of the public header
 #define SDRM_HAND_MAX_LOOKS (1 << 21)  // bounded waits: ~2 s of looks 1 us apart, then the call fails loudly instead of hanging the device
 
 // one kernel launch, described: what launch_* puts on a stream and what the explicitly built graph of the one-channel

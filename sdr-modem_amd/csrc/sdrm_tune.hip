@@ -15,7 +15,7 @@
 int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
     const size_t C = b->plan.design.size();
     const char *env = getenv("SDRM_AUTOTUNE");
-    if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->clock_early || b->n_gen > 0 ||
+    if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->n_gen > 0 ||
         (b->flags & SDRM_FLAG_NO_CALIBRATION) != 0) {
         return 0;
     }
@@ -240,7 +240,7 @@ void sdrm_online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig) {
             return;
         }
         const char *env = getenv("SDRM_AUTOTUNE");  // read per batch, like the calibration does
-        if (b->serial || b->clock_early || b->plan.design.size() < 32 || (env != nullptr && atoi(env) == 0) || b->n_gen > 0 ||
+        if (b->serial || b->plan.design.size() < 32 || (env != nullptr && atoi(env) == 0) || b->n_gen > 0 ||
             sdrm::front_hold_is_forced() || getenv("SDRM_K3_COMPANY") != nullptr) {
             t.state = 2;
             return;

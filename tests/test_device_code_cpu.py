@@ -30,11 +30,11 @@ def test_pipeline_kernels_do_not_spill(tmp_path):
         assert len(hits) == 1, (parts, hits)
         return meta[hits[0]]
     # (the last template argument of k1_front / k2_dc / k3_clock: the in-call hand-off build)
-    for parts in (("k1_front", "ILb0ELb0E"), ("k1_front", "ILb1ELb0E"), ("k1_front", "ILb0ELb1E"), ("k2_dcILb0E",), ("k2_dcILb1E",),
+    for parts in (("k1_frontILb0E",), ("k1_frontILb1E",), ("k2_dcILb0E",), ("k2_dcILb1E",),
                   ("k2_dc_generic",), ("k3_clock_generic",), ("k0_nco_phase",), ("k0_nco_mix",),
                   ("k3_clock", "ILi16ELi1024ELb0ELb0E"), ("k3_clock", "ILi16ELi1024ELb0ELb1E"), ("k3_clock", "ILi32ELi512ELb0ELb0E"), ("k3_clock", "ILi32ELi512ELb0ELb1E"),
                   ("k3_clock", "ILi64ELi256ELb1ELb0E"), ("k3_clock", "ILi64ELi256ELb0ELb0E")):
         scratch, vgprs = find(*parts)
         assert scratch == 0, (parts, "spills %d bytes per lane" % scratch)
-    for parts in (("k1_front", "ILb0ELb0E"), ("k1_front", "ILb1ELb0E"), ("k1_front", "ILb0ELb1E")):
+    for parts in (("k1_frontILb0E",), ("k1_frontILb1E",)):
         assert find(*parts)[1] <= 128, parts  # 4 workgroups x 4 waves per CU = 4 waves per SIMD of 512 registers

@@ -28,9 +28,3 @@ def test_a_few_seconds_of_the_batch_soak(capsys):
 
 def test_a_few_seconds_of_the_batcher_soak(capsys):
     run_tool("soak_batcher.py", 6, 1, capsys)
-
-
-def test_a_few_seconds_of_the_batch_soak_with_the_clock_stage_resident_early(capsys, monkeypatch):
-    # the opt-in overlap of consecutive calls' clock stages (SDRM_K3_EARLY), forced for every batch of the soak's rounds
-    monkeypatch.setenv("SDRM_K3_EARLY", "100000")
-    run_tool("soak_fuzz.py", 8, 5001, capsys)

@@ -11,7 +11,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
 cfg = (48000, 9600, 5000, 1, 2000, True, N)
 base = np.stack([siggen.gmsk_channel(i, 2 * N) for i in range(8)])
 x = torch.from_numpy(np.tile(base, (Cn // 8, 1)).view(np.float32)).cuda()
-b = binding.Batch([cfg] * Cn, fast_fma=bool(os.environ.get("SDRM_STAGE_FAST")))  # SDRM_STAGE_FAST=1: the opt-in FMA build of the front-end
+b = binding.Batch([cfg] * Cn)
 st = torch.cuda.current_stream().cuda_stream
 for i in range(2):
     b.process_device(x.data_ptr() + (i % 2) * N * 8, 2 * N, [N] * Cn, st); b.sync()
