@@ -99,13 +99,15 @@ def spawn_ranks(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    import tempfile
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        errs.append(tempfile.TemporaryFile())  # every rank's stderr is kept: a failing run says why, in the parent
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r]))
     deadline = time.time() + args.watchdog_seconds + 60.0
     line, code = None, 0
     try:
@@ -128,6 +130,15 @@ def spawn_ranks(args):
         sys.stderr.write("bench.py: rank 0 printed no result\n")
     else:
         print(line, flush=True)
+    # the ranks' stderr: rank 0's always (warnings travel with a good run too), and on failure the tail of every rank that failed
+    for r, f in enumerate(errs):
+        f.seek(0)
+        text = f.read().decode(errors="replace")
+        f.close()
+        failed = code != 0 and (procs[r].returncode not in (0, None) or r == 0)
+        if text and (r == 0 or failed):
+            tail = text[-4000:] if failed else text[-1500:]
+            sys.stderr.write("---- rank %d stderr%s (exit %s)\n%s\n" % (r, " tail" if len(text) > len(tail) else "", procs[r].returncode, tail))
     sys.exit(code)
 
 
@@ -302,12 +313,18 @@ def end_to_end(binding, siggen, channels, chunk, calls=72, slots=4):
 WARMUP5 = 192
 
 
-def config5_table(total, chunk):
-    """BASELINE configs[4]: half 240 kHz / 19200 baud (decimation 5), half 48 kHz / 1200 baud (decimation 8).  One GPU's
-    share interleaves them; a node-wide table keeps each source's channels together (heavy block first), which is what
-    the cost-balanced contiguous shards are for."""
-    return [(240000, 19200, 5000, 5, 2000, True, chunk) if c < total // 2 else (48000, 1200, 5000, 8, 2000, True, chunk)
-            for c in range(total)]
+def config5_kinds(chunk, decimated=True):
+    """the two kinds of channel of BASELINE configs[4]; decimated: d = 5 / 8 (2.5 / 5 samples per symbol, chunk-invariant),
+    else the reference's default d = 1 (12.5 / 40 samples per symbol, LPF2 of 289 taps at the full rate, the clock stage's
+    tail quirk active -- clock_recovery_mm.c:127-133 -- so the chunking must be the oracle's)"""
+    return ((240000, 19200, 5000, 5 if decimated else 1, 2000, True, chunk), (48000, 1200, 5000, 8 if decimated else 1, 2000, True, chunk))
+
+
+def config5_table(total, chunk, decimated=True):
+    """BASELINE configs[4]: half 240 kHz / 19200 baud, half 48 kHz / 1200 baud.  One GPU's share interleaves them; a node-wide
+    table keeps each source's channels together (heavy block first), which is what the cost-balanced contiguous shards are for."""
+    heavy, light = config5_kinds(chunk, decimated)
+    return [heavy if c < total // 2 else light for c in range(total)]
 
 
 def config5_segments(channels, chunk):
@@ -316,14 +333,31 @@ def config5_segments(channels, chunk):
                     dtype=np.int64).reshape(-1, 3)
 
 
-def config5(torch, binding, siggen, dev, cfgs, chunk, steps=24, plan_step=None, local_rank=-1):
+DISTINCT5 = 16  # seeded waveforms per KIND of channel (32 in all, as the headline has); further channels are circular shifts
+
+
+def config5(torch, binding, siggen, dev, cfgs, chunk, steps=24, plan_step=None, local_rank=-1, first_channel=0, warmup=None):
     """BASELINE configs[4]: every channel corrected by its own Doppler ramp (three NCO batches per channel and call) in
     front of the demodulator.  `plan_step()` returns the call's batches as [(local_channel, len, freq_hz)] -- with N > 1
-    ranks that is the per-call fan-out from rank 0 (shard.fanout_nco_segments), inside the timed loop."""
+    ranks that is the per-call fan-out from rank 0 (shard.fanout_nco_segments), inside the timed loop.
+    Input: per kind DISTINCT5 waveforms of their own seed (a seed per channel; lanes of the clock stage that see the
+    same samples would flatter it), the n-th channel of a kind takes waveform n % DISTINCT5 shifted by 977 (n // DISTINCT5)."""
     channels = len(cfgs)
-    a = siggen.gmsk_channel(1, 2 * chunk, fs=240000, baud=19200)
-    b_ = siggen.gmsk_channel(2, 2 * chunk, fs=48000, baud=1200)
-    x = torch.from_numpy(np.stack([a if c[0] == 240000 else b_ for c in cfgs]).view(np.float32)).to(dev)
+    n_total = 2 * chunk
+    kinds = sorted(set((c[0], c[1]) for c in cfgs), reverse=True)
+    waves = {k: np.stack([siggen.gmsk_channel(0x500 + first_channel + 64 * j + i, n_total, fs=k[0], baud=k[1]) for i in range(DISTINCT5)])
+             for j, k in enumerate(kinds)}
+    waves_t = {k: torch.from_numpy(w.view(np.float32).reshape(DISTINCT5, 2 * n_total).copy()).to(dev) for k, w in waves.items()}
+    seen = {k: 0 for k in kinds}
+    pick = []
+    x = torch.empty((channels, 2 * n_total), dtype=torch.float32, device=dev)
+    for c, cf in enumerate(cfgs):
+        k = (cf[0], cf[1])
+        n = seen[k]
+        seen[k] += 1
+        pick.append((k, n % DISTINCT5, 977 * (n // DISTINCT5)))
+        x[c] = torch.roll(waves_t[k][n % DISTINCT5], shifts=2 * 977 * (n // DISTINCT5))
+    del waves_t
     b = binding.Batch(cfgs, device=local_rank)
     if b.code != 0:
         raise RuntimeError("create failed %d" % b.code)
@@ -339,30 +373,35 @@ def config5(torch, binding, siggen, dev, cfgs, chunk, steps=24, plan_step=None, 
         fed.append(i % 2)
     # warm-up: the pipeline's fill, then the batch's online refinement for calls with NCO batches (about 130 calls from the 17th on:
     # steady state, six blocks of eight calls, the winner's probation; sdrm_batch_schedule_info.online_*) -- outside the timed region, like the creation-time calibration
-    for i in range(WARMUP5):
+    for i in range(WARMUP5 if warmup is None else warmup):
         step(i)
     torch.cuda.synchronize()
     b.timing_enable(True)
     step.fed = fed
-    step.row = lambda c: a if cfgs[c][0] == 240000 else b_
+    step.row = lambda c: np.roll(waves[pick[c][0]][pick[c][1]], pick[c][2])
     return b, x, step
 
 
-def config5_single(torch, binding, siggen, dev, channels, chunk, steps=96, verify=True, check_at=()):
+def config5_single(torch, binding, siggen, dev, channels, chunk, steps=96, verify=True, check_at=(), decimated=True):
     """configs[4] in one GPU's share (N = 1): the two kinds of channel interleaved, batches planned locally.  96 timed steps: the
     timed region ends with the pipeline's drain (about two steps' worth), which 24 steps overstated the step time by 8 % with.  After the
     timed loop (and at the step counts in `check_at`, for the tests) spot channels are compared with the oracle:
-    orc.Nco on the channel's three batches per call, then orc.Fsk."""
-    cfgs = [(240000, 19200, 5000, 5, 2000, True, chunk) if c % 2 == 0 else (48000, 1200, 5000, 8, 2000, True, chunk)
-            for c in range(channels)]
+    orc.Nco on the channel's three batches per call, then orc.Fsk.  decimated=False: SURVEY 8d's other half of Config 5, the
+    reference-default decimation 1 (every call is one oracle call of the same length: the tail quirk is chunk-faithful)."""
+    heavy, light = config5_kinds(chunk, decimated)
+    cfgs = [heavy if c % 2 == 0 else light for c in range(channels)]
     mine = config5_segments(range(channels), chunk)
-    b, x, step = config5(torch, binding, siggen, dev, cfgs, chunk, steps, plan_step=lambda: mine)
+    # (decimation 1: a shorter warm-up -- the spot check replays every call through the oracle, whose 289-tap LPF2 at the full rate
+    # makes a 240 kHz channel cost a second per 1e6 samples; the online refinement then may not have settled, and the schedule says so)
+    b, x, step = config5(torch, binding, siggen, dev, cfgs, chunk, steps, plan_step=lambda: mine, warmup=None if decimated else 48)
     checker, ok, bad = None, None, []
     if verify:
         per_channel = {}
         for c, ln, f in mine:
             per_channel.setdefault(int(c), []).append((int(ln), int(f)))
-        spots = sorted(set(c for c in (0, 1, 16, 17, channels - 2, channels - 1) if 0 <= c < channels))
+        spots = sorted(set(c for c in (0, 1, 16, 17, 2 * DISTINCT5, 2 * DISTINCT5 + 1, channels - 2, channels - 1) if 0 <= c < channels))
+        if not decimated:
+            spots = spots[:2] + spots[-2:]  # (the oracle's 289-tap LPF2 at the full rate: a channel costs ten of the others')
         checker = SpotChecker(cfgs, step.row, chunk, spots, segments_of=lambda c: per_channel[c])
     t0 = time.perf_counter()
     dt = 0.0
@@ -383,6 +422,7 @@ def config5_single(torch, binding, siggen, dev, channels, chunk, steps=96, verif
         ok = good if ok is None else (ok and good)
         bad += detail["mismatches"]
     schedule = b.schedule()
+    wild = b.wild_calls()
     b.close()
     del x
     torch.cuda.empty_cache()
@@ -398,8 +438,100 @@ def config5_single(torch, binding, siggen, dev, channels, chunk, steps=96, verif
             "without_online_refinement": unrefined,
             "verified_vs_oracle": ok, "verify_mismatches": bad, "schedule": schedule,
             "channels": channels, "steps": steps, "kernel_ms": [round(m / max(n, 1), 3) for m, n in km],
-            "workload": "half (240000,19200,5000,5,2000,dc) + half (48000,1200,5000,8,2000,dc), per-channel Doppler NCO "
-                        "(3 batches per channel and call), inputs in HBM"}
+            "wild_channel_calls": wild,
+            "workload": "half (240000,19200,5000,%d,2000,dc) + half (48000,1200,5000,%d,2000,dc), per-channel Doppler NCO "
+                        "(3 batches per channel and call), %d seeded waveforms per kind + circular shifts, inputs in HBM"
+                        % (heavy[3], light[3], DISTINCT5)}
+
+
+def blocking_calls(torch, binding, siggen, dev, chunk, verify=True, calls=12):
+    """The call the reference's caller blocks on (src/dsp_worker.c:75; test/perf_fsk_modem.c:70-98 times it in a loop): ONE call at a
+    time, the next one only when its results are there -- nothing of an earlier call to hide the front-end and the DC blocker
+    behind.  Batches of 256 and 1024 channels (device-resident input, sdrm_batch_process_device + sdrm_batch_sync) and one plain
+    fsk_demod handle (host buffer in, soft bits out: fsk_demod_process as the reference calls it), each with the in-call
+    hand-off (the default) and with SDRM_HANDOFF=0 (the variable is read when the batch is created), median of `calls` calls
+    after 3, the last call checked against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc  # the checker, outside the timed calls
+    out = {"how": "host clock around one call at a time (enqueue + wait), median of %d after 3 warm-up calls; ms" % calls,
+           "reference": "src/dsp_worker.c:75 (the caller blocks on fsk_demod_process), test/perf_fsk_modem.c:70-98"}
+    cfg = (FS, BAUD, DEV, DECIM, TW, DC)
+    base = np.stack([siggen.gmsk_channel(0x700 + i, 2 * chunk) for i in range(DISTINCT)])
+    base_t = torch.from_numpy(base.view(np.float32).reshape(DISTINCT, 4 * chunk).copy()).to(dev)
+    saved = os.environ.get("SDRM_HANDOFF")
+
+    def with_handoff(on):
+        if on:
+            os.environ.pop("SDRM_HANDOFF", None)
+        else:
+            os.environ["SDRM_HANDOFF"] = "0"
+
+    try:
+        for channels in (256, 1024):
+            x = torch.empty((channels, 4 * chunk), dtype=torch.float32, device=dev)
+            for c in range(channels):
+                x[c] = torch.roll(base_t[c % DISTINCT], shifts=2 * 977 * (c // DISTINCT))
+            rec = {"channels": channels, "samples": chunk}
+            for on in (True, False):
+                with_handoff(on)
+                b = binding.Batch([cfg + (chunk,)] * channels, device=dev.index)
+                if b.code != 0:
+                    raise RuntimeError("create failed %d" % b.code)
+                st = torch.cuda.current_stream().cuda_stream
+                lens = (binding.C.c_size_t * channels)(*([chunk] * channels))
+                fed, ts = [], []
+                for i in range(3 + calls):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    b.process_device(x.data_ptr() + (i % 2) * chunk * 8, 2 * chunk, lens, st)
+                    b.sync()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                    fed.append(i % 2)
+                key = "handoff" if on else "handoff_off"
+                rec[key + "_ms"] = round(float(np.median(ts[3:])), 4)
+                rec[key + "_calls_taken"] = b.handoff_calls()
+                if verify:
+                    ok, det = SpotChecker([cfg + (chunk,)] * channels, lambda c: np.roll(base[c % DISTINCT], 977 * (c // DISTINCT)), chunk,
+                                          spot_channels(channels)).check(b, fed)
+                    rec[key + "_verified"] = ok
+                b.close()
+            del x
+            torch.cuda.empty_cache()
+            out["%dx%d" % (channels, chunk)] = rec
+        # one plain handle: the reference's own call, host buffer in.  Two configurations: the workload's (9600 baud: 26214 symbols
+        # per call, the clock recursion's ~97 ns per symbol is 2.5 ms whatever overlaps it) and the reference perf harness's
+        # (4800 baud, decimation 2: half the symbols), which is the one round 5 quoted at 1.53 ms
+        for label, hcfg in (("one_handle_48000_9600", cfg), ("one_handle_48000_4800_d2", (48000, 4800, 5000, 2, 2000, True))):
+            sig = siggen.gmsk_channel(0x7f0, 2 * chunk, fs=hcfg[0], baud=hcfg[1])
+            rec = {"samples": chunk, "config": list(hcfg)}
+            for on in (True, False):
+                with_handoff(on)
+                d = binding.FskDemod(*hcfg, chunk)
+                o = orc.Fsk(*hcfg, chunk) if verify else None
+                ts, got, want = [], None, None
+                for i in range(3 + calls):
+                    part = sig[(i % 2) * chunk:(i % 2 + 1) * chunk]
+                    t0 = time.perf_counter()
+                    got = d.process(part)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                    if o is not None:
+                        want, _ = o.process(part)
+                key = "handoff" if on else "handoff_off"
+                rec[key + "_ms"] = round(float(np.median(ts[3:])), 4)
+                if verify:
+                    rec[key + "_verified"] = bool(np.array_equal(np.asarray(got), want))
+                d.close()
+            out[label] = rec
+        taken, refused, peak = binding.handoff_stats(dev.index)
+        out["device_ledger"] = {"taken": taken, "refused": refused, "peak_waiting_workgroups": peak}
+    finally:
+        if saved is None:
+            os.environ.pop("SDRM_HANDOFF", None)
+        else:
+            os.environ["SDRM_HANDOFF"] = saved
+    del base_t
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -671,6 +803,14 @@ def main():
                 out["config5"] = config5_single(torch, binding, siggen, dev, C, N, verify=not args.no_verify)
             except Exception as exc:  # informative sub-blocks: never cost the headline its line
                 out["config5"] = {"error": str(exc)[:200]}
+            try:  # SURVEY 8d Config 5, the other half: the reference-default decimation 1 (tail quirk active)
+                out["config5_d1"] = config5_single(torch, binding, siggen, dev, C, N, steps=48, verify=not args.no_verify, decimated=False)
+            except Exception as exc:
+                out["config5_d1"] = {"error": str(exc)[:200]}
+            try:
+                out["blocking_call"] = blocking_calls(torch, binding, siggen, dev, N, verify=not args.no_verify)
+            except Exception as exc:
+                out["blocking_call"] = {"error": str(exc)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import orc

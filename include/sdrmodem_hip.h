@@ -218,6 +218,13 @@ int sdrm_batch_wild_calls(sdrm_batch *batch, uint64_t *count);
  * blocking: 4.28 -> 2.72 ms.  Used for batches small enough that waiting workgroups cannot starve the stage they wait for;
  * SDRM_HANDOFF=0 (environment, read at batch creation) switches it off.  This counts the calls that took it. */
 int sdrm_batch_handoff_calls(sdrm_batch *batch, uint64_t *count);
+/* The workgroups of a hand-off call that wait for the stage in front of them hold compute units of the DEVICE, and a server
+ * runs one handle per client (src/dsp_worker.c:188, src/tcp_server.c:659): admission is therefore counted per device across
+ * every batch and handle of the process -- a call takes the hand-off only while the waiting workgroups on the device, its own
+ * included, stay within the limit (192; 16 where a DC workgroup leaves a front-end workgroup no room beside it), and runs its
+ * stages in stream order otherwise.  Process-wide totals for a device (< 0: the current one): calls admitted, calls that
+ * qualified but found the budget taken, the largest number of workgroups that were waiting at once.  Any pointer may be NULL. */
+int sdrm_handoff_stats(int device, uint64_t *taken, uint64_t *refused, uint32_t *peak_waiting);
 
 /* Stage probes for tests: run ONE stage of the device pipeline on a host vector (state-free where the
  * stage is). Return 0 on success. */

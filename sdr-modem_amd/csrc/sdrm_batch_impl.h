@@ -1,5 +1,5 @@
-// sdrm_batch_impl.h -- what the translation units of the batch share: the batch's state and the few functions the schedule
-// tuning (sdrm_tune.hip) needs from the call path (sdrm_api.hip).  Internal: not installed, not part of the C-ABI.
+// sdrm_batch_impl.h -- what the translation units of the library share: the batch's state and the internal functions that cross
+// file boundaries.  Internal: not installed, not part of the C-ABI.
 #ifndef SDRM_BATCH_IMPL_H
 #define SDRM_BATCH_IMPL_H
 
@@ -110,6 +110,8 @@ struct sdrm_batch_t {
     hipStream_t s_hand_dc = nullptr, s_hand_clock = nullptr;  // a one-stream (serial) batch: side streams for a hand-off call's DC and clock stages, created on first use
     bool hand_side_last = false;     // the call enqueued last ran on them: the next call's first stream waits for its end
     uint64_t hand_calls = 0;         // diagnostics: calls enqueued with the hand-off
+    uint64_t hand_refused = 0;       // ... calls that qualified but found the DEVICE's budget of waiting workgroups taken (sdrm_api.hip, HandLedger)
+    bool hand_listed = false;        // this batch may have an entry in the device's ledger (only the owner's thread touches this)
     uint64_t last_hand_call = 0;     // index of the last call that took the hand-off
     bool hand_follow = true;         // the two calls behind it: their front-ends wait for the DC workgroups' placement
     uint64_t hand_epoch = 0;  // hand-off calls since the batch was created -- never reset: a call's stamp value must be new
@@ -200,13 +202,44 @@ static inline uint32_t *outlen_of(const sdrm_batch_t *b, uint64_t call) {
     return (b->d_outlen_b && (call & 1)) ? b->d_outlen_b : b->d_outlen;
 }
 
-// the call path, for the tuning (sdrm_api.hip)
-int sdrm_enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
-                      const sdrm_nco_segment *segs, size_t n_segs);
-int sdrm_wait_for_all_calls(sdrm_batch_t *b);
-// every stream of the batch back to its initial state (after a calibration: the caller's first call finds a fresh batch)
-int sdrm_reset_all_streams(sdrm_batch_t *b);
-// the schedule tuning, for the call path (sdrm_tune.hip)
+// What the translation units of the library share beyond the C-ABI (internal linkage would do if they were one file).
+//   sdrm_batch.hip   the batch object's life: create / destroy / grow / reset, timing lanes, oscillator buffers
+//   sdrm_call.hip    the process path: enqueue_call and every entry point built on it, hand-off admission, waits
+//   sdrm_tune.hip    the schedule: creation-time calibration, online refinement
+//   sdrm_handle.hip  fsk_demod_* on a batch of one, probes, diagnostics
+namespace sdrm_impl {
+template <typename T>
+int dev_alloc_zero(T **ptr, size_t count) {
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **) ptr, bytes);
+    if (e != hipSuccess) {
+        fprintf(stderr, "<3>sdrmodem_hip: hipMalloc(%zu) failed: %s\n", bytes, hipGetErrorString(e));
+        return -ENOMEM;
+    }
+    // hipMemset returns before the device has written the zeros, and the pipeline's streams are non-blocking streams:
+    // they do not wait for the null stream.  A buffer allocated lazily (the staged input of the first host call, the NCO
+    // buffers) would otherwise be zeroed while the first copy or kernel is already using it.
+    e = hipMemset(*ptr, 0, bytes);
+    e = e ? e : hipStreamSynchronize(nullptr);
+    return e == hipSuccess ? 0 : -EIO;
+}
+// sdrm_batch.hip
+void batch_free(sdrm_batch_t *b);
+int quiesce(sdrm_batch_t *b);              // waits for everything this batch has put on the device -- its own streams only
+int reset_all_streams(sdrm_batch_t *b);    // every stream of the batch back to its initial state (after a calibration)
+uint32_t carried_cap(const sdrm_chan_params &p);                 // most samples the clock stage carries between calls
+uint32_t symbols_bound(const sdrm_chan_params &p, uint32_t nz);  // most symbols a channel can produce from nz samples
+int ensure_nco(sdrm_batch_t *b);           // the Doppler oscillator's buffers, allocated on first use
+void timing_begin(sdrm_batch_t *b, int which, hipStream_t s, std::pair<hipEvent_t, hipEvent_t> *pr);
+void timing_end(sdrm_batch_t *b, int which, hipStream_t s, const std::pair<hipEvent_t, hipEvent_t> &pr);
+void timing_collect(sdrm_batch_t *b);
+// sdrm_call.hip
+int enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stride, const size_t *lens, hipStream_t caller,
+                 const sdrm_nco_segment *segs, size_t n_segs);
+int wait_for_all_calls(sdrm_batch_t *b);
+void hand_release(sdrm_batch_t *b);        // this batch's entry in the device's ledger of waiting workgroups, if it has one
+}  // namespace sdrm_impl
+// the schedule tuning (sdrm_tune.hip)
 int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs);
 void sdrm_online_tune_before(sdrm_batch_t *b, bool with_nco, uint64_t sig);
 void sdrm_online_tune_after(sdrm_batch_t *b, hipStream_t s_clock);

@@ -259,16 +259,18 @@ void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride,
 
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) { return sdrm_k1_lds_bytes_for(t1_max, t2_max); }
 
-// grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
+// grid (channels, max_tiles), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
 // per-thread boundary samples | arctan table.
 template <bool HAND>
 __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
                                                             size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
-    // grid (tiles, channels); with the in-call hand-off (channels, tiles): workgroups are dispatched x first, so every channel's
-    // tile 0 comes before anybody's tile 1 and the stages behind can start on all channels at once
-    const int c = HAND ? blockIdx.x : blockIdx.y;
-    const unsigned tile_id = HAND ? blockIdx.y : blockIdx.x;
+    // grid (channels, tiles): workgroups are dispatched x first, so every channel's tile 0 comes before anybody's tile 1 -- with the
+    // in-call hand-off the stages behind can then start on all channels at once; without it, the workgroups dispatched LAST are
+    // every channel's last tile, the short one (131072 samples are 34.65 tiles), which is what a grid's tail should be made of
+    // (until round 6 the ordinary build ran (tiles, channels): its last workgroups were the last channel's 34 full tiles)
+    const int c = blockIdx.x;
+    const unsigned tile_id = blockIdx.y + blockIdx.z * gridDim.y;  // (z: calls of more than 65535 tiles, a quarter of a billion samples)
     const sdrm_chunk_ctl ctl = b.ctl[c];
     const sdrm_chan_params p = b.params[c];
     if (tile_id == 0) {
@@ -430,10 +432,8 @@ KernelLaunch describe_front(const DeviceBatch &b) {
         allow_lds(k1_front<false>, k.lds, &granted);
         k.func = reinterpret_cast<const void *>(k1_front<false>);
     }
-    k.grid = dim3(b.max_tiles ? b.max_tiles : 1u, (unsigned) b.n_channels);  // tile 0 of every channel also rolls its history
-    if (b.handoff) {
-        k.grid = dim3((unsigned) b.n_channels, b.max_tiles ? b.max_tiles : 1u);
-    }
+    const unsigned tiles = b.max_tiles ? b.max_tiles : 1u;  // tile 0 of every channel also rolls its history
+    k.grid = dim3((unsigned) b.n_channels, tiles < 65535u ? tiles : 65535u, (tiles + 65534u) / 65535u);
     k.block = dim3(SDRM_K1_THREADS);
     return k;
 }
@@ -516,7 +516,7 @@ __device__ __forceinline__ uint32_t hand_prog_of(const DeviceBatch &b, int c) {
     const unsigned long long v = __hip_atomic_load(b.hand_prog + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (uint32_t) (v >> 32) == b.epoch ? (uint32_t) v : 0u;
 }
-// Device-scope (sc1) vector accesses through a raw buffer resource over the whole array: written THROUGH / read PAST this XCD's
+// Device-scope (sc1) vector accesses through a raw buffer resource over the workgroup's rows of the array: written THROUGH / read PAST this XCD's
 // L2, so that a producer and a consumer running at the same time on different XCDs meet in memory -- a store is there once it
 // has been acknowledged (s_waitcnt vmcnt), a load issued after that sees it; no cache write-back or invalidation involved.
 // (Buffer instructions because the cache policy of a 16-byte access cannot be said otherwise; the compiler tracks them like any load.)
@@ -769,8 +769,10 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     };
     // this call's front-end output as the feeder reads it: plainly, or -- while the front-end is still running (hand-off) -- with
     // device scope, past this XCD's L2 (hand_load*)
-    const __amdgpu_buffer_rsrc_t z_rsrc = hand_rsrc(b.z);
-    const size_t z_row = (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
+    // (the resource starts at the row of the workgroup's first channel: the 32-bit byte offsets then span dc_group rows, not the
+    // whole array -- 1024 channels x 1 M samples is 4 GiB; the host refuses the hand-off beyond 2^32 bytes per group)
+    const __amdgpu_buffer_rsrc_t z_rsrc = hand_rsrc(b.z + (size_t) c0 * b.z_stride);
+    const size_t z_row = (size_t) (L.on ? L.s.chan - c0 : 0) * b.z_stride;
     auto x4 = [&](int m, float *v) {    // x[m .. m+3]: any alignment, maybe carried samples
         if (m >= 0 && (m & 3) == 0) {
             if (HAND) {
@@ -845,8 +847,8 @@ __global__ __launch_bounds__(64 * SDRM_K2_WAVES) void k2_dc(DeviceBatch b) {
     // 0.54 -> 1.02 us per block).  Stores of a wave are acknowledged in order.
 #define K2_LAG 4
     int done_said = 0;
-    const __amdgpu_buffer_rsrc_t out_rsrc = hand_rsrc(b.dcout);
-    const size_t out_row = (size_t) (L.on ? L.s.chan : 0) * b.z_stride;
+    const __amdgpu_buffer_rsrc_t out_rsrc = hand_rsrc(b.dcout + (size_t) c0 * b.z_stride);
+    const size_t out_row = (size_t) (L.on ? L.s.chan - c0 : 0) * b.z_stride;
     auto publish = [&](int k, int n0, const float (&o)[K2_P], int valid, bool whole, bool suspicious) {
         int done;  // blocks 0 .. done - 1 of this wave's slots are in memory
         if (whole) {

@@ -56,17 +56,17 @@ int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
     auto measure = [&](double *ms) -> int {
         const int warm = 3;
         for (int k = 0; k < warm; k++) {
-            int c2 = sdrm_enqueue_call(b, d_row, 0, lens.data(), b->stream, nullptr, 0);
+            int c2 = sdrm_impl::enqueue_call(b, d_row, 0, lens.data(), b->stream, nullptr, 0);
             if (c2 != 0) return c2;
         }
-        int c2 = sdrm_wait_for_all_calls(b);
+        int c2 = sdrm_impl::wait_for_all_calls(b);
         if (c2 != 0) return c2;
         const auto t0 = std::chrono::steady_clock::now();
         for (int k = 0; k < timed; k++) {
-            c2 = sdrm_enqueue_call(b, d_row, 0, lens.data(), b->stream, nullptr, 0);
+            c2 = sdrm_impl::enqueue_call(b, d_row, 0, lens.data(), b->stream, nullptr, 0);
             if (c2 != 0) return c2;
         }
-        c2 = sdrm_wait_for_all_calls(b);
+        c2 = sdrm_impl::wait_for_all_calls(b);
         *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
         return c2;
     };
@@ -131,7 +131,7 @@ int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
         }
     }
     if (code == 0) {
-        code = sdrm_reset_all_streams(b);
+        code = sdrm_impl::reset_all_streams(b);
     }
     (void) hipFree(d_row);
     b->calibrated = code == 0;

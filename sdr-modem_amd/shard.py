@@ -129,7 +129,7 @@ def fanout_configs(cfgs_rank0, total, device="cpu", balance="count"):
     table = torch.zeros((total, FIELDS), dtype=torch.int64, device=device)
     if rank == 0:
         table.copy_(encode(cfgs_rank0))
-    if world > 1:
+    if dist.is_initialized():  # (a world of one included: the collective then still runs through the backend -- RCCL on a GPU)
         dist.broadcast(table, src=0)
     if balance == "cost":
         lo, hi = shard_by_cost(decode(table.cpu()), world)[rank]
@@ -168,7 +168,7 @@ def fanout_nco_segments(segments_rank0, shard, device="cpu", as_array=False, cap
             table[0, 1] = len(rows0)
             if fits and len(rows0):
                 table[1:1 + len(rows0)].copy_(torch.from_numpy(rows0))
-        if world > 1:
+        if dist.is_initialized():
             dist.broadcast(table, src=0)
         host = table.cpu().numpy()
         if int(host[0, 0]) < 0:
@@ -178,13 +178,13 @@ def fanout_nco_segments(segments_rank0, shard, device="cpu", as_array=False, cap
         count = torch.zeros(1, dtype=torch.int64, device=device)
         if rank == 0:
             count[0] = len(rows0)
-        if world > 1:
+        if dist.is_initialized():
             dist.broadcast(count, src=0)
         n = int(count.item())
         table = torch.zeros((max(n, 1), 3), dtype=torch.int64, device=device)
         if rank == 0 and n:
             table[:n].copy_(torch.from_numpy(rows0))
-        if world > 1:
+        if dist.is_initialized():
             dist.broadcast(table, src=0)
         rows = table[:n].cpu().numpy()
     mine = rows[(rows[:, 0] >= shard.lo) & (rows[:, 0] < shard.hi)].copy()

@@ -85,6 +85,31 @@ def test_config5_workload_as_benchmarked(torch_dev):
     assert all(ms > 0 for ms in res["schedule"]["online"]["ms_per_call"][:4]), res["schedule"]
 
 
+def test_config5_at_the_reference_default_decimation_as_benchmarked(torch_dev):
+    """bench.py's `config5_d1` block (SURVEY 8d Config 5, "run both"): the same mix at decimation 1 -- 12.5 and 40 samples per
+    symbol, LPF2 of 289 taps at the full rate, DC boxcars of 400 and 1280 samples, the clock stage's tail quirk active
+    (clock_recovery_mm.c:127-133: chunking must equal the oracle's, and does: one oracle call per device call) -- on per-kind
+    seeded waveforms with circular shifts; spot channels of both kinds against orc.Nco + orc.Fsk."""
+    torch, dev = torch_dev
+    res = bench.config5_single(torch, binding, siggen, dev, 256, N, steps=3, verify=True, check_at=(2,), decimated=False)
+    assert res["verified_vs_oracle"] is True, res["verify_mismatches"]
+    assert res["wild_channel_calls"] == 0
+
+
+def test_blocking_call_block_as_benchmarked(torch_dev):
+    """bench.py's `blocking_call` block: one call at a time (src/dsp_worker.c:75) on 256 and 1024 channels and on one plain handle,
+    with the in-call hand-off and with SDRM_HANDOFF=0, every last call against the oracle; the hand-off is taken by every call
+    of the batches when it is on and by none when it is off."""
+    torch, dev = torch_dev
+    res = bench.blocking_calls(torch, binding, siggen, dev, N, verify=True, calls=3)
+    for key in ("256x131072", "1024x131072"):
+        r = res[key]
+        assert r["handoff_verified"] is True and r["handoff_off_verified"] is True, r
+        assert r["handoff_calls_taken"] >= 6 and r["handoff_off_calls_taken"] == 0, r
+    for key in ("one_handle_48000_9600", "one_handle_48000_4800_d2"):
+        assert res[key]["handoff_verified"] is True and res[key]["handoff_off_verified"] is True, res[key]
+
+
 def test_bench_line_carries_the_spot_check(torch_dev, capsys):
     """`python bench.py` (short) prints verified_vs_oracle: true on the headline, the sweep and config5"""
     import json
@@ -96,6 +121,9 @@ def test_bench_line_carries_the_spot_check(torch_dev, capsys):
     assert line["verified_vs_oracle"] is True, line.get("verify")
     assert line["channel_sweep"]["1024"]["verified_vs_oracle"] is True
     assert line["config5"]["verified_vs_oracle"] is True, line["config5"]
+    assert line["config5_d1"]["verified_vs_oracle"] is True, line["config5_d1"]
+    assert line["blocking_call"]["256x131072"]["handoff_verified"] is True, line["blocking_call"]
+    assert line["blocking_call"]["one_handle_48000_9600"]["handoff_verified"] is True, line["blocking_call"]
 
 
 def test_self_calibration_leaves_every_stream_as_new(torch_dev, monkeypatch):

@@ -1,0 +1,117 @@
+"""`-m gpu`: the reference's process model at the reference's scale -- one demodulator and one blocking call per client and buffer
+(src/dsp_worker.c:188 thread per client, :75 the call, src/tcp_server.c:659), buffers of 131072 samples
+(src/resources/config.conf:11) -- through tools/handles_bench, a plain C program on the public header: many PRIVATE fsk_demod
+handles (and private dsp_workers) calling at once, each long enough to take the in-call hand-off.  What must hold: no handle ends
+in the sticky error state, every client's soft-bit stream is the oracle's for its input, and the device-wide ledger of waiting
+workgroups (sdrm_handoff_stats) admits and refuses hand-offs as designed -- admission per batch (round 5) let the waiting
+workgroups of different handles add up CU by CU."""
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import orc
+import sdrm_pkg
+
+sdrm_pkg.load()
+from sdr_modem_amd import binding, siggen  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = (48000, 9600, 5000, 1, 2000, True)
+BUF = 131072
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert binding.load().sdrm_device_count() > 0, "these tests need an MI355X; the library has no CPU path"
+
+
+def _exe():
+    exe = os.path.join(ROOT, "tools", "handles_bench")
+    src = os.path.join(ROOT, "tools", "handles_bench.c")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-pthread", src, "-I" + os.path.join(ROOT, "include"),
+                               "-L" + os.path.join(ROOT, "sdr-modem_amd", "csrc"), "-lsdrmodem_hip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "sdr-modem_amd", "csrc"), "-lm", "-o", exe])
+    return exe
+
+
+def fnv1a(data):
+    h = 0xcbf29ce484222325
+    for b in bytes(data):
+        h = ((h ^ b) * 0x100000001b3) & 0xffffffffffffffff
+    return h
+
+
+@pytest.fixture(scope="module")
+def streams():
+    """eight client recordings of 6 buffers each, and what the oracle makes of each (symbol count, FNV-1a of the int8 stream)"""
+    tmp = tempfile.TemporaryDirectory()
+    files, want = [], []
+    for k in range(8):
+        iq = siggen.gmsk_channel(900 + k, 6 * BUF, carrier_offset_hz=37.0 * k - 120.0)
+        path = os.path.join(tmp.name, "client%d.cf32" % k)
+        iq.tofile(path)
+        files.append(path)
+        prefix = {}
+        for calls in (3, 6):
+            soft, _ = orc.demod_stream(CFG, iq[:calls * BUF], BUF)
+            prefix[calls] = (len(soft), fnv1a(soft.tobytes()))
+        want.append(prefix)
+    yield files, want
+    tmp.cleanup()
+
+
+def _run(args, files, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([_exe()] + [str(a) for a in args] + files, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
+    classes = {int(m.group(1)): (int(m.group(2)), int(m.group(3)), int(m.group(4), 16), m.group(5))
+               for m in re.finditer(r"class (\d+): handles (\d+) symbols (\d+) fnv ([0-9a-f]+) agree (\w+)", out.stdout)}
+    tail = re.search(r"errors (\d+), hand-off taken (\d+) refused (\d+) peak waiting (\d+)", out.stdout)
+    assert tail, out.stdout
+    ms = float(re.search(r"\): ([0-9.]+) ms,", out.stdout).group(1))
+    return classes, tuple(int(x) for x in tail.groups()), ms, out.stderr
+
+
+def _check(classes, want, calls, handles):
+    assert len(classes) == min(len(want), handles)
+    for k, (members, symbols, digest, agree) in classes.items():
+        assert agree == "yes", "handles fed the same recording disagree (class %d)" % k
+        assert (symbols, digest) == want[k][calls], "class %d: %d symbols, the oracle has %d (or other bits)" % (k, symbols, want[k][calls][0])
+
+
+@pytest.mark.parametrize("handles,calls", [(64, 6), (256, 3)])
+def test_many_private_handles_call_at_once_with_the_references_buffer_size(streams, handles, calls):
+    files, want = streams
+    classes, (errors, taken, refused, peak), ms, err = _run([handles, BUF, calls], files)
+    assert errors == 0 and "<3>" not in err, err[-1500:]
+    _check(classes, want, calls, handles)
+    # every call is long enough for the hand-off (>= 12288 samples) and meets an idle batch: it either took it or was refused
+    # by the device's ledger, and the workgroups waiting at once never exceeded the limit
+    assert taken + refused == handles * calls and taken > 0
+    assert peak <= 192
+    if handles == 256:
+        assert refused > 0, "256 handles x (a clock-stage and a DC workgroup each) cannot all have been admitted at once"
+
+
+def test_the_same_streams_without_the_hand_off(streams):
+    files, want = streams
+    classes, (errors, taken, refused, _), _, err = _run([64, BUF, 3], files, env={"SDRM_HANDOFF": "0"})
+    assert errors == 0 and taken == 0 and refused == 0
+    _check(classes, want, 3, 64)
+
+
+def test_thirty_two_private_workers_with_the_references_buffer_size(streams):
+    """dsp_worker_create x 32 (private handle each, file sink), buffer_size 131072, fed from 32 source threads through
+    dsp_worker_put: the files the workers wrote are the oracle's streams"""
+    files, want = streams
+    classes, (errors, taken, refused, peak), _, err = _run(["-w", 32, BUF, 6], files)
+    assert errors == 0 and "<3>" not in err, err[-1500:]
+    _check(classes, want, 6, 32)
+    assert taken > 0 and peak <= 192

@@ -149,8 +149,8 @@ def test_reference_signature_adapter_on_the_device(tmp_path):
     struct server_config *, struct RxRequest *, &worker) -- built here and driven on the device (until round 5 only over the
     kernel emulation): (1) workers that own a private demodulator, as the reference lays them out, one of them dumping its IQ;
     (2) workers placed by a node of two batchers on this device; (3) a worker with RxRequest.doppler set, the predictor built
-    by the shipped factory (integration/doppler_factory_ref.c on the reference's own src/sgpsdp, prebuilt into oracle/_ref)
-    from the TLE and the station of the reference's Doppler test.  The files the reference's worker writes
+    by a factory installed with sdrm_ref_set_doppler_factory (a synthetic one here: the shipped SGP4 factory is host-only and is
+    pinned in the CPU suite).  The files the reference's worker writes
     (rx.demod2client.<id>.s8, rx.sdr2demod.<id>.cf32; src/dsp_worker.c:154,165) hold the oracle's bytes."""
     import test_abi_cpu as T
     A = T._ref_adapter(tmp_path)
@@ -206,14 +206,27 @@ def test_reference_signature_adapter_on_the_device(tmp_path):
     assert [node.stat(d).clients for d in range(2)] == [0, 0]
     A.sdrm_ref_attach_node(None)
     node.close()
-    # (3) Doppler from the request, through the shipped factory
-    if not os.path.exists(T.FACTORY_SO):
-        pytest.skip("oracle/_ref/libsdrm_doppler_factory.so is built where the reference tree is")
-    F = C.CDLL(T.FACTORY_SO)
+    # (3) Doppler from the request, through a factory (sdrm_ref_set_doppler_factory).  The orbit model is host-only and the shipped
+    # factory (integration/doppler_factory_ref.c on the reference's src/sgpsdp) is pinned against the reference's shifts in the
+    # CPU suite (test_abi_cpu.py::test_shipped_doppler_factory_returns_the_references_shifts) -- nothing built from the
+    # reference's sources travels to the GPU box.  Here a synthetic factory hands out the same station's recorded shifts
+    # (tests/golden/doppler_shifts_lucky7.json): what is under test is the request -> factory -> predictor -> device NCO path.
+    import json
+    recorded = json.load(open(os.path.join(GOLDEN, "doppler_shifts_lucky7.json")))["shifts_hz"]
+    shift_cb = binding.SHIFT_FN(lambda user, k: float(recorded[min(int(k), len(recorded) - 1)]))
+    FACTORY = C.CFUNCTYPE(C.c_int, C.POINTER(T._RxRequest), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
+    asked = []
+
+    def factory(req, cfg_, fn_out, user_out):
+        asked.append((bool(req.contents.doppler), bool(req.contents.file_settings)))
+        fn_out[0] = C.cast(shift_cb, C.c_void_p)
+        user_out[0] = None
+        return 0
+    factory_cb = FACTORY(factory)
     A.sdrm_ref_set_doppler_factory.argtypes = [C.c_void_p]
     A.sdrm_ref_set_doppler_release.argtypes = [C.c_void_p]
-    A.sdrm_ref_set_doppler_factory(C.cast(F.sdrm_ref_doppler_factory, C.c_void_p))
-    A.sdrm_ref_set_doppler_release(C.cast(F.sdrm_ref_doppler_close, C.c_void_p))
+    A.sdrm_ref_set_doppler_factory(C.cast(factory_cb, C.c_void_p))
+    A.sdrm_ref_set_doppler_release(None)
     lines = (C.c_char_p * 3)(*T.LUCKY7_TLE)
     ds = T._DopplerSettings(n_tle=3, tle=lines, latitude=537200000, longitude=475700000, altitude=0)
     fs_ = T._FileSettings(filename=b"x.cf32", start_time_seconds=1583840449)
@@ -225,15 +238,10 @@ def test_reference_signature_adapter_on_the_device(tmp_path):
         return req
     iq = np.fromfile(os.path.join(GOLDEN, "lucky7.cf32"), dtype=np.complex64)
     got = run([821], doppler_request, [iq])
-    # the oracle's Doppler block with the same station's shifts (the factory evaluated directly), then its demodulator
-    fn, user = C.c_void_p(), C.c_void_p()
-    F.sdrm_ref_doppler_factory.argtypes = [C.POINTER(T._RxRequest), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
-    req = doppler_request(0)
-    assert F.sdrm_ref_doppler_factory(C.byref(req), None, C.byref(fn), C.byref(user)) == 0
-    SHIFT = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_uint64)
-    shifts = [SHIFT(fn.value)(user, k) for k in range(len(iq) // 48000 + 3)]
+    assert asked == [(True, True)]
+    # the oracle's Doppler block with the same shifts, then its demodulator
     o = orc.Fsk(*cfg)
-    d = orc.Doppler(48000, shifts, 4096)
+    d = orc.Doppler(48000, recorded, 4096)
     want = np.concatenate([o.process(d.process(iq[off:off + 4096].view(np.float32)))[0] for off in range(0, len(iq), 4096)])
     assert np.array_equal(got[0], want)
     A.sdrm_ref_set_doppler_factory(None)
