@@ -207,7 +207,12 @@ int sdrm_batch_timing_read(sdrm_batch *batch, int which, double *total_ms, uint6
  * the channel's safe amplitude -- discriminator gains in the thousands, i.e. a deviation of a few Hz, on noise; or fewer
  * than ~1.01 samples per symbol): the reference's loop may then stand still or walk BACKWARDS through its buffer
  * (src/dsp/clock_recovery_mm.c:121-122), which the LDS-resident stage cannot follow, so such a call is run from global
- * memory, statement by statement -- same bits, slower.  Counted since the batch was created; waits for enqueued calls. */
+ * memory, statement by statement -- same bits, slower.  Counted since the batch was created; waits for enqueued calls.
+ * One bound applies to such a channel as to every other: at most 255 samples are carried from one call to the next (the
+ * newest ones).  The reference carries working_len - last_index samples (clock_recovery_mm.c:127-135), which after a backward
+ * walk that ends at a negative position can be tens of thousands -- as long as they and the next call still fit its
+ * output_len + 8 working buffer; a full-length next call writes past it.  From such a call on the two streams may differ;
+ * the oracle applies the same bound, so "equals the oracle" holds with it.  A loop in lock carries fewer than 24 samples. */
 int sdrm_batch_wild_calls(sdrm_batch *batch, uint64_t *count);
 
 /* In-call hand-off.  A call that meets an idle batch -- every blocking call (the reference's caller waits for

@@ -464,6 +464,8 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
                 const double sym = cfgs[c].sampling_freq ? n * (double) cfgs[c].baud_rate / (double) cfgs[c].sampling_freq : 0.0;
                 symbols = sym > symbols ? sym : symbols;
             }
+            b->est_front_ms = (float) (macs / 18.4e12 * 1e3);   // (the calibration asks only where these leave the rule in doubt)
+            b->est_clock_ms = (float) (symbols * 97e-9 * 1e3);
             if (macs / 18.4e12 > 0.7 * symbols * 97e-9) {
                 blocks = 0;
             }

@@ -110,7 +110,7 @@ struct sdrm_batch_t {
     hipStream_t s_hand_dc = nullptr, s_hand_clock = nullptr;  // a one-stream (serial) batch: side streams for a hand-off call's DC and clock stages, created on first use
     bool hand_side_last = false;     // the call enqueued last ran on them: the next call's first stream waits for its end
     uint64_t hand_calls = 0;         // diagnostics: calls enqueued with the hand-off
-    uint64_t hand_refused = 0;       // ... calls that qualified but found the DEVICE's budget of waiting workgroups taken (sdrm_api.hip, HandLedger)
+    uint64_t hand_refused = 0;       // ... calls that qualified but found the DEVICE's budget of waiting workgroups taken (../host/ledger.h)
     bool hand_listed = false;        // this batch may have an entry in the device's ledger (only the owner's thread touches this)
     uint64_t last_hand_call = 0;     // index of the last call that took the hand-off
     bool hand_follow = true;         // the two calls behind it: their front-ends wait for the DC workgroups' placement
@@ -127,6 +127,7 @@ struct sdrm_batch_t {
     bool hold_front = false;         // the front-end waits for the clock stage of call i-2 to have its workgroups placed
     // what the batch's self-calibration decided (sdrm_batch_create -> calibrate), for inspection: sdrm_batch_schedule
     bool calibrated = false;
+    float est_front_ms = 0.0f, est_clock_ms = 0.0f;  // the creation-time estimates behind the companion grid's rule (full-length call)
     float calib_ms[3] = {0.0f, 0.0f, 0.0f};  // ms per full-length call: before, after, and what the calibration itself took
     // Online refinement (online_tune_*): the calibration at creation times calls WITHOUT Doppler correction; the first
     // stretch of calls that carry NCO batches re-decides the two settings that may change between any two calls (front

@@ -21,138 +21,63 @@
 #include "sdrm_tables.h"
 
 #include "sdrm_batch_impl.h"
+#include "../host/ledger.h"
 
 using namespace sdrm_impl;
 
 #define SDRM_HAND_SERIAL_MIN_NZ 12288u  // LPF2 outputs from which a plain handle's blocking call takes the in-call hand-off
 
-// ---- Device-wide admission of in-call hand-offs.
-// A hand-off call's DC and clock-stage workgroups sit on their compute units and WAIT (for the front-end's first tiles, for the DC
-// stage's first blocks).  The compute units they hold belong to the whole device, not to the batch: a server with one handle per
-// client (src/dsp_worker.c:188, src/tcp_server.c:659) runs hundreds of batches of one channel side by side, and every one of them
-// parks a clock-stage workgroup (141 KB of LDS: a whole CU) and a DC workgroup beside nothing.  Admission per batch (round 5) let the
-// waiting workgroups of different handles add up CU by CU until no front-end found a place: every stage then sat out its 2 s
-// bound and the handles of innocent clients went into their sticky error state.  So the count is kept per device, process-wide:
-// a call takes the hand-off only while the workgroups waiting on the device, its own included, stay within the limit -- otherwise
-// it runs its stages in stream order like any call behind a running one, which is always safe.  An entry leaves the ledger when
-// its call has finished: the owner says so when it sees the call's end, and anybody's admission reaps the entries whose event
-// has fired, so that a client that goes quiet after a call holds nothing.
-// Streams and hardware queues: every wait of a hand-off call looks at work enqueued BEFORE the waiting kernel by the same
-// thread (front-end, then DC stage, then clock stage), queues are served in order, and the front-end waits for nobody -- the
-// oldest unfinished kernel on the device is therefore always at the head of its queue and runnable as soon as it finds a CU,
-// whatever shares its queue.  What the ledger guarantees is the CU.
+// ---- Device-wide admission of in-call hand-offs: the ledger itself is host logic of its own (../host/ledger.h, also built with the
+// sanitizers); here its per-device instances and what ties an entry to a batch's HIP event.
 namespace {
-struct HandLedger {
-    std::mutex m;
-    struct Entry {
-        const sdrm_batch_t *owner;
-        hipEvent_t done;
-        unsigned waiting;
-        bool armed;  // `done` has been recorded behind the call (an event not yet recorded reads as complete)
-    };
-    std::vector<Entry> held;
-    uint64_t taken = 0, refused = 0;
-    unsigned peak = 0;
-    // blocking calls of plain handles (one-channel batches) in flight on the device, with or without the hand-off.  Each is a chain
-    // of one-workgroup kernels on a stream of its own, and HIP serves all streams of a priority level from FOUR hardware queues:
-    // beyond a handful of such calls every queue holds other handles' whole chains (3.6 ms each at 131072 samples), a hand-off
-    // call's front-end then waits behind them while its DC and clock workgroups spin on their CUs, and the run as a whole gets
-    // slower (64 handles x 131072 samples: 73 against 91 Msamples/s, profiles/r06_handles.txt).  The hand-off is an optimisation
-    // of latency on a quiet device: it is taken only while fewer than SDRM_HAND_MAX_PLAIN other such calls are in flight.
-    std::atomic<int> plain_calls{0};
-};
-#define SDRM_HAND_MAX_PLAIN 4
-HandLedger g_hand_ledger[16];
-
-HandLedger &hand_ledger(int device) { return g_hand_ledger[device & 15]; }
+sdrm::WaitLedger g_hand_ledger[16];
+sdrm::WaitLedger &hand_ledger(int device) { return g_hand_ledger[device & 15]; }
+bool hand_event_fired(void *event) {
+    const bool fired = hipEventQuery((hipEvent_t) event) == hipSuccess;
+    (void) hipGetLastError();  // hipErrorNotReady is not an error
+    return fired;
+}
 }  // namespace
 
 void sdrm_impl::hand_release(sdrm_batch_t *b) {
-    if (!b->hand_listed) {
-        return;
+    if (b->hand_listed) {
+        hand_ledger(b->device).release(b);
+        b->hand_listed = false;
     }
-    HandLedger &l = hand_ledger(b->device);
-    std::lock_guard<std::mutex> g(l.m);
-    for (size_t i = 0; i < l.held.size(); i++) {
-        if (l.held[i].owner == b) {
-            l.held[i] = l.held.back();
-            l.held.pop_back();
-            break;
-        }
-    }
-    b->hand_listed = false;
 }
 
-// true: `waiting` workgroups of b's next call may wait on the device (listed, not armed yet); false: the device's budget is taken
+// true: `waiting` workgroups of b's next call may wait on the device; false: the device's budget is taken
 static bool hand_admit(sdrm_batch_t *b, unsigned waiting, unsigned limit, hipEvent_t done) {
-    HandLedger &l = hand_ledger(b->device);
-    std::lock_guard<std::mutex> g(l.m);
-    if (l.plain_calls.load(std::memory_order_relaxed) - (b->serial ? 1 : 0) >= SDRM_HAND_MAX_PLAIN) {
-        l.refused++;
-        return false;
-    }
-    unsigned sum = 0;
-    for (size_t i = 0; i < l.held.size();) {
-        HandLedger::Entry &e = l.held[i];
-        if (e.owner == b || (e.armed && hipEventQuery(e.done) == hipSuccess)) {
-            // (b's own entry: the caller has seen its previous call end.  Somebody else's: its owner still believes it is listed
-            // and finds out when it looks -- hand_release tolerates a missing entry; only the owner ever touches hand_listed)
-            l.held[i] = l.held.back();
-            l.held.pop_back();
-            continue;
-        }
-        sum += e.waiting;
-        i++;
-    }
-    (void) hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
-    if (sum + waiting > limit) {
-        l.refused++;
-        return false;
-    }
-    l.held.push_back({b, done, waiting, false});
-    l.taken++;
-    l.peak = std::max(l.peak, sum + waiting);
-    b->hand_listed = true;
-    return true;
+    const bool ok = hand_ledger(b->device).admit(b, (void *) done, waiting, limit, b->serial, hand_event_fired);
+    b->hand_listed = ok;
+    return ok;
 }
+
+static void hand_arm(sdrm_batch_t *b) { hand_ledger(b->device).arm(b); }
 
 // a plain handle's blocking call, from its first enqueue to its results (process_host)
 struct PlainCallInFlight {
-    std::atomic<int> *count = nullptr;
+    sdrm::WaitLedger *ledger = nullptr;
     explicit PlainCallInFlight(const sdrm_batch_t *b) {
         if (b->serial) {
-            count = &hand_ledger(b->device).plain_calls;
-            count->fetch_add(1, std::memory_order_relaxed);
+            ledger = &hand_ledger(b->device);
+            ledger->plain_begin();
         }
     }
     ~PlainCallInFlight() {
-        if (count != nullptr) {
-            count->fetch_sub(1, std::memory_order_relaxed);
+        if (ledger != nullptr) {
+            ledger->plain_end();
         }
     }
     PlainCallInFlight(const PlainCallInFlight &) = delete;
     PlainCallInFlight &operator=(const PlainCallInFlight &) = delete;
 };
 
-static void hand_arm(sdrm_batch_t *b) {
-    HandLedger &l = hand_ledger(b->device);
-    std::lock_guard<std::mutex> g(l.m);
-    for (HandLedger::Entry &e : l.held) {
-        if (e.owner == b) {
-            e.armed = true;
-        }
-    }
-}
-
 extern "C" int sdrm_handoff_stats(int device, uint64_t *taken, uint64_t *refused, uint32_t *peak_waiting) {
     if (device < 0 && hipGetDevice(&device) != hipSuccess) {
         return -ENODEV;
     }
-    HandLedger &l = hand_ledger(device);
-    std::lock_guard<std::mutex> g(l.m);
-    if (taken) *taken = l.taken;
-    if (refused) *refused = l.refused;
-    if (peak_waiting) *peak_waiting = l.peak;
+    hand_ledger(device).stats(taken, refused, peak_waiting);
     return 0;
 }
 

@@ -12,12 +12,30 @@
 // keeps what was fastest by more than the noise, and then puts every stream back to its initial state.  Costs a few dozen
 // calls (tens of milliseconds for 256 channels, a few hundred for 4096) once per batch.
 // SDRM_AUTOTUNE=0 switches it off; SDRM_K3_LANES / SDRM_FRONT_HOLD / SDRM_K3_COMPANY pin their dimension as before.
+// Round 6: a dimension is measured only where its rule is in doubt.  On the bench's five batches the calibration had confirmed the
+// rules on four (88 - 376 ms each, `ms_per_call_before == ms_per_call_after`, BENCH_r05.json); the measurements of rounds 3-5
+// say where the rules are safe: the clock stage's shape away from the two channel counts where it changes (1280, 2560: asked
+// within a quarter of them), the front-end's hold outside 640 .. 1280 channels (it costs 2-3 % below, gains 2-5 % from 896 to
+// 1024, profiles/r03_front_hold_bounds.txt), the companion grid where the front-end's estimate is under half the rule's
+// threshold and the clock stage runs long (on), or beyond 1024 channels / a front-end well above the threshold / a clock stage
+// too short to pay for the grid (off).  A batch with no open question is not timed at all.  SDRM_AUTOTUNE=2 asks every
+// question regardless (measurements, and the regression test that needs a calibrated small batch).
 int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
     const size_t C = b->plan.design.size();
     const char *env = getenv("SDRM_AUTOTUNE");
     if (b->serial || C < 32 || (env != nullptr && atoi(env) == 0) || b->n_gen > 0 ||
         (b->flags & SDRM_FLAG_NO_CALIBRATION) != 0) {
         return 0;
+    }
+    const bool every = env != nullptr && atoi(env) >= 2;
+    auto near = [&](size_t at) { return 4 * C >= 3 * at && 4 * C <= 5 * at; };
+    const bool ask_shape = !sdrm::k3_shape_is_forced() && b->plan.clock_carried_max <= 128 && C >= 512 && (every || near(1280) || near(2560));
+    const bool ask_hold = !sdrm::front_hold_is_forced() && C >= 256 && (every || (C >= 640 && C <= 1280));
+    const bool company_on_for_sure = C <= 576 && b->est_front_ms < 0.35f * b->est_clock_ms && b->est_clock_ms >= 0.6f;
+    const bool company_off_for_sure = C > 1024 || b->est_front_ms > 1.4f * b->est_clock_ms || b->est_clock_ms < 0.15f;
+    const bool ask_company = getenv("SDRM_K3_COMPANY") == nullptr && C <= 2048 && (every || !(company_on_for_sure || company_off_for_sure));
+    if (!ask_shape && !ask_hold && !ask_company) {
+        return 0;  // the rules decide: nothing to time
     }
     uint32_t longest = 0;
     std::vector<size_t> lens(C);
@@ -79,7 +97,7 @@ int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
     const double before = best;
     const double margin = 0.97;  // a candidate replaces the incumbent only when it is more than 3 % faster
     // (1) the clock stage's workgroup shape
-    if (code == 0 && !sdrm::k3_shape_is_forced() && b->plan.clock_carried_max <= 128 && C >= 512) {
+    if (code == 0 && ask_shape) {
         const int shapes[3][3] = {{16, 1024, 0}, {32, 512, 0}, {64, 256, 1}};
         const sdrm_k3_shape cur = sdrm_k3_shape_for((int) C, 0, 0, 0, (int) b->plan.clock_carried_max);
         int keep[3] = {cur.lanes, cur.ring, cur.plain};
@@ -107,7 +125,7 @@ int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
         b->dev.k3_plain = keep[2];
     }
     // (2) the front-end's hold for the clock stage's placement
-    if (code == 0 && !sdrm::front_hold_is_forced() && C >= 256) {
+    if (code == 0 && ask_hold) {
         const bool was = b->hold_front;
         b->hold_front = !was;
         double ms = 0.0;
@@ -119,7 +137,7 @@ int sdrm_calibrate(sdrm_batch_t *b, const sdrm_fsk_config *cfgs) {
         }
     }
     // (3) the companion grid beside the clock stage
-    if (code == 0 && getenv("SDRM_K3_COMPANY") == nullptr && C <= 2048) {
+    if (code == 0 && ask_company) {
         const int was = b->company_blocks;
         b->company_blocks = was > 0 ? 0 : b->company_grid;
         double ms = 0.0;

@@ -2,6 +2,7 @@
 // (sdr-modem_amd/host/queue.c and host/batcher.cpp over the kernel emulation), built and run under AddressSanitizer +
 // UndefinedBehaviorSanitizer and under ThreadSanitizer by tests/san/run.sh (CPU build only: the GPU pool has no sanitizer
 // support).  What the reference does with valgrind memcheck (test/resources/run_tests.sh:10).  Exit code 0 = clean run.
+#include "../../sdr-modem_amd/host/ledger.h"
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -232,8 +233,63 @@ static void node_round() {
     sdrm_node_destroy(node);
 }
 
+// The device-wide ledger of waiting hand-off workgroups (sdr-modem_amd/host/ledger.cpp): 24 "batches" on their own threads ask for
+// admission, arm their entry, let their "event" fire a little later (a flag another thread of the pair sets) and release -- some
+// release themselves, some go quiet and are reaped by somebody else's admission, some are plain handles with a blocking call in
+// flight.  Invariants: the workgroups listed at once never exceed the limit, every attempt is counted once, nothing is left behind.
+static bool flag_fired(void *event) { return static_cast<std::atomic<bool> *>(event)->load(std::memory_order_acquire); }
+static void ledger_round() {
+    sdrm::WaitLedger ledger;
+    const unsigned limit = 40;
+    const int n_threads = 24, rounds = 400;
+    std::atomic<int> listed{0};      // workgroups of admitted calls whose event has not fired yet (what really waits)
+    std::atomic<long> attempts{0}, admitted{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) {
+        th.emplace_back([&, t] {
+            std::atomic<bool> event{false};
+            int owner_tag = t;
+            const bool plain = t % 3 == 0;
+            const unsigned mine = plain ? 2u : 5u + (unsigned) (t % 7);
+            unsigned seed = 99u + (unsigned) t;
+            for (int r = 0; r < rounds; r++) {
+                seed = seed * 1664525u + 1013904223u;
+                if (plain) ledger.plain_begin();
+                attempts++;
+                event.store(false, std::memory_order_release);
+                if (ledger.admit(&owner_tag, &event, mine, limit, plain, flag_fired)) {
+                    admitted++;
+                    const int now = listed.fetch_add((int) mine) + (int) mine;
+                    CHECK(now <= (int) limit);
+                    ledger.arm(&owner_tag);
+                    if ((seed >> 8) % 4 == 0) std::this_thread::yield();
+                    listed.fetch_sub((int) mine);                      // the call ends: its workgroups are gone BEFORE the event says so
+                    event.store(true, std::memory_order_release);
+                    if ((seed >> 12) % 3 != 0) ledger.release(&owner_tag);  // ... or the owner goes quiet: somebody else reaps the entry
+                }
+                if (plain) ledger.plain_end();
+            }
+            ledger.release(&owner_tag);  // going away: the event is about to be destroyed
+        });
+    }
+    for (auto &t : th) t.join();
+    uint64_t taken = 0, refused = 0;
+    uint32_t peak = 0;
+    ledger.stats(&taken, &refused, &peak);
+    CHECK((long) (taken + refused) == attempts.load());
+    CHECK((long) taken == admitted.load());
+    CHECK(peak <= limit);
+    CHECK(taken > 0 && refused > 0);
+    // everything has fired or been released: a caller that wants the whole budget gets it
+    std::atomic<bool> event{false};
+    int tag = -1;
+    CHECK(ledger.admit(&tag, &event, limit, limit, false, flag_fired));
+    ledger.release(&tag);
+}
+
 int main() {
     for (int rep = 0; rep < 3; rep++) {
+        ledger_round();
         queue_round(true, 400, 4);
         queue_round(false, 400, 3);
         queue_round(true, 50, 1);

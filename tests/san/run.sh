@@ -1,13 +1,13 @@
 #!/bin/bash
 # Builds the host-side code (queue.c, batcher.cpp, node.cpp, the planner and the kernel emulation the CPU tests drive) with the
 # sanitizers and runs (1) the threaded stress driver, (2) the CPU test-suite's emulation / batcher tests with the
-# sanitized emulation library preloaded.  CPU build only.  Logs -> profiles/r04_sanitizers.txt when $1 = "record".
+# sanitized emulation library preloaded.  CPU build only.  Logs -> profiles/<round>_sanitizers.txt when called as `run.sh record <round>` (e.g. r06).
 set -u
 cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=build/san
 mkdir -p $OUT
-SRC="tests/san/host_stress.cpp tests/emu/sdrm_emu.cpp tests/emu/emu_batcher.cpp sdr-modem_amd/host/batcher.cpp sdr-modem_amd/host/node.cpp sdr-modem_amd/csrc/sdrm_plan.cpp sdr-modem_amd/csrc/sdrm_design.cpp"
+SRC="tests/san/host_stress.cpp sdr-modem_amd/host/ledger.cpp tests/emu/sdrm_emu.cpp tests/emu/emu_batcher.cpp sdr-modem_amd/host/batcher.cpp sdr-modem_amd/host/node.cpp sdr-modem_amd/csrc/sdrm_plan.cpp sdr-modem_amd/csrc/sdrm_design.cpp"
 LIBSRC="tests/emu/sdrm_emu.cpp tests/emu/emu_batcher.cpp sdr-modem_amd/host/batcher.cpp sdr-modem_amd/host/node.cpp sdr-modem_amd/csrc/sdrm_plan.cpp sdr-modem_amd/csrc/sdrm_design.cpp"
 FLAGS="-O1 -g -mfma -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-omit-frame-pointer -pthread -Wno-unknown-pragmas"
 LOG=$OUT/log.txt
@@ -36,6 +36,6 @@ echo "pytest exit $rc" | tee -a $LOG
 [ $rc -ne 0 ] && status=1
 grep -cE "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer" $LOG | sed 's/^/sanitizer reports: /' | tee -a $LOG
 if [ "${1:-}" = "record" ]; then
-  { echo "tests/san/run.sh  ($(date -u +%Y-%m-%d), gcc $(gcc -dumpversion), CPU build)"; grep -E "^==|exit|host_stress:|passed|failed|sanitizer reports|ERROR|WARNING: Thread|runtime error" $LOG; } > profiles/r04_sanitizers.txt
+  { echo "tests/san/run.sh  ($(date -u +%Y-%m-%d), gcc $(gcc -dumpversion), CPU build)"; grep -E "^==|exit|host_stress:|passed|failed|sanitizer reports|ERROR|WARNING: Thread|runtime error" $LOG; } > profiles/${2:-r06}_sanitizers.txt
 fi
 exit $status

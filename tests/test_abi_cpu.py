@@ -5,6 +5,7 @@ import ctypes as C
 import errno
 import os
 import re
+import subprocess
 import threading
 import time
 
@@ -546,3 +547,16 @@ def test_a_batcher_client_whose_iq_dump_cannot_be_written_is_ended(tmp_path, cap
     assert np.array_equal(got0, orc.demod_stream(cfg[:6], sigs[0], 4096)[0])
     assert os.path.getsize(os.path.join(str(tmp_path), "rx.demod2client.71.s8")) == 0  # ended before its first buffer was demodulated
     bt.close()
+
+
+def test_device_wide_ledger_of_waiting_hand_off_workgroups(tmp_path):
+    """sdr-modem_amd/host/ledger.cpp (what decides, per device and across every batch and handle of the process, whether a call
+    may take the in-call hand-off): the budget of waiting workgroups with each caller's own limit, entries that are reaped once
+    their call's event has fired -- but never before the event was recorded --, an owner's new call replacing its old entry, and
+    the count of plain handles' calls in flight.  Deterministic scenario (tests/ledger_check.cpp); the threaded stress runs under
+    the sanitizers (tests/san/host_stress.cpp, profiles/r06_sanitizers.txt)."""
+    exe = os.path.join(str(tmp_path), "ledger_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(ROOT, "tests", "ledger_check.cpp"),
+                           os.path.join(ROOT, "sdr-modem_amd", "host", "ledger.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "ledger ok" in out.stdout, out.stderr

@@ -3,8 +3,8 @@
 (src/resources/config.conf:11) -- through tools/handles_bench, a plain C program on the public header: many PRIVATE fsk_demod
 handles (and private dsp_workers) calling at once, each long enough to take the in-call hand-off.  What must hold: no handle ends
 in the sticky error state, every client's soft-bit stream is the oracle's for its input, and the device-wide ledger of waiting
-workgroups (sdrm_handoff_stats) admits and refuses hand-offs as designed -- admission per batch (round 5) let the waiting
-workgroups of different handles add up CU by CU."""
+workgroups and of plain handles' calls in flight (sdrm_handoff_stats) admits and refuses hand-offs as designed -- admission per
+batch (round 5) let the waiting workgroups of different handles add up CU by CU."""
 import os
 import re
 import subprocess
@@ -89,20 +89,30 @@ def _check(classes, want, calls, handles):
 @pytest.mark.parametrize("handles,calls", [(64, 6), (256, 3)])
 def test_many_private_handles_call_at_once_with_the_references_buffer_size(streams, handles, calls):
     files, want = streams
-    classes, (errors, taken, refused, peak), ms, err = _run([handles, BUF, calls], files)
+    classes, (errors, taken, refused, peak), ms, err = _run(["-W", 0, handles, BUF, calls], files)
     assert errors == 0 and "<3>" not in err, err[-1500:]
     _check(classes, want, calls, handles)
-    # every call is long enough for the hand-off (>= 12288 samples) and meets an idle batch: it either took it or was refused
-    # by the device's ledger, and the workgroups waiting at once never exceeded the limit
-    assert taken + refused == handles * calls and taken > 0
-    assert peak <= 192
-    if handles == 256:
-        assert refused > 0, "256 handles x (a clock-stage and a DC workgroup each) cannot all have been admitted at once"
+    # every call is long enough for the hand-off (>= 12288 samples) and meets an idle batch: it asked the device's ledger, which
+    # admits a plain handle's call only while fewer than two others are in flight -- with dozens of threads calling at once nearly
+    # every call is refused and runs its stages in stream order (the hand-off loses from three concurrent handles on,
+    # profiles/r06_handles.txt); whatever was admitted stayed within the device's budget of waiting workgroups
+    assert taken + refused == handles * calls
+    assert refused >= handles * (calls - 1) and peak <= 192
+
+
+def test_two_private_handles_take_the_hand_off(streams):
+    """one or two clients calling at once: every call is admitted (two workgroups waiting per call) and the streams are the oracle's"""
+    files, want = streams
+    for handles in (1, 2):
+        classes, (errors, taken, refused, peak), ms, err = _run(["-W", 0, handles, BUF, 6], files)
+        assert errors == 0 and "<3>" not in err, err[-1500:]
+        _check(classes, want, 6, handles)
+        assert taken == handles * 6 and refused == 0 and peak in (2, 2 * handles)
 
 
 def test_the_same_streams_without_the_hand_off(streams):
     files, want = streams
-    classes, (errors, taken, refused, _), _, err = _run([64, BUF, 3], files, env={"SDRM_HANDOFF": "0"})
+    classes, (errors, taken, refused, _), _, err = _run(["-W", 0, 64, BUF, 3], files, env={"SDRM_HANDOFF": "0"})
     assert errors == 0 and taken == 0 and refused == 0
     _check(classes, want, 3, 64)
 
@@ -111,7 +121,7 @@ def test_thirty_two_private_workers_with_the_references_buffer_size(streams):
     """dsp_worker_create x 32 (private handle each, file sink), buffer_size 131072, fed from 32 source threads through
     dsp_worker_put: the files the workers wrote are the oracle's streams"""
     files, want = streams
-    classes, (errors, taken, refused, peak), _, err = _run(["-w", 32, BUF, 6], files)
+    classes, (errors, taken, refused, peak), _, err = _run(["-w", "-W", 0, 32, BUF, 6], files)
     assert errors == 0 and "<3>" not in err, err[-1500:]
     _check(classes, want, 6, 32)
-    assert taken > 0 and peak <= 192
+    assert taken + refused == 32 * 6 and peak <= 192

@@ -1381,6 +1381,7 @@ def test_hand_off_after_the_creation_time_calibration_starts_from_fresh_stamps(m
     import threading
     from test_gpu_fuzz import _cases
     monkeypatch.setenv("SDRM_BATCHER_CALIBRATE", "1")
+    monkeypatch.setenv("SDRM_AUTOTUNE", "2")  # every question asked, also where the rules decide (round 6): the batch IS timed
     seed = 90173
     for rep in range(12):
         rng = np.random.default_rng(seed)

@@ -2,7 +2,7 @@
  * per buffer (src/dsp_worker.c:188 thread per client, :75 the blocking call, src/tcp_server.c:659 one worker per request,
  * src/resources/config.conf:11 buffer_size 131072).
  *
- *   tools/handles_bench [-w] [-q] threads buffer_samples buffers_per_thread [input.cf32 ...]
+ *   tools/handles_bench [-w] [-q] [-W warm_up_buffers] threads buffer_samples buffers_per_thread [input.cf32 ...]
  *
  * Default mode: every thread owns an fsk_demod handle and calls fsk_demod_process once per buffer.  -w: every thread owns a
  * dsp_worker (private handle, file sink into a scratch directory) and feeds it with dsp_worker_put; the worker's own thread
@@ -10,7 +10,9 @@
  * `buffer_samples`: the file must hold that many) or, without files, one synthetic buffer repeated.
  * Output: per input file ("class") the number of handles, whether every handle of the class produced the same stream, its
  * symbol count and FNV-1a hash -- tests/test_gpu_handles.py compares those with the oracle's stream for the same file --, the
- * number of handles in the sticky error state, the device's hand-off ledger (sdrm_handoff_stats) and the wall time.
+ * number of handles in the sticky error state, the device's hand-off ledger (sdrm_handoff_stats) and the wall time of the
+ * buffers behind the first `warm_up_buffers` of every thread (default 2: a process's first calls load code objects, create streams
+ * and grow the runtime's pools; they are part of every stream and of its hash, not of the time).
  * Run it with SDRM_HANDOFF=0 for the comparison, with SDRM_SHARED_SLOTS=T for handles that share one batcher.
  * Build: gcc -O2 -pthread tools/handles_bench.c -Iinclude -Lsdr-modem_amd/csrc -lsdrmodem_hip
  *            -Wl,-rpath,'$ORIGIN/../sdr-modem_amd/csrc' -lm -o tools/handles_bench */
@@ -27,11 +29,11 @@
 
 #define MAX_FILES 64
 
-static size_t n_buf = 131072, n_calls = 20;
+static size_t n_buf = 131072, n_calls = 20, n_warm = 2;
 static int n_files = 0, worker_mode = 0;
 static float *file_iq[MAX_FILES];
 static float *synth_iq;
-static pthread_barrier_t go;
+static pthread_barrier_t go, warm;
 static char scratch[256];
 
 struct client {
@@ -68,6 +70,9 @@ static void *client_main(void *arg) {
     c->hash = 0xcbf29ce484222325ull;
     pthread_barrier_wait(&go);
     for (size_t k = 0; k < n_calls; k++) {
+        if (k == n_warm) {
+            pthread_barrier_wait(&warm);  /* everybody's warm-up buffers are through: the clock starts (main) */
+        }
         if (worker_mode) {
             dsp_worker_put((sdrm_cf32 *) buffer_of(c, k), n_buf, c->worker);  /* blocks while the queue is full (file source) */
             continue;
@@ -89,6 +94,7 @@ int main(int argc, char **argv) {
     for (; a < argc && argv[a][0] == '-'; a++) {
         if (strcmp(argv[a], "-w") == 0) worker_mode = 1;
         if (strcmp(argv[a], "-q") == 0) quiet = 1;
+        if (strcmp(argv[a], "-W") == 0 && a + 1 < argc) n_warm = (size_t) atol(argv[++a]);
     }
     int threads = a < argc ? atoi(argv[a++]) : 64;
     if (a < argc) n_buf = (size_t) atol(argv[a++]);
@@ -150,9 +156,12 @@ int main(int argc, char **argv) {
         }
     }
     pthread_t *t = calloc((size_t) threads, sizeof(*t));
+    if (n_warm >= n_calls) n_warm = 0;
     pthread_barrier_init(&go, NULL, (unsigned) threads + 1);
+    pthread_barrier_init(&warm, NULL, (unsigned) threads + 1);
     for (int i = 0; i < threads; i++) pthread_create(&t[i], NULL, client_main, &cl[i]);
     pthread_barrier_wait(&go);
+    pthread_barrier_wait(&warm);
     const double t0 = now();
     for (int i = 0; i < threads; i++) pthread_join(t[i], NULL);
     if (worker_mode) {
@@ -204,9 +213,9 @@ int main(int argc, char **argv) {
     const char *hand = getenv("SDRM_HANDOFF");
     printf("%d %s x %zu buffers of %zu samples (%s%s): %.1f ms, %.1f Msamples/s, %.0f symbols per buffer, errors %d, "
            "hand-off taken %llu refused %llu peak waiting %u\n",
-           threads, worker_mode ? "workers" : "handles", n_calls, n_buf,
+           threads, worker_mode ? "workers" : "handles", n_calls - n_warm, n_buf,
            getenv("SDRM_SHARED_SLOTS") ? "shared batcher" : "private batches", (hand && atoi(hand) == 0) ? ", SDRM_HANDOFF=0" : "", dt * 1e3,
-           (double) threads * (double) n_calls * (double) n_buf / dt / 1e6, (double) symbols / ((double) threads * (double) n_calls), errors,
+           (double) threads * (double) (n_calls - n_warm) * (double) n_buf / dt / 1e6, (double) symbols / ((double) threads * (double) n_calls), errors,
            (unsigned long long) taken, (unsigned long long) refused, peak);
     if (!worker_mode) {
         for (int i = 0; i < threads; i++) fsk_demod_destroy(cl[i].demod);

@@ -1,6 +1,9 @@
 #!/bin/bash
 # vector instructions per launch and duration of the front-end alone (stages serialised): tools/k1_valu.sh [channels]
 export TMPDIR=/tmp
+# tools/stage_times.py waits for every call, and counter collection serialises dispatches: with the in-call hand-off a DC or clock
+# workgroup could then be started before the front-end it waits for.  The stages are measured one after the other here.
+export SDRM_HANDOFF=0
 R=${GRAFT_REPO_ROOT:?run this on the gpurun box (GRAFT_REPO_ROOT is the snapshot root)}
 CH=${1:-256}
 python $R/tools/stage_times.py $CH

@@ -2,6 +2,9 @@
 # PMC passes for the pipeline kernels (separate passes; no trace domains besides kernel-trace)
 set +e
 export TMPDIR=/tmp
+# tools/stage_times.py waits for every call, and counter collection serialises dispatches: with the in-call hand-off a DC or clock
+# workgroup could then be started before the front-end it waits for.  The stages are measured one after the other here.
+export SDRM_HANDOFF=0
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
 mkdir -p $OUT
 cd /tmp
