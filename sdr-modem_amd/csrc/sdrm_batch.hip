@@ -500,9 +500,6 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     if (const char *env = getenv("SDRM_HANDOFF")) {
         b->hand_allowed = atoi(env) != 0;
     }
-    if (const char *env = getenv("SDRM_HAND_FOLLOW")) {  // measurements: 0 = no placement hold for the two calls behind a hand-off call
-        b->hand_follow = atoi(env) != 0;
-    }
     if (const char *env = getenv("SDRM_HAND_EPOCH0")) {  // tests: start the hand-off's call count near the end of its 32-bit stamp values
         b->hand_epoch = strtoull(env, nullptr, 0);
     }
@@ -542,10 +539,6 @@ extern "C" int sdrm_batch_create(const sdrm_fsk_config *cfgs, size_t n_channels,
     d.dc_lds = (uint32_t) pl.dc_lds_bytes();
     d.any_dc = any_dc;
     d.k3_carried_max = (int) pl.clock_carried_max;
-    {
-        const char *q = getenv("SDRM_K1_QUAD");
-        d.quad_flat = (q != nullptr && strcmp(q, "flat") == 0) ? 1 : 0;
-    }
     b->in_stride = pl.in_stride;
     code = sync_generic(b, -1);
     if (code != 0) {

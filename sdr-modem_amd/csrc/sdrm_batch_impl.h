@@ -113,7 +113,6 @@ struct sdrm_batch_t {
     uint64_t hand_refused = 0;       // ... calls that qualified but found the DEVICE's budget of waiting workgroups taken (../host/ledger.h)
     bool hand_listed = false;        // this batch may have an entry in the device's ledger (only the owner's thread touches this)
     uint64_t last_hand_call = 0;     // index of the last call that took the hand-off
-    bool hand_follow = true;         // the two calls behind it: their front-ends wait for the DC workgroups' placement
     uint64_t hand_epoch = 0;  // hand-off calls since the batch was created -- never reset: a call's stamp value must be new
     uint32_t *d_placed = nullptr;    // [2] DC / clock-stage workgroups started, all launches (what the stream holds wait for)
     uint32_t k2_placed_target = 0, k3_placed_target = 0;  // the counters' values once every enqueued launch has started

@@ -194,10 +194,7 @@ int sdrm_impl::enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stri
         const unsigned waiting = sdrm::clock_workgroups(d) + (d.any_dc ? sdrm::dc_workgroups(d) : 0u);
         const bool room = !d.any_dc || (size_t) d.dc_lds + sdrm::k1_lds_bytes(d.t1_max, d.t2_max) <= 160 * 1024;
         // (a DC workgroup that fills its CU -- long boxcars -- leaves the front-end no room beside it: then only a handful may wait)
-        unsigned most = room ? 192u : 16u;
-        if (const char *env = getenv("SDRM_HAND_MAX_WAITING")) {  // measurements (profiles/r05_incall_handoff.txt)
-            most = (unsigned) atoi(env);
-        }
+        const unsigned most = room ? 192u : 16u;  // (192 against 64: 1024 channels 5.71 -> 3.07 ms per blocking call, profiles/r05_incall_handoff.txt)
         // (32-bit byte offsets inside a DC workgroup's rows of z / dcout: sdrm_kernels.hip, hand_rsrc)
         const bool offsets_fit = (uint64_t) (d.dc_group ? d.dc_group : 1u) * d.z_stride * sizeof(float) < (1ull << 32);
         hand = idle && waiting <= most && offsets_fit && sdrm::clock_shape_hands_off(d);
@@ -297,8 +294,7 @@ int sdrm_impl::enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stri
         HIP_TRY(hipStreamWaitEvent(b->s_front, b->slot_done[(i + SDRM_CTL_SLOTS - 3) % SDRM_CTL_SLOTS], 0));
         sdrm::launch_hold_until(b->d_placed + 1, b->k3_placed_after[(i + SDRM_CTL_SLOTS - 2) % SDRM_CTL_SLOTS], 100, b->s_front);
     }
-    if (!b->serial && !hand && d.any_dc && b->d_placed != nullptr && b->hand_calls > 0 && i - b->last_hand_call <= 2 &&
-        b->hand_follow) {
+    if (!b->serial && !hand && d.any_dc && b->d_placed != nullptr && b->hand_calls > 0 && i - b->last_hand_call <= 2) {
         // The two calls behind a hand-off call: this front-end and the DC stage of the call before it are released by the same event
         // (the hand-off call's DC stage ending), and the hand-off call's companion grid, started on an empty chip, sits on every
         // CU until its clock stage ends.  If this grid covers the chip first, a DC workgroup (117 KB of LDS, 11 waves) may find

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     sdrm_k1_phase_lpf1(tid, t, p, taps1, xs, bnd, regs);
     __syncthreads();
     unsigned long long t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    sdrm_k1_phase_quad(tid, t, p, tab, b.quad_flat ? nullptr : tab2, bnd, regs, qs);
+    sdrm_k1_phase_quad(tid, t, p, tab, tab2, bnd, regs, qs);
     __syncthreads();
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_lpf2(tid, t, p, taps2, qs, zs, b.nonfinite + c);

@@ -49,7 +49,6 @@ struct DeviceBatch {
     uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
     int k3_carried_max;              // most samples a channel can carry between calls of the clock stage (sizes its ring)
-    int quad_flat;                   // measurements (SDRM_K1_QUAD=flat): the discriminator always takes its general form
     uint32_t *placed;                // [2] DC / clock-stage workgroups that have started, cumulative over calls (k_hold_until)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches; the companion grid watches); nullptr: nobody is watching
     const int *gen_list;             // generic channels (sdrm_kernels.h): their indices, n_gen of them, and each one's state

@@ -22,12 +22,6 @@ static size_t dc_lds_bytes_for(uint32_t l_cap, uint32_t group) {
 
 static uint32_t dc_group_for(uint32_t l_cap) {
     uint32_t group = SDRM_K2_SLOTS;
-    if (const char *e = getenv("SDRM_DC_GROUP")) {  // measurements: channels per DC workgroup (a power of two <= 16)
-        const int g = atoi(e);
-        if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) {
-            group = (uint32_t) g;
-        }
-    }
     while (group > 1 && dc_lds_bytes_for(l_cap, group) > 150 * 1024) {
         group /= 2;
     }

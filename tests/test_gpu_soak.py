@@ -28,3 +28,8 @@ def test_a_few_seconds_of_the_batch_soak(capsys):
 
 def test_a_few_seconds_of_the_batcher_soak(capsys):
     run_tool("soak_batcher.py", 6, 1, capsys)
+
+
+def test_a_few_seconds_of_the_private_handles_soak(capsys):
+    # 1 .. 10 client threads with a private handle each, long buffers: hand-offs admitted and refused by the device's ledger in turn
+    run_tool("soak_handles.py", 8, 1, capsys)
