@@ -13,9 +13,11 @@ GPU at every N); the only collective is the RCCL broadcast of the channel config
 `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.  Rank 0 prints ONE JSON line:
 the contract's fields, `roofline` (front-end kernel), `cpu_baseline`, and -- informative sub-blocks, outside the timed
 region -- `config3_sharded` (BASELINE configs[3]: 512 channels per GPU, N > 1 only), and at N = 1 `channel_sweep`,
-`end_to_end` (host buffers in, soft bits out: PCIe-inclusive), `config5` (mixed rates with per-channel Doppler) and
+`end_to_end` (host buffers in, soft bits out: PCIe-inclusive), `config5` / `config5_d1` (mixed rates with per-channel Doppler, at
+decimation 5 / 8 and at the reference-default decimation 1), `blocking_call` (one call at a time, the call the reference's caller
+blocks on: 256 and 1024 channels and one plain handle, with the in-call hand-off and with SDRM_HANDOFF=0) and
 `perf_fsk_modem_style`.  Every timed region is followed by a spot check of its last call against the CPU restatement of the
-reference (`verified_vs_oracle`).
+reference (`verified_vs_oracle` / `*_verified`).
 """
 import argparse
 import glob

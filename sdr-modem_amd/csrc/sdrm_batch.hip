@@ -92,6 +92,9 @@ void sdrm_impl::batch_free(sdrm_batch_t *b) {
     if (b->ev_company) {
         (void) hipEventDestroy(b->ev_company);
     }
+    if (b->ev_hand_done) {
+        (void) hipEventDestroy(b->ev_hand_done);  // (its ledger entry went with hand_release above)
+    }
     (void) hipFree(b->d_k3_done);
     (void) hipFree(b->d_placed);
     (void) hipFree(b->d_counters);

@@ -111,6 +111,7 @@ struct sdrm_batch_t {
     bool hand_side_last = false;     // the call enqueued last ran on them: the next call's first stream waits for its end
     uint64_t hand_calls = 0;         // diagnostics: calls enqueued with the hand-off
     uint64_t hand_refused = 0;       // ... calls that qualified but found the DEVICE's budget of waiting workgroups taken (../host/ledger.h)
+    hipEvent_t ev_hand_done = nullptr;  // recorded behind a hand-off call (and nothing else): what its entry in the device's ledger names
     bool hand_listed = false;        // this batch may have an entry in the device's ledger (only the owner's thread touches this)
     uint64_t last_hand_call = 0;     // index of the last call that took the hand-off
     uint64_t hand_epoch = 0;  // hand-off calls since the batch was created -- never reset: a call's stamp value must be new

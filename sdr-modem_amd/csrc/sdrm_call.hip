@@ -181,13 +181,14 @@ int sdrm_impl::enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stri
     // ---- in-call hand-off?  A call that meets an idle batch -- every blocking call, the first of a pipelined run -- cannot
     // hide its front-end and DC blocker behind an earlier call's clock stage: its three stages are made resident together
     // instead, each starting on the first finished pieces of the one in front (tile stamps / output counts, sdrm_launch.h).
-    // Waiting workgroups hold their CUs, so this is bounded: at most 192 of them (every batch of the 16 x 1024 clock-stage shape: 160 at
-    // 1280 channels, one per CU; batches of the 32 x 512 shape up to 2048 channels -- the front-end keeps the other CUs and the room beside the DC workgroups; measured 1024 channels
-    // 5.71 -> 3.07 ms per blocking call, the limit had been 64) when a DC workgroup leaves room for a front-end workgroup beside it
-    // (then the front-end can always be placed, whatever else waits on the chip), 16 when it does not; the
-    // clock stage is launched only when the DC stage's workgroups are resident, the front-end only when both are -- then the
-    // front-end, which waits for nobody, always finds a CU, the DC stage waits only for the front-end and the clock stage
-    // only for the DC stage.  Every wait in the kernels is bounded besides (a void call, loudly, never a hung device).
+    // Waiting workgroups hold their CUs, so this is bounded twice.  Per call: at most 192 of them (every batch of the 16 x 1024
+    // clock-stage shape -- 160 at 1280 channels, one per CU -- and those of the 32 x 512 shape up to 2048 channels: the front-end
+    // keeps the other CUs and the room beside the DC workgroups) when a DC workgroup leaves room for a front-end workgroup
+    // beside it, 16 when it does not.  Per device: the ledger (../host/ledger.h) adds up what every batch and handle of the
+    // process has waiting, and counts plain handles' calls in flight.  Order: the clock stage is launched only when the DC
+    // stage's workgroups are resident, the front-end only when both are -- then the front-end, which waits for nobody, always
+    // finds a CU, the DC stage waits only for the front-end and the clock stage only for the DC stage.  Every wait in the
+    // kernels is bounded besides (a void call, loudly, never a hung device).
     bool hand = false;
     if (b->hand_allowed && b->n_gen == 0 && (b->serial || b->d_placed != nullptr) && max_tiles > 0) {
         const bool idle = b->last_slot < 0 || hipEventQuery(b->slot_done[b->last_slot]) == hipSuccess;
@@ -210,7 +211,14 @@ int sdrm_impl::enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stri
             }
             hand = longest >= SDRM_HAND_SERIAL_MIN_NZ;
         }
-        const bool admitted = hand && hand_admit(b, waiting, most, b->slot_done[slot]);
+        // (the ledger's entry names an event of its own, recorded behind this call only: the slot's event is recorded again eight
+        // calls later, and a pipelined run that began with a hand-off call would look unfinished for as long as it lasts)
+        if (hand && b->ev_hand_done == nullptr && hipEventCreateWithFlags(&b->ev_hand_done, hipEventDisableTiming) != hipSuccess) {
+            (void) hipGetLastError();
+            b->ev_hand_done = nullptr;
+            hand = false;
+        }
+        const bool admitted = hand && hand_admit(b, waiting, most, b->ev_hand_done);
         if (hand && !admitted) {
             hand = false;  // the DEVICE's budget is taken by other batches and handles: stages in stream order, always safe
             b->hand_refused++;
@@ -417,6 +425,7 @@ int sdrm_impl::enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stri
     }
     HIP_TRY(hipEventRecord(b->slot_done[slot], s_clock));
     if (hand) {
+        HIP_TRY(hipEventRecord(b->ev_hand_done, s_clock));
         hand_arm(b);  // from here on anybody's admission may find the call over and take its place
     }
     sdrm_online_tune_after(b, s_clock);

@@ -86,7 +86,7 @@ def _check(classes, want, calls, handles):
         assert (symbols, digest) == want[k][calls], "class %d: %d symbols, the oracle has %d (or other bits)" % (k, symbols, want[k][calls][0])
 
 
-@pytest.mark.parametrize("handles,calls", [(64, 6), (256, 3)])
+@pytest.mark.parametrize("handles,calls", [(3, 6), (8, 6), (64, 6), (256, 3)])
 def test_many_private_handles_call_at_once_with_the_references_buffer_size(streams, handles, calls):
     files, want = streams
     classes, (errors, taken, refused, peak), ms, err = _run(["-W", 0, handles, BUF, calls], files)
@@ -96,8 +96,10 @@ def test_many_private_handles_call_at_once_with_the_references_buffer_size(strea
     # admits a plain handle's call only while fewer than two others are in flight -- with dozens of threads calling at once nearly
     # every call is refused and runs its stages in stream order (the hand-off loses from three concurrent handles on,
     # profiles/r06_handles.txt); whatever was admitted stayed within the device's budget of waiting workgroups
-    assert taken + refused == handles * calls
-    assert refused >= handles * (calls - 1) and peak <= 192
+    # (3 and 8 handles: admitted and refused calls alternate on the same handle -- its side streams and its own stream in turn)
+    assert taken + refused == handles * calls and peak <= 192
+    if handles >= 64:
+        assert refused >= handles * (calls - 1)
 
 
 def test_two_private_handles_take_the_hand_off(streams):
