@@ -259,18 +259,19 @@ void launch_nco_mix(const DeviceBatch &b, const sdrm_f2 *d_in, size_t in_stride,
 
 size_t k1_lds_bytes(uint32_t t1_max, uint32_t t2_max) { return sdrm_k1_lds_bytes_for(t1_max, t2_max); }
 
-// grid (channels, max_tiles), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
+// grid (max_tiles, channels), 256 threads.  LDS: raw IQ tile + (T1-1) halo | quadrature-demod samples |
 // per-thread boundary samples | arctan table.
 template <bool HAND>
 __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceBatch b, const sdrm_f2 *__restrict__ d_in,
                                                             size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_lds[];
-    // grid (channels, tiles): workgroups are dispatched x first, so every channel's tile 0 comes before anybody's tile 1 -- with the
-    // in-call hand-off the stages behind can then start on all channels at once; without it, the workgroups dispatched LAST are
-    // every channel's last tile, the short one (131072 samples are 34.65 tiles), which is what a grid's tail should be made of
-    // (until round 6 the ordinary build ran (tiles, channels): its last workgroups were the last channel's 34 full tiles)
-    const int c = blockIdx.x;
-    const unsigned tile_id = blockIdx.y + blockIdx.z * gridDim.y;  // (z: calls of more than 65535 tiles, a quarter of a billion samples)
+    // grid (tiles, channels); with the in-call hand-off (channels, tiles): workgroups are dispatched x first, so every channel's
+    // tile 0 comes before anybody's tile 1 and the stages behind can start on all channels at once.  (Round 6 tried (channels,
+    // tiles) for the ordinary build too -- the workgroups dispatched last are then every channel's short last tile --: alone the
+    // kernel ties, 0.434 vs 0.430 ms, in the pipeline it loses 6 %, 0.494 vs 0.465 ms on one box, profiles/r06_ab.txt: consecutive
+    // workgroups then read 256 different channels' rows, a megabyte apart, beside the other stages' streams.)
+    const int c = HAND ? blockIdx.x : blockIdx.y;
+    const unsigned tile_id = HAND ? blockIdx.y + blockIdx.z * gridDim.y : blockIdx.x;  // (z: hand-off calls of more than 65535 tiles)
     const sdrm_chunk_ctl ctl = b.ctl[c];
     const sdrm_chan_params p = b.params[c];
     if (tile_id == 0) {
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(SDRM_K1_THREADS, SDRM_K1_WGS) void k1_front(DeviceB
     sdrm_k1_phase_lpf1(tid, t, p, taps1, xs, bnd, regs);
     __syncthreads();
     unsigned long long t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-    sdrm_k1_phase_quad(tid, t, p, tab, tab2, bnd, regs, qs);
+    sdrm_k1_phase_quad(tid, t, p, tab, b.quad_general ? nullptr : tab2, bnd, regs, qs);
     __syncthreads();
     unsigned long long t3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     sdrm_k1_phase_lpf2(tid, t, p, taps2, qs, zs, b.nonfinite + c);
@@ -433,7 +434,10 @@ KernelLaunch describe_front(const DeviceBatch &b) {
         k.func = reinterpret_cast<const void *>(k1_front<false>);
     }
     const unsigned tiles = b.max_tiles ? b.max_tiles : 1u;  // tile 0 of every channel also rolls its history
-    k.grid = dim3((unsigned) b.n_channels, tiles < 65535u ? tiles : 65535u, (tiles + 65534u) / 65535u);
+    k.grid = dim3(tiles, (unsigned) b.n_channels);
+    if (b.handoff) {
+        k.grid = dim3((unsigned) b.n_channels, tiles < 65535u ? tiles : 65535u, (tiles + 65534u) / 65535u);
+    }
     k.block = dim3(SDRM_K1_THREADS);
     return k;
 }

@@ -49,6 +49,11 @@ struct DeviceBatch {
     uint32_t dc_lds;                 // dynamic LDS of the DC kernel
     int any_dc;
     int k3_carried_max;              // most samples a channel can carry between calls of the clock stage (sizes its ring)
+    int quad_general;                // 1: the front-end's discriminator always takes its general form.  Nothing sets it any more (the
+                                     //   SDRM_K1_QUAD switch went in round 6); it stays a launch parameter because the choice made at run time
+                                     //   keeps the two forms apart in the compiler's eyes and the kernel at 118 registers -- 126 when it can
+                                     //   prove the short form's table is always there, and four waves of 128 registers fill a SIMD: the
+                                     //   front-end then runs 6 % slower beside the other stages (0.494 vs 0.465 ms, profiles/r06_ab.txt)
     uint32_t *placed;                // [2] DC / clock-stage workgroups that have started, cumulative over calls (k_hold_until)
     uint32_t *k3_done;               // clock-stage workgroups finished so far (all launches; the companion grid watches); nullptr: nobody is watching
     const int *gen_list;             // generic channels (sdrm_kernels.h): their indices, n_gen of them, and each one's state

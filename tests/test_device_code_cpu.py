@@ -37,4 +37,7 @@ def test_pipeline_kernels_do_not_spill(tmp_path):
         scratch, vgprs = find(*parts)
         assert scratch == 0, (parts, "spills %d bytes per lane" % scratch)
     for parts in (("k1_frontILb0E",), ("k1_frontILb1E",)):
-        assert find(*parts)[1] <= 128, parts  # 4 workgroups x 4 waves per CU = 4 waves per SIMD of 512 registers
+        # 4 workgroups x 4 waves per CU = 4 waves per SIMD of 512 registers -- and not all of them: at 121 .. 128 (allocated in
+        # eights) the front-end's waves fill the register file and it runs 6 % slower beside the other stages' waves
+        # (round 6: 126 registers after a harmless-looking simplification of the discriminator's call, profiles/r06_ab.txt)
+        assert find(*parts)[1] <= 120, parts
