@@ -223,6 +223,16 @@ int sdrm_batch_wild_calls(sdrm_batch *batch, uint64_t *count);
  * blocking: 4.28 -> 2.72 ms.  Used for batches small enough that waiting workgroups cannot starve the stage they wait for;
  * SDRM_HANDOFF=0 (environment, read at batch creation) switches it off.  This counts the calls that took it. */
 int sdrm_batch_handoff_calls(sdrm_batch *batch, uint64_t *count);
+/* Many clients, one handle each (the reference's layout, src/dsp_worker.c:188): every private handle's call is a chain of
+ * one-workgroup kernels and the device runs about three such chains at once -- 70-95 Msamples/s in total whatever the number of
+ * handles.  sdrm_fsk_demod_share(n, wait_us) makes the fsk_demod handles created FROM NOW ON share one batcher of n slots
+ * (geometry = the first such handle's configuration; a handle that does not fit it gets a private batch): fsk_demod_process
+ * stays the blocking call it is, and the clients' buffers go to the device as one call per round (a round waits up to wait_us
+ * for the clients that have not delivered yet) -- 1.7 Gsamples/s with 64 clients, 3.0 with 256 (profiles/r06_handles.txt).
+ * The same as SDRM_SHARED_SLOTS / SDRM_SHARED_WAIT_US in the environment, for a server that would rather say it in main().
+ * slots = 0: handles created from now on are private again.  Returns 0, -1 (more than 65536 slots), -EBUSY (the pool exists
+ * with another size). */
+int sdrm_fsk_demod_share(size_t slots, uint32_t max_wait_us);
 /* The workgroups of a hand-off call that wait for the stage in front of them hold compute units of the DEVICE, and a server
  * runs one handle per client (src/dsp_worker.c:188, src/tcp_server.c:659): admission is therefore counted per device across
  * every batch and handle of the process -- a call takes the hand-off only while the waiting workgroups on the device, its own

@@ -55,7 +55,7 @@ EXPORTS = [
     "fsk_demod_create", "fsk_demod_process", "fsk_demod_destroy",
     "sdrm_batch_create", "sdrm_batch_destroy", "sdrm_batch_channels", "sdrm_batch_info", "sdrm_batch_taps",
     "sdrm_batch_process", "sdrm_batch_process_device", "sdrm_batch_device_outputs", "sdrm_batch_last_soft",
-    "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read", "sdrm_batch_wild_calls", "sdrm_batch_handoff_calls", "sdrm_handoff_stats",
+    "sdrm_batch_fetch", "sdrm_batch_wait", "sdrm_batch_sync", "sdrm_batch_timing_enable", "sdrm_batch_timing_read", "sdrm_batch_wild_calls", "sdrm_batch_handoff_calls", "sdrm_handoff_stats", "sdrm_fsk_demod_share",
     "sdrm_batch_process_nco", "sdrm_batch_process_device_nco", "sdrm_batch_last_mixed",
     "sdrm_batch_arena", "sdrm_batch_submit", "sdrm_batch_collect", "sdrm_batch_reset_channel",
     "sdrm_dsp_worker_create", "sdrm_batcher_create", "sdrm_batcher_put", "sdrm_batcher_take", "sdrm_batcher_complete", "sdrm_batcher_interrupt", "sdrm_batcher_abandon", "sdrm_fsk_demod_error", "sdrm_last_error", "sdrm_batch_wait_input", "sdrm_wire_write_response",
@@ -202,6 +202,8 @@ def load():
     L.sdrm_batch_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     if hasattr(L, "sdrm_batch_handoff_calls"):
         L.sdrm_batch_handoff_calls.argtypes = [vp, C.POINTER(C.c_uint64)]
+    if hasattr(L, "sdrm_fsk_demod_share"):
+        L.sdrm_fsk_demod_share.argtypes = [C.c_size_t, C.c_uint32]
     if hasattr(L, "sdrm_handoff_stats"):
         L.sdrm_handoff_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     if hasattr(L, "sdrm_batch_wild_calls"):  # absent only from older builds loaded through SDRM_LIB_PATH for A/B measurements

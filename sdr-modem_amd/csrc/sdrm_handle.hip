@@ -52,18 +52,28 @@ struct SharedPool {
     bool failed = false;
 };
 SharedPool g_pool;
+// what sdrm_fsk_demod_share asked for (-1: nothing, the environment decides)
+std::atomic<long> g_share_slots{-1};
+std::atomic<long> g_share_wait_us{-1};
 
 bool shared_attach(fsk_demod_t *d, const sdrm_fsk_config &cfg) {
-    const char *env = getenv("SDRM_SHARED_SLOTS");
-    const long n = env ? atol(env) : 0;
+    long n = g_share_slots.load();
+    if (n < 0) {
+        const char *env = getenv("SDRM_SHARED_SLOTS");
+        n = env ? atol(env) : 0;
+    }
     if (n <= 0) {
         return false;
     }
     std::lock_guard<std::mutex> g(g_pool.m);
     if (g_pool.bt == nullptr && !g_pool.failed) {
         std::vector<sdrm_fsk_config> cfgs((size_t) n, cfg);
-        const char *w = getenv("SDRM_SHARED_WAIT_US");
-        sdrm_batcher_config bc = {4, (uint32_t) (w ? atol(w) : 1000), true};
+        long wait_us = g_share_wait_us.load();
+        if (wait_us < 0) {
+            const char *w = getenv("SDRM_SHARED_WAIT_US");
+            wait_us = w ? atol(w) : 1000;
+        }
+        sdrm_batcher_config bc = {4, (uint32_t) wait_us, true};
         if (sdrm_batcher_create(cfgs.data(), cfgs.size(), -1, &bc, &g_pool.bt) != 0) {
             g_pool.bt = nullptr;
             g_pool.failed = true;
@@ -95,6 +105,21 @@ bool shared_attach(fsk_demod_t *d, const sdrm_fsk_config &cfg) {
     return false;
 }
 }  // namespace
+
+// the programmatic form of SDRM_SHARED_SLOTS / SDRM_SHARED_WAIT_US: handles created from now on share one batcher of `slots`
+// slots (0: private batches for handles created from now on).  The pool itself is made by the first handle that joins it.
+extern "C" int sdrm_fsk_demod_share(size_t slots, uint32_t max_wait_us) {
+    if (slots > 65536) {
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(g_pool.m);
+    if (g_pool.bt != nullptr && slots != 0 && slots != g_pool.used.size()) {
+        return -EBUSY;  // the pool exists with another size: handles are attached to it
+    }
+    g_share_wait_us.store((long) max_wait_us);
+    g_share_slots.store((long) slots);
+    return 0;
+}
 
 extern "C" int fsk_demod_create(uint64_t sampling_freq, uint32_t baud_rate, int64_t deviation, uint8_t decimation,
                                 uint32_t transition_width, bool use_dc_block, uint32_t max_input_buffer_length,

@@ -415,7 +415,7 @@ static void allow_lds(K kernel, size_t bytes, lds_grant *granted) {
 }
 
 // Every stage's launch is described once (kernel, grid, block, dynamic LDS) and then either launched on a stream or put
-// into an explicitly built graph (sdrm_api.hip: the one-channel blocking call).  func == nullptr: nothing to launch.
+// into an explicitly built graph (sdrm_call.hip: the one-channel blocking call).  func == nullptr: nothing to launch.
 static void launch_described(const KernelLaunch &k, void **args, hipStream_t s) {
     if (k.func != nullptr) {
         (void) hipLaunchKernel(k.func, k.grid, k.block, args, k.lds, s);
@@ -2140,7 +2140,7 @@ __global__ __launch_bounds__(128) void k3_clock(DeviceBatch b) {
 // int8 soft bits from the float ones (reference src/dsp/fsk_demod.c:106), pointwise behind the clock stage, for the
 // workgroup shapes whose staging wave has no time for it (K3_FUSED_INT8).
 // grid (ceil(max_symbols / 1024), channels), 256 threads, four symbols per thread
-// The grid covers the most symbols a channel in lock can have produced (sdrm_api.hip, symbols_bound); a channel far out of
+// The grid covers the most symbols a channel in lock can have produced (sdrm_batch.hip, symbols_bound); a channel far out of
 // lock can have more: the row's LAST workgroup walks on to the real count.
 __global__ __launch_bounds__(256) void k3_quantize(DeviceBatch b) {
     const int c = blockIdx.y;
@@ -2183,7 +2183,7 @@ static KernelLaunch describe_clock_as(const DeviceBatch &b) {
 sdrm_k3_shape k3_shape(const DeviceBatch &b) {
     int lanes = 0, ring = 0, plain = 0;
     sdrm_k3_parse_shape(getenv("SDRM_K3_LANES"), &lanes, &ring, &plain);  // tests and measurements: force one workgroup shape (read per launch)
-    if (lanes == 0 && b.k3_lanes != 0) {  // the shape the batch measured to be its fastest (sdrm_api.hip, calibrate)
+    if (lanes == 0 && b.k3_lanes != 0) {  // the shape the batch measured to be its fastest (sdrm_tune.hip, sdrm_calibrate)
         lanes = b.k3_lanes;
         ring = b.k3_ring;
         plain = b.k3_plain;
@@ -2208,7 +2208,7 @@ static KernelLaunch describe_clock_hand32(const DeviceBatch &b) {
     return k;
 }
 // the in-call hand-off exists for these two clock-stage shapes (batches of up to 2560 channels; the admission rule of
-// sdrm_api.hip, at most 192 waiting workgroups, ends at 2048): blocking 1536 x 131072 call 7.10 -> 4.10 ms, 2048: 7.83 -> 6.23
+// sdrm_call.hip, at most 192 waiting workgroups, ends at 2048): blocking 1536 x 131072 call 7.10 -> 4.10 ms, 2048: 7.83 -> 6.23
 bool clock_shape_hands_off(const DeviceBatch &b) {
     const sdrm_k3_shape sh = k3_shape(b);
     return !sh.plain && ((sh.lanes == 16 && sh.ring == 1024) || (sh.lanes == 32 && sh.ring == 512));

@@ -1,4 +1,4 @@
-// sdrm_plan.h -- host-side planning shared by the C-ABI (sdrm_api.hip) and the CPU kernel emulation used by the
+// sdrm_plan.h -- host-side planning shared by the C-ABI (sdrm_batch.hip, sdrm_call.hip) and the CPU kernel emulation used by the
 // CPU-only tests: packs the per-channel device parameters from the designs, and turns the per-channel input
 // lengths of one call into the control blocks the kernels consume (decimation phase, tile counts, history parity).
 // Plain C++, no HIP.

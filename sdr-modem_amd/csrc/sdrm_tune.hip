@@ -1,6 +1,6 @@
 // sdrm_tune.hip -- the two tuners of a batch's schedule: the self-calibration at creation and the online refinement on the
 // caller's own calls.  Neither touches a result: they choose between settings (clock-stage workgroup shape, front-end hold,
-// companion grid) that every call is bit-identical under.  Split from sdrm_api.hip in round 5.
+// companion grid) that every call is bit-identical under.  (The rest of the C-ABI: sdrm_batch.hip, sdrm_call.hip, sdrm_handle.hip.)
 #include "sdrm_batch_impl.h"
 
 // ---- self-calibration of the schedule ------------------------------------------------------------------------------

@@ -90,7 +90,7 @@ extern "C" int emu_reset_channel(EmuBatch *b, size_t c, const sdrm_fsk_config *c
     int code = plan_growth(pl, use, growth);
     if (code != 0) return code;
     if (growth.needed) {
-        // the emulation's counterpart of grow_geometry (sdrm_api.hip): the same planning calls, vectors instead of device memory
+        // the emulation's counterpart of grow_geometry (sdrm_batch.hip): the same planning calls, vectors instead of device memory
         const size_t n = pl.params.size();
         const uint32_t old_hist = pl.hist_stride, old_hx = pl.dc_hx_cap, old_l = pl.dc_l_cap;
         const size_t old_region = pl.dc_region_floats;

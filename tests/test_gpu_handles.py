@@ -127,3 +127,13 @@ def test_thirty_two_private_workers_with_the_references_buffer_size(streams):
     assert errors == 0 and "<3>" not in err, err[-1500:]
     _check(classes, want, 6, 32)
     assert taken + refused == 32 * 6 and peak <= 192
+
+
+def test_the_same_clients_sharing_one_batcher(streams):
+    """sdrm_fsk_demod_share(64, 1000) -- the programmatic form of SDRM_SHARED_SLOTS -- before the handles are created: the 64 client
+    threads' blocking calls become one device call per round of buffers; the streams stay the oracle's.  (What a server with more
+    than a handful of clients wants: 1.7 instead of 0.09 Gsamples/s, profiles/r06_handles.txt.)"""
+    files, want = streams
+    classes, (errors, taken, refused, peak), ms, err = _run(["-s", "-W", 0, 64, BUF, 6], files)
+    assert errors == 0 and "<3>" not in err, err[-1500:]
+    _check(classes, want, 6, 64)

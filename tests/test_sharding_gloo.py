@@ -228,3 +228,43 @@ def test_cost_balanced_shards_of_the_config5_mix():
     uni = [(48000, 9600, 5000, 1, 2000, True, 4096)] * 4096
     assert shard.shard_by_cost(uni, 8) == [(512 * r, 512 * (r + 1)) for r in range(8)]
     assert shard.shard_by_cost(uni[:3], 8)[:3] == [(0, 1), (1, 2), (2, 3)]
+
+
+def _worker_alone(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sdrm_pkg
+    sdrm_pkg.load()
+    from sdr_modem_amd import shard
+    calls = {"n": 0}
+    real = dist.broadcast
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    dist.broadcast = counting
+    table = [(48000, 9600, 5000, 1, 2000, True, 4096)] * 3 + [(240000, 19200, 5000, 5, 2000, True, 4096)] * 2
+    part = shard.fanout_configs(table, len(table))
+    cost = shard.fanout_configs(table, len(table), balance="cost")
+    rows = np.array([(c, 4096, 10 * c) for c in range(len(table))], dtype=np.int64)
+    fixed = shard.fanout_nco_segments(rows, part, as_array=True, capacity=16)
+    loose = shard.fanout_nco_segments(rows, part, as_array=True)
+    dist.broadcast = real
+    ret["alone"] = (part.cfgs == table and (part.lo, part.hi) == (0, len(table)) and len(cost) == len(table)
+                    and np.array_equal(fixed, rows) and np.array_equal(loose, rows), calls["n"])
+    dist.destroy_process_group()
+
+
+def test_a_world_of_one_still_runs_its_collectives():
+    """shard.py broadcasts whenever a process group exists -- a world of one included -- so that on a one-GPU box the rank code's
+    collectives really go through the backend (RCCL in tests/test_gpu_rccl.py, gloo here): five broadcasts for two table fan-outs, one
+    fixed-capacity and one count-then-rows NCO fan-out."""
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_alone, args=(1, port, ret), nprocs=1, join=True)
+    ok, broadcasts = ret["alone"]
+    assert ok and broadcasts == 5

@@ -2,7 +2,7 @@
  * per buffer (src/dsp_worker.c:188 thread per client, :75 the blocking call, src/tcp_server.c:659 one worker per request,
  * src/resources/config.conf:11 buffer_size 131072).
  *
- *   tools/handles_bench [-w] [-q] [-W warm_up_buffers] threads buffer_samples buffers_per_thread [input.cf32 ...]
+ *   tools/handles_bench [-w] [-q] [-s] [-W warm_up_buffers] threads buffer_samples buffers_per_thread [input.cf32 ...]
  *
  * Default mode: every thread owns an fsk_demod handle and calls fsk_demod_process once per buffer.  -w: every thread owns a
  * dsp_worker (private handle, file sink into a scratch directory) and feeds it with dsp_worker_put; the worker's own thread
@@ -13,7 +13,8 @@
  * number of handles in the sticky error state, the device's hand-off ledger (sdrm_handoff_stats) and the wall time of the
  * buffers behind the first `warm_up_buffers` of every thread (default 2: a process's first calls load code objects, create streams
  * and grow the runtime's pools; they are part of every stream and of its hash, not of the time).
- * Run it with SDRM_HANDOFF=0 for the comparison, with SDRM_SHARED_SLOTS=T for handles that share one batcher.
+ * Run it with SDRM_HANDOFF=0 for the comparison, with SDRM_SHARED_SLOTS=T -- or -s, which calls sdrm_fsk_demod_share(T, 1000) instead
+ * -- for handles that share one batcher.
  * Build: gcc -O2 -pthread tools/handles_bench.c -Iinclude -Lsdr-modem_amd/csrc -lsdrmodem_hip
  *            -Wl,-rpath,'$ORIGIN/../sdr-modem_amd/csrc' -lm -o tools/handles_bench */
 #include <math.h>
@@ -90,10 +91,11 @@ static void *client_main(void *arg) {
 }
 
 int main(int argc, char **argv) {
-    int quiet = 0, a = 1;
+    int quiet = 0, share = 0, a = 1;
     for (; a < argc && argv[a][0] == '-'; a++) {
         if (strcmp(argv[a], "-w") == 0) worker_mode = 1;
         if (strcmp(argv[a], "-q") == 0) quiet = 1;
+        if (strcmp(argv[a], "-s") == 0) share = 1;
         if (strcmp(argv[a], "-W") == 0 && a + 1 < argc) n_warm = (size_t) atol(argv[++a]);
     }
     int threads = a < argc ? atoi(argv[a++]) : 64;
@@ -126,6 +128,10 @@ int main(int argc, char **argv) {
         }
     }
     struct client *cl = calloc((size_t) threads, sizeof(*cl));
+    if (share && sdrm_fsk_demod_share((size_t) threads, 1000) != 0) {
+        fprintf(stderr, "sdrm_fsk_demod_share failed\n");
+        return 1;
+    }
     if (worker_mode) {
         snprintf(scratch, sizeof(scratch), "/tmp/handles_bench.%d", (int) getpid());
         mkdir(scratch, 0700);
@@ -214,7 +220,7 @@ int main(int argc, char **argv) {
     printf("%d %s x %zu buffers of %zu samples (%s%s): %.1f ms, %.1f Msamples/s, %.0f symbols per buffer, errors %d, "
            "hand-off taken %llu refused %llu peak waiting %u\n",
            threads, worker_mode ? "workers" : "handles", n_calls - n_warm, n_buf,
-           getenv("SDRM_SHARED_SLOTS") ? "shared batcher" : "private batches", (hand && atoi(hand) == 0) ? ", SDRM_HANDOFF=0" : "", dt * 1e3,
+           (share || getenv("SDRM_SHARED_SLOTS")) ? "shared batcher" : "private batches", (hand && atoi(hand) == 0) ? ", SDRM_HANDOFF=0" : "", dt * 1e3,
            (double) threads * (double) (n_calls - n_warm) * (double) n_buf / dt / 1e6, (double) symbols / ((double) threads * (double) n_calls), errors,
            (unsigned long long) taken, (unsigned long long) refused, peak);
     if (!worker_mode) {
