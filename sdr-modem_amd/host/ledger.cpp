@@ -7,10 +7,6 @@ namespace sdrm {
 
 bool WaitLedger::admit(const void *owner, void *event, unsigned waiting, unsigned limit, bool plain, DoneFn done) {
     std::lock_guard<std::mutex> g(m_);
-    if (plain_calls_.load(std::memory_order_relaxed) - (plain ? 1 : 0) >= SDRM_HAND_MAX_PLAIN) {
-        refused_++;
-        return false;
-    }
     unsigned sum = 0;
     for (size_t i = 0; i < held_.size();) {
         const Entry &e = held_[i];
@@ -24,7 +20,8 @@ bool WaitLedger::admit(const void *owner, void *event, unsigned waiting, unsigne
         sum += e.waiting;
         i++;
     }
-    if (sum + waiting > limit) {
+    // (the owner's old entry is gone whatever the answer: after a refusal it holds nothing)
+    if (plain_calls_.load(std::memory_order_relaxed) - (plain ? 1 : 0) >= SDRM_HAND_MAX_PLAIN || sum + waiting > limit) {
         refused_++;
         return false;
     }

@@ -54,11 +54,24 @@ int main() {
     l.plain_end();
     EXPECT(!l.admit(&d, &ev[3], 40, 192, false, fired) == false);  // one plain call left: the batch is admitted
     l.plain_end();
+    // a refusal leaves the owner nothing: d (40 workgroups listed) asks again while three plain calls are in flight, is refused --
+    // and its old entry is gone with that, so that somebody else gets the whole budget (a and b, plain, released themselves)
+    l.release(&a);
+    l.release(&b);
+    l.plain_begin();
+    l.plain_begin();
+    l.plain_begin();
+    EXPECT(!l.admit(&d, &ev[3], 40, 192, false, fired));
+    l.plain_end();
+    l.plain_end();
+    l.plain_end();
+    EXPECT(l.admit(&c, &ev[2], 192, 192, false, fired));
+    l.release(&c);
     uint64_t taken = 0, refused = 0;
     uint32_t peak = 0;
     l.stats(&taken, &refused, &peak);
-    EXPECT(taken == 8 && refused == 6);
-    EXPECT(peak == 180);
+    EXPECT(taken == 9 && refused == 7);
+    EXPECT(peak == 192);
     printf(failures ? "ledger FAILED\n" : "ledger ok\n");
     return failures ? 1 : 0;
 }
