@@ -13,7 +13,8 @@
 // Streams and hardware queues: every wait of a hand-off call looks at work enqueued BEFORE the waiting kernel by the same thread
 // (front-end, then DC stage, then clock stage), queues are served in order, and the front-end waits for nobody -- the oldest
 // unfinished kernel on the device is therefore always at the head of its queue and runnable as soon as it finds a CU, whatever
-// shares its queue.  What the ledger guarantees is the CU.
+// shares its queue.  (The one look FORWARD is the placement hold in front of a multi-channel batch's front-end -- it lets the DC and
+// clock workgroups take their CUs first -- and that is bounded at 0.4 ms, not at two seconds.)  What the ledger guarantees is the CU.
 //
 // The second count: blocking calls of plain handles (one-channel batches) in flight, with or without the hand-off.  Each is a chain
 // of one-workgroup kernels on a stream of its own, and HIP serves the streams of a priority level from a handful of hardware
