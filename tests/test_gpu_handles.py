@@ -137,3 +137,43 @@ def test_the_same_clients_sharing_one_batcher(streams):
     classes, (errors, taken, refused, peak), ms, err = _run(["-s", "-W", 0, 64, BUF, 6], files)
     assert errors == 0 and "<3>" not in err, err[-1500:]
     _check(classes, want, 6, 64)
+
+
+def test_three_batches_call_at_once_and_share_the_devices_budget():
+    """Three threads, each with its own 96-channel batch, blocking calls of 32768 samples at once: every call meets an idle batch and
+    asks for the hand-off with 12 waiting workgroups (6 clock-stage + 6 DC); the ledger adds them up per device (36 <= 192: all
+    admitted while they overlap) and every channel's stream stays the oracle's."""
+    import threading
+    n, calls, C_ = 32768, 5, 96
+    cfg = CFG + (n,)
+    sig = siggen.gmsk_batch(8, calls * n, first_channel=950)
+    want = [orc.demod_stream(CFG, sig[c], n)[0] for c in range(8)]
+    before = binding.handoff_stats()
+    bad = []
+
+    def run(t):
+        g = binding.Batch([cfg] * C_)
+        if g.code != 0:
+            bad.append((t, "create", g.code))
+            return
+        got = [[] for _ in range(C_)]
+        for k in range(calls):
+            out = g.process([sig[(c + t) % 8, k * n:(k + 1) * n] for c in range(C_)])
+            for c in range(C_):
+                got[c].append(out[c])
+        for c in range(C_):
+            if not np.array_equal(np.concatenate(got[c]), want[(c + t) % 8]):
+                bad.append((t, c))
+        if g.handoff_calls() == 0:
+            bad.append((t, "no hand-off"))
+        g.close()
+
+    th = [threading.Thread(target=run, args=(t,)) for t in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+        assert not t.is_alive()
+    assert not bad, bad[:5]
+    after = binding.handoff_stats()
+    assert after[0] > before[0] and after[2] <= 192
