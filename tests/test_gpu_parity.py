@@ -1315,6 +1315,46 @@ def test_any_samples_per_symbol_on_the_device():
 
 # ---------------------------------------------------------------- stages of ONE call overlap (in-call hand-off, round 5)
 
+def test_hand_off_in_a_batch_whose_stage_buffers_exceed_four_gibibytes():
+    """2048 channels x 524288 samples: the front-end's output array is 4 GiB, the DC blocker's likewise.  The hand-off's device-
+    scope accesses go through raw buffer resources with 32-bit byte offsets; until round 6 one resource spanned the whole array
+    and the offset of channel 1024's row wrapped to channel 0's (advisor's finding: the DC stage then read and wrote other
+    channels' rows, silently).  Now a resource starts at the row of the DC workgroup's first channel.  One blocking call with
+    the hand-off (64 clock-stage + 128 DC workgroups waiting: the limit exactly), every channel reading the same row
+    (input stride 0: no 8 GiB of input needed); channels on both sides of the 4 GiB line and the last one against the oracle."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 48 * (1 << 30):
+        pytest.skip("needs ~40 GB of device memory")
+    n, C_ = 524288, 2048
+    cfg = (48000, 9600, 5000, 1, 2000, True)
+    row = siggen.gmsk_channel(77, n)
+    want8, _ = orc.demod_stream(cfg, row, n)
+    x = torch.from_numpy(row.view(np.float32).copy()).cuda()
+    g = binding.Batch([cfg + (n,)] * C_, calibrate=False)
+    assert g.code == 0
+    assert g.schedule()["clock_stage"] == "32x512"
+    g.process_device(x.data_ptr(), 0, [n] * C_, torch.cuda.current_stream().cuda_stream)
+    g.sync()
+    assert g.handoff_calls() == 1
+    data, got = g.fetch(len(want8) + 64)
+    for c in (0, 1, 1023, 1024, 1025, 1535, 2047):
+        assert got[c] == len(want8) and np.array_equal(data[c, :got[c]], want8), c
+    # a second call behind it (stream order, no hand-off: the batch is not idle when it is enqueued) continues every stream
+    g.process_device(x.data_ptr(), 0, [n] * C_, torch.cuda.current_stream().cuda_stream)
+    g.process_device(x.data_ptr(), 0, [n] * C_, torch.cuda.current_stream().cuda_stream)
+    g.sync()
+    o = orc.Fsk(*cfg, n)
+    for _ in range(3):
+        last, _ = o.process(row)
+    data, got = g.fetch(len(last) + 64)
+    for c in (0, 1024, 2047):
+        assert got[c] == len(last) and np.array_equal(data[c, :got[c]], last), c
+    g.close()
+    del x
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("handoff", ["1", "0"])
 def test_blocking_calls_with_the_stages_of_one_call_resident_together(handoff, monkeypatch):
     """A blocking call meets an idle batch (the reference's caller waits for fsk_demod_process, src/dsp_worker.c:75): its
