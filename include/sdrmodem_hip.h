@@ -236,8 +236,10 @@ int sdrm_fsk_demod_share(size_t slots, uint32_t max_wait_us);
 /* The workgroups of a hand-off call that wait for the stage in front of them hold compute units of the DEVICE, and a server
  * runs one handle per client (src/dsp_worker.c:188, src/tcp_server.c:659): admission is therefore counted per device across
  * every batch and handle of the process -- a call takes the hand-off only while the waiting workgroups on the device, its own
- * included, stay within the limit (192; 16 where a DC workgroup leaves a front-end workgroup no room beside it), and runs its
- * stages in stream order otherwise.  Process-wide totals for a device (< 0: the current one): calls admitted, calls that
+ * included, stay within the limit (192; 16 where a DC workgroup leaves a front-end workgroup no room beside it) and no OTHER plain
+ * handle's blocking call is in flight (such calls are chains of one-workgroup kernels that share a handful of hardware queues:
+ * the hand-off pays for a client that calls alone and costs the others when several call together), and runs its stages in
+ * stream order otherwise.  Process-wide totals for a device (< 0: the current one): calls admitted, calls that
  * qualified but found the budget taken, the largest number of workgroups that were waiting at once.  Any pointer may be NULL. */
 int sdrm_handoff_stats(int device, uint64_t *taken, uint64_t *refused, uint32_t *peak_waiting);
 

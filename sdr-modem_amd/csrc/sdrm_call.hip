@@ -55,6 +55,25 @@ static bool hand_admit(sdrm_batch_t *b, unsigned waiting, unsigned limit, hipEve
 
 static void hand_arm(sdrm_batch_t *b) { hand_ledger(b->device).arm(b); }
 
+// a call that would qualify for the hand-off by its length, on a device with too many plain handles' calls in flight: refused at once
+// (what hundreds of client threads calling together meet on every call: no event query, no kernel geometry, one atomic load)
+static bool hand_crowded(sdrm_batch_t *b, const sdrm_chunk_ctl *h) {
+    if (b->serial) {
+        uint32_t longest = 0;
+        for (size_t c = 0; c < b->plan.design.size(); c++) {
+            longest = std::max(longest, h[c].nz);
+        }
+        if (longest < SDRM_HAND_SERIAL_MIN_NZ) {
+            return false;  // does not qualify anyway (the block below says so too): not a refusal
+        }
+    }
+    if (!hand_ledger(b->device).crowded(b->serial)) {
+        return false;
+    }
+    b->hand_refused++;
+    return true;
+}
+
 // a plain handle's blocking call, from its first enqueue to its results (process_host)
 struct PlainCallInFlight {
     sdrm::WaitLedger *ledger = nullptr;
@@ -190,7 +209,7 @@ int sdrm_impl::enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stri
     // finds a CU, the DC stage waits only for the front-end and the clock stage only for the DC stage.  Every wait in the
     // kernels is bounded besides (a void call, loudly, never a hung device).
     bool hand = false;
-    if (b->hand_allowed && b->n_gen == 0 && (b->serial || b->d_placed != nullptr) && max_tiles > 0) {
+    if (b->hand_allowed && b->n_gen == 0 && (b->serial || b->d_placed != nullptr) && max_tiles > 0 && !hand_crowded(b, h)) {
         const bool idle = b->last_slot < 0 || hipEventQuery(b->slot_done[b->last_slot]) == hipSuccess;
         const unsigned waiting = sdrm::clock_workgroups(d) + (d.any_dc ? sdrm::dc_workgroups(d) : 0u);
         const bool room = !d.any_dc || (size_t) d.dc_lds + sdrm::k1_lds_bytes(d.t1_max, d.t2_max) <= 160 * 1024;
@@ -224,10 +243,16 @@ int sdrm_impl::enqueue_call(sdrm_batch_t *b, const sdrm_f2 *d_in, size_t in_stri
             b->hand_refused++;
         }
         if (hand && b->serial && b->s_hand_clock == nullptr) {
+            // Both side streams at the MIDDLE priority level, the one the handle's copy stream lives on anyway.  HIP keeps a pool of
+            // hardware queues per level in use: with the clock stage's stream at the highest level (round 5) the first hand-off call
+            // of a process that otherwise runs plain handles only brought a third pool to life, and every later call of every
+            // handle paid for it -- 256 handles x 131072 samples: 8.5-9.5 s per 20 rounds after a single admitted call, 7.4-7.9
+            // without (profiles/r06_handles.txt); a lone handle has nothing to take priority over.
             int prio_low = 0, prio_high = 0;
             (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-            if (hipStreamCreateWithPriority(&b->s_hand_dc, hipStreamNonBlocking, (prio_low + prio_high) / 2) != hipSuccess ||
-                hipStreamCreateWithPriority(&b->s_hand_clock, hipStreamNonBlocking, prio_high) != hipSuccess) {
+            const int prio_mid = (prio_low + prio_high) / 2;
+            if (hipStreamCreateWithPriority(&b->s_hand_dc, hipStreamNonBlocking, prio_mid) != hipSuccess ||
+                hipStreamCreateWithPriority(&b->s_hand_clock, hipStreamNonBlocking, prio_mid) != hipSuccess) {
                 (void) hipGetLastError();
                 hand = false;
             }

@@ -54,7 +54,7 @@ void WaitLedger::release(const void *owner) {
 void WaitLedger::stats(uint64_t *taken, uint64_t *refused, uint32_t *peak_waiting) {
     std::lock_guard<std::mutex> g(m_);
     if (taken) *taken = taken_;
-    if (refused) *refused = refused_;
+    if (refused) *refused = refused_ + crowded_refusals_.load(std::memory_order_relaxed);
     if (peak_waiting) *peak_waiting = peak_;
 }
 

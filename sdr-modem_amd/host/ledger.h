@@ -20,10 +20,13 @@
 // of one-workgroup kernels on a stream of its own, and HIP serves the streams of a priority level from a handful of hardware
 // queues: about three such chains run at once, whatever the number of handles (64 handles x 131072 samples: 1.4 ms per call
 // against 3.9 alone; more queues -- GPU_MAX_HW_QUEUES -- make it worse, profiles/r06_handles.txt).  A hand-off call adds two
-// streams and two spinning workgroups to that: with one or two handles calling it wins a millisecond per call (3.9 -> 2.9 ms), from
-// three on it loses or ties, and behind dozens of queued chains its front-end would wait for tens of milliseconds with its DC and
-// clock workgroups holding CUs.  The hand-off is an optimisation of latency on a quiet device: it is taken only while fewer than
-// SDRM_HAND_MAX_PLAIN OTHER such calls are in flight.
+// streams and two spinning workgroups to that: with one handle calling it wins a millisecond per call (3.9 -> 2.9 ms); with two, only
+// while the clock stage's side stream sits on the highest priority level (3.0 against 3.9 ms) -- and a process's first stream on that
+// level brings a third pool of hardware queues to life, which cost 256 plain handles 15 % for the rest of their run; with both side
+// streams on the middle level two handles collide (6.8 against 3.9 ms); from three on it loses or ties either way, and behind dozens
+// of queued chains its front-end would wait for tens of milliseconds with its DC and clock workgroups holding CUs.  The hand-off is an
+// optimisation of latency on a quiet device: a plain handle's call takes it only while NO other such call is in flight
+// (SDRM_HAND_MAX_PLAIN = 1), on side streams of the middle level.
 #ifndef SDRM_LEDGER_H
 #define SDRM_LEDGER_H
 
@@ -33,7 +36,7 @@
 #include <mutex>
 #include <vector>
 
-#define SDRM_HAND_MAX_PLAIN 2
+#define SDRM_HAND_MAX_PLAIN 1
 
 namespace sdrm {
 
@@ -50,6 +53,15 @@ class WaitLedger {
     void arm(const void *owner);
     // owner has seen its call end (or is going away: its event is about to be destroyed); tolerates a missing entry
     void release(const void *owner);
+    // too many plain handles' calls in flight for anybody's hand-off?  (one atomic load: asked first, so that a crowded device's calls
+    // are refused before they look at an event or a kernel's geometry; counted as a refusal)
+    bool crowded(bool plain) {
+        if (plain_calls_.load(std::memory_order_relaxed) - (plain ? 1 : 0) < SDRM_HAND_MAX_PLAIN) {
+            return false;
+        }
+        crowded_refusals_.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
     void plain_begin() { plain_calls_.fetch_add(1, std::memory_order_relaxed); }
     void plain_end() { plain_calls_.fetch_sub(1, std::memory_order_relaxed); }
     void stats(uint64_t *taken, uint64_t *refused, uint32_t *peak_waiting);
@@ -66,6 +78,7 @@ class WaitLedger {
     uint64_t taken_ = 0, refused_ = 0;
     unsigned peak_ = 0;
     std::atomic<int> plain_calls_{0};
+    std::atomic<uint64_t> crowded_refusals_{0};
 };
 
 }  // namespace sdrm

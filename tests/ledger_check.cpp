@@ -42,35 +42,31 @@ int main() {
     EXPECT(l.admit(&d, &ev[3], 20, 192, false, fired));
     l.release(&b);
     l.release(&d);
-    // plain handles: a call is admitted while fewer than SDRM_HAND_MAX_PLAIN OTHER plain calls are in flight
+    // plain handles: a call is admitted while NO other plain call is in flight (SDRM_HAND_MAX_PLAIN = 1)
     l.plain_begin();                                      // a's own call
     EXPECT(l.admit(&a, &ev[0], 2, 192, true, fired));
-    l.plain_begin();                                      // b's
-    EXPECT(l.admit(&b, &ev[1], 2, 192, true, fired));
-    l.plain_begin();                                      // c's: two others in flight
-    EXPECT(!l.admit(&c, &ev[2], 2, 192, true, fired));
-    EXPECT(!l.admit(&d, &ev[3], 40, 192, false, fired)); // a batch sees three plain calls in flight
-    l.plain_end();
-    l.plain_end();
-    EXPECT(!l.admit(&d, &ev[3], 40, 192, false, fired) == false);  // one plain call left: the batch is admitted
-    l.plain_end();
+    l.plain_begin();                                      // b's: a's is in flight
+    EXPECT(!l.admit(&b, &ev[1], 2, 192, true, fired));
+    EXPECT(l.crowded(true) && l.crowded(false));          // ... which the one-load test in front says too (two refusals counted)
+    EXPECT(!l.admit(&d, &ev[3], 40, 192, false, fired)); // a batch sees two plain calls in flight
+    l.plain_end();                                        // b's call ends
+    EXPECT(!l.admit(&d, &ev[3], 40, 192, false, fired)); // one plain call in flight is still one too many for a batch
+    l.plain_end();                                        // a's ends
+    EXPECT(!l.crowded(false));
+    EXPECT(l.admit(&d, &ev[3], 40, 192, false, fired));
     // a refusal leaves the owner nothing: d (40 workgroups listed) asks again while three plain calls are in flight, is refused --
     // and its old entry is gone with that, so that somebody else gets the whole budget (a and b, plain, released themselves)
     l.release(&a);
     l.release(&b);
     l.plain_begin();
-    l.plain_begin();
-    l.plain_begin();
     EXPECT(!l.admit(&d, &ev[3], 40, 192, false, fired));
-    l.plain_end();
-    l.plain_end();
     l.plain_end();
     EXPECT(l.admit(&c, &ev[2], 192, 192, false, fired));
     l.release(&c);
     uint64_t taken = 0, refused = 0;
     uint32_t peak = 0;
     l.stats(&taken, &refused, &peak);
-    EXPECT(taken == 9 && refused == 7);
+    EXPECT(taken == 8 && refused == 10);
     EXPECT(peak == 192);
     printf(failures ? "ledger FAILED\n" : "ledger ok\n");
     return failures ? 1 : 0;
